@@ -1,0 +1,116 @@
+"""
+Seeded synthetic inputs for tests and bench.py.  numpy only; runs on
+both the build container and the GPU box.  Also a fake capture object with the duck type
+`run()` needs (reference base.py:48-51, 227-233: isOpened/read/get/release).
+"""
+import numpy as np
+
+CAP_PROP_FRAME_WIDTH = 3
+CAP_PROP_FRAME_HEIGHT = 4
+CAP_PROP_FPS = 5
+
+
+def _lowpass_noise(rng, h, w, cutoff=0.06):
+    """Seeded low-pass noise in [-1, 1]."""
+    n = rng.standard_normal((h, w))
+    fy = np.fft.fftfreq(h)[:, None]
+    fx = np.fft.rfftfreq(w)[None, :]
+    filt = np.exp(-(fy * fy + fx * fx) / (2 * cutoff * cutoff))
+    t = np.fft.irfft2(np.fft.rfft2(n) * filt, s=(h, w))
+    t -= t.mean()
+    m = np.abs(t).max()
+    return t / m if m > 0 else t
+
+
+def synth_breathing(T, H, W, seed=1234, fps=10.0, breath_hz=0.4, amplitude=0.2, noise=0.02,
+                    center=(0.6, 0.4), sigma=(0.10, 0.08), block=8):
+    """uint8 [T,H,W] gray video: static low-pass texture + a Gaussian blob whose brightness
+    oscillates at `breath_hz` (inside the 0.1-1.0 Hz calibration band) + white noise.
+    The blob is off-centre so bounding-box bugs show.  Frames enter the path as
+    uint8_to_float(g) like reference base.py:231.  Generated `block` frames at a time to
+    bound host memory at 1080p x 256."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tex = _lowpass_noise(rng, H, W)
+    yy = (np.arange(H)[:, None] - center[0] * H) / (sigma[0] * H)
+    xx = (np.arange(W)[None, :] - center[1] * W) / (sigma[1] * W)
+    blob = np.exp(-0.5 * (yy * yy + xx * xx))
+    base = 0.5 + 0.25 * tex
+    out = np.empty((T, H, W), dtype=np.uint8)
+    for t0 in range(0, T, block):
+        t1 = min(T, t0 + block)
+        s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps)[:, None, None]
+        g = base[None] + amplitude * blob[None] * s + noise * rng.standard_normal((t1 - t0, H, W))
+        out[t0:t1] = np.clip(np.round(255 * g), 0, 255).astype(np.uint8)
+    return out
+
+
+def synth_brightness_video(T, H, W, fps=10.0, hz=0.4):
+    """Config 1: whole-frame brightness 0.5 + 0.2 sin(2 pi hz t / fps), BGR uint8 [T,H,W,3]."""
+    t = np.arange(T)
+    lvl = np.clip(np.round(255 * (0.5 + 0.2 * np.sin(2 * np.pi * hz * t / fps))), 0, 255).astype(np.uint8)
+    return np.broadcast_to(lvl[:, None, None, None], (T, H, W, 3)).copy()
+
+
+def synth_texture(H, W, seed=4321, n_waves=12, n_spots=40):
+    """Config 3: analytic texture (random 2-D sinusoids + Gaussian spots) as a callable
+    f(dx, dy) -> uint8 [H,W] rendered at a sub-pixel shift, so ground-truth flow is known."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kx = rng.uniform(-0.9, 0.9, n_waves)
+    ky = rng.uniform(-0.9, 0.9, n_waves)
+    ph = rng.uniform(0, 2 * np.pi, n_waves)
+    am = rng.uniform(0.3, 1.0, n_waves)
+    sx = rng.uniform(0, W, n_spots)
+    sy = rng.uniform(0, H, n_spots)
+    ss = rng.uniform(1.5, 4.0, n_spots)
+    sa = rng.uniform(-1.0, 1.0, n_spots)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+
+    def render(dx=0.0, dy=0.0):
+        x = xx - dx
+        y = yy - dy
+        v = np.zeros((H, W))
+        for i in range(n_waves):
+            v += am[i] * np.sin(kx[i] * x + ky[i] * y + ph[i])
+        v /= max(1.0, am.sum() / 2)
+        for i in range(n_spots):
+            v += sa[i] * np.exp(-0.5 * ((x - sx[i]) ** 2 + (y - sy[i]) ** 2) / (ss[i] * ss[i]))
+        g = 0.5 + 0.22 * v
+        return np.clip(np.round(255 * g), 0, 255).astype(np.uint8)
+
+    return render
+
+
+class FakeCapture:
+    """Stands in for cv2.VideoCapture (reference base.py:48-51, 227-233).
+    frames: uint8 [T,H,W,3] BGR (or [T,H,W] gray, returned as 3 equal channels)."""
+
+    def __init__(self, frames, fps=10):
+        self._frames = frames
+        self._i = 0
+        self._fps = fps
+        self._open = True
+
+    def isOpened(self):
+        return self._open
+
+    def get(self, prop):
+        f = self._frames
+        if prop == CAP_PROP_FPS:
+            return float(self._fps)
+        if prop == CAP_PROP_FRAME_WIDTH:
+            return float(f.shape[2])
+        if prop == CAP_PROP_FRAME_HEIGHT:
+            return float(f.shape[1])
+        return 0.0
+
+    def read(self):
+        if self._i >= len(self._frames):
+            return False, None
+        f = self._frames[self._i]
+        self._i += 1
+        if f.ndim == 2:
+            f = np.repeat(f[:, :, None], 3, axis=2)
+        return True, f
+
+    def release(self):
+        self._open = False

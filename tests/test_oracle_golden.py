@@ -1,0 +1,105 @@
+"""The oracle's restatement of the reference glue must reproduce, bit for bit, the outputs the
+reference itself produced in the build container (tests/golden/*.npz, made by oracle/make_golden.py)."""
+import hashlib
+import warnings
+
+import numpy as np
+
+from respmon_amd import synth
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_g1_temporal_fft(oracle, golden):
+    g = golden("g1_temporal_fft.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        y = oracle.temporal_bandpass_filter_fft(g["x%d" % i].copy(), fps, fmin, fmax, amplification_factor=amp)
+        assert np.array_equal(y, g["y%d" % i]), i
+        if "M%d" % i in g.files:
+            M = oracle.temporal_operator(int(n), fps, fmin, fmax)
+            assert np.array_equal(M, g["M%d" % i])
+            # the operator form reproduces the FFT form to rounding
+            x = g["x%d" % i].reshape(int(n), -1)
+            assert np.allclose((M @ x) * amp, g["y%d" % i].reshape(int(n), -1), rtol=0, atol=1e-10)
+
+
+def test_g1_band_survivors(oracle):
+    # surviving packed indices [bl,bh) U [n-bh, n-bl)
+    assert oracle.band_bounds(128, 10, 0.1, 1.0) == (1, 13)
+    assert oracle.band_bounds(256, 10, 0.1, 1.0) == (3, 26)
+    assert oracle.band_bounds(512, 10, 0.1, 1.0) == (5, 51)
+    assert oracle.band_bounds(128, 30, 0.1, 1.0) == (0, 4)
+    assert oracle.band_bounds(64, 10, 0.1, 1.0) == (1, 6)
+    assert np.linalg.matrix_rank(oracle.temporal_operator(128, 10, 0.1, 1.0)) == 13
+
+
+def test_g2_lut(oracle, golden):
+    g = golden("g2_u8_float_lut.npz")
+    k = np.arange(256, dtype=np.uint8)
+    f = oracle.uint8_to_float(k)
+    assert np.array_equal(f, g["f"])
+    lut = oracle.float_to_uint8(f)
+    assert np.array_equal(lut, g["lut"])
+    lossy = np.flatnonzero(lut != k)
+    assert lossy.tolist() == [33, 37, 41, 45, 49, 53, 57, 61, 66, 74, 82, 90, 98, 106, 114, 122,
+                              132, 148, 164, 180, 196, 212, 228, 244]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(oracle.float_to_uint8(g["edge_in"]), g["edge_out"])
+
+
+def test_g3_eulerian(oracle, golden):
+    g = golden("g3_eulerian.npz")
+    vid = oracle.uint8_to_float(g["vid_u8"])
+    for i in range(int(g["ncases"])):
+        L, S, fps = g["meta%d" % i]
+        masked, raw = oracle.eulerian_magnification_bandpass(vid.copy(), fps, 0.1, 1.0, 500,
+                                                             pyramid_levels=int(L), skip_levels_at_top=int(S))
+        assert np.array_equal(raw, g["raw%d" % i])
+        assert _sha(masked) == str(g["masked_sha%d" % i])
+        mn, mx, cnt = g["masked_stats%d" % i]
+        assert raw.min() == mn and raw.max() == mx and (masked == mn).sum() == cnt
+        assert np.array_equal(np.average(masked, axis=0), g["avg%d" % i])
+
+
+def test_g4_locate(oracle, golden):
+    g = golden("g4_locate.npz")
+    for i in range(int(g["ncases"])):
+        T, H, W, seed, L, S, fps = (int(v) for v in g["meta%d" % i])
+        vid_u8 = synth.synth_breathing(T, H, W, seed=seed)
+        assert _sha(vid_u8) == str(g["vid_sha%d" % i]), "synthetic generator drifted"
+        roi, mid = oracle.locate(oracle.uint8_to_float(vid_u8), fps, pyramid_levels=L, skip_levels_at_top=S,
+                                 return_intermediates=True)
+        assert tuple(roi) == tuple(int(v) for v in g["roi%d" % i])
+        assert np.array_equal(mid["avg_u8"], g["avg_u8_%d" % i])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert oracle.locate(np.full((16, 40, 48), 0.5), 10, pyramid_levels=4, skip_levels_at_top=2) is None
+    assert bool(g["roi_const_is_none"])
+
+
+def test_g5_extract_motion_scripted(oracle, golden):
+    g = golden("g5_extract_motion.npz")
+    pts = g["pts0"]
+    motion = []
+    vals = [0.0]  # first call = corner init (base.py:369)
+    for t in range(int(g["nframes"])):
+        p1, st = g["p1_%d" % t], g["st_%d" % t]
+        good_new = p1[st == 1]
+        good_old = pts[st == 1]
+        pts = good_new.reshape(-1, 1, 2)
+        motion.append(list(np.mean(good_old - good_new, axis=0)))
+        vals.append(oracle.pca_first_component(motion))
+    assert np.array_equal(np.array(motion, dtype=np.float32), g["motion_data_f32"])
+    assert np.array_equal(np.array(vals, dtype=np.float64), g["values"])
+
+
+def test_g7_misc(oracle, golden):
+    g = golden("g7_misc.npz")
+    for c, r in zip(g["rbb_in"], g["rbb_out"]):
+        x, y, w, h, a = c
+        assert tuple(oracle.reduce_bounding_box(int(x), int(y), int(w), int(h), a)) == tuple(int(v) for v in r)
+    assert np.array_equal(oracle.butter_lowpass_filter(g["sig"], 0.5, 10, 3), g["filt"])
