@@ -1,0 +1,153 @@
+/*
+ * include/respmon_hip.h -- C-ABI of librespmon_hip.so, the MI355X (gfx950) implementation of
+ * respmon's Eulerian-magnification calibration and ROI motion-extraction hot path.
+ *
+ * The reference (kevroy314/respmon) is pure Python and has no FFI layer; the "interface each
+ * entry point replaces" is therefore the Python function (and the cv2 / scipy / numpy calls
+ * under it) cited next to each declaration, paths relative to the reference root.
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; every pointer named *_dev is a DEVICE pointer (HBM) unless the
+ *    comment says host; images are row-major, videos are [T,H,W] with frame stride H*W.
+ *  - every function returns int: RM_OK (0) or a negative RM_E_* code; rm_last_error_string()
+ *    gives the text for the calling thread's last failure.  RM_NO_CONTOUR (+1) is the
+ *    reference's `return None` (base.py:569-570).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work on
+ *    it; functions that return host results synchronise that stream before returning.
+ *  - a context is not thread-safe; use one per stream / GPU.
+ */
+#ifndef RESPMON_HIP_H
+#define RESPMON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_OK 0
+#define RM_NO_CONTOUR 1
+#define RM_E_BADARG (-1)
+#define RM_E_HIP (-2)
+#define RM_E_NOMEM (-3)
+#define RM_E_UNSUPPORTED (-4)
+#define RM_E_INTERNAL (-5)
+
+/* element type of a frame buffer handed to the library */
+#define RM_U8 0  /* gray uint8; the kernels apply uint8_to_float's  k * (1./255)  (transforms.py:20-23) */
+#define RM_F16 1 /* IEEE half, widened exactly */
+#define RM_F32 2 /* float, widened exactly */
+#define RM_F64 3 /* double: the reference's calibration_buffer dtype (base.py:119-120) */
+
+/* rm_calibrate flags */
+#define RM_FLAG_NO_PRUNE 1u      /* evaluate every (tile, frame) of the collapse passes (A/B + verification) */
+#define RM_FLAG_UNFUSED_DOWN 2u  /* build the Gaussian levels one pyrDown launch per level */
+
+typedef struct rm_ctx rm_ctx;
+
+/* ---- context -------------------------------------------------------------------------- */
+int rm_ctx_create(int device, rm_ctx **out);
+int rm_ctx_destroy(rm_ctx *ctx);
+const char *rm_last_error_string(void);
+int rm_abi_version(void);
+/* bytes of device workspace currently held by the context */
+size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
+
+/* ---- dtype helpers: transforms.py:20-23 uint8_to_float, transforms.py:26-29 float_to_uint8 */
+int rm_uint8_to_float(rm_ctx *ctx, const uint8_t *src_dev, double *dst_dev, size_t n, void *stream);
+int rm_float_to_uint8(rm_ctx *ctx, const double *src_dev, uint8_t *dst_dev, size_t n, void *stream);
+
+/* ---- pyramid.py building blocks (materialising forms, API parity + tests) ------------- */
+/* cv2.pyrDown on every frame of src[T,h,w] -> dst[T,(h+1)/2,(w+1)/2] float64.  pyramid.py:14 */
+int rm_pyr_down(rm_ctx *ctx, const void *src_dev, int src_dtype, int T, int h, int w,
+                double *dst_dev, void *stream);
+/* cv2.pyrUp(src, dstsize=(dw,dh)) on every frame, fused with the reference's add/subtract:
+ *   mode 0: dst = up(src)                      pyramid.py:55 with a zero level
+ *   mode 1: dst = other - up(src)              pyramid.py:24-26  (Laplacian level)
+ *   mode 2: dst = up(src) + other              pyramid.py:55     (collapse step)
+ * `other_dev` is [T,dh,dw] (ignored for mode 0); dst may alias other. */
+int rm_pyr_up(rm_ctx *ctx, const double *src_dev, int T, int sh, int sw, double *dst_dev, int dh, int dw,
+              int mode, const double *other_dev, void *stream);
+/* pyramid.py:31-48 create_laplacian_video_pyramid: level_ptrs_host[l] -> device [T,h_l,w_l] float64,
+ * h_0=H, h_{l+1}=(h_l+1)/2.  All `levels` arrays are written. */
+int rm_create_laplacian_video_pyramid(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W,
+                                      int levels, double *const *level_ptrs_host, void *stream);
+/* pyramid.py:60-69 collapse_laplacian_video_pyramid: result into out_dev[T,H,W] (may be level 0). */
+int rm_collapse_laplacian_video_pyramid(rm_ctx *ctx, const double *const *level_ptrs_host, int T, int H, int W,
+                                        int levels, double *out_dev, void *stream);
+
+/* ---- transforms.py:82-102 temporal_bandpass_filter_fft -------------------------------- */
+/* out[s,p] = amplification * sum_t M[s,t] data[t,p], M = the reference's packed-rfft / mask /
+ * Re(ifft) operator (quirk kept).  data/out: [T, npix] float64. */
+int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data_dev, int T, size_t npix, double fps,
+                                    double freq_min, double freq_max, double amplification,
+                                    double *out_dev, void *stream);
+/* the operator itself (host, row-major [T,T], without the amplification) and the band bounds */
+int rm_temporal_operator(int T, double fps, double freq_min, double freq_max, double *M_host,
+                         int *bound_low, int *bound_high);
+
+/* ---- transforms.py:144-198 eulerian_magnification_bandpass (materialised outputs) ------ */
+/* masked_dev / raw_dev: [T,H,W] float64 (either may be NULL); minmax_host[2] = {min, max} of raw. */
+int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W,
+                                       double fps, double freq_min, double freq_max, double amplification,
+                                       int pyramid_levels, int skip_levels_at_top, double threshold,
+                                       double *masked_dev, double *raw_dev, double *minmax_host, void *stream);
+
+/* ---- the fused calibration path: base.py:555-562 (eulerian ... np.average(op, axis=0)) -- */
+/* Reads the frame buffer once; never materialises a [T,H,W] intermediate.  heatmap_dev[H*W]
+ * receives np.average(masked, axis=0) (sequential-in-t float64 sum / T).  minmax_host (may be
+ * NULL) receives {raw.min(), raw.max()}.  Asynchronous unless minmax_host != NULL. */
+int rm_calibrate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W,
+                 double fps, double freq_min, double freq_max, double amplification,
+                 int pyramid_levels, int skip_levels_at_top, double temporal_threshold,
+                 unsigned flags, double *heatmap_dev, double *minmax_host, void *stream);
+
+/* ---- base.py:563-575: normalise, float_to_uint8, threshold, findContours(EXTERNAL,SIMPLE),
+ *      max contourArea, boundingRect.  avg_u8_dev / binary_dev (device, H*W, may be NULL) receive
+ *      the uint8 heatmap and the thresholded image.  Returns RM_OK + xywh_host[4], or RM_NO_CONTOUR. */
+int rm_heatmap_to_roi(rm_ctx *ctx, const double *heatmap_dev, int H, int W, int threshold,
+                      int32_t *xywh_host, uint8_t *avg_u8_dev, uint8_t *binary_dev, void *stream);
+
+/* ---- base.py:547-601 RespiratoryMonitor.locate = rm_calibrate + rm_heatmap_to_roi ------- */
+int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W, double fps,
+              double freq_min, double freq_max, double amplification, int pyramid_levels,
+              int skip_levels_at_top, double temporal_threshold, int threshold, unsigned flags,
+              int32_t *xywh_host, void *stream);
+
+/* ---- base.py:355-358 + 471: extract_motion('average') = np.average(frame[y:y+h, x:x+w]) -- */
+int rm_roi_mean(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h,
+                double *out_host, void *stream);
+/* ROI crop + float_to_uint8 (base.py:364, 371, 381): dst_dev[h*w] uint8 */
+int rm_roi_to_uint8(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h,
+                    uint8_t *dst_dev, void *stream);
+
+/* ---- base.py:365-366 cv2.goodFeaturesToTrack(img_u8, mask=None, maxCorners, qualityLevel,
+ *      minDistance, blockSize).  pts_host: float32 (x,y) pairs, capacity max_corners; *n_host = count
+ *      (0 <=> cv2 returns None). */
+int rm_good_features_to_track(rm_ctx *ctx, const uint8_t *img_dev, int h, int w, int max_corners,
+                              double quality_level, double min_distance, int block_size,
+                              float *pts_host, int *n_host, void *stream);
+
+/* ---- base.py:371-372 cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize, maxLevel,
+ *      criteria=(EPS|COUNT, max_count, epsilon)).  pts in/out: host float32 (x,y) pairs; status host u8. */
+int rm_calc_optical_flow_pyr_lk(rm_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int h, int w,
+                                const float *pts_in_host, int npts, int win_w, int win_h, int max_level,
+                                int max_count, double epsilon, float *pts_out_host, uint8_t *status_host,
+                                void *stream);
+
+/* ---- base.py:388: np.mean(good_old - good_new, axis=0) (float32, sequential over points) and
+ *      base.py:396-405: np.cov -> np.linalg.eig -> argsort desc -> ROW unpack -> projection[-1].
+ *      motion_host: float32 [n,2] (the motion_data deque); *out_host = the value extract_motion returns. */
+int rm_mean_flow(rm_ctx *ctx, const float *old_host, const float *new_host, const uint8_t *status_host,
+                 int npts, float *mean_xy_host, int *n_good_host, void *stream);
+int rm_pca_reduce(rm_ctx *ctx, const float *motion_host, int n, double *out_host, void *stream);
+
+/* ---- base.py:230-231: cv2.cvtColor(BGR2GRAY) then uint8_to_float, on device ("next" row f3) */
+int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gray_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESPMON_HIP_H */

@@ -1,0 +1,83 @@
+"""
+ctypes declarations for the C-ABI in include/respmon_hip.h and the loader of the HIP library.
+
+The product path is librespmon_hip.so built by hipcc for gfx950 -- there is NO CPU fallback:
+`load()` raises if the library is missing or cannot be loaded.
+"""
+import ctypes
+import os
+
+RM_OK = 0
+RM_NO_CONTOUR = 1
+RM_U8, RM_F16, RM_F32, RM_F64 = 0, 1, 2, 3
+RM_FLAG_NO_PRUNE = 1
+RM_FLAG_UNFUSED_DOWN = 2
+
+_c = ctypes
+_vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint
+
+# name -> (restype, argtypes); every symbol include/respmon_hip.h declares
+SIGNATURES = {
+    "rm_ctx_create": (_i, [_i, _c.POINTER(_vp)]),
+    "rm_ctx_destroy": (_i, [_vp]),
+    "rm_last_error_string": (_c.c_char_p, []),
+    "rm_abi_version": (_i, []),
+    "rm_ctx_workspace_bytes": (_sz, [_vp]),
+    "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "rm_float_to_uint8": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "rm_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rm_pyr_up": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "rm_create_laplacian_video_pyramid": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _c.POINTER(_vp), _vp]),
+    "rm_collapse_laplacian_video_pyramid": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _vp]),
+    "rm_temporal_bandpass_filter_fft": (_i, [_vp, _vp, _i, _sz, _d, _d, _d, _d, _vp, _vp]),
+    "rm_temporal_operator": (_i, [_i, _d, _d, _d, _vp, _c.POINTER(_i), _c.POINTER(_i)]),
+    "rm_eulerian_magnification_bandpass": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _vp, _vp, _vp, _vp]),
+    "rm_calibrate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _u, _vp, _vp, _vp]),
+    "rm_heatmap_to_roi": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rm_locate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
+    "rm_roi_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rm_roi_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rm_good_features_to_track": (_i, [_vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
+    "rm_calc_optical_flow_pyr_lk": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
+    "rm_mean_flow": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "rm_pca_reduce": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "rm_bgr_to_gray": (_i, [_vp, _vp, _sz, _vp, _vp]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librespmon_hip.so")
+
+
+class RespmonError(RuntimeError):
+    pass
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every declared symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_LIB = None
+
+
+def load():
+    """Load the gfx950 HIP library.  Fails loudly: there is no other implementation to fall back to."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RespmonError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` or `make -C respmon_amd/csrc`)" % LIB_PATH)
+        try:
+            _LIB = bind(ctypes.CDLL(LIB_PATH))
+        except OSError as e:
+            raise RespmonError("cannot load HIP extension %s: %s" % (LIB_PATH, e))
+    return _LIB
+
+
+def check(lib, rc, what):
+    if rc < 0:
+        raise RespmonError("%s failed (%d): %s" % (what, rc, lib.rm_last_error_string().decode("utf-8", "replace")))
+    return rc

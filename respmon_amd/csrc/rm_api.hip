@@ -1,0 +1,714 @@
+// respmon_amd/csrc/rm_api.hip -- C-ABI host side of librespmon_hip.so (see include/respmon_hip.h).
+// Owns the context (device workspace, cached temporal operator, pinned staging) and sequences
+// the kernels of rm_kernels.h on the caller's HIP stream.
+#include "../../include/respmon_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rm_contour.h"
+#include "rm_kernels.h"
+#include "rm_flow.h"
+
+using namespace rm;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(RM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+#define RM_TRY(expr)                \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ < 0) return rc_;    \
+    } while (0)
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+
+struct rm_ctx {
+    int device = 0;
+    std::map<std::string, DevBuf> bufs;
+    CollapseState *d_state = nullptr;
+    CollapseState *h_state = nullptr;  // pinned
+    uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
+    uint32_t *h_rowany = nullptr; size_t h_rowany_cap = 0;  // pinned
+    // cached temporal operator
+    int op_T = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
+    FlowWorkspace flow;
+};
+
+static int ws_get(rm_ctx *ctx, const std::string &name, size_t bytes, void **out)
+{
+    DevBuf &b = ctx->bufs[name];
+    if (b.cap < bytes) {
+        if (b.p) HIP_TRY(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+        size_t cap = (bytes + 255) / 256 * 256;
+        HIP_TRY(hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return RM_OK;
+}
+template <typename T> static int ws(rm_ctx *ctx, const std::string &name, size_t count, T **out)
+{
+    void *p = nullptr;
+    RM_TRY(ws_get(ctx, name, count * sizeof(T), &p));
+    *out = (T *)p;
+    return RM_OK;
+}
+
+extern "C" int rm_abi_version(void) { return 1; }
+extern "C" const char *rm_last_error_string(void) { return g_err.c_str(); }
+
+extern "C" int rm_ctx_create(int device, rm_ctx **out)
+{
+    if (!out) return fail(RM_E_BADARG, "rm_ctx_create: out is NULL");
+    HIP_TRY(hipSetDevice(device));
+    rm_ctx *c = new rm_ctx();
+    c->device = device;
+    HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(CollapseState)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(CollapseState), hipHostMallocDefault));
+    *out = c;
+    return RM_OK;
+}
+
+extern "C" int rm_ctx_destroy(rm_ctx *ctx)
+{
+    if (!ctx) return RM_OK;
+    hipSetDevice(ctx->device);
+    for (auto &kv : ctx->bufs)
+        if (kv.second.p) hipFree(kv.second.p);
+    if (ctx->d_state) hipFree(ctx->d_state);
+    if (ctx->h_state) hipHostFree(ctx->h_state);
+    if (ctx->h_bin) hipHostFree(ctx->h_bin);
+    if (ctx->h_rowany) hipHostFree(ctx->h_rowany);
+    delete ctx;
+    return RM_OK;
+}
+
+extern "C" size_t rm_ctx_workspace_bytes(const rm_ctx *ctx)
+{
+    size_t n = 0;
+    if (ctx)
+        for (auto &kv : ctx->bufs) n += kv.second.cap;
+    return n;
+}
+
+static inline unsigned nblk(size_t n, unsigned per, unsigned cap = 8192)
+{
+    size_t b = (n + per - 1) / per;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+// ------------------------------------------------------------------------------------------
+// dtype helpers
+// ------------------------------------------------------------------------------------------
+extern "C" int rm_uint8_to_float(rm_ctx *ctx, const uint8_t *src, double *dst, size_t n, void *stream)
+{
+    if (!ctx || !src || !dst) return fail(RM_E_BADARG, "rm_uint8_to_float: NULL argument");
+    if (n == 0) return RM_OK;
+    hipLaunchKernelGGL(k_u8_to_f64, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+extern "C" int rm_float_to_uint8(rm_ctx *ctx, const double *src, uint8_t *dst, size_t n, void *stream)
+{
+    if (!ctx || !src || !dst) return fail(RM_E_BADARG, "rm_float_to_uint8: NULL argument");
+    if (n == 0) return RM_OK;
+    hipLaunchKernelGGL(k_f64_to_u8, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+extern "C" int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray, void *stream)
+{
+    if (!ctx || !bgr || !gray) return fail(RM_E_BADARG, "rm_bgr_to_gray: NULL argument");
+    if (npix == 0) return RM_OK;
+    hipLaunchKernelGGL(k_bgr_to_gray, dim3(nblk(npix, 256)), dim3(256), 0, (hipStream_t)stream, bgr, npix, gray);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pyramid building blocks
+// ------------------------------------------------------------------------------------------
+static int launch_pyr_down(const void *src, int dtype, int T, int h, int w, double *dst, hipStream_t s)
+{
+    int dh = (h + 1) / 2, dw = (w + 1) / 2;
+    dim3 grid((dw + PD_TX - 1) / PD_TX, (dh + PD_TY - 1) / PD_TY, T), block(256);
+    size_t fs = (size_t)h * w;
+    switch (dtype) {
+    case RM_U8: hipLaunchKernelGGL((k_pyr_down<uint8_t>), grid, block, 0, s, (const uint8_t *)src, h, w, fs, dst, dh, dw); break;
+    case RM_F16: hipLaunchKernelGGL((k_pyr_down<__half>), grid, block, 0, s, (const __half *)src, h, w, fs, dst, dh, dw); break;
+    case RM_F32: hipLaunchKernelGGL((k_pyr_down<float>), grid, block, 0, s, (const float *)src, h, w, fs, dst, dh, dw); break;
+    case RM_F64: hipLaunchKernelGGL((k_pyr_down<double>), grid, block, 0, s, (const double *)src, h, w, fs, dst, dh, dw); break;
+    default: return fail(RM_E_BADARG, "unknown dtype %d", dtype);
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+static int launch_pyr_up(const double *src, int T, int sh, int sw, double *dst, int dh, int dw, int mode,
+                         const double *other, hipStream_t s)
+{
+    if (!((dw == 2 * sw || dw == 2 * sw - 1) && (dh == 2 * sh || dh == 2 * sh - 1)))
+        return fail(RM_E_BADARG, "pyrUp: dstsize (%d,%d) incompatible with source (%d,%d)", dw, dh, sw, sh);
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, T), block(256);
+    hipLaunchKernelGGL(k_pyr_up, grid, block, 0, s, src, sh, sw, dst, dh, dw, mode, other);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+static bool valid_dtype(int d) { return d == RM_U8 || d == RM_F16 || d == RM_F32 || d == RM_F64; }
+
+extern "C" int rm_pyr_down(rm_ctx *ctx, const void *src, int dtype, int T, int h, int w, double *dst, void *stream)
+{
+    if (!ctx || !src || !dst || T < 0 || h < 1 || w < 1 || !valid_dtype(dtype))
+        return fail(RM_E_BADARG, "rm_pyr_down: bad argument");
+    if (T == 0) return RM_OK;
+    return launch_pyr_down(src, dtype, T, h, w, dst, (hipStream_t)stream);
+}
+
+extern "C" int rm_pyr_up(rm_ctx *ctx, const double *src, int T, int sh, int sw, double *dst, int dh, int dw, int mode,
+                         const double *other, void *stream)
+{
+    if (!ctx || !src || !dst || T < 0 || sh < 1 || sw < 1 || mode < 0 || mode > 2 || (mode != 0 && !other))
+        return fail(RM_E_BADARG, "rm_pyr_up: bad argument");
+    if (T == 0) return RM_OK;
+    return launch_pyr_up(src, T, sh, sw, dst, dh, dw, mode, other, (hipStream_t)stream);
+}
+
+template <typename Tin>
+__global__ __launch_bounds__(256) void k_to_f64(const Tin *src, double *dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = load_px(src, i);
+}
+
+static int launch_to_f64(const void *src, int dtype, size_t n, double *dst, hipStream_t s)
+{
+    dim3 grid(nblk(n, 256)), block(256);
+    switch (dtype) {
+    case RM_U8: hipLaunchKernelGGL((k_to_f64<uint8_t>), grid, block, 0, s, (const uint8_t *)src, dst, n); break;
+    case RM_F16: hipLaunchKernelGGL((k_to_f64<__half>), grid, block, 0, s, (const __half *)src, dst, n); break;
+    case RM_F32: hipLaunchKernelGGL((k_to_f64<float>), grid, block, 0, s, (const float *)src, dst, n); break;
+    case RM_F64: hipLaunchKernelGGL((k_to_f64<double>), grid, block, 0, s, (const double *)src, dst, n); break;
+    default: return fail(RM_E_BADARG, "unknown dtype %d", dtype);
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+static void level_sizes(int H, int W, int levels, std::vector<int> &h, std::vector<int> &w)
+{
+    h.assign(levels, 0); w.assign(levels, 0);
+    h[0] = H; w[0] = W;
+    for (int l = 1; l < levels; ++l) { h[l] = (h[l - 1] + 1) / 2; w[l] = (w[l - 1] + 1) / 2; }
+}
+
+extern "C" int rm_create_laplacian_video_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W,
+                                                 int levels, double *const *lv, void *stream)
+{
+    if (!ctx || !frames || !lv || T < 1 || H < 1 || W < 1 || levels < 1 || !valid_dtype(dtype))
+        return fail(RM_E_BADARG, "rm_create_laplacian_video_pyramid: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> h, w;
+    level_sizes(H, W, levels, h, w);
+    // Gaussian chain into the level arrays themselves (pyramid.py:9-17), then in place
+    // L_i = G_i - pyrUp(G_{i+1}) from fine to coarse (pyramid.py:23-27)
+    RM_TRY(launch_to_f64(frames, dtype, (size_t)T * H * W, lv[0], s));
+    for (int l = 1; l < levels; ++l) RM_TRY(launch_pyr_down(lv[l - 1], RM_F64, T, h[l - 1], w[l - 1], lv[l], s));
+    for (int l = 0; l + 1 < levels; ++l)
+        RM_TRY(launch_pyr_up(lv[l + 1], T, h[l + 1], w[l + 1], lv[l], h[l], w[l], 1, lv[l], s));
+    return RM_OK;
+}
+
+extern "C" int rm_collapse_laplacian_video_pyramid(rm_ctx *ctx, const double *const *lv, int T, int H, int W, int levels,
+                                                   double *out, void *stream)
+{
+    if (!ctx || !lv || !out || T < 1 || H < 1 || W < 1 || levels < 1)
+        return fail(RM_E_BADARG, "rm_collapse_laplacian_video_pyramid: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> h, w;
+    level_sizes(H, W, levels, h, w);
+    if (levels == 1) {
+        if (out != lv[0]) HIP_TRY(hipMemcpyAsync(out, lv[0], sizeof(double) * (size_t)T * H * W, hipMemcpyDeviceToDevice, s));
+        return RM_OK;
+    }
+    const double *cur = lv[levels - 1];
+    for (int l = levels - 2; l >= 0; --l) {
+        double *dst = nullptr;
+        if (l == 0) dst = out;
+        else RM_TRY(ws(ctx, (l & 1) ? "collapse_a" : "collapse_b", (size_t)T * h[l] * w[l], &dst));
+        RM_TRY(launch_pyr_up(cur, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, lv[l], s));
+        cur = dst;
+    }
+    return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// temporal operator  (transforms.py:82-102)
+// ------------------------------------------------------------------------------------------
+// scipy.fftpack.fftfreq(n, d) == numpy.fft.fftfreq: val = 1.0/(n*d); f[i] = i*val (i < (n-1)/2+1),
+// f[i] = (i - n)*val otherwise (i.e. -(n/2) .. -1)
+static void band_bounds(int n, double fps, double fmin, double fmax, int *lo, int *hi)
+{
+    double d = 1.0 / fps;
+    double val = 1.0 / (n * d);
+    int N = (n - 1) / 2 + 1;
+    double best_lo = 0, best_hi = 0;
+    *lo = 0; *hi = 0;
+    for (int i = 0; i < n; ++i) {
+        double f = (double)(i < N ? i : i - n) * val;
+        double a = std::fabs(f - fmin), b = std::fabs(f - fmax);
+        if (i == 0 || a < best_lo) { best_lo = a; *lo = i; }  // argmin keeps the first minimum
+        if (i == 0 || b < best_hi) { best_hi = b; *hi = i; }
+    }
+}
+
+extern "C" int rm_temporal_operator(int T, double fps, double fmin, double fmax, double *M, int *blo, int *bhi)
+{
+    if (T < 1 || !(fps > 0) || !M) return fail(RM_E_BADARG, "rm_temporal_operator: bad argument");
+    int lo, hi;
+    band_bounds(T, fps, fmin, fmax, &lo, &hi);
+    if (blo) *blo = lo;
+    if (bhi) *bhi = hi;
+    const int n = T;
+    // keep[k] for the PACKED rfft array: fft[hi:-hi] = 0; if lo != 0: fft[:lo] = 0, fft[-lo:] = 0
+    std::vector<char> keep(n, 1);
+    {
+        // python slice [hi : n-hi] (when hi == 0 the stop is -0 == 0 -> empty slice)
+        int start = hi, stop = (hi == 0) ? 0 : n - hi;
+        for (int k = start; k < stop; ++k) keep[k] = 0;
+        if (lo != 0) {
+            for (int k = 0; k < lo && k < n; ++k) keep[k] = 0;
+            for (int k = (n - lo > 0 ? n - lo : 0); k < n; ++k) keep[k] = 0;
+        }
+    }
+    // packed real FFT rows: R[0,t] = 1; R[2j-1,t] = cos(2 pi j t / n); R[2j,t] = -sin(2 pi j t / n);
+    // (n even) R[n-1,t] = (-1)^t.  Inverse as the reference applies it: Re(ifft(packed))[s] =
+    // (1/n) sum_k packed[k] cos(2 pi k s / n).   M[s,t] = (1/n) sum_{k kept} cos(2 pi k s/n) R[k,t]
+    const double two_pi = 6.283185307179586476925286766559;
+    std::vector<double> R((size_t)n * n, 0.0);
+    for (int k = 0; k < n; ++k) {
+        if (!keep[k]) continue;
+        for (int t = 0; t < n; ++t) {
+            double v;
+            if (k == 0) v = 1.0;
+            else if ((n % 2 == 0) && k == n - 1) v = (t % 2 == 0) ? 1.0 : -1.0;
+            else {
+                int j = (k + 1) / 2;
+                long long jt = ((long long)j * t) % n;  // exact argument reduction
+                double ang = two_pi * (double)jt / (double)n;
+                v = (k % 2 == 1) ? std::cos(ang) : -std::sin(ang);
+            }
+            R[(size_t)k * n + t] = v;
+        }
+    }
+    for (int s = 0; s < n; ++s)
+        for (int t = 0; t < n; ++t) {
+            long double acc = 0.0L;
+            for (int k = 0; k < n; ++k) {
+                if (!keep[k]) continue;
+                long long ks = ((long long)k * s) % n;
+                acc += (long double)std::cos(two_pi * (double)ks / (double)n) * (long double)R[(size_t)k * n + t];
+            }
+            M[(size_t)s * n + t] = (double)(acc / (long double)n);
+        }
+    return RM_OK;
+}
+
+static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax, const double **M_dev, hipStream_t s)
+{
+    double *d = nullptr;
+    RM_TRY(ws(ctx, "temporal_M", (size_t)T * T, &d));
+    if (!(ctx->op_T == T && ctx->op_fps == fps && ctx->op_fmin == fmin && ctx->op_fmax == fmax)) {
+        std::vector<double> M((size_t)T * T);
+        RM_TRY(rm_temporal_operator(T, fps, fmin, fmax, M.data(), nullptr, nullptr));
+        HIP_TRY(hipMemcpyAsync(d, M.data(), sizeof(double) * (size_t)T * T, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // M is a stack-lifetime vector
+        ctx->op_T = T; ctx->op_fps = fps; ctx->op_fmin = fmin; ctx->op_fmax = fmax;
+    }
+    *M_dev = d;
+    return RM_OK;
+}
+
+static int launch_temporal(const double *x, int T, size_t npix, const double *M, double amp, double *out, hipStream_t s)
+{
+    size_t shmem = sizeof(double) * (size_t)T * TS_CHUNK;
+    if (shmem > 64 * 1024) return fail(RM_E_UNSUPPORTED, "temporal filter: T=%d exceeds the LDS-staged operator (T <= 512)", T);
+    dim3 grid((unsigned)((npix + 255) / 256), (T + TS_CHUNK - 1) / TS_CHUNK), block(256);
+    hipLaunchKernelGGL(k_temporal, grid, block, shmem, s, x, T, npix, M, amp, out);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, int T, size_t npix, double fps, double fmin,
+                                               double fmax, double amp, double *out, void *stream)
+{
+    if (!ctx || !data || !out || T < 1 || !(fps > 0)) return fail(RM_E_BADARG, "rm_temporal_bandpass_filter_fft: bad argument");
+    if (npix == 0) return RM_OK;
+    if (data == out) return fail(RM_E_BADARG, "rm_temporal_bandpass_filter_fft: in-place filtering is not supported");
+    hipStream_t s = (hipStream_t)stream;
+    const double *M = nullptr;
+    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &M, s));
+    return launch_temporal(data, T, npix, M, amp, out, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// shared front half of calibration: frames -> collapsed band-passed level S  (C_S [T,hS,wS])
+// ------------------------------------------------------------------------------------------
+struct SmallLevels {
+    std::vector<int> h, w;
+    int S = 0;             // level the collapse stopped at (== skip when any level is filtered)
+    const double *cS = nullptr;
+    bool all_zero = false;  // no level is filtered: the band-passed pyramid is all zeros
+};
+
+static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
+                      double amp, int levels, int skip, unsigned flags, SmallLevels &out, hipStream_t s)
+{
+    (void)flags;
+    level_sizes(H, W, levels, out.h, out.w);
+    const std::vector<int> &h = out.h, &w = out.w;
+    const int L = levels;
+    if (skip >= L - 1) { out.all_zero = true; out.S = 0; return RM_OK; }
+    const int S = skip;
+    out.S = S;
+    // Gaussian chain (pyramid.py:9-17).  Levels < S are stepping stones (ping-pong scratch);
+    // levels S..L-1 are kept for the Laplacians.
+    std::vector<double *> g(L, nullptr);
+    const void *cur = frames; int cur_dtype = dtype;
+    for (int l = 1; l < L; ++l) {
+        double *dst = nullptr;
+        if (l < S) RM_TRY(ws(ctx, (l & 1) ? "g_ping" : "g_pong", (size_t)T * h[l] * w[l], &dst));
+        else RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &dst));
+        RM_TRY(launch_pyr_down(cur, cur_dtype, T, h[l - 1], w[l - 1], dst, s));
+        g[l] = dst; cur = dst; cur_dtype = RM_F64;
+    }
+    if (S == 0) {
+        double *g0 = nullptr;
+        RM_TRY(ws(ctx, "g0", (size_t)T * H * W, &g0));
+        RM_TRY(launch_to_f64(frames, dtype, (size_t)T * H * W, g0, s));
+        g[0] = g0;
+    }
+    const double *M = nullptr;
+    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &M, s));
+    // Laplacian (pyramid.py:23-26), temporal filter (transforms.py:162,169), collapse of the
+    // band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x)
+    double *c = nullptr;
+    for (int l = L - 2; l >= S; --l) {
+        size_t n = (size_t)T * h[l] * w[l];
+        double *lap = nullptr, *bp = nullptr;
+        RM_TRY(ws(ctx, "lap", (size_t)T * h[S] * w[S], &lap));
+        RM_TRY(ws(ctx, "bp" + std::to_string(l), n, &bp));
+        RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap, h[l], w[l], 1, g[l], s));
+        RM_TRY(launch_temporal(lap, T, (size_t)h[l] * w[l], M, amp, bp, s));
+        if (c) RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], bp, h[l], w[l], 2, bp, s));
+        c = bp;
+    }
+    out.cS = c;
+    return RM_OK;
+}
+
+static int make_geom(const SmallLevels &sl, ChainGeom &g)
+{
+    const int S = sl.S;
+    if (S < 1 || S >= MAX_CHAIN) return fail(RM_E_UNSUPPORTED, "fused collapse supports 1 <= skip_levels_at_top <= %d", MAX_CHAIN - 1);
+    g.S = S;
+    for (int k = 0; k <= S; ++k) { g.h[k] = sl.h[k]; g.w[k] = sl.w[k]; }
+    int off = 0;
+    g.lds_off[0] = 0;
+    for (int k = 1; k <= S; ++k) {
+        g.lds_off[k] = off;
+        off += (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k) + 1);
+    }
+    g.lds_total = off;
+    g.tiles_x = (sl.w[0] + CT_W - 1) / CT_W;
+    g.tiles_y = (sl.h[0] + CT_H - 1) / CT_H;
+    return RM_OK;
+}
+
+static int zero_result(rm_ctx *ctx, size_t npix, double *heat, double *minmax_host, hipStream_t s)
+{
+    (void)ctx;
+    HIP_TRY(hipMemsetAsync(heat, 0, sizeof(double) * npix, s));
+    if (minmax_host) { minmax_host[0] = 0.0; minmax_host[1] = 0.0; HIP_TRY(hipStreamSynchronize(s)); }
+    return RM_OK;
+}
+
+extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin,
+                            double fmax, double amp, int levels, int skip, double thr, unsigned flags, double *heat,
+                            double *minmax_host, void *stream)
+{
+    if (!ctx || !frames || !heat || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_dtype(dtype))
+        return fail(RM_E_BADARG, "rm_calibrate: bad argument");
+    if (T > 64 * MAX_T_WORDS) return fail(RM_E_UNSUPPORTED, "rm_calibrate: T=%d > %d", T, 64 * MAX_T_WORDS);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    SmallLevels sl;
+    RM_TRY(front_half(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, flags, sl, s));
+    if (sl.all_zero) return zero_result(ctx, npix, heat, minmax_host, s);
+    CollapseState *st = ctx->d_state;
+    double *heat_sum = nullptr;
+    RM_TRY(ws(ctx, "heat_sum", npix, &heat_sum));
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
+    LAUNCH_CHECK();
+    const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
+    if (sl.S == 0) {
+        size_t n = (size_t)T * npix;
+        hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, sl.cS, n, st);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_masked_sum_plain, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, sl.cS, T, npix, st, heat_sum);
+        LAUNCH_CHECK();
+    } else {
+        ChainGeom g;
+        RM_TRY(make_geom(sl, g));
+        const int ntiles = g.tiles_x * g.tiles_y;
+        const int npairs = ntiles * T;
+        double *lo = nullptr, *hi = nullptr;
+        unsigned int *cand = nullptr;
+        RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
+        RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
+        RM_TRY(ws(ctx, "tile_cand", (size_t)npairs, &cand));
+        hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, lo, hi);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 256)), dim3(256), 0, s, lo, hi, npairs, st);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_select_candidates, dim3((npairs + 255) / 256), dim3(256), 0, s, lo, hi, npairs, st, cand, no_prune);
+        LAUNCH_CHECK();
+        size_t shmem = sizeof(double) * (size_t)g.lds_total;
+        unsigned cgrid = (unsigned)(npairs < 8192 ? npairs : 8192);
+        hipLaunchKernelGGL(k_minmax_tiles, dim3(cgrid), dim3(64), shmem, s, sl.cS, g, T, cand, st);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(64), shmem, s, sl.cS, g, T, lo, st, no_prune, heat_sum);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 1024)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
+    LAUNCH_CHECK();
+    if (minmax_host) {
+        HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        minmax_host[0] = ctx->h_state->min_val;
+        minmax_host[1] = ctx->h_state->max_val;
+    }
+    return RM_OK;
+}
+
+extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps,
+                                                  double fmin, double fmax, double amp, int levels, int skip, double thr,
+                                                  double *masked, double *raw, double *minmax_host, void *stream)
+{
+    if (!ctx || !frames || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_dtype(dtype))
+        return fail(RM_E_BADARG, "rm_eulerian_magnification_bandpass: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)T * H * W;
+    SmallLevels sl;
+    RM_TRY(front_half(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, 0, sl, s));
+    if (sl.all_zero) {
+        if (masked) HIP_TRY(hipMemsetAsync(masked, 0, sizeof(double) * n, s));
+        if (raw) HIP_TRY(hipMemsetAsync(raw, 0, sizeof(double) * n, s));
+        if (minmax_host) { minmax_host[0] = minmax_host[1] = 0.0; }
+        HIP_TRY(hipStreamSynchronize(s));
+        return RM_OK;
+    }
+    double *raw_buf = raw;
+    if (!raw_buf) RM_TRY(ws(ctx, "raw_full", n, &raw_buf));
+    // materialised collapse of the all-zero levels below `skip` (pyramid.py:55 with zero levels)
+    const double *cur = sl.cS;
+    for (int l = sl.S - 1; l >= 0; --l) {
+        double *dst = nullptr;
+        if (l == 0) dst = raw_buf;
+        else RM_TRY(ws(ctx, (l & 1) ? "collapse_a" : "collapse_b", (size_t)T * sl.h[l] * sl.w[l], &dst));
+        RM_TRY(launch_pyr_up(cur, T, sl.h[l + 1], sl.w[l + 1], dst, sl.h[l], sl.w[l], 0, nullptr, s));
+        cur = dst;
+    }
+    if (sl.S == 0) HIP_TRY(hipMemcpyAsync(raw_buf, sl.cS, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    CollapseState *st = ctx->d_state;
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, raw_buf, n, st);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
+    LAUNCH_CHECK();
+    if (masked) {
+        hipLaunchKernelGGL(k_mask_plain, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, raw_buf, n, st, masked);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (minmax_host) { minmax_host[0] = ctx->h_state->min_val; minmax_host[1] = ctx->h_state->max_val; }
+    return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// heatmap -> ROI  (base.py:563-575)
+// ------------------------------------------------------------------------------------------
+__global__ void k_heat_state_init(CollapseState *st) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
+
+extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
+                                 uint8_t *binary, void *stream)
+{
+    if (!ctx || !heat || !xywh || H < 1 || W < 1) return fail(RM_E_BADARG, "rm_heatmap_to_roi: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    CollapseState *st = ctx->d_state;
+    uint8_t *bin = binary;
+    if (!bin) RM_TRY(ws(ctx, "binary", npix, &bin));
+    uint32_t *row_any = nullptr;
+    RM_TRY(ws(ctx, "row_any", (size_t)H, &row_any));
+    if (ctx->h_bin_cap < npix) {
+        if (ctx->h_bin) HIP_TRY(hipHostFree(ctx->h_bin));
+        ctx->h_bin = nullptr; ctx->h_bin_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, npix, hipHostMallocDefault));
+        ctx->h_bin_cap = npix;
+    }
+    if (ctx->h_rowany_cap < (size_t)H) {
+        if (ctx->h_rowany) HIP_TRY(hipHostFree(ctx->h_rowany));
+        ctx->h_rowany = nullptr; ctx->h_rowany_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_rowany, sizeof(uint32_t) * H, hipHostMallocDefault));
+        ctx->h_rowany_cap = H;
+    }
+    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(row_any, 0, sizeof(uint32_t) * H, s));
+    hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 1024)), dim3(256), 0, s, heat, npix, st);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, bin, row_any, W);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(ctx->h_rowany, row_any, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ctx->h_bin, bin, npix, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    RoiResult r;
+    largest_external_contour(ctx->h_bin, H, W, ctx->h_rowany, &r);
+    if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
+    xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;
+    return RM_OK;
+}
+
+extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
+                         double amp, int levels, int skip, double temporal_thr, int threshold, unsigned flags, int32_t *xywh,
+                         void *stream)
+{
+    if (!ctx || !xywh) return fail(RM_E_BADARG, "rm_locate: bad argument");
+    double *heat = nullptr;
+    RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
+    RM_TRY(rm_calibrate(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream));
+    return rm_heatmap_to_roi(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// ROI reductions (base.py:355-358, 364)
+// ------------------------------------------------------------------------------------------
+static bool roi_ok(int H, int W, int x, int y, int w, int h) { return x >= 0 && y >= 0 && w >= 1 && h >= 1 && x + w <= W && y + h <= H; }
+
+extern "C" int rm_roi_mean(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, double *out,
+                           void *stream)
+{
+    if (!ctx || !frame || !out || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h)) return fail(RM_E_BADARG, "rm_roi_mean: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double *d = nullptr;
+    RM_TRY(ws(ctx, "roi_mean", 1, &d));
+    switch (dtype) {
+    case RM_U8: hipLaunchKernelGGL((k_roi_mean<uint8_t>), dim3(1), dim3(256), 0, s, (const uint8_t *)frame, W, x, y, w, h, d); break;
+    case RM_F16: hipLaunchKernelGGL((k_roi_mean<__half>), dim3(1), dim3(256), 0, s, (const __half *)frame, W, x, y, w, h, d); break;
+    case RM_F32: hipLaunchKernelGGL((k_roi_mean<float>), dim3(1), dim3(256), 0, s, (const float *)frame, W, x, y, w, h, d); break;
+    default: hipLaunchKernelGGL((k_roi_mean<double>), dim3(1), dim3(256), 0, s, (const double *)frame, W, x, y, w, h, d); break;
+    }
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(out, d, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+extern "C" int rm_roi_to_uint8(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, uint8_t *dst,
+                               void *stream)
+{
+    if (!ctx || !frame || !dst || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h)) return fail(RM_E_BADARG, "rm_roi_to_uint8: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nblk((size_t)w * h, 256, 1024)), block(256);
+    switch (dtype) {
+    case RM_U8: hipLaunchKernelGGL((k_roi_to_u8<uint8_t>), grid, block, 0, s, (const uint8_t *)frame, W, x, y, w, h, dst); break;
+    case RM_F16: hipLaunchKernelGGL((k_roi_to_u8<__half>), grid, block, 0, s, (const __half *)frame, W, x, y, w, h, dst); break;
+    case RM_F32: hipLaunchKernelGGL((k_roi_to_u8<float>), grid, block, 0, s, (const float *)frame, W, x, y, w, h, dst); break;
+    default: hipLaunchKernelGGL((k_roi_to_u8<double>), grid, block, 0, s, (const double *)frame, W, x, y, w, h, dst); break;
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// optical-flow path (rm_flow.h)
+// ------------------------------------------------------------------------------------------
+extern "C" int rm_good_features_to_track(rm_ctx *ctx, const uint8_t *img, int h, int w, int max_corners, double quality,
+                                         double min_distance, int block_size, float *pts, int *n, void *stream)
+{
+    if (!ctx || !img || !pts || !n || h < 3 || w < 3 || block_size < 1 || (block_size & 1) == 0)
+        return fail(RM_E_BADARG, "rm_good_features_to_track: bad argument");
+    std::string err;
+    int rc = flow_good_features(ctx->flow, img, h, w, max_corners, quality, min_distance, block_size, pts, n, (hipStream_t)stream, err);
+    if (rc < 0) return fail(rc, "%s", err.c_str());
+    return rc;
+}
+
+extern "C" int rm_calc_optical_flow_pyr_lk(rm_ctx *ctx, const uint8_t *prev, const uint8_t *next, int h, int w, const float *pts_in,
+                                           int npts, int win_w, int win_h, int max_level, int max_count, double epsilon,
+                                           float *pts_out, uint8_t *status, void *stream)
+{
+    if (!ctx || !prev || !next || !pts_in || !pts_out || !status || h < 1 || w < 1 || npts < 0 || win_w < 3 || win_h < 3 || max_level < 0)
+        return fail(RM_E_BADARG, "rm_calc_optical_flow_pyr_lk: bad argument");
+    std::string err;
+    int rc = flow_pyr_lk(ctx->flow, prev, next, h, w, pts_in, npts, win_w, win_h, max_level, max_count, epsilon, pts_out, status,
+                         (hipStream_t)stream, err);
+    if (rc < 0) return fail(rc, "%s", err.c_str());
+    return rc;
+}
+
+extern "C" int rm_mean_flow(rm_ctx *ctx, const float *old_pts, const float *new_pts, const uint8_t *status, int npts, float *mean_xy,
+                            int *n_good, void *stream)
+{
+    if (!ctx || !old_pts || !new_pts || !status || !mean_xy || !n_good || npts < 0) return fail(RM_E_BADARG, "rm_mean_flow: bad argument");
+    std::string err;
+    int rc = flow_mean(ctx->flow, old_pts, new_pts, status, npts, mean_xy, n_good, (hipStream_t)stream, err);
+    if (rc < 0) return fail(rc, "%s", err.c_str());
+    return rc;
+}
+
+extern "C" int rm_pca_reduce(rm_ctx *ctx, const float *motion, int n, double *out, void *stream)
+{
+    if (!ctx || !motion || !out || n < 0) return fail(RM_E_BADARG, "rm_pca_reduce: bad argument");
+    std::string err;
+    int rc = flow_pca(ctx->flow, motion, n, out, (hipStream_t)stream, err);
+    if (rc < 0) return fail(rc, "%s", err.c_str());
+    return rc;
+}

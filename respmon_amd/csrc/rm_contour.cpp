@@ -1,0 +1,142 @@
+// respmon_amd/csrc/rm_contour.cpp -- host stage of locate(): base.py:568-575
+//   cv2.findContours(thresh, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) -> max(contours, key=cv2.contourArea)
+//   -> cv2.boundingRect
+//
+// The thresholded image is a few MB and the border following is inherently serial, so this
+// stage runs on the host over the binary image the GPU wrote to pinned memory.  Only what
+// locate() consumes is produced: for every external border the shoelace area and the bounding
+// box are accumulated while the border is followed (no point lists; CHAIN_APPROX_SIMPLE only
+// removes collinear points, which changes neither quantity: all terms are exact integers).
+//
+// Border following is Suzuki-Abe as used by OpenCV (8-connected foreground, outer borders
+// only, components nested inside a hole are skipped), on a zero-framed working copy so that
+// image-frame pixels count (OpenCV >= 3.2 rule).  Selection rule: cv2 lists
+// contours in reverse discovery order and Python's max() keeps the first maximum, i.e. among
+// equal areas the LAST discovered border wins.
+#include "rm_contour.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace rm {
+
+namespace {
+enum : signed char { BG = 0, FG = 1, SEEN = 2, SEEN_RIGHT_EXIT = (signed char)(2 | -128) };
+
+struct Tracer {
+    std::vector<signed char> buf;
+    int step = 0;
+    int nbr[16];
+
+    void prepare(const uint8_t *bin, int H, int W, const uint32_t *row_any)
+    {
+        step = W + 2;
+        buf.assign((size_t)step * (H + 2), BG);
+        for (int y = 0; y < H; ++y) {
+            if (row_any && !row_any[y]) continue;
+            const uint8_t *s = bin + (size_t)y * W;
+            signed char *d = buf.data() + (size_t)(y + 1) * step + 1;
+            for (int x = 0; x < W; ++x) d[x] = s[x] ? FG : BG;
+        }
+        const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+        const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+        for (int i = 0; i < 8; ++i) nbr[i] = nbr[i + 8] = dy[i] * step + dx[i];
+    }
+
+    // follow the outer border that starts at `start` (padded coords px,py); returns twice the signed area
+    long long follow(signed char *start, int px, int py, int &minx, int &miny, int &maxx, int &maxy)
+    {
+        static const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+        static const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+        minx = maxx = px; miny = maxy = py;
+        int dir = 4, stop = 4;
+        signed char *first_nb;
+        do {  // clockwise search for the first foreground neighbour, starting after "left"
+            dir = (dir - 1) & 7;
+            first_nb = start + nbr[dir];
+        } while (*first_nb == BG && dir != stop);
+        if (dir == stop) { *start = SEEN_RIGHT_EXIT; return 0; }
+        long long twice_area = 0;
+        signed char *cur = start;
+        int cx = px, cy = py;
+        for (;;) {
+            int from = dir;
+            signed char *nxt;
+            for (;;) {  // counter-clockwise search from the direction we came from
+                nxt = cur + nbr[++dir];
+                if (*nxt != BG) break;
+            }
+            dir &= 7;
+            if ((unsigned)(dir - 1) < (unsigned)from) *cur = SEEN_RIGHT_EXIT;
+            else if (*cur == FG) *cur = SEEN;
+            int nx = cx + dx[dir], ny = cy + dy[dir];
+            twice_area += (long long)cx * ny - (long long)nx * cy;
+            cx = nx; cy = ny;
+            if (cx < minx) minx = cx;
+            if (cx > maxx) maxx = cx;
+            if (cy < miny) miny = cy;
+            if (cy > maxy) maxy = cy;
+            if (nxt == start && cur == first_nb) break;
+            cur = nxt;
+            dir = (dir + 4) & 7;
+        }
+        return twice_area;
+    }
+};
+}  // namespace
+
+int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out)
+{
+    out->found = 0; out->n_contours = 0; out->area = 0.0;
+    out->x = out->y = out->w = out->h = 0;
+    if (H <= 0 || W <= 0) return 0;
+    Tracer tr;
+    tr.prepare(bin, H, W, row_any);
+    const int step = tr.step;
+    double best = -1.0;
+    for (int y = 0; y < H; ++y) {
+        if (row_any && !row_any[y]) continue;
+        signed char *row = tr.buf.data() + (size_t)(y + 1) * step;
+        int prev = BG;
+        int last_border_x = 0;  // column 0 is the zero frame: "outside"
+        int x = 1;
+        while (x < step) {
+            // skip to the next transition, 8 pixels at a time
+            {
+                unsigned long long pat = 0x0101010101010101ull * (unsigned char)prev;
+                while (x + 8 <= step) {
+                    unsigned long long wv;
+                    std::memcpy(&wv, row + x, 8);
+                    if (wv != pat) break;
+                    x += 8;
+                }
+                while (x < step && row[x] == prev) ++x;
+                if (x >= step) break;
+            }
+            int p = row[x];
+            bool outer_start = (prev == BG && p == FG);
+            // RETR_EXTERNAL: ignore hole borders and outer borders lying inside a component
+            if (outer_start && !(row[last_border_x] > 0)) {
+                int minx, miny, maxx, maxy;
+                long long a2 = tr.follow(row + x, x, y + 1, minx, miny, maxx, maxy);
+                double area = 0.5 * (double)(a2 < 0 ? -a2 : a2);
+                ++out->n_contours;
+                if (area >= best) {
+                    best = area;
+                    out->found = 1;
+                    out->x = minx - 1; out->y = miny - 1;
+                    out->w = maxx - minx + 1; out->h = maxy - miny + 1;
+                    out->area = area;
+                }
+                p = row[x];
+            }
+            prev = p;
+            if (prev & -2) last_border_x = x;
+            ++x;
+        }
+    }
+    return 0;
+}
+
+}  // namespace rm

@@ -1,0 +1,610 @@
+// respmon_amd/csrc/rm_kernels.h -- gfx950 HIP kernels of the calibration path.
+//
+// All arithmetic that decides the ROI is float64 with the operation order of the reference's
+// numpy / OpenCV-scalar path (no FMA contraction: the library is built with -ffp-contract=off),
+// so results are reproducible op-for-op against the CPU oracle.
+//
+// Reference functions restated (paths relative to the reference root):
+//   pyramid.py:9-28   Gaussian / Laplacian image pyramid (cv2.pyrDown / cv2.pyrUp)
+//   pyramid.py:51-69  collapse
+//   transforms.py:82-102  temporal FFT band-pass (as the explicit linear operator M)
+//   transforms.py:184-192 global min/max mask
+//   base.py:562-566   time average, normalise, float_to_uint8, threshold
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace rm {
+
+// ----------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// widening loads; uint8 applies uint8_to_float's  k * (1./255)  (transforms.py:20-23)
+__device__ __forceinline__ double load_px(const uint8_t *p, size_t i) { return (double)p[i] * (1.0 / 255); }
+__device__ __forceinline__ double load_px(const __half *p, size_t i) { return (double)__half2float(p[i]); }
+__device__ __forceinline__ double load_px(const float *p, size_t i) { return (double)p[i]; }
+__device__ __forceinline__ double load_px(const double *p, size_t i) { return p[i]; }
+
+// order-preserving map double -> uint64 so that atomicMin/atomicMax on the key orders doubles
+__device__ __forceinline__ unsigned long long f64_key(double d)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unkey(unsigned long long k)
+{
+    unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// float_to_uint8 (transforms.py:26-29): v*255 then C cast (truncate toward zero, low byte;
+// NaN / |v| >= 2^31 -> 0, the x86 cvttsd2si result numpy produces)
+__device__ __forceinline__ uint8_t f64_to_u8_trunc(double v255)
+{
+    if (!(v255 == v255) || v255 >= 2147483648.0 || v255 <= -2147483649.0) return 0;
+    return (uint8_t)((int)v255 & 255);
+}
+
+// wave (64-lane) min / max reduction by shuffles; result valid in every lane
+__device__ __forceinline__ double wave_min(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m); v = (o < v) ? o : v; }
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m); v = (o > v) ? o : v; }
+    return v;
+}
+
+// ----------------------------------------------------------------------------------------
+// K1  cv2.pyrDown (pyramid.py:14) on every frame: [T,h,w] Tin -> [T,dh,dw] f64
+//     LDS-staged tile; horizontal 5-tap first, vertical second (OpenCV order).
+// ----------------------------------------------------------------------------------------
+constexpr int PD_TY = 8, PD_TX = 64;
+constexpr int PD_SY = 2 * PD_TY + 3, PD_SX = 2 * PD_TX + 3;
+
+template <typename Tin>
+__global__ __launch_bounds__(256) void k_pyr_down(const Tin *src, int h, int w, size_t frame_stride,
+                                                  double *dst, int dh, int dw)
+{
+    __shared__ double s_src[PD_SY][PD_SX + 1];
+    __shared__ double s_row[PD_SY][PD_TX];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.z, ty0 = blockIdx.y * PD_TY, tx0 = blockIdx.x * PD_TX;
+    const Tin *sp = src + (size_t)t * frame_stride;
+    for (int i = tid; i < PD_SY * PD_SX; i += 256) {
+        int r = i / PD_SX, c = i - r * PD_SX;
+        int sy = reflect101(2 * ty0 - 2 + r, h), sx = reflect101(2 * tx0 - 2 + c, w);
+        s_src[r][c] = load_px(sp, (size_t)sy * w + sx);
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_SY * PD_TX; i += 256) {
+        int r = i / PD_TX, x = i - r * PD_TX;
+        const double *s = &s_src[r][2 * x];
+        s_row[r][x] = s[2] * 6 + (s[1] + s[3]) * 4 + s[0] + s[4];
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_TY * PD_TX; i += 256) {
+        int y = i / PD_TX, x = i - y * PD_TX;
+        int oy = ty0 + y, ox = tx0 + x;
+        if (oy < dh && ox < dw) {
+            int r = 2 * y;
+            double v = (s_row[r + 2][x] * 6 + (s_row[r + 1][x] + s_row[r + 3][x]) * 4 + s_row[r][x] + s_row[r + 4][x]) *
+                       (1.0 / 256);
+            dst[((size_t)t * dh + oy) * dw + ox] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// K2  cv2.pyrUp with explicit dstsize (pyramid.py:25-26, 55), SURVEY B2.
+//     `up_at` evaluates one output pixel from a source image addressed through a functor so the
+//     same code serves global memory (materialising kernels) and LDS tiles (fused collapse).
+// ----------------------------------------------------------------------------------------
+// horizontal value of source row r at destination column x (unnormalised, x8 kernel)
+template <typename Src>
+__device__ __forceinline__ double up_h(const Src &s, int r, int x, int sw)
+{
+    if (sw == 1) return s(r, 0) * 8;
+    int j = x >> 1;
+    if (x & 1) {
+        if (j == sw - 1) return s(r, j) * 8;
+        return (s(r, j) + s(r, j + 1)) * 4;
+    }
+    if (j == 0) return s(r, 0) * 6 + s(r, 1) * 2;
+    if (j == sw - 1) return s(r, j - 1) + s(r, j) * 7;
+    return s(r, j - 1) + s(r, j) * 6 + s(r, j + 1);
+}
+
+template <typename Src>
+__device__ __forceinline__ double up_at(const Src &s, int y, int x, int sh, int sw)
+{
+    int i = y >> 1;
+    if (y & 1) {
+        int r2 = (i == sh - 1) ? i : i + 1;
+        return ((up_h(s, i, x, sw) + up_h(s, r2, x, sw)) * 4) * (1.0 / 64);
+    }
+    int r0 = (i == 0) ? (sh > 1 ? 1 : 0) : i - 1;
+    int r2 = (i == sh - 1) ? i : i + 1;
+    return (up_h(s, r0, x, sw) + up_h(s, i, x, sw) * 6 + up_h(s, r2, x, sw)) * (1.0 / 64);
+}
+
+struct GlobalImg {
+    const double *p; int w;
+    __device__ __forceinline__ double operator()(int r, int c) const { return p[(size_t)r * w + c]; }
+};
+
+// mode 0: dst = up(src); 1: dst = other - up(src); 2: dst = up(src) + other
+__global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int sw, double *dst, int dh, int dw,
+                                                int mode, const double *other)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int t = blockIdx.z;
+    if (x >= dw || y >= dh) return;
+    GlobalImg s{src + (size_t)t * sh * sw, sw};
+    double u = up_at(s, y, x, sh, sw);
+    size_t o = ((size_t)t * dh + y) * dw + x;
+    if (mode == 1) u = other[o] - u;
+    else if (mode == 2) u = u + other[o];
+    dst[o] = u;
+}
+
+// ----------------------------------------------------------------------------------------
+// K5-K8  temporal band-pass as the explicit operator (transforms.py:82-102):
+//        out[s,p] = amp * sum_t M[s,t] x[t,p]     (sequential in t, mul then add)
+//        block: 256 pixels x TS_CHUNK output frames; M chunk staged transposed in LDS.
+// ----------------------------------------------------------------------------------------
+constexpr int TS_CHUNK = 16;
+
+__global__ __launch_bounds__(256) void k_temporal(const double *x, int T, size_t npix, const double *M, double amp,
+                                                  double *out)
+{
+    HIP_DYNAMIC_SHARED(double, s_m)  // [T][TS_CHUNK]
+    const int s0 = blockIdx.y * TS_CHUNK;
+    for (int i = threadIdx.x; i < T * TS_CHUNK; i += 256) {
+        int t = i / TS_CHUNK, k = i - t * TS_CHUNK;
+        s_m[i] = (s0 + k < T) ? M[(size_t)(s0 + k) * T + t] : 0.0;
+    }
+    __syncthreads();
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    double acc[TS_CHUNK];
+#pragma unroll
+    for (int k = 0; k < TS_CHUNK; ++k) acc[k] = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double v = x[(size_t)t * npix + p];
+        const double *m = &s_m[t * TS_CHUNK];
+#pragma unroll
+        for (int k = 0; k < TS_CHUNK; ++k) acc[k] = acc[k] + m[k] * v;
+    }
+#pragma unroll
+    for (int k = 0; k < TS_CHUNK; ++k)
+        if (s0 + k < T) out[(size_t)(s0 + k) * npix + p] = acc[k] * amp;
+}
+
+// ----------------------------------------------------------------------------------------
+// Fused collapse from level S to full resolution (pyramid.py:51-69 for the levels below
+// skip_levels_at_top, which are all-zero in the band-passed pyramid: transforms.py:150-160).
+//
+// One single-wave workgroup owns a CT_W x CT_H tile of the full-resolution frame.  For a frame
+// t it stages the level-S footprint of the tile in LDS, runs the pyrUp chain S..1 inside LDS
+// and evaluates level 0 in registers (thread = column, marching down CT_H rows so every
+// horizontal value is computed once).  No [T,H,W] array is ever written.
+// ----------------------------------------------------------------------------------------
+constexpr int CT_W = 64, CT_H = 16;
+constexpr int MAX_CHAIN = 8;
+
+struct ChainGeom {
+    int S;                       // number of pyrUp steps (== skip_levels_at_top), 1..MAX_CHAIN-1
+    int h[MAX_CHAIN], w[MAX_CHAIN];  // level sizes, index 0 = full resolution
+    int lds_off[MAX_CHAIN];      // offset (doubles) of level k's tile buffer in LDS, k = 1..S
+    int lds_total;               // doubles
+    int tiles_x, tiles_y;
+};
+
+struct TileRegion { int y0[MAX_CHAIN], y1[MAX_CHAIN], x0[MAX_CHAIN], x1[MAX_CHAIN]; };  // inclusive
+
+__device__ __forceinline__ int floordiv2(int a) { return a >> 1; }  // arithmetic shift == floor for negatives
+
+__device__ __forceinline__ void tile_regions(const ChainGeom &g, int tile, TileRegion &R)
+{
+    int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    R.y0[0] = ty * CT_H; R.y1[0] = min(R.y0[0] + CT_H, g.h[0]) - 1;
+    R.x0[0] = tx * CT_W; R.x1[0] = min(R.x0[0] + CT_W, g.w[0]) - 1;
+    for (int k = 1; k <= g.S; ++k) {
+        R.y0[k] = max(0, floordiv2(R.y0[k - 1]) - 1);
+        R.y1[k] = min(g.h[k] - 1, floordiv2(R.y1[k - 1]) + 1);
+        R.x0[k] = max(0, floordiv2(R.x0[k - 1]) - 1);
+        R.x1[k] = min(g.w[k] - 1, floordiv2(R.x1[k - 1]) + 1);
+    }
+}
+
+// worst-case tile-buffer extent of level k (host + device agree on the LDS layout)
+__host__ __device__ inline int chain_extent(int base, int k)
+{
+    int lo = 0, hi = base - 1;  // worst case is an interior tile starting at a multiple of `base`
+    for (int i = 0; i < k; ++i) { lo = (lo >> 1) - 1; hi = (hi >> 1) + 1; }
+    return hi - lo + 1;
+}
+
+struct LdsImg {  // a level's tile buffer: absolute coordinates -> LDS
+    const double *p; int y0, x0, pitch;
+    __device__ __forceinline__ double operator()(int r, int c) const { return p[(r - y0) * pitch + (c - x0)]; }
+};
+
+// per (tile, frame) bounds of the level-S footprint: every full-resolution value of the tile
+// is a convex combination of these, so  lo - margin <= raw <= hi + margin.
+__global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
+                                                     double *lo, double *hi)
+{
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ntiles * T) return;
+    int tile = idx / T, t = idx - tile * T;
+    TileRegion R;
+    tile_regions(g, tile, R);
+    const int S = g.S;
+    const double *p = cS + (size_t)t * g.h[S] * g.w[S];
+    double mn = p[(size_t)R.y0[S] * g.w[S] + R.x0[S]], mx = mn;
+    for (int y = R.y0[S]; y <= R.y1[S]; ++y)
+        for (int x = R.x0[S]; x <= R.x1[S]; ++x) {
+            double v = p[(size_t)y * g.w[S] + x];
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
+        }
+    lo[idx] = mn; hi[idx] = mx;
+}
+
+// device-side scalars shared by the collapse passes
+struct CollapseState {
+    unsigned long long lb_max_key;  // max over (tile,t) of lo  (lower bound of raw.max())
+    unsigned long long ub_min_key;  // min over (tile,t) of hi  (upper bound of raw.min())
+    unsigned long long abs_max_key; // max |bound| (scale of the safety margin)
+    unsigned long long min_key, max_key;  // exact raw.min() / raw.max()
+    unsigned int n_cand;            // candidate (tile,t) pairs for the exact min/max pass
+    unsigned int pad;
+    double min_val, max_val, top;   // decoded by k_finish_minmax
+    double heat_min_max[2];
+    unsigned long long heat_min_key, heat_max_key;
+};
+
+__global__ void k_state_init(CollapseState *st)
+{
+    st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->abs_max_key = 0ull;
+    st->min_key = ~0ull; st->max_key = 0ull; st->n_cand = 0; st->pad = 0;
+    st->min_val = 0; st->max_val = 0; st->top = 0;
+    st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_bounds(const double *lo, const double *hi, int n, CollapseState *st)
+{
+    double a = -1.0 / 0.0, b = 1.0 / 0.0, m = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double l = lo[i], h = hi[i];
+        a = (l > a) ? l : a;
+        b = (h < b) ? h : b;
+        double al = l < 0 ? -l : l, ah = h < 0 ? -h : h;
+        m = (al > m) ? al : m;
+        m = (ah > m) ? ah : m;
+    }
+    a = wave_max(a); b = wave_min(b); m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&st->lb_max_key, f64_key(a));
+        atomicMin(&st->ub_min_key, f64_key(b));
+        atomicMax(&st->abs_max_key, f64_key(m));
+    }
+}
+
+constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 rounding of the S-level chain
+
+// candidates for the exact min/max pass: pairs whose bounds reach the extreme bounds
+__global__ __launch_bounds__(256) void k_select_candidates(const double *lo, const double *hi, int n,
+                                                           CollapseState *st, unsigned int *cand, int no_prune)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double margin = PRUNE_REL_MARGIN * f64_unkey(st->abs_max_key);
+    double lb_max = f64_unkey(st->lb_max_key), ub_min = f64_unkey(st->ub_min_key);
+    bool keep = no_prune || !(hi[i] + margin < lb_max - margin) || !(lo[i] - margin > ub_min + margin);
+    if (keep) cand[atomicAdd(&st->n_cand, 1u)] = (unsigned)i;
+}
+
+// stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
+__device__ __forceinline__ void chain_to_level1(const ChainGeom &g, const TileRegion &R, const double *cS_t,
+                                                double *lds)
+{
+    const int lane = threadIdx.x;
+    const int S = g.S;
+    {
+        double *d = lds + g.lds_off[S];
+        int nw = R.x1[S] - R.x0[S] + 1, n = (R.y1[S] - R.y0[S] + 1) * nw;
+        for (int i = lane; i < n; i += 64) {
+            int r = i / nw, c = i - r * nw;
+            d[i] = cS_t[(size_t)(R.y0[S] + r) * g.w[S] + R.x0[S] + c];
+        }
+    }
+    __syncthreads();
+    for (int k = S; k >= 2; --k) {
+        LdsImg s{lds + g.lds_off[k], R.y0[k], R.x0[k], R.x1[k] - R.x0[k] + 1};
+        double *d = lds + g.lds_off[k - 1];
+        int nw = R.x1[k - 1] - R.x0[k - 1] + 1, n = (R.y1[k - 1] - R.y0[k - 1] + 1) * nw;
+        for (int i = lane; i < n; i += 64) {
+            int r = i / nw, c = i - r * nw;
+            d[i] = up_at(s, R.y0[k - 1] + r, R.x0[k - 1] + c, g.h[k], g.w[k]);
+        }
+        __syncthreads();
+    }
+}
+
+// level 1 (LDS) -> level 0 for this lane's column; out[j] = raw[t, y0+j, x]
+__device__ __forceinline__ void level0_column(const ChainGeom &g, const TileRegion &R, const double *lds, int x,
+                                              double (&out)[CT_H])
+{
+    LdsImg s{lds + g.lds_off[1], R.y0[1], R.x0[1], R.x1[1] - R.x0[1] + 1};
+    const int sh = g.h[1], sw = g.w[1];
+    const int y0 = R.y0[0];  // multiple of CT_H (even)
+    // horizontal values of source rows i0-1 .. i0+CT_H/2 (border rules applied by row index)
+    const int i0 = y0 >> 1;
+    double hv[CT_H / 2 + 2];
+#pragma unroll
+    for (int k = 0; k < CT_H / 2 + 2; ++k) {
+        int i = i0 - 1 + k;
+        int r = (i < 0) ? (sh > 1 ? 1 : 0) : (i > sh - 1 ? sh - 1 : i);
+        hv[k] = up_h(s, r, x, sw);
+    }
+#pragma unroll
+    for (int j = 0; j < CT_H; ++j) {
+        int k = (j >> 1) + 1;  // hv index of source row i = (y0+j)/2
+        if (j & 1) out[j] = ((hv[k] + hv[k + 1]) * 4) * (1.0 / 64);
+        else out[j] = (hv[k - 1] + hv[k] * 6 + hv[k + 1]) * (1.0 / 64);
+    }
+}
+
+// pass C: exact min / max of raw over the candidate (tile, frame) pairs
+__global__ __launch_bounds__(64) void k_minmax_tiles(const double *cS, ChainGeom g, int T, const unsigned int *cand,
+                                                     CollapseState *st)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const unsigned n = st->n_cand;
+    const int lane = threadIdx.x;
+    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
+        unsigned idx = cand[c];
+        int tile = idx / T, t = idx - tile * T;
+        TileRegion R;
+        tile_regions(g, tile, R);
+        chain_to_level1(g, R, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
+        int x = R.x0[0] + lane;
+        if (x <= R.x1[0]) {
+            double v[CT_H];
+            level0_column(g, R, lds, x, v);
+            int rows = R.y1[0] - R.y0[0] + 1;
+#pragma unroll
+            for (int j = 0; j < CT_H; ++j)
+                if (j < rows) { mn = (v[j] < mn) ? v[j] : mn; mx = (v[j] > mx) ? v[j] : mx; }
+        }
+        __syncthreads();
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if (lane == 0 && blockIdx.x < n) {
+        atomicMin(&st->min_key, f64_key(mn));
+        atomicMax(&st->max_key, f64_key(mx));
+    }
+}
+
+// transforms.py:184-189: min, max, top = max - (max - min) * threshold
+__global__ void k_finish_minmax(CollapseState *st, double threshold)
+{
+    double mn = f64_unkey(st->min_key), mx = f64_unkey(st->max_key);
+    st->min_val = mn; st->max_val = mx;
+    st->top = mx - (mx - mn) * threshold;
+}
+
+// pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order,
+// base.py:562).  Frames whose whole footprint is provably >= top add `min` without evaluation.
+constexpr int MAX_T_WORDS = 64;  // T <= 4096
+
+__global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, const double *lo,
+                                                         const CollapseState *st, int no_prune, double *heat_sum)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    __shared__ unsigned long long s_pruned[MAX_T_WORDS];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const double top = st->top, min_val = st->min_val;
+    const double margin = PRUNE_REL_MARGIN * f64_unkey(st->abs_max_key);
+    TileRegion R;
+    tile_regions(g, tile, R);
+    for (int w0 = 0; w0 * 64 < T; ++w0) {
+        int t = w0 * 64 + lane;
+        bool pr = (!no_prune) && (t < T) && (lo[(size_t)tile * T + t] - margin >= top);
+        // ballot through LDS (keeps the kernel free of wave intrinsics the host emulation lacks)
+        if (lane == 0) s_pruned[w0] = 0ull;
+        __syncthreads();
+        if (pr) atomicOr(&s_pruned[w0], 1ull << lane);
+        __syncthreads();
+    }
+    const int x = R.x0[0] + lane;
+    const int rows = R.y1[0] - R.y0[0] + 1;
+    double acc[CT_H];
+#pragma unroll
+    for (int j = 0; j < CT_H; ++j) acc[j] = 0.0;
+    for (int t = 0; t < T; ++t) {
+        bool pruned = (s_pruned[t >> 6] >> (t & 63)) & 1ull;
+        if (pruned) {
+#pragma unroll
+            for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + min_val;
+        } else {
+            chain_to_level1(g, R, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
+            if (x <= R.x1[0]) {
+                double v[CT_H];
+                level0_column(g, R, lds, x, v);
+#pragma unroll
+                for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
+            }
+            __syncthreads();
+        }
+    }
+    if (x <= R.x1[0])
+#pragma unroll
+        for (int j = 0; j < CT_H; ++j)
+            if (j < rows) heat_sum[(size_t)(R.y0[0] + j) * g.w[0] + x] = acc[j];
+}
+
+// ----------------------------------------------------------------------------------------
+// plain (materialised) forms: global min/max, mask, time sum  -- transforms.py:184-192, base.py:562
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax_plain(const double *a, size_t n, CollapseState *st)
+{
+    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = a[i];
+        mn = (v < mn) ? v : mn;
+        mx = (v > mx) ? v : mx;
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&st->min_key, f64_key(mn));
+        atomicMax(&st->max_key, f64_key(mx));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mask_plain(const double *raw, size_t n, const CollapseState *st, double *masked)
+{
+    const double top = st->top, mn = st->min_val;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = raw[i];
+        masked[i] = (v >= top) ? mn : v;
+    }
+}
+
+// heat_sum[p] = sum_t (raw[t,p] >= top ? min : raw[t,p])   (sequential in t)
+__global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int T, size_t npix, const CollapseState *st,
+                                                          double *heat_sum)
+{
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const double top = st->top, mn = st->min_val;
+    double acc = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double v = raw[(size_t)t * npix + p];
+        acc = acc + ((v >= top) ? mn : v);
+    }
+    heat_sum[p] = acc;
+}
+
+// ----------------------------------------------------------------------------------------
+// base.py:562-566: avg = sum / T ; normalise ; float_to_uint8 ; threshold
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum, size_t npix, int T, double *heat,
+                                                         CollapseState *st)
+{
+    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    const double cnt = (double)T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        double v = heat_sum[i] / cnt;
+        heat[i] = v;
+        mn = (v < mn) ? v : mn;
+        mx = (v > mx) ? v : mx;
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&st->heat_min_key, f64_key(mn));
+        atomicMax(&st->heat_max_key, f64_key(mx));
+    }
+}
+
+// min/max of an existing heatmap (rm_heatmap_to_roi entry point)
+__global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t npix, CollapseState *st)
+{
+    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        double v = heat[i];
+        mn = (v < mn) ? v : mn;
+        mx = (v > mx) ? v : mx;
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&st->heat_min_key, f64_key(mn));
+        atomicMax(&st->heat_max_key, f64_key(mx));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, const CollapseState *st,
+                                                    int threshold, uint8_t *avg_u8, uint8_t *binary,
+                                                    unsigned int *row_any, int W)
+{
+    const double mn = f64_unkey(st->heat_min_key), mx = f64_unkey(st->heat_max_key);
+    const double range = mx - mn;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        double nrm = (heat[i] - mn) / range;          // base.py:563 (NaN when the heatmap is flat)
+        uint8_t u = f64_to_u8_trunc(nrm * 255);       // transforms.py:26-29
+        uint8_t b = (u > threshold) ? 255 : 0;        // cv2.threshold THRESH_BINARY, base.py:566
+        if (avg_u8) avg_u8[i] = u;
+        binary[i] = b;
+        if (b && row_any) row_any[i / W] = 1u;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// dtype helpers and ROI reductions
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_u8_to_f64(const uint8_t *src, double *dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dst[i] = (double)src[i] * (1.0 / 255);
+}
+
+__global__ __launch_bounds__(256) void k_f64_to_u8(const double *src, uint8_t *dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dst[i] = f64_to_u8_trunc(src[i] * 255);
+}
+
+// np.average(frame[y:y+h, x:x+w]) (base.py:357): numpy's pairwise order is not reproduced; any
+// float64 order is within ~1e-13 relative of it.  One block; wave partials summed in lane order.
+template <typename Tin>
+__global__ __launch_bounds__(256) void k_roi_mean(const Tin *frame, int W, int x, int y, int w, int h, double *out)
+{
+    __shared__ double s_part[4];
+    double acc = 0.0;
+    int n = w * h;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        int r = i / w, c = i - r * w;
+        acc = acc + load_px(frame, (size_t)(y + r) * W + x + c);
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc = acc + __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]) / (double)n;
+}
+
+template <typename Tin>
+__global__ __launch_bounds__(256) void k_roi_to_u8(const Tin *frame, int W, int x, int y, int w, int h, uint8_t *dst)
+{
+    int n = w * h;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int r = i / w, c = i - r * w;
+        dst[i] = f64_to_u8_trunc(load_px(frame, (size_t)(y + r) * W + x + c) * 255);
+    }
+}
+
+// cv2.cvtColor(BGR2GRAY), base.py:230: Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14
+__global__ __launch_bounds__(256) void k_bgr_to_gray(const uint8_t *bgr, size_t npix, uint8_t *gray)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+    }
+}
+
+}  // namespace rm

@@ -1,0 +1,34 @@
+"""tests/emu/build.py -- TEST INFRASTRUCTURE ONLY.
+
+Compiles the PRODUCT sources respmon_amd/csrc/*.hip with g++ against the host emulation of
+the HIP subset in tests/emu/include (which shadows <hip/hip_runtime.h> by include path), into
+tests/emu/_build/librespmon_emu.so.  Used only by tests/test_emu_*.py to exercise the kernels'
+index / border / ordering logic and the host orchestration on a machine without a GPU.
+The product package never loads this library; the product library is built by hipcc for gfx950
+(respmon_amd/csrc/Makefile)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "respmon_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "librespmon_emu.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs += [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "respmon_hip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
+           "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", "-Wno-unused-function", "-o", OUT]
+    for u in units:
+        cmd += ["-x", "c++", os.path.join(CSRC, u)]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,104 @@
+"""Kernel-logic tests WITHOUT a GPU: the product sources in respmon_amd/csrc are compiled with g++
+against a host emulation of the HIP subset they use (tests/emu, test infrastructure only) and
+driven through the same C-ABI as the real library.  They catch index / border / ordering bugs
+before GPU time is spent; the parity tests proper are the `-m gpu` tests."""
+import numpy as np
+import pytest
+
+from respmon_amd import synth
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests.emu_harness import Emu
+    return Emu()
+
+
+def test_emu_pyr_ops_bit_exact(emu, oracle):
+    rng = np.random.default_rng(0)
+    for shape in [(2, 21, 30), (1, 5, 8), (1, 1, 1), (1, 2, 3), (1, 9, 15), (1, 70, 131)]:
+        a = rng.random(shape)
+        d = emu.pyr_down(a)
+        for t in range(shape[0]):
+            assert np.array_equal(d[t], oracle.pyrDown(a[t]))
+        u = emu.pyr_up(d, shape[1], shape[2])
+        assert np.array_equal(u[0], oracle.pyrUp(d[0], (shape[2], shape[1])))
+        lap = emu.pyr_up(d, shape[1], shape[2], mode=1, other=a)
+        assert np.array_equal(lap[0], a[0] - oracle.pyrUp(d[0], (shape[2], shape[1])))
+    u8 = (rng.random((1, 9, 15)) * 255).astype(np.uint8)
+    assert np.array_equal(emu.pyr_down(u8)[0], oracle.pyrDown(oracle.uint8_to_float(u8[0])))
+    f32 = rng.random((1, 12, 7)).astype(np.float32)
+    assert np.array_equal(emu.pyr_down(f32)[0], oracle.pyrDown(f32[0].astype(np.float64)))
+
+
+def test_emu_temporal_operator_and_filter(emu, oracle, golden):
+    g = golden("g1_temporal_fft.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        n = int(n)
+        if n > 256:
+            continue
+        M, lo, hi = emu.operator(n, fps, fmin, fmax)
+        assert (lo, hi) == oracle.band_bounds(n, fps, fmin, fmax)
+        if "M%d" % i in g.files:
+            assert np.abs(M - g["M%d" % i]).max() < 1e-15
+        y = emu.temporal(g["x%d" % i], fps, fmin, fmax, amp)
+        ref = g["y%d" % i]
+        assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_emu_eulerian_and_fused_calibrate_match_golden(emu, golden):
+    g = golden("g3_eulerian.npz")
+    vid8 = g["vid_u8"]
+    for i in range(int(g["ncases"])):
+        L, S, fps = g["meta%d" % i]
+        masked, raw, mm = emu.eulerian(vid8, fps, 0.1, 1.0, 500.0, int(L), int(S))
+        ref = g["raw%d" % i]
+        assert np.abs(raw - ref).max() <= 1e-12 * np.abs(ref).max()   # north_star gate: 1e-4 relative
+        assert np.allclose(mm, [ref.min(), ref.max()], rtol=1e-12, atol=0)
+        heat, mm2 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S))
+        avg = g["avg%d" % i]
+        assert np.abs(heat - avg).max() <= 1e-12 * np.abs(avg).max()
+        assert np.array_equal(mm, mm2)                                 # fused == materialised min/max
+        heat_np, mm3 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S), flags=1)
+        assert np.array_equal(heat, heat_np) and np.array_equal(mm2, mm3)  # pruning never changes a bit
+        assert np.array_equal(np.average(masked, axis=0), heat)        # fused == materialised heatmap
+
+
+def test_emu_locate_matches_golden_roi(emu, golden):
+    g = golden("g4_locate.npz")
+    for i in range(int(g["ncases"])):
+        T, H, W, seed, L, S, fps = (int(v) for v in g["meta%d" % i])
+        v8 = synth.synth_breathing(T, H, W, seed=seed)
+        assert emu.locate(v8, fps, levels=L, skip=S) == tuple(int(v) for v in g["roi%d" % i])
+        heat, _ = emu.calibrate(v8, fps, levels=L, skip=S)
+        roi, u8, binary = emu.heatmap_to_roi(heat)
+        assert np.array_equal(u8, g["avg_u8_%d" % i])
+        assert np.array_equal(binary, np.where(u8 > 20, 255, 0).astype(np.uint8))
+    assert emu.locate(np.full((16, 40, 48), 0.5), 10, levels=4, skip=2) is None  # base.py:569-570
+
+
+def test_emu_ragged_shapes_and_degenerate_levels(emu, oracle):
+    rng = np.random.default_rng(5)
+    cases = [(8, 17, 23, 3, 1), (8, 5, 9, 3, 1), (6, 33, 70, 5, 3), (4, 16, 64, 2, 1), (4, 1, 9, 2, 1),
+             (5, 30, 31, 4, 3), (4, 20, 20, 1, 0), (4, 20, 20, 2, 0), (6, 40, 130, 4, 1)]
+    for (T, H, W, L, S) in cases:
+        v = rng.random((T, H, W))
+        heat, mm = emu.calibrate(v, 10.0, levels=L, skip=S)
+        mo, ro = oracle.eulerian_magnification_bandpass(v, 10.0, 0.1, 1.0, 500.0, pyramid_levels=L, skip_levels_at_top=S)
+        ho = np.average(mo, axis=0)
+        assert np.abs(heat - ho).max() <= 1e-12 * max(np.abs(ho).max(), 1e-300), (T, H, W, L, S)
+        assert np.allclose(mm, [ro.min(), ro.max()], rtol=1e-12, atol=0)
+
+
+def test_emu_contour_stage_matches_oracle(emu, oracle):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(9)
+    for k in range(12):
+        heat = ndi.gaussian_filter(rng.standard_normal((37, 61)), 2.5)
+        if k % 3 == 0:
+            heat[:, 0] = heat.max()      # blobs touching the frame
+        roi, u8, binary = emu.heatmap_to_roi(heat, threshold=150)
+        ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
+        assert np.array_equal(u8, ref_u8)
+        assert roi == oracle.roi_from_heatmap_u8(ref_u8, 150)
