@@ -1,0 +1,162 @@
+"""bench.py -- Eulerian-calibration frames/sec on a 1080p x 256 buffer (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one locate() (calibration + ROI) over one [T,H,W] frame buffer already resident in HBM.
+N>1: one process per GPU, each with its own stream (weak scaling, Mode B of respmon_amd/dist.py) and
+one RCCL all-reduce(sum) of the [H,W] heatmap per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+DT_BYTES = {"f64": 8, "f32": 4, "f16": 2, "u8": 1}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--in-dtype", default="f64", choices=list(DT_BYTES), help="device frame-buffer element type; "
+                    "f64 is the reference's calibration_buffer dtype (base.py:119)")
+    ap.add_argument("--levels", type=int, default=9)
+    ap.add_argument("--skip", type=int, default=4)
+    ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the same workload timed on the CPU oracle (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(vid_u8, n_frames, levels, skip):
+    """The oracle (a port: the reference's materialising algorithm with the build's C restatement of the
+    cv2 calls) timed on this host, single thread like the reference, on the first n_frames frames."""
+    from oracle import respmon_oracle as oracle
+    oracle.build()
+    frames = oracle.uint8_to_float(vid_u8[:n_frames])
+    t0 = time.perf_counter()
+    roi = oracle.locate(frames, 10, pyramid_levels=levels, skip_levels_at_top=skip)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d frames of the same %dx%d video, oracle.locate (L=%d,S=%d), %.1f s, host has %d cores"
+                      % (n_frames, vid_u8.shape[0], vid_u8.shape[1], vid_u8.shape[2], levels, skip, dt, os.cpu_count()),
+            "roi": roi}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from respmon_amd import _capi, device, synth
+    from respmon_amd import dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+
+    T, H, W = a.frames, a.height, a.width
+    vid_u8 = synth.synth_breathing(T, H, W, seed=1234 + rank)  # config 4: independent stream per GPU
+    tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[a.in_dtype]
+    dev_u8 = torch.from_numpy(vid_u8).cuda()
+    if a.in_dtype == "u8":
+        buf = dev_u8
+    else:
+        buf = torch.empty((T, H, W), dtype=tdt, device="cuda")
+        for t0 in range(0, T, 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype
+            buf[t0:t0 + 16] = (dev_u8[t0:t0 + 16].to(torch.float64) * (1.0 / 255)).to(tdt)
+        del dev_u8
+    torch.cuda.synchronize()
+
+    lib = _capi.load()
+    ctx = device.ctx()
+    flags = _capi.RM_FLAG_NO_PRUNE if a.no_prune else 0
+    kw = dict(pyramid_levels=a.levels, skip_levels_at_top=a.skip, flags=flags)
+
+    def step():
+        return rdist.locate_streams(buf, 10, threshold=20, **kw)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    roi = None
+    for _ in range(a.warmup):
+        roi = step()
+    barrier()
+    _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        roi = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_double * 4)()
+    ncalls = ctypes.c_int()
+    _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
+    _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+
+    if rank == 0:
+        frames_total = world * T * a.steps
+        b_alg = T * H * W * DT_BYTES[a.in_dtype] + H * W * 8  # one read of the buffer + the heatmap
+        k_ms = ms[0] / max(ncalls.value, 1)
+        achieved = b_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%s_%dx%dx%d" % (a.in_dtype, T, H, W)
+                traffic = tj.get(key, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s",
+            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Eulerian calibration + ROI (locate) on a %dx%dx%d frame buffer, %d-level Laplacian pyramid, "
+                                   "skip %d, temporal FFT band-pass 0.1-1.0 Hz @10 fps; one independent stream per GPU + one RCCL "
+                                   "heatmap all-reduce" % (T, H, W, a.levels, a.skip),
+                       "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "prune": not a.no_prune},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "frame-buffer pyrDown kernel (reads [T,H,W] once)", "kernel_ms": k_ms,
+                         "algorithmic_bytes": b_alg},
+            "phases_ms_per_step": {"frame_buffer_kernel": k_ms, "pyramid_rest_and_temporal": ms[1] / max(ncalls.value, 1),
+                                   "collapse_passes": ms[2] / max(ncalls.value, 1), "heatmap_to_roi": ms[3] / max(ncalls.value, 1)},
+            "roi": roi,
+        }
+        if world == 1 and a.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(vid_u8, min(a.cpu_frames, T), a.levels, a.skip)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

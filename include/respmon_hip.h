@@ -55,6 +55,15 @@ int rm_abi_version(void);
 /* bytes of device workspace currently held by the context */
 size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
 
+/* ---- measurement hook for bench.py: when on, rm_calibrate / rm_heatmap_to_roi bracket their phases
+ *      with hipEvents on the caller's stream.  rm_profile_read waits for them and returns the summed
+ *      milliseconds since the last read: ms_host[0] = the kernel that reads the [T,H,W] frame buffer
+ *      (the roofline kernel), [1] = remaining pyramid + temporal kernels, [2] = collapse passes,
+ *      [3] = heatmap -> ROI (device part + host contour stage); *n_host = rm_calibrate calls covered. */
+#define RM_PROFILE_PHASES 4
+int rm_profile_enable(rm_ctx *ctx, int on);
+int rm_profile_read(rm_ctx *ctx, double *ms_host, int *n_host);
+
 /* ---- dtype helpers: transforms.py:20-23 uint8_to_float, transforms.py:26-29 float_to_uint8 */
 int rm_uint8_to_float(rm_ctx *ctx, const uint8_t *src_dev, double *dst_dev, size_t n, void *stream);
 int rm_float_to_uint8(rm_ctx *ctx, const double *src_dev, uint8_t *dst_dev, size_t n, void *stream);

@@ -23,6 +23,8 @@ SIGNATURES = {
     "rm_last_error_string": (_c.c_char_p, []),
     "rm_abi_version": (_i, []),
     "rm_ctx_workspace_bytes": (_sz, [_vp]),
+    "rm_profile_enable": (_i, [_vp, _i]),
+    "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "rm_float_to_uint8": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "rm_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -56,6 +57,38 @@ struct rm_ctx {
     // cached temporal operator
     int op_T = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     FlowWorkspace flow;
+    // measurement hook (rm_profile_*)
+    bool prof_on = false;
+    int prof_calls = 0;
+    std::vector<hipEvent_t> prof_ev[RM_PROFILE_PHASES];  // start/stop pairs per phase
+    std::vector<hipEvent_t> prof_pool;
+    double prof_host_ms[RM_PROFILE_PHASES] = {0, 0, 0, 0};
+};
+
+// RAII bracket: records a start event now and a stop event at scope exit (no-op when profiling is off)
+struct PhaseTimer {
+    rm_ctx *c; int phase; hipStream_t s; bool on;
+    static hipEvent_t get(rm_ctx *c)
+    {
+        hipEvent_t e = nullptr;
+        if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    }
+    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_on)
+    {
+        if (!on) return;
+        hipEvent_t e = get(c);
+        (void)hipEventRecord(e, s);
+        c->prof_ev[phase].push_back(e);
+    }
+    ~PhaseTimer()
+    {
+        if (!on) return;
+        hipEvent_t e = get(c);
+        (void)hipEventRecord(e, s);
+        c->prof_ev[phase].push_back(e);
+    }
 };
 
 static int ws_get(rm_ctx *ctx, const std::string &name, size_t bytes, void **out)
@@ -97,14 +130,46 @@ extern "C" int rm_ctx_create(int device, rm_ctx **out)
 extern "C" int rm_ctx_destroy(rm_ctx *ctx)
 {
     if (!ctx) return RM_OK;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs)
-        if (kv.second.p) hipFree(kv.second.p);
-    if (ctx->d_state) hipFree(ctx->d_state);
-    if (ctx->h_state) hipHostFree(ctx->h_state);
-    if (ctx->h_bin) hipHostFree(ctx->h_bin);
-    if (ctx->h_rowany) hipHostFree(ctx->h_rowany);
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (ctx->d_state) (void)hipFree(ctx->d_state);
+    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
+    if (ctx->h_rowany) (void)hipHostFree(ctx->h_rowany);
+    for (int p = 0; p < RM_PROFILE_PHASES; ++p)
+        for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
+    return RM_OK;
+}
+
+extern "C" int rm_profile_enable(rm_ctx *ctx, int on)
+{
+    if (!ctx) return fail(RM_E_BADARG, "rm_profile_enable: ctx is NULL");
+    ctx->prof_on = on != 0;
+    return RM_OK;
+}
+
+extern "C" int rm_profile_read(rm_ctx *ctx, double *ms, int *n)
+{
+    if (!ctx || !ms) return fail(RM_E_BADARG, "rm_profile_read: bad argument");
+    for (int p = 0; p < RM_PROFILE_PHASES; ++p) {
+        double total = ctx->prof_host_ms[p];
+        ctx->prof_host_ms[p] = 0;
+        std::vector<hipEvent_t> &v = ctx->prof_ev[p];
+        for (size_t i = 0; i + 1 < v.size(); i += 2) {
+            HIP_TRY(hipEventSynchronize(v[i + 1]));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, v[i], v[i + 1]));
+            total += t;
+        }
+        for (hipEvent_t e : v) ctx->prof_pool.push_back(e);
+        v.clear();
+        ms[p] = total;
+    }
+    if (n) *n = ctx->prof_calls;
+    ctx->prof_calls = 0;
     return RM_OK;
 }
 
@@ -406,7 +471,10 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
         double *dst = nullptr;
         if (l < S) RM_TRY(ws(ctx, (l & 1) ? "g_ping" : "g_pong", (size_t)T * h[l] * w[l], &dst));
         else RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &dst));
-        RM_TRY(launch_pyr_down(cur, cur_dtype, T, h[l - 1], w[l - 1], dst, s));
+        {
+            PhaseTimer pt(ctx, l == 1 ? 0 : 1, s);
+            RM_TRY(launch_pyr_down(cur, cur_dtype, T, h[l - 1], w[l - 1], dst, s));
+        }
         g[l] = dst; cur = dst; cur_dtype = RM_F64;
     }
     if (S == 0) {
@@ -417,6 +485,7 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
     }
     const double *M = nullptr;
     RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &M, s));
+    PhaseTimer pt_small(ctx, 1, s);
     // Laplacian (pyramid.py:23-26), temporal filter (transforms.py:162,169), collapse of the
     // band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x)
     double *c = nullptr;
@@ -472,10 +541,13 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     const size_t npix = (size_t)H * W;
     SmallLevels sl;
     RM_TRY(front_half(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, flags, sl, s));
+    if (ctx->prof_on) ctx->prof_calls++;
     if (sl.all_zero) return zero_result(ctx, npix, heat, minmax_host, s);
     CollapseState *st = ctx->d_state;
     double *heat_sum = nullptr;
     RM_TRY(ws(ctx, "heat_sum", npix, &heat_sum));
+    PhaseTimer *pt_collapse = new PhaseTimer(ctx, 2, s);
+    struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_collapse};
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
     LAUNCH_CHECK();
     const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
@@ -514,6 +586,7 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     }
     hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 1024)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
     LAUNCH_CHECK();
+    delete pt_collapse; pt_collapse = nullptr;
     if (minmax_host) {
         HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -599,6 +672,8 @@ extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, 
         HIP_TRY(hipHostMalloc((void **)&ctx->h_rowany, sizeof(uint32_t) * H, hipHostMallocDefault));
         ctx->h_rowany_cap = H;
     }
+    PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
+    struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
     hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
     LAUNCH_CHECK();
     HIP_TRY(hipMemsetAsync(row_any, 0, sizeof(uint32_t) * H, s));
@@ -608,9 +683,15 @@ extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, 
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(ctx->h_rowany, row_any, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(ctx->h_bin, bin, npix, hipMemcpyDeviceToHost, s));
+    delete pt_roi; pt_roi = nullptr;
     HIP_TRY(hipStreamSynchronize(s));
     RoiResult r;
-    largest_external_contour(ctx->h_bin, H, W, ctx->h_rowany, &r);
+    {
+        auto t0 = std::chrono::steady_clock::now();
+        largest_external_contour(ctx->h_bin, H, W, ctx->h_rowany, &r);
+        if (ctx->prof_on)
+            ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
     xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;
     return RM_OK;

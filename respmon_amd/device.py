@@ -1,0 +1,77 @@
+"""Device plumbing: PyTorch-ROCm tensors are only the device-memory container; every computation
+goes through the C-ABI of librespmon_hip.so (respmon_amd/_capi.py)."""
+import ctypes
+
+import numpy as np
+
+from . import _capi
+
+_CTX = {}
+
+_NP_CODES = {np.dtype(np.uint8): _capi.RM_U8, np.dtype(np.float16): _capi.RM_F16,
+             np.dtype(np.float32): _capi.RM_F32, np.dtype(np.float64): _capi.RM_F64}
+
+
+def torch():
+    import torch as _t
+    return _t
+
+
+def require_gpu():
+    t = torch()
+    if not t.cuda.is_available():
+        raise _capi.RespmonError("respmon_amd needs an MI355X (HIP) device: torch.cuda.is_available() is False "
+                                 "and there is no CPU implementation of the hot path")
+    return t
+
+
+def ctx(device_index=None):
+    """One library context per GPU (lazily created)."""
+    t = require_gpu()
+    if device_index is None:
+        device_index = t.cuda.current_device()
+    if device_index not in _CTX:
+        lib = _capi.load()
+        h = ctypes.c_void_p()
+        _capi.check(lib, lib.rm_ctx_create(int(device_index), ctypes.byref(h)), "rm_ctx_create")
+        _CTX[device_index] = h
+    return _CTX[device_index]
+
+
+def stream_ptr():
+    t = torch()
+    return ctypes.c_void_p(t.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(tensor):
+    t = torch()
+    table = {t.uint8: _capi.RM_U8, t.float16: _capi.RM_F16, t.float32: _capi.RM_F32, t.float64: _capi.RM_F64}
+    if tensor.dtype not in table:
+        raise TypeError("unsupported frame dtype %s (uint8, float16, float32, float64)" % tensor.dtype)
+    return table[tensor.dtype]
+
+
+def to_device(a, dtype=None):
+    """numpy array or torch tensor -> contiguous CUDA(HIP) tensor (no copy if already there)."""
+    t = require_gpu()
+    if isinstance(a, t.Tensor):
+        x = a
+    else:
+        x = t.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        x = x.to(dtype)
+    if not x.is_cuda:
+        x = x.cuda()
+    return x.contiguous()
+
+
+def ptr(tensor):
+    return ctypes.c_void_p(tensor.data_ptr()) if tensor is not None else None
+
+
+def like_input(result_tensor, original):
+    """Return numpy when the caller passed numpy (the reference's convention), else the tensor."""
+    t = torch()
+    if isinstance(original, t.Tensor):
+        return result_tensor
+    return result_tensor.cpu().numpy()

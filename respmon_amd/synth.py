@@ -33,14 +33,20 @@ def synth_breathing(T, H, W, seed=1234, fps=10.0, breath_hz=0.4, amplitude=0.2, 
     tex = _lowpass_noise(rng, H, W)
     yy = (np.arange(H)[:, None] - center[0] * H) / (sigma[0] * H)
     xx = (np.arange(W)[None, :] - center[1] * W) / (sigma[1] * W)
-    blob = np.exp(-0.5 * (yy * yy + xx * xx))
-    base = 0.5 + 0.25 * tex
+    blob = (amplitude * 255.0 * np.exp(-0.5 * (yy * yy + xx * xx))).astype(np.float32)
+    base = (255.0 * (0.5 + 0.25 * tex)).astype(np.float32)
+    sig = np.float32(255.0 * noise)
     out = np.empty((T, H, W), dtype=np.uint8)
     for t0 in range(0, T, block):
         t1 = min(T, t0 + block)
-        s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps)[:, None, None]
-        g = base[None] + amplitude * blob[None] * s + noise * rng.standard_normal((t1 - t0, H, W))
-        out[t0:t1] = np.clip(np.round(255 * g), 0, 255).astype(np.uint8)
+        s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps).astype(np.float32)[:, None, None]
+        g = rng.standard_normal((t1 - t0, H, W), dtype=np.float32)
+        g *= sig
+        g += base[None]
+        g += blob[None] * s
+        np.rint(g, out=g)
+        np.clip(g, 0, 255, out=g)
+        out[t0:t1] = g.astype(np.uint8)
     return out
 
 

@@ -171,6 +171,11 @@ inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memcpy
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 

