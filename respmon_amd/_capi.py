@@ -12,6 +12,8 @@ RM_NO_CONTOUR = 1
 RM_U8, RM_F16, RM_F32, RM_F64 = 0, 1, 2, 3
 RM_FLAG_NO_PRUNE = 1
 RM_FLAG_UNFUSED_DOWN = 2
+RM_FLAG_TINY_STORE = 4
+RM_FLAG_TINY_STRIPS = 8
 
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint

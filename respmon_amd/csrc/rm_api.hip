@@ -16,6 +16,7 @@
 
 #include "rm_contour.h"
 #include "rm_kernels.h"
+#include "rm_down_chain.h"
 #include "rm_flow.h"
 
 using namespace rm;
@@ -444,6 +445,49 @@ extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, 
 }
 
 // ------------------------------------------------------------------------------------------
+// fused Gaussian chain (rm_down_chain.h)
+// ------------------------------------------------------------------------------------------
+template <typename Tin>
+static int launch_down_chain_t(const void *frames, int T, const DownGeom &g, double *out, hipStream_t s)
+{
+    const size_t fs = (size_t)g.h[0] * g.w[0];
+    const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g.strips * g.segs);
+    const size_t shmem = sizeof(double) * (size_t)g.lds_total;
+    const Tin *f = (const Tin *)frames;
+    switch (g.S) {
+    case 1: hipLaunchKernelGGL((k_down_chain<Tin, 1>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
+    case 2: hipLaunchKernelGGL((k_down_chain<Tin, 2>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
+    case 3: hipLaunchKernelGGL((k_down_chain<Tin, 3>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
+    case 4: hipLaunchKernelGGL((k_down_chain<Tin, 4>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
+    case 5: hipLaunchKernelGGL((k_down_chain<Tin, 5>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
+    default: return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", g.S);
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+static int dtype_vec(int dtype) { return dtype == RM_F64 ? 2 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 8 : 16; }
+static size_t dtype_size(int dtype) { return dtype == RM_F64 ? 8 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 2 : 1; }
+
+// frames[T,H,W] -> G_S[T,h_S,w_S] in one launch
+static int launch_down_chain(const void *frames, int dtype, int T, const std::vector<int> &h, const std::vector<int> &w, int S,
+                             double *out, hipStream_t s, bool tiny)
+{
+    const int V = dtype_vec(dtype);
+    const size_t esz = dtype_size(dtype);
+    const bool vec_ok = (w[0] % V == 0) && (((size_t)h[0] * w[0] * esz) % 16 == 0) && (((uintptr_t)frames) % 16 == 0);
+    DownGeom g;
+    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok ? 1 : 0, V, g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+    switch (dtype) {
+    case RM_U8: return launch_down_chain_t<uint8_t>(frames, T, g, out, s);
+    case RM_F16: return launch_down_chain_t<__half>(frames, T, g, out, s);
+    case RM_F32: return launch_down_chain_t<float>(frames, T, g, out, s);
+    case RM_F64: return launch_down_chain_t<double>(frames, T, g, out, s);
+    }
+    return fail(RM_E_BADARG, "unknown dtype %d", dtype);
+}
+
+// ------------------------------------------------------------------------------------------
 // shared front half of calibration: frames -> collapsed band-passed level S  (C_S [T,hS,wS])
 // ------------------------------------------------------------------------------------------
 struct SmallLevels {
@@ -456,7 +500,6 @@ struct SmallLevels {
 static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
                       double amp, int levels, int skip, unsigned flags, SmallLevels &out, hipStream_t s)
 {
-    (void)flags;
     level_sizes(H, W, levels, out.h, out.w);
     const std::vector<int> &h = out.h, &w = out.w;
     const int L = levels;
@@ -467,12 +510,24 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
     // levels S..L-1 are kept for the Laplacians.
     std::vector<double *> g(L, nullptr);
     const void *cur = frames; int cur_dtype = dtype;
-    for (int l = 1; l < L; ++l) {
+    int first = 1;
+    if (S >= 1 && S <= 5 && !(flags & RM_FLAG_UNFUSED_DOWN)) {
+        // one launch reads the frame buffer once and writes only G_S
+        double *dst = nullptr;
+        RM_TRY(ws(ctx, "g" + std::to_string(S), (size_t)T * h[S] * w[S], &dst));
+        {
+            PhaseTimer pt(ctx, 0, s);
+            RM_TRY(launch_down_chain(frames, dtype, T, h, w, S, dst, s, (flags & RM_FLAG_TINY_STRIPS) != 0));
+        }
+        g[S] = dst; cur = dst; cur_dtype = RM_F64;
+        first = S + 1;
+    }
+    for (int l = first; l < L; ++l) {
         double *dst = nullptr;
         if (l < S) RM_TRY(ws(ctx, (l & 1) ? "g_ping" : "g_pong", (size_t)T * h[l] * w[l], &dst));
         else RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &dst));
         {
-            PhaseTimer pt(ctx, l == 1 ? 0 : 1, s);
+            PhaseTimer pt(ctx, (l == 1) ? 0 : 1, s);
             RM_TRY(launch_pyr_down(cur, cur_dtype, T, h[l - 1], w[l - 1], dst, s));
         }
         g[l] = dst; cur = dst; cur_dtype = RM_F64;
@@ -535,7 +590,7 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
 {
     if (!ctx || !frames || !heat || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_dtype(dtype))
         return fail(RM_E_BADARG, "rm_calibrate: bad argument");
-    if (T > 64 * MAX_T_WORDS) return fail(RM_E_UNSUPPORTED, "rm_calibrate: T=%d > %d", T, 64 * MAX_T_WORDS);
+    if (T > MAX_T) return fail(RM_E_UNSUPPORTED, "rm_calibrate: T=%d > %d", T, MAX_T);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
@@ -553,7 +608,7 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
     if (sl.S == 0) {
         size_t n = (size_t)T * npix;
-        hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, sl.cS, n, st);
+        hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, sl.cS, n, st);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
         LAUNCH_CHECK();
@@ -564,27 +619,40 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         RM_TRY(make_geom(sl, g));
         const int ntiles = g.tiles_x * g.tiles_y;
         const int npairs = ntiles * T;
-        double *lo = nullptr, *hi = nullptr;
-        unsigned int *cand = nullptr;
+        // value store for the pairs the masked sum needs: 1/8 of all pairs (>= 4096 slots); pairs beyond
+        // the capacity are re-evaluated inside the sum kernel, so the size is a speed knob, not a limit
+        size_t slot_cap = (size_t)npairs / 8;
+        if (slot_cap < 4096) slot_cap = 4096;
+        if (slot_cap > (size_t)npairs) slot_cap = (size_t)npairs;
+        if (flags & RM_FLAG_TINY_STORE) slot_cap = 3;
+        double *lo = nullptr, *hi = nullptr, *store = nullptr;
+        unsigned int *list = nullptr;
+        int *slot_of = nullptr;
         RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
         RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
-        RM_TRY(ws(ctx, "tile_cand", (size_t)npairs, &cand));
+        RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &list));
+        RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &slot_of));
+        RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &store));
         hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, lo, hi);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 256)), dim3(256), 0, s, lo, hi, npairs, st);
+        hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 128)), dim3(256), 0, s, lo, hi, npairs, st);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_select_candidates, dim3((npairs + 255) / 256), dim3(256), 0, s, lo, hi, npairs, st, cand, no_prune);
+        const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
+        hipLaunchKernelGGL(k_prepare_select, dim3(1), dim3(1), 0, s, st, thr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 255) / 256), dim3(256), 0, s, lo, hi, npairs, st, list, slot_of,
+                           (unsigned)slot_cap, prune_ok ? 0 : 1);
         LAUNCH_CHECK();
         size_t shmem = sizeof(double) * (size_t)g.lds_total;
-        unsigned cgrid = (unsigned)(npairs < 8192 ? npairs : 8192);
-        hipLaunchKernelGGL(k_minmax_tiles, dim3(cgrid), dim3(64), shmem, s, sl.cS, g, T, cand, st);
+        unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
+        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), shmem, s, sl.cS, g, ntiles, list, slot_of, st, store);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(64), shmem, s, sl.cS, g, T, lo, st, no_prune, heat_sum);
+        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(64), shmem, s, sl.cS, g, T, ntiles, slot_of, store, st, heat_sum);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 1024)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
+    hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
     LAUNCH_CHECK();
     delete pt_collapse; pt_collapse = nullptr;
     if (minmax_host) {
@@ -629,7 +697,7 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
     CollapseState *st = ctx->d_state;
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, raw_buf, n, st);
+    hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, raw_buf, n, st);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
     LAUNCH_CHECK();
@@ -677,7 +745,7 @@ extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, 
     hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
     LAUNCH_CHECK();
     HIP_TRY(hipMemsetAsync(row_any, 0, sizeof(uint32_t) * H, s));
-    hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 1024)), dim3(256), 0, s, heat, npix, st);
+    hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, bin, row_any, W);
     LAUNCH_CHECK();

@@ -181,11 +181,19 @@ __global__ __launch_bounds__(256) void k_temporal(const double *x, int T, size_t
     double acc[TS_CHUNK];
 #pragma unroll
     for (int k = 0; k < TS_CHUNK; ++k) acc[k] = 0.0;
-    for (int t = 0; t < T; ++t) {
-        double v = x[(size_t)t * npix + p];
-        const double *m = &s_m[t * TS_CHUNK];
+    constexpr int U = 8;  // loads in flight per lane (the sum itself stays sequential in t)
+    for (int t0 = 0; t0 < T; t0 += U) {
+        double v[U];
 #pragma unroll
-        for (int k = 0; k < TS_CHUNK; ++k) acc[k] = acc[k] + m[k] * v;
+        for (int u = 0; u < U; ++u) v[u] = (t0 + u < T) ? x[(size_t)(t0 + u) * npix + p] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u < T) {
+                const double *m = &s_m[(t0 + u) * TS_CHUNK];
+#pragma unroll
+                for (int k = 0; k < TS_CHUNK; ++k) acc[k] = acc[k] + m[k] * v[u];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < TS_CHUNK; ++k)
@@ -242,14 +250,29 @@ struct LdsImg {  // a level's tile buffer: absolute coordinates -> LDS
     __device__ __forceinline__ double operator()(int r, int c) const { return p[(r - y0) * pitch + (c - x0)]; }
 };
 
-// per (tile, frame) bounds of the level-S footprint: every full-resolution value of the tile
+// block-wide min / max: wave shuffles, then one LDS hop across the block's waves (blockDim.x <= 256)
+__device__ __forceinline__ void block_minmax(double &mn, double &mx)
+{
+    __shared__ double s_mn[4], s_mx[4];
+    mn = wave_min(mn); mx = wave_max(mx);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
+    mn = s_mn[0]; mx = s_mx[0];
+    for (int i = 1; i < nw; ++i) { mn = (s_mn[i] < mn) ? s_mn[i] : mn; mx = (s_mx[i] > mx) ? s_mx[i] : mx; }
+    __syncthreads();
+}
+
+// per (frame, tile) bounds of the level-S footprint: every full-resolution value of the tile
 // is a convex combination of these, so  lo - margin <= raw <= hi + margin.
+// Layout [t][tile]: consecutive lanes take consecutive tiles of one frame (overlapping, x-contiguous
+// footprints -> coalesced reads).
 __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
                                                      double *lo, double *hi)
 {
     int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= ntiles * T) return;
-    int tile = idx / T, t = idx - tile * T;
+    int t = idx / ntiles, tile = idx - t * ntiles;
     TileRegion R;
     tile_regions(g, tile, R);
     const int S = g.S;
@@ -266,56 +289,82 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom
 
 // device-side scalars shared by the collapse passes
 struct CollapseState {
-    unsigned long long lb_max_key;  // max over (tile,t) of lo  (lower bound of raw.max())
-    unsigned long long ub_min_key;  // min over (tile,t) of hi  (upper bound of raw.min())
-    unsigned long long abs_max_key; // max |bound| (scale of the safety margin)
+    unsigned long long lb_max_key;  // max over pairs of lo  (lower bound of raw.max())
+    unsigned long long ub_min_key;  // min over pairs of hi  (upper bound of raw.min())
+    unsigned long long ub_max_key;  // max over pairs of hi  (upper bound of raw.max())
+    unsigned long long lb_min_key;  // min over pairs of lo  (lower bound of raw.min())
     unsigned long long min_key, max_key;  // exact raw.min() / raw.max()
-    unsigned int n_cand;            // candidate (tile,t) pairs for the exact min/max pass
-    unsigned int pad;
-    double min_val, max_val, top;   // decoded by k_finish_minmax
-    double heat_min_max[2];
+    unsigned int n_list;            // (frame, tile) pairs that must be evaluated
+    unsigned int n_slots;           // pairs whose values are kept for the masked time sum
+    double margin;                  // absolute safety margin of the bounds
+    double top_ub;                  // upper bound of `top`, from the bounds alone
+    double min_val, max_val, top;   // transforms.py:185-189, decoded by k_finish_minmax
     unsigned long long heat_min_key, heat_max_key;
 };
 
 __global__ void k_state_init(CollapseState *st)
 {
-    st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->abs_max_key = 0ull;
-    st->min_key = ~0ull; st->max_key = 0ull; st->n_cand = 0; st->pad = 0;
-    st->min_val = 0; st->max_val = 0; st->top = 0;
+    st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->ub_max_key = 0ull; st->lb_min_key = ~0ull;
+    st->min_key = ~0ull; st->max_key = 0ull; st->n_list = 0; st->n_slots = 0;
+    st->margin = 0; st->top_ub = 0; st->min_val = 0; st->max_val = 0; st->top = 0;
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_reduce_bounds(const double *lo, const double *hi, int n, CollapseState *st)
 {
-    double a = -1.0 / 0.0, b = 1.0 / 0.0, m = 0.0;
+    const double inf = __builtin_huge_val();
+    double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         double l = lo[i], h = hi[i];
-        a = (l > a) ? l : a;
-        b = (h < b) ? h : b;
-        double al = l < 0 ? -l : l, ah = h < 0 ? -h : h;
-        m = (al > m) ? al : m;
-        m = (ah > m) ? ah : m;
+        lo_mn = (l < lo_mn) ? l : lo_mn; lo_mx = (l > lo_mx) ? l : lo_mx;
+        hi_mn = (h < hi_mn) ? h : hi_mn; hi_mx = (h > hi_mx) ? h : hi_mx;
     }
-    a = wave_max(a); b = wave_min(b); m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&st->lb_max_key, f64_key(a));
-        atomicMin(&st->ub_min_key, f64_key(b));
-        atomicMax(&st->abs_max_key, f64_key(m));
+    block_minmax(lo_mn, lo_mx);
+    block_minmax(hi_mn, hi_mx);
+    if (threadIdx.x == 0) {
+        atomicMax(&st->lb_max_key, f64_key(lo_mx));
+        atomicMin(&st->lb_min_key, f64_key(lo_mn));
+        atomicMax(&st->ub_max_key, f64_key(hi_mx));
+        atomicMin(&st->ub_min_key, f64_key(hi_mn));
     }
 }
 
-constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 rounding of the S-level chain
+constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
 
-// candidates for the exact min/max pass: pairs whose bounds reach the extreme bounds
-__global__ __launch_bounds__(256) void k_select_candidates(const double *lo, const double *hi, int n,
-                                                           CollapseState *st, unsigned int *cand, int no_prune)
+// margin and the bounds-only upper bound of top = max - (max - min) * thr (increasing in max and min
+// for 0 <= thr <= 1)
+__global__ void k_prepare_select(CollapseState *st, double thr)
+{
+    double a = f64_unkey(st->ub_max_key), b = f64_unkey(st->lb_min_key);
+    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+    double m = PRUNE_REL_MARGIN * (a > b ? a : b);
+    st->margin = m;
+    double mx = f64_unkey(st->ub_max_key) + m, mn = f64_unkey(st->ub_min_key) + m;
+    st->top_ub = (mx - (mx - mn) * thr) + m;
+}
+
+constexpr int SLOT_PRUNED = -1;    // every value of the pair is provably >= top: contributes `min`
+constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is full
+
+// which pairs need their full-resolution values:
+//   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max
+//   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum
+__global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
+                                                      unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double margin = PRUNE_REL_MARGIN * f64_unkey(st->abs_max_key);
-    double lb_max = f64_unkey(st->lb_max_key), ub_min = f64_unkey(st->ub_min_key);
-    bool keep = no_prune || !(hi[i] + margin < lb_max - margin) || !(lo[i] - margin > ub_min + margin);
-    if (keep) cand[atomicAdd(&st->n_cand, 1u)] = (unsigned)i;
+    const double m = st->margin;
+    const double lb_max = f64_unkey(st->lb_max_key), ub_min = f64_unkey(st->ub_min_key);
+    bool isC = no_prune || !(hi[i] + m < lb_max - m) || !(lo[i] - m > ub_min + m);
+    bool isD = no_prune || (lo[i] - m < st->top_ub);
+    int slot = SLOT_PRUNED;
+    if (isD) {
+        unsigned sidx = atomicAdd(&st->n_slots, 1u);
+        slot = (sidx < slot_cap) ? (int)sidx : SLOT_ON_THE_FLY;
+    }
+    slot_of[i] = slot;
+    if (isC || slot >= 0) list[atomicAdd(&st->n_list, 1u)] = (unsigned)i;
 }
 
 // stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
@@ -369,21 +418,25 @@ __device__ __forceinline__ void level0_column(const ChainGeom &g, const TileRegi
     }
 }
 
-// pass C: exact min / max of raw over the candidate (tile, frame) pairs
-__global__ __launch_bounds__(64) void k_minmax_tiles(const double *cS, ChainGeom g, int T, const unsigned int *cand,
-                                                     CollapseState *st)
+// the one evaluation pass: full-resolution values of every listed (frame, tile) pair, once.
+// Exact raw.min()/raw.max() (transforms.py:185,187) come from here; values of pairs that can fall
+// below `top` are parked in `store` ([slot][row][lane], coalesced) for the masked time sum.
+__global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list,
+                                                   const int *slot_of, CollapseState *st, double *store)
 {
     HIP_DYNAMIC_SHARED(double, lds)
-    const unsigned n = st->n_cand;
+    const unsigned n = st->n_list;
     const int lane = threadIdx.x;
-    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    const double inf = __builtin_huge_val();
+    double mn = inf, mx = -inf;
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
-        unsigned idx = cand[c];
-        int tile = idx / T, t = idx - tile * T;
+        unsigned idx = list[c];
+        int t = idx / ntiles, tile = idx - t * ntiles;
         TileRegion R;
         tile_regions(g, tile, R);
         chain_to_level1(g, R, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
         int x = R.x0[0] + lane;
+        int slot = slot_of[idx];
         if (x <= R.x1[0]) {
             double v[CT_H];
             level0_column(g, R, lds, x, v);
@@ -391,6 +444,11 @@ __global__ __launch_bounds__(64) void k_minmax_tiles(const double *cS, ChainGeom
 #pragma unroll
             for (int j = 0; j < CT_H; ++j)
                 if (j < rows) { mn = (v[j] < mn) ? v[j] : mn; mx = (v[j] > mx) ? v[j] : mx; }
+            if (slot >= 0) {
+                double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
+#pragma unroll
+                for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
+            }
         }
         __syncthreads();
     }
@@ -410,42 +468,45 @@ __global__ void k_finish_minmax(CollapseState *st, double threshold)
 }
 
 // pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order,
-// base.py:562).  Frames whose whole footprint is provably >= top add `min` without evaluation.
-constexpr int MAX_T_WORDS = 64;  // T <= 4096
+// base.py:562).  Pruned pairs add `min`; kept pairs read their values back from `store`.
+constexpr int MAX_T = 4096;
 
-__global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, const double *lo,
-                                                         const CollapseState *st, int no_prune, double *heat_sum)
+__global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, int ntiles,
+                                                         const int *slot_of, const double *store,
+                                                         const CollapseState *st, double *heat_sum)
 {
     HIP_DYNAMIC_SHARED(double, lds)
-    __shared__ unsigned long long s_pruned[MAX_T_WORDS];
+    __shared__ int s_slot[MAX_T];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     const double top = st->top, min_val = st->min_val;
-    const double margin = PRUNE_REL_MARGIN * f64_unkey(st->abs_max_key);
     TileRegion R;
     tile_regions(g, tile, R);
-    for (int w0 = 0; w0 * 64 < T; ++w0) {
-        int t = w0 * 64 + lane;
-        bool pr = (!no_prune) && (t < T) && (lo[(size_t)tile * T + t] - margin >= top);
-        // ballot through LDS (keeps the kernel free of wave intrinsics the host emulation lacks)
-        if (lane == 0) s_pruned[w0] = 0ull;
-        __syncthreads();
-        if (pr) atomicOr(&s_pruned[w0], 1ull << lane);
-        __syncthreads();
-    }
+    for (int t = lane; t < T; t += 64) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
+    __syncthreads();
     const int x = R.x0[0] + lane;
     const int rows = R.y1[0] - R.y0[0] + 1;
+    const bool active = x <= R.x1[0];
     double acc[CT_H];
 #pragma unroll
     for (int j = 0; j < CT_H; ++j) acc[j] = 0.0;
     for (int t = 0; t < T; ++t) {
-        bool pruned = (s_pruned[t >> 6] >> (t & 63)) & 1ull;
-        if (pruned) {
+        const int slot = s_slot[t];
+        if (slot == SLOT_PRUNED) {
 #pragma unroll
             for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + min_val;
+        } else if (slot >= 0) {
+            if (active) {
+                const double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
+                double v[CT_H];
+#pragma unroll
+                for (int j = 0; j < CT_H; ++j) v[j] = d[j * CT_W];
+#pragma unroll
+                for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
+            }
         } else {
             chain_to_level1(g, R, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
-            if (x <= R.x1[0]) {
+            if (active) {
                 double v[CT_H];
                 level0_column(g, R, lds, x, v);
 #pragma unroll
@@ -454,7 +515,7 @@ __global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, Chain
             __syncthreads();
         }
     }
-    if (x <= R.x1[0])
+    if (active)
 #pragma unroll
         for (int j = 0; j < CT_H; ++j)
             if (j < rows) heat_sum[(size_t)(R.y0[0] + j) * g.w[0] + x] = acc[j];
@@ -465,14 +526,14 @@ __global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, Chain
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_minmax_plain(const double *a, size_t n, CollapseState *st)
 {
-    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         double v = a[i];
         mn = (v < mn) ? v : mn;
         mx = (v > mx) ? v : mx;
     }
-    mn = wave_min(mn); mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) {
+    block_minmax(mn, mx);
+    if (threadIdx.x == 0) {
         atomicMin(&st->min_key, f64_key(mn));
         atomicMax(&st->max_key, f64_key(mx));
     }
@@ -508,7 +569,7 @@ __global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int
 __global__ __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum, size_t npix, int T, double *heat,
                                                          CollapseState *st)
 {
-    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
     const double cnt = (double)T;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         double v = heat_sum[i] / cnt;
@@ -516,8 +577,8 @@ __global__ __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum,
         mn = (v < mn) ? v : mn;
         mx = (v > mx) ? v : mx;
     }
-    mn = wave_min(mn); mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) {
+    block_minmax(mn, mx);
+    if (threadIdx.x == 0) {
         atomicMin(&st->heat_min_key, f64_key(mn));
         atomicMax(&st->heat_max_key, f64_key(mx));
     }
@@ -526,14 +587,14 @@ __global__ __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum,
 // min/max of an existing heatmap (rm_heatmap_to_roi entry point)
 __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t npix, CollapseState *st)
 {
-    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         double v = heat[i];
         mn = (v < mn) ? v : mn;
         mx = (v > mx) ? v : mx;
     }
-    mn = wave_min(mn); mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) {
+    block_minmax(mn, mx);
+    if (threadIdx.x == 0) {
         atomicMin(&st->heat_min_key, f64_key(mn));
         atomicMax(&st->heat_max_key, f64_key(mx));
     }

@@ -62,6 +62,8 @@ def test_emu_eulerian_and_fused_calibrate_match_golden(emu, golden):
         assert np.array_equal(mm, mm2)                                 # fused == materialised min/max
         heat_np, mm3 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S), flags=1)
         assert np.array_equal(heat, heat_np) and np.array_equal(mm2, mm3)  # pruning never changes a bit
+        heat_ts, mm4 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S), flags=4)
+        assert np.array_equal(heat, heat_ts) and np.array_equal(mm2, mm4)  # value-store overflow path
         assert np.array_equal(np.average(masked, axis=0), heat)        # fused == materialised heatmap
 
 
@@ -102,3 +104,18 @@ def test_emu_contour_stage_matches_oracle(emu, oracle):
         ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
         assert np.array_equal(u8, ref_u8)
         assert roi == oracle.roi_from_heatmap_u8(ref_u8, 150)
+
+
+def test_emu_fused_down_chain_equals_per_level(emu):
+    """The marching fused pyrDown chain (rm_down_chain.h) must equal the per-level kernel bit for bit,
+    for every frame dtype, vector and scalar load paths, and many-strip / many-segment decompositions."""
+    rng = np.random.default_rng(3)
+    for dt in (np.float64, np.uint8, np.float32, np.float16):
+        for (T, H, W, L, S) in [(3, 64, 96, 4, 2), (2, 67, 131, 5, 3), (2, 48, 64, 3, 1), (2, 135, 240, 6, 4),
+                                (9, 32, 48, 4, 2), (2, 33, 47, 4, 2), (1, 200, 320, 7, 5)]:
+            v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
+            per_level, _ = emu.calibrate(v, 10.0, levels=L, skip=S, flags=2)
+            fused, _ = emu.calibrate(v, 10.0, levels=L, skip=S)
+            tiny, _ = emu.calibrate(v, 10.0, levels=L, skip=S, flags=8)
+            assert np.array_equal(fused, per_level), (dt, T, H, W, L, S)
+            assert np.array_equal(tiny, per_level), (dt, T, H, W, L, S)

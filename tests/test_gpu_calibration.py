@@ -92,6 +92,23 @@ def test_eulerian_golden_and_fused_equals_materialised(hip, golden):
             assert _rel(heat, g["avg%d" % i]) < 1e-11
             heat_np = dist.hip_calibrate(buf, fps, pyramid_levels=int(L), skip_levels_at_top=int(S), flags=1).cpu().numpy()
             assert np.array_equal(heat, heat_np)                      # pruning never changes a bit
+            heat_ts = dist.hip_calibrate(buf, fps, pyramid_levels=int(L), skip_levels_at_top=int(S), flags=4).cpu().numpy()
+            assert np.array_equal(heat, heat_ts)                      # value-store overflow path
+
+
+def test_fused_down_chain_equals_per_level(hip):
+    import torch
+    from respmon_amd import dist
+    rng = np.random.default_rng(3)
+    for dt in (np.float64, np.uint8, np.float32, np.float16):
+        for (T, H, W, L, S) in [(3, 64, 96, 4, 2), (2, 67, 131, 5, 3), (2, 135, 240, 6, 4), (9, 32, 48, 4, 2),
+                                (1, 200, 320, 7, 5), (16, 270, 480, 9, 4), (8, 360, 640, 4, 2)]:
+            v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
+            buf = torch.from_numpy(v).cuda()
+            kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+            per_level = dist.hip_calibrate(buf, 10, flags=2, **kw)
+            assert torch.equal(dist.hip_calibrate(buf, 10, **kw), per_level), (dt, T, H, W, L, S)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=8, **kw), per_level), (dt, T, H, W, L, S)
 
 
 def test_locate_golden_roi_bit_exact(hip, golden):
@@ -144,6 +161,7 @@ def test_full_size_properties_1080p(hip, oracle):
     assert torch.equal(heat, heat_u8in)                       # uint8 ingest == float64 buffer, bit for bit
     heat_np = dist.hip_calibrate(buf, 10, flags=1)
     assert torch.equal(heat, heat_np)                         # pruned == exhaustive, bit for bit
+    assert torch.equal(heat, dist.hip_calibrate(buf, 10, flags=2))   # fused pyrDown chain == per-level kernels
     assert torch.equal(heat, dist.hip_calibrate(buf, 10))     # deterministic
     roi = dist.hip_heatmap_to_roi(heat, 20)
     # the host contour stage against the oracle's, on the GPU's own heatmap
