@@ -447,22 +447,48 @@ extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, 
 // ------------------------------------------------------------------------------------------
 // fused Gaussian chain (rm_down_chain.h)
 // ------------------------------------------------------------------------------------------
-template <typename Tin>
-static int launch_down_chain_t(const void *frames, int T, const DownGeom &g, double *out, hipStream_t s)
+template <typename Tin, bool VB>
+static int launch_down_chain_g(const Tin *f, int T, const DownGeom &g, double *out, hipStream_t s)
 {
     const size_t fs = (size_t)g.h[0] * g.w[0];
     const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g.strips * g.segs);
-    const size_t shmem = sizeof(double) * (size_t)g.lds_total;
-    const Tin *f = (const Tin *)frames;
+#define RM_DC_CASE(SS)                                                                                         \
+    case SS:                                                                                                   \
+        hipLaunchKernelGGL((k_down_chain<Tin, SS, VB>), dim3(grid), dim3(64), (sizeof(double) * down_chain_lds_doubles<Tin, SS>()), s, \
+                           f, fs, g, out);                                                                     \
+        break;
     switch (g.S) {
-    case 1: hipLaunchKernelGGL((k_down_chain<Tin, 1>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
-    case 2: hipLaunchKernelGGL((k_down_chain<Tin, 2>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
-    case 3: hipLaunchKernelGGL((k_down_chain<Tin, 3>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
-    case 4: hipLaunchKernelGGL((k_down_chain<Tin, 4>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
-    case 5: hipLaunchKernelGGL((k_down_chain<Tin, 5>), dim3(grid), dim3(64), shmem, s, f, fs, g, out); break;
+        RM_DC_CASE(1) RM_DC_CASE(2) RM_DC_CASE(3) RM_DC_CASE(4) RM_DC_CASE(5)
     default: return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", g.S);
     }
+#undef RM_DC_CASE
     LAUNCH_CHECK();
+    return RM_OK;
+}
+
+// interior rows with the lean instantiation, the thin top / bottom bands with the generic one
+template <typename Tin>
+static int launch_down_chain_t(const void *frames, int T, const std::vector<int> &h, const std::vector<int> &w, int S, int vec_ok,
+                               double *out, hipStream_t s, bool tiny)
+{
+    const Tin *f = (const Tin *)frames;
+    int y0, y1;
+    down_chain_interior(S, h.data(), &y0, &y1);
+    if (y1 - y0 < 4) { y0 = 0; y1 = 0; }  // image too small for a lean region: everything generic
+    DownGeom g;
+    if (y1 > y0) {
+        if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, y0, y1, g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+        RM_TRY((launch_down_chain_g<Tin, false>(f, T, g, out, s)));
+        if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, y0, g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+        RM_TRY((launch_down_chain_g<Tin, true>(f, T, g, out, s)));
+        if (y1 < h[S]) {
+            if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, y1, h[S], g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+            RM_TRY((launch_down_chain_g<Tin, true>(f, T, g, out, s)));
+        }
+    } else {
+        if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+        RM_TRY((launch_down_chain_g<Tin, true>(f, T, g, out, s)));
+    }
     return RM_OK;
 }
 
@@ -476,13 +502,13 @@ static int launch_down_chain(const void *frames, int dtype, int T, const std::ve
     const int V = dtype_vec(dtype);
     const size_t esz = dtype_size(dtype);
     const bool vec_ok = (w[0] % V == 0) && (((size_t)h[0] * w[0] * esz) % 16 == 0) && (((uintptr_t)frames) % 16 == 0);
-    DownGeom g;
-    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok ? 1 : 0, V, g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+    if (S < 1 || S > 5) return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", S);
+    const int vo = vec_ok ? 1 : 0;
     switch (dtype) {
-    case RM_U8: return launch_down_chain_t<uint8_t>(frames, T, g, out, s);
-    case RM_F16: return launch_down_chain_t<__half>(frames, T, g, out, s);
-    case RM_F32: return launch_down_chain_t<float>(frames, T, g, out, s);
-    case RM_F64: return launch_down_chain_t<double>(frames, T, g, out, s);
+    case RM_U8: return launch_down_chain_t<uint8_t>(frames, T, h, w, S, vo, out, s, tiny);
+    case RM_F16: return launch_down_chain_t<__half>(frames, T, h, w, S, vo, out, s, tiny);
+    case RM_F32: return launch_down_chain_t<float>(frames, T, h, w, S, vo, out, s, tiny);
+    case RM_F64: return launch_down_chain_t<double>(frames, T, h, w, S, vo, out, s, tiny);
     }
     return fail(RM_E_BADARG, "unknown dtype %d", dtype);
 }

@@ -3,39 +3,106 @@
 //
 // The frame buffer is read from HBM exactly once; levels 1..S-1 never leave the CU.
 //
-// Decomposition: one single-wave workgroup owns (frame, strip of level-S columns, segment of level-S
-// rows) and MARCHES down the input rows.  Per level k it keeps in LDS one row buffer and a 5-row ring
-// of horizontally filtered rows; whenever rows 2y-2..2y+2 of level k are in the ring, row y of level
-// k+1 is produced by the vertical pass and pushed down the cascade (template recursion over levels).
-// Nothing is recomputed vertically; horizontally a strip re-filters its halo (2^(S+1)-2 columns/side).
-// Operation order per output is OpenCV's (horizontal 5-tap then vertical 5-tap), so
-// the result is bit-identical to the per-level kernel and to the CPU oracle.
+// Decomposition: one single-wave workgroup owns (frame, strip of SW level-S columns, segment of
+// level-S rows) and MARCHES down the input rows.  Per level k it keeps one row buffer in LDS (for the
+// horizontal taps, which cross lanes) and the 5 most recent horizontally filtered rows in REGISTERS
+// (each lane owns fixed columns, so the vertical pass needs no memory at all); whenever rows
+// 2y-2..2y+2 of level k are in the ring, row y of level k+1 is produced by the vertical pass and
+// pushed down the cascade (template recursion over levels).  Nothing is recomputed vertically; horizontally a strip re-filters its halo
+// (2^(S+1)-2 input columns per side).  Operation order per output is OpenCV's (horizontal 5-tap then
+// vertical 5-tap): bit-identical to the per-level kernel and to the CPU oracle.
 //
-// LDS layout: row buffers are de-interleaved (even columns | odd columns) so the stride-2 taps of the
-// horizontal pass are unit-stride, bank-conflict-free ds_read_b64.  Global loads are 16 B per lane,
-// coalesced, software-prefetched DC_PREFETCH rows ahead in registers.  Workgroups are mapped so that
-// all strips/segments of a frame run on one XCD (blockIdx % 8), sharing halo lines in that XCD's L2.
+// Leanness (the kernel is issue-bound before it is HBM-bound): the LDS layout is a compile-time
+// function of (S, SW), every lane owns fixed elements of every level, row buffers are
+// de-interleaved (even | odd columns) so the stride-2 taps are unit-stride conflict-free
+// ds_read_b64 at immediate offsets from one per-lane base, and image borders are handled by writing
+// the two reflected columns next to the row (as OpenCV does) so the tap code has no border branch.
+// Global loads are 16 B per lane, coalesced, software-prefetched DC_PREFETCH rows ahead in registers.
+// Workgroups of one frame are placed on one XCD (blockIdx % 8) so halo lines are shared in its L2.
 #pragma once
 #include "rm_kernels.h"
 
 namespace rm {
 
-constexpr int DC_PREFETCH = 4;   // rows in flight per wave
-constexpr int DC_MAX_LOADS = 3;  // 16-byte lane-loads per lane per row (strip width <= 64*3*V pixels)
+#ifndef RM_DC_PREFETCH
+#define RM_DC_PREFETCH 2
+#endif
+constexpr int DC_PREFETCH = RM_DC_PREFETCH;  // input rows in flight per wave
 
 struct DownGeom {
     int S;
     int h[MAX_CHAIN], w[MAX_CHAIN];  // level sizes, 0 = input
-    int strip_w, seg_h;              // strip / segment size in level-S columns / rows
+    int seg_h;                       // segment size in level-S rows
+    int y_begin, y_end;              // level-S rows [y_begin, y_end) covered by this launch
     int strips, segs;                // per frame
-    int half[MAX_CHAIN];             // half-length (doubles) of the de-interleaved row buffer of level k
-    int rowbuf_off[MAX_CHAIN];       // LDS offsets (doubles), k = 0..S-1
-    int ring_off[MAX_CHAIN];
-    int ring_pitch[MAX_CHAIN];       // >= width of the level k+1 column range
-    int lds_total;
     int T;
     int vec;                         // 1: 16-byte aligned vector loads are legal for this buffer
 };
+
+// compile-time strip width (level-S columns) per chain depth: level-0 span stays <= ~380 pixels
+#ifndef RM_DC_SW4
+#define RM_DC_SW4 20
+#endif
+template <int S> struct StripWidth;
+template <> struct StripWidth<1> { static constexpr int SW = 160; };
+template <> struct StripWidth<2> { static constexpr int SW = 88; };
+template <> struct StripWidth<3> { static constexpr int SW = 44; };
+template <> struct StripWidth<4> { static constexpr int SW = RM_DC_SW4; };
+template <> struct StripWidth<5> { static constexpr int SW = 8; };
+
+constexpr int dc_max(int a, int b) { return a > b ? a : b; }
+
+template <int S, int SW, int V> struct DCLayout {
+    static constexpr int width(int k) { int w = SW; for (int i = S; i > k; --i) w = 2 * w + 3; return w; }
+    static constexpr int nq(int k) { return (width(k) + 63) / 64; }  // elements per lane at level k
+    static constexpr int nl() { return (width(0) + 2 * (V - 1) + V - 1) / V / 64 + 1; }  // 16-byte lane-loads per lane per row
+    // de-interleaved row buffer of level k: columns [c0-2, c0-2+2*half) ; even | odd halves.  Sized so that
+    // every lane may run every tap / store unmasked (lanes beyond the strip compute garbage nobody reads).
+    static constexpr int half(int k)
+    {
+        return dc_max(dc_max((width(k) + 8) / 2 + 2, 64 * nq(k + 1) + 4), k == 0 ? 32 * nl() * V + 4 : 32 * nq(k) + 4);
+    }
+    static constexpr int rowbuf_size(int k) { return 2 * half(k); }
+    static constexpr int rowbuf_off(int k) { int o = 0; for (int i = 0; i < k; ++i) o += rowbuf_size(i); return o; }
+    static constexpr int total() { return rowbuf_off(S); }
+};
+
+// LDS hand-off between the lanes of ONE wave: the LDS executes a wave's DS instructions in order, so a
+// read issued after a write sees it; only the compiler must be kept from reordering them.  (The host
+// emulation models lanes as fibers and needs a real barrier.)
+__device__ __forceinline__ void wave_sync()
+{
+#ifdef RM_HIPEMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// whole-wave shift by one lane (DPP wave_shr:1 / wave_shl:1): lane i receives lane i-1 / i+1;
+// the end lane keeps its own value (callers never use it)
+__device__ __forceinline__ double wave_from_prev(double v)
+{
+#ifdef RM_HIPEMU
+    return __shfl_up(v, 1);
+#else
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+#endif
+}
+__device__ __forceinline__ double wave_from_next(double v)
+{
+#ifdef RM_HIPEMU
+    return __shfl_down(v, 1);
+#else
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+#endif
+}
 
 template <typename Tin> struct VecTraits;
 template <> struct VecTraits<double> { static constexpr int V = 2; };
@@ -70,153 +137,360 @@ template <> __device__ __forceinline__ double unpack_px<uint8_t>(const Raw16 &r,
     return (double)((wd >> (8 * (e & 3))) & 0xffu) * (1.0 / 255);  // uint8_to_float, transforms.py:20-23
 }
 
-template <typename Tin, int S>
+// Vertical-pass state of level K for this lane's columns, in REGISTERS.  The 5-tap vertical filter
+//   out[y] = ((r[2y]*6 + (r[2y-1] + r[2y+1])*4) + r[2y-2]) + r[2y+2]      (OpenCV's operation order)
+// is evaluated as rows stream by: on odd row 2y+1 the partial t = (c*6 + (b + n)*4) + a is formed, on
+// even row 2y+2 the output is t + n.  Only (a, b, c, t) are live per column -- no 5-row ring, no shifting.
+template <typename LL, int S, int K> struct VState : VState<LL, S, K + 1> {
+    double a[LL::nq(K + 1)], b[LL::nq(K + 1)], c[LL::nq(K + 1)], t[LL::nq(K + 1)];
+};
+template <typename LL, int S> struct VState<LL, S, S> {};
+
+// VB = false: the launch covers only level-S rows whose whole dependency cone stays inside the image
+// vertically, so the streaming vertical pass has a single, branch-free form (the hot instantiation);
+// VB = true: generic form with BORDER_REFLECT_101 on the row index (thin bands at the image top / bottom).
+template <typename Tin, int S, bool VB>
 struct DownChain {
+    static constexpr int SW = StripWidth<S>::SW;
+    static constexpr int V = VecTraits<Tin>::V;
+    using L = DCLayout<S, SW, V>;
+    static constexpr int NL = L::nl();
+
     const DownGeom &g;
     double *lds;
     const int lane;
     int cx0[S + 1], cx1[S + 1];  // column range of each level held by this strip (inclusive, clamped)
-    int c0[S];                   // even-aligned base column of row buffer k
+    int c0[S];                   // even (level 0: vector-aligned) base column of row buffer k
     int next[S + 1], last[S + 1];
-    int slot[S];                 // ring slot of the row being pushed at level k (row % 5)
+    const double *tap[S];        // per-lane LDS address of the centre tap of this lane's first column, level k
+    double *rowdst[S];           // per-lane LDS address of this lane's first column in row buffer k (k >= 1)
+    int border_src[S], border_dst[S];  // lanes 0..3: reflected-column copy of level k (-1: not this lane)
+    bool has_border[S];
     double *out_frame;           // G_S of this frame
+    int col1_lane;               // level-1 column of this lane's q = 0 element
+    int q1;                      // level-1 columns between consecutive q (64; 62 on the register/DPP front end)
+    bool lane_ok1;               // this lane's level-1 elements are real (DPP front end: lanes 1..62)
+    VState<L, S, 0> vs;
 
     __device__ __forceinline__ DownChain(const DownGeom &g_, double *lds_) : g(g_), lds(lds_), lane(threadIdx.x) {}
 
-    __device__ __forceinline__ int rb_index(int k, int c) const
+    // index of column c inside row buffer K (columns c0-2 .. are stored de-interleaved)
+    template <int K> __device__ __forceinline__ int rb_index(int c) const
     {
-        int i = c - c0[k];
-        return g.rowbuf_off[k] + (i >> 1) + (i & 1) * g.half[k];
+        int i = c - c0[K] + 2;
+        return L::rowbuf_off(K) + (i >> 1) + (i & 1) * L::half(K);
     }
 
-    // horizontal 5-tap at level K for output column x of level K+1 (unnormalised)
-    template <int K> __device__ __forceinline__ double hfilter(int x) const
+    // OpenCV-style border: write the two reflected columns beside the row so taps never branch
+    template <int K> __device__ __forceinline__ void make_border()
     {
-        const int c = 2 * x, wk = g.w[K];
-        if (c - 2 >= 0 && c + 2 < wk) {
-            const double *ev = lds + g.rowbuf_off[K] + ((c - c0[K]) >> 1);
-            const double *od = ev + g.half[K];
-            return ev[0] * 6 + (od[-1] + od[0]) * 4 + ev[-1] + ev[1];
+        if (has_border[K]) {
+            if (border_dst[K] >= 0) lds[border_dst[K]] = lds[border_src[K]];
         }
-        double m2 = lds[rb_index(K, reflect101(c - 2, wk))], m1 = lds[rb_index(K, reflect101(c - 1, wk))];
-        double p1 = lds[rb_index(K, reflect101(c + 1, wk))], p2 = lds[rb_index(K, reflect101(c + 2, wk))];
-        return lds[rb_index(K, reflect101(c, wk))] * 6 + (m1 + p1) * 4 + m2 + p2;
     }
 
-    // level-K row p sits in row buffer K: filter it into the ring, fire every level K+1 row that became
-    // computable, and cascade
-    template <int K> __device__ __forceinline__ void push(int p)
+    // horizontal 5-tap of the row in buffer K for this lane's columns (unnormalised, like OpenCV's row pass)
+    template <int K> __device__ __forceinline__ void taps(double (&n)[L::nq(K + 1)])
     {
-        const int sl = slot[K];
-        slot[K] = (sl == 4) ? 0 : sl + 1;
-        {
-            double *ring = lds + g.ring_off[K] + sl * g.ring_pitch[K];
-            for (int x = cx0[K + 1] + lane; x <= cx1[K + 1]; x += 64) ring[x - cx0[K + 1]] = hfilter<K>(x);
+        const double *ev = tap[K];
+#pragma unroll
+        for (int q = 0; q < L::nq(K + 1); ++q) {
+            const double *e = ev + 64 * q;
+            const double *o = e + L::half(K);
+            n[q] = e[0] * 6 + (o[-1] + o[0]) * 4 + e[-1] + e[1];
         }
-        __syncthreads();
+    }
+
+    // row y of level K+1 is complete: store it (G_S) or hand it to the next level of the cascade
+    template <int K> __device__ __forceinline__ void emit(int y, const double (&v)[L::nq(K + 1)])
+    {
+        next[K + 1] = y + 1;
+        const int qs = (K == 0) ? q1 : 64;                       // columns between this lane's consecutive elements
+        const bool ok = (K == 0) ? lane_ok1 : true;
+        if constexpr (K + 1 == S) {
+            const int col = ((K == 0) ? col1_lane : cx0[S] + lane);
+#pragma unroll
+            for (int q = 0; q < L::nq(K + 1); ++q) {
+                const int cq = col + qs * q;
+                if (ok && cq >= cx0[S] && cq <= cx1[S]) out_frame[(size_t)y * g.w[S] + cq] = v[q] * (1.0 / 256);
+            }
+        } else {
+            if (ok) {
+#pragma unroll
+                for (int q = 0; q < L::nq(K + 1); ++q) rowdst[K + 1][(qs >> 1) * q] = v[q] * (1.0 / 256);  // +qs columns: same parity
+            }
+            wave_sync();
+            make_border<K + 1>();
+            wave_sync();
+            double n[L::nq(K + 2)];
+            taps<K + 1>(n);
+            wave_sync();  // row buffer K+1 is free again
+            step<K + 1>(y, n);
+        }
+    }
+
+    // feed the horizontally filtered row p of level K (values n) into the streaming vertical pass.
+    // There is exactly ONE emit site per level (the cascade below it is inlined once).
+    template <int K> __device__ __forceinline__ void step(int p, const double (&n)[L::nq(K + 1)])
+    {
+        constexpr int NQ = L::nq(K + 1);
+        VState<L, S, K> &st = vs;
+        if constexpr (!VB) {
+            if (p & 1) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    st.t[q] = (st.c[q] * 6 + (st.b[q] + n[q]) * 4) + st.a[q];
+                    st.a[q] = st.c[q]; st.b[q] = n[q];
+                }
+            } else {
+                const int y = (p >> 1) - 1;
+                if (y == next[K + 1] && y <= last[K + 1]) {
+                    double v[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) v[q] = st.t[q] + n[q];
+                    emit<K>(y, v);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) st.c[q] = n[q];
+            }
+            return;
+        }
         const int hk = g.h[K];
-        while (next[K + 1] <= last[K + 1]) {
-            const int y = next[K + 1];
-            const int need = (2 * y + 2 < hk - 1) ? 2 * y + 2 : hk - 1;
-            if (need > p) break;
-            next[K + 1] = y + 1;
-            // ring slot of physical row r: rows are pushed consecutively, row p is in slot sl
-            int s0, s1, s2, s3, s4;
-            {
-                auto slot_of_row = [&](int r) { int d = (p - r) % 5; int q = sl - d; return q < 0 ? q + 5 : q; };
-                s0 = slot_of_row(reflect101(2 * y - 2, hk));
-                s1 = slot_of_row(reflect101(2 * y - 1, hk));
-                s2 = slot_of_row(reflect101(2 * y, hk));
-                s3 = slot_of_row(reflect101(2 * y + 1, hk));
-                s4 = slot_of_row(reflect101(2 * y + 2, hk));
+        const bool odd = (p & 1) != 0;
+        const bool lastrow = p == hk - 1;
+        if (hk > 2 && odd) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) st.t[q] = (st.c[q] * 6 + (st.b[q] + n[q]) * 4) + st.a[q];
+        }
+        if (hk <= 2) {
+            // degenerate level: the single output row reflects everything onto rows 0 (and 1)
+            if (p == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { st.a[q] = n[q]; st.b[q] = n[q]; st.c[q] = n[q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) st.b[q] = n[q];
             }
-            const double *rbase = lds + g.ring_off[K];
-            const int pitch = g.ring_pitch[K];
-            for (int x = cx0[K + 1] + lane; x <= cx1[K + 1]; x += 64) {
-                const int i = x - cx0[K + 1];
-                double v = (rbase[s2 * pitch + i] * 6 + (rbase[s1 * pitch + i] + rbase[s3 * pitch + i]) * 4 +
-                            rbase[s0 * pitch + i] + rbase[s4 * pitch + i]) * (1.0 / 256);
-                if constexpr (K + 1 == S) out_frame[(size_t)y * g.w[S] + x] = v;
-                else lds[rb_index(K + 1, x)] = v;
+        }
+        // which output rows complete with this input row?  (at most two: the odd-height bottom case)
+        //   kind 0: steady state   v = t + n               (even p, y = p/2 - 1 >= 1)
+        //   kind 1: image top      v = ((a*6+(b+b)*4)+n)+n (even p, y = 0)
+        //   kind 2: even-h bottom  v = t + c               (odd  p = h-1, y = (p-1)/2)
+        //   kind 3: odd-h bottom   v = ((n*6+(b+b)*4)+a)+a (even p = h-1, y = p/2), after kind 0/1 of the same row
+        //   kind 4: degenerate     v = ((a*6+(b+b)*4)+c)+c (h <= 2, p = h-1, y = 0)
+#pragma nounroll
+        for (int rep = 0; rep < 2; ++rep) {
+            int kind = -1, y = 0;
+            if (hk <= 2) { if (rep == 0 && lastrow) { kind = 4; y = 0; } }
+            else if (odd) { if (rep == 0 && lastrow) { kind = 2; y = (p - 1) >> 1; } }
+            else if (rep == 0) { if (p >= 2) { y = (p >> 1) - 1; kind = (y == 0) ? 1 : 0; } }
+            else if (lastrow) { kind = 3; y = p >> 1; }
+            if (kind < 0 || y != next[K + 1] || y > last[K + 1]) continue;
+            double v[NQ];
+            if (kind == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v[q] = st.t[q] + n[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const double t = st.t[q], a = st.a[q], b = st.b[q], c = st.c[q], m = n[q];
+                    double r = ((a * 6 + (b + b) * 4) + c) + c;             // kind 4
+                    if (kind == 1) r = ((a * 6 + (b + b) * 4) + m) + m;
+                    if (kind == 2) r = t + c;
+                    if (kind == 3) r = ((m * 6 + (b + b) * 4) + a) + a;
+                    v[q] = r;
+                }
             }
-            __syncthreads();
-            if constexpr (K + 1 < S) push<K + 1>(y);
+            emit<K>(y, v);
+        }
+        if (hk > 2) {
+            if (odd) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { st.a[q] = st.c[q]; st.b[q] = n[q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) st.c[q] = n[q];
+            }
         }
     }
 
-    __device__ __forceinline__ void run(const Tin *frame, double *out_t, int strip, int seg)
+    template <int K> __device__ __forceinline__ void setup_level()
     {
-        constexpr int V = VecTraits<Tin>::V;
-        out_frame = out_t;
-        // ranges, from level S back to 0
-        cx0[S] = strip * g.strip_w; cx1[S] = min(cx0[S] + g.strip_w, g.w[S]) - 1;
-        next[S] = seg * g.seg_h; last[S] = min(next[S] + g.seg_h, g.h[S]) - 1;
-#pragma unroll
-        for (int k = S - 1; k >= 0; --k) {
-            cx0[k] = max(0, 2 * cx0[k + 1] - 2); cx1[k] = min(g.w[k] - 1, 2 * cx1[k + 1] + 2);
-            next[k] = max(0, 2 * next[k + 1] - 2); last[k] = min(g.h[k] - 1, 2 * last[k + 1] + 2);
-            c0[k] = cx0[k] & ~1;
-            slot[k] = 0;
+        const int wk = g.w[K];
+        tap[K] = lds + L::rowbuf_off(K) + (((2 * cx0[K + 1] - c0[K] + 2) >> 1) + lane);
+        if constexpr (K >= 1) rowdst[K] = lds + rb_index<K>(K == 1 ? col1_lane : cx0[K] + lane);
+        const bool left = cx0[K] == 0, right = cx1[K] == wk - 1;
+        has_border[K] = left || right;
+        border_src[K] = 0; border_dst[K] = -1;
+        if (lane < 4) {
+            const bool is_left = lane < 2;
+            const int c = is_left ? lane - 2 : wk + lane - 2;
+            if (is_left ? left : right) { border_dst[K] = rb_index<K>(c); border_src[K] = rb_index<K>(reflect101(c, wk)); }
         }
-        const bool vec = g.vec != 0;
-        if (vec) c0[0] = cx0[0] & ~(V - 1);
-        const int W = g.w[0];
-        const int nload = vec ? (cx1[0] - c0[0] + V) / V : 0;  // lane-loads per row (vector path)
+        if constexpr (K + 1 < S) setup_level<K + 1>();
+    }
 
-        auto issue = [&](int row, Raw16 (&r)[DC_MAX_LOADS]) {
-            const Tin *src = frame + (size_t)row * W + c0[0];
+    // ---- level-0 front end A (float64, 16-byte aligned rows): horizontal pass in REGISTERS ---------------
+    // A lane-load is two adjacent pixels (a = s[c], b = s[c+1], c even); the 5 taps of output column c/2 are
+    //   s[c]*6 + (s[c-1] + s[c+1])*4 + s[c-2] + s[c+2] = a*6 + (b_prev + b)*4 + a_prev + a_next
+    // with a_prev, b_prev, a_next taken from the neighbouring lanes by DPP wave shifts: no LDS, no waits.
+    // Chunk q covers columns P + 124*q + [0,128): consecutive chunks overlap by two lanes so that lanes
+    // 1..62 of every chunk own 62 consecutive level-1 columns and lanes 0 / 63 only provide halo.
+    __device__ __forceinline__ void run_dpp(const Tin *frame, int p_first, int p_last)
+    {
+        constexpr int NQ1 = L::nq(1);
+        const int W = g.w[0];
+        const int P = 2 * cx0[1] - 2;  // first column of chunk 0 (-2 at the left image border)
+        const bool fix_l = cx0[0] == 0, fix_r = cx1[0] == W - 1;
+        const Tin *lane_src[NQ1];
 #pragma unroll
-            for (int q = 0; q < DC_MAX_LOADS; ++q) {
-                int j = lane + 64 * q;
-                if (j < nload) r[q] = *reinterpret_cast<const Raw16 *>(src + (size_t)j * V);
+        for (int q = 0; q < NQ1; ++q) lane_src[q] = frame + min(max(P + 124 * q + 2 * lane, 0), W - 2);
+        auto issue = [&](int row, Raw16 (&r)[NQ1]) __attribute__((always_inline)) {
+#ifdef RM_DC_SAMEROW  // developer experiment: every load hits the same (cached) row
+            row = p_first;
+#endif
+            const size_t ro = (size_t)row * W;
+#pragma unroll
+            for (int q = 0; q < NQ1; ++q) r[q] = *reinterpret_cast<const Raw16 *>(lane_src[q] + ro);
+        };
+        // BORDER_REFLECT_101 on the column index: only chunks that contain slots outside the image need it
+        // (chunk 0 at the left image edge, the chunk(s) holding columns W, W+1 at the right edge).  Per lane
+        // and flagged chunk one packed word is precomputed: source lane and component for a and for b.
+        unsigned fixq = 0;       // bit q: chunk q has out-of-image slots (wave-uniform)
+        int fixw[NQ1];           // per lane: bits 0-5 src lane of a, 6 src comp, 7 fix a; 8-13 / 14 / 15 the same for b
+#pragma unroll
+        for (int q = 0; q < NQ1; ++q) {
+            const int base = P + 124 * q;
+            fixw[q] = 0;
+            if ((fix_l && base < 0) || (fix_r && base + 127 >= W)) {
+                fixq |= 1u << q;
+                const int ca = base + 2 * lane, cb = ca + 1;
+                const int ra = reflect101(ca, W) - base, rb = reflect101(cb, W) - base;
+                fixw[q] = ((ra >> 1) & 63) | ((ra & 1) << 6) | ((ca < 0 || ca >= W) ? 0x80 : 0) |
+                          (((rb >> 1) & 63) << 8) | ((rb & 1) << 14) | ((cb < 0 || cb >= W) ? 0x8000 : 0);
+            }
+        }
+        auto hrow = [&](const Raw16 (&r)[NQ1], double (&n)[NQ1]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NQ1; ++q) {
+                double a = unpack_px<Tin>(r[q], 0), b = unpack_px<Tin>(r[q], 1);
+                if (fixq & (1u << q)) {
+                    const int fw = fixw[q];
+                    const double a_from_a = __shfl(a, fw & 63), a_from_b = __shfl(b, fw & 63);
+                    const double b_from_a = __shfl(a, (fw >> 8) & 63), b_from_b = __shfl(b, (fw >> 8) & 63);
+                    if (fw & 0x80) a = (fw & 0x40) ? a_from_b : a_from_a;
+                    if (fw & 0x8000) b = (fw & 0x4000) ? b_from_b : b_from_a;
+                }
+                const double a_prev = wave_from_prev(a), b_prev = wave_from_prev(b), a_next = wave_from_next(a);
+                n[q] = a * 6 + (b_prev + b) * 4 + a_prev + a_next;
             }
         };
-        auto stash = [&](const Raw16 (&r)[DC_MAX_LOADS]) {
+        Raw16 regs[DC_PREFETCH][NQ1];
 #pragma unroll
-            for (int q = 0; q < DC_MAX_LOADS; ++q) {
-                int j = lane + 64 * q;
-                if (j < nload) {
-                    double *ev = lds + g.rowbuf_off[0] + (j * V) / 2;
-                    double *od = ev + g.half[0];
+        for (int i = 0; i < DC_PREFETCH; ++i) issue(min(p_first + i, p_last), regs[i]);
+        for (int base = p_first; base <= p_last; base += DC_PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < DC_PREFETCH; ++i) {
+                const int p = base + i;
+                if (p <= p_last) {
+                    double n[NQ1];
+                    hrow(regs[i], n);
+                    issue(min(p + DC_PREFETCH, p_last), regs[i]);
+                    step<0>(p, n);
+                }
+            }
+        }
+    }
+
+    // ---- level-0 front end B (any dtype / alignment): rows staged through the LDS row buffer ---------------
+    __device__ __forceinline__ void run_lds(const Tin *frame, int p_first, int p_last, bool vec)
+    {
+        const int W = g.w[0];
+        auto consume = [&](int p) __attribute__((always_inline)) {
+            wave_sync();
+            make_border<0>();
+            wave_sync();
+            double n[L::nq(1)];
+            taps<0>(n);
+            wave_sync();  // the row buffer is free again
+            step<0>(p, n);
+        };
+        if (vec) {
+            // lane-load j covers columns c0 + j*V ..; lanes past the strip re-load its last chunk (no exec masking)
+            const int nload = (cx1[0] - c0[0] + V) / V;
+            const Tin *lane_src[NL];
+#pragma unroll
+            for (int q = 0; q < NL; ++q) lane_src[q] = frame + c0[0] + (size_t)min(lane + 64 * q, nload - 1) * V;
+            auto issue = [&](int row, Raw16 (&r)[NL]) __attribute__((always_inline)) {
+                const size_t ro = (size_t)row * W;
+#pragma unroll
+                for (int q = 0; q < NL; ++q) r[q] = *reinterpret_cast<const Raw16 *>(lane_src[q] + ro);
+            };
+            // column c0 + j*V + e sits at buffer index j*V + e + 2: even half (j*V)/2 + e/2 + 1
+            double *ev0 = lds + L::rowbuf_off(0) + (lane * V) / 2 + 1;
+            auto stash = [&](const Raw16 (&r)[NL]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < NL; ++q) {
+                    double *ev = ev0 + (64 * q * V) / 2;
+                    double *od = ev + L::half(0);
 #pragma unroll
                     for (int e = 0; e < V; e += 2) {
                         ev[e >> 1] = unpack_px<Tin>(r[q], e);
                         od[e >> 1] = unpack_px<Tin>(r[q], e + 1);
                     }
                 }
-            }
-        };
-
-        const int p_first = next[0], p_last = last[0];
-        if (vec) {
-            Raw16 regs[DC_PREFETCH][DC_MAX_LOADS];
+            };
+            Raw16 regs[DC_PREFETCH][NL];
 #pragma unroll
-            for (int i = 0; i < DC_PREFETCH; ++i)
-                if (p_first + i <= p_last) issue(p_first + i, regs[i]);
+            for (int i = 0; i < DC_PREFETCH; ++i) issue(min(p_first + i, p_last), regs[i]);
             for (int base = p_first; base <= p_last; base += DC_PREFETCH) {
 #pragma unroll
                 for (int i = 0; i < DC_PREFETCH; ++i) {
                     const int p = base + i;
                     if (p <= p_last) {
                         stash(regs[i]);
-                        if (p + DC_PREFETCH <= p_last) issue(p + DC_PREFETCH, regs[i]);
-                        __syncthreads();
-                        push<0>(p);
+                        issue(min(p + DC_PREFETCH, p_last), regs[i]);
+                        consume(p);
                     }
                 }
             }
         } else {
             for (int p = p_first; p <= p_last; ++p) {
                 const Tin *src = frame + (size_t)p * W;
-                for (int c = cx0[0] + lane; c <= cx1[0]; c += 64) lds[rb_index(0, c)] = load_px(src, (size_t)c);
-                __syncthreads();
-                push<0>(p);
+                for (int c = cx0[0] + lane; c <= cx1[0]; c += 64) lds[rb_index<0>(c)] = load_px(src, (size_t)c);
+                consume(p);
             }
         }
     }
+
+    __device__ __forceinline__ void run(const Tin *frame, double *out_t, int strip, int seg)
+    {
+        // ranges, from level S back to 0
+        cx0[S] = strip * SW; cx1[S] = min(cx0[S] + SW, g.w[S]) - 1;
+        next[S] = g.y_begin + seg * g.seg_h; last[S] = min(next[S] + g.seg_h, g.y_end) - 1;
+#pragma unroll
+        for (int k = S - 1; k >= 0; --k) {
+            cx0[k] = max(0, 2 * cx0[k + 1] - 2); cx1[k] = min(g.w[k] - 1, 2 * cx1[k + 1] + 2);
+            next[k] = max(0, 2 * next[k + 1] - 2); last[k] = min(g.h[k] - 1, 2 * last[k + 1] + 2);
+            c0[k] = cx0[k] & ~1;
+        }
+        const bool vec = g.vec != 0;
+        constexpr bool kF64 = (V == 2);
+        const bool dpp = kF64 && vec;
+        if (vec) c0[0] = cx0[0] & ~(V - 1);
+        q1 = dpp ? 62 : 64;
+        col1_lane = dpp ? (cx0[1] - 1 + lane) : (cx0[1] + lane);
+        lane_ok1 = dpp ? (lane >= 1 && lane <= 62) : true;
+        out_frame = out_t;
+        setup_level<0>();
+        if constexpr (kF64) {
+            if (dpp) { run_dpp(frame, next[0], last[0]); return; }
+        }
+        run_lds(frame, next[0], last[0], vec);
+    }
 };
 
-template <typename Tin, int S>
+template <typename Tin, int S, bool VB>
 __global__ __launch_bounds__(64) void k_down_chain(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
 {
     HIP_DYNAMIC_SHARED(double, lds)
@@ -228,71 +502,48 @@ __global__ __launch_bounds__(64) void k_down_chain(const Tin *frames, size_t fra
     if (t >= g.T) return;
     const int inner = j % per_frame;
     const int seg = inner / g.strips, strip = inner - seg * g.strips;
-    DownChain<Tin, S> dc(g, lds);
+    DownChain<Tin, S, VB> dc(g, lds);
     dc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }
 
 // host-side geometry
-inline int down_chain_level0_width(int S, int strip_w)
-{
-    int w = strip_w;
-    for (int k = 0; k < S; ++k) w = 2 * w + 3;  // 2*(x1)+2 - (2*x0-2) + 1
-    return w;
-}
+template <typename Tin, int S> inline int down_chain_lds_doubles() { return DCLayout<S, StripWidth<S>::SW, VecTraits<Tin>::V>::total(); }
 
-constexpr int DC_LDS_BUDGET = 2304;  // doubles per wave (18 KB): >= 8 resident waves per CU
-
-inline void down_chain_layout(DownGeom &g, int V)
+// level-S row range [y0, y1) whose dependency cone needs no vertical border handling at any level
+inline void down_chain_interior(int S, const int *h, int *y0, int *y1)
 {
-    const int S = g.S;
-    int widths[MAX_CHAIN];
-    widths[S] = g.strip_w;
-    for (int k = S - 1; k >= 0; --k) widths[k] = 2 * widths[k + 1] + 3;
-    int off = 0;
-    for (int k = 0; k < S; ++k) {
-        int span = widths[k] + 2 + (k == 0 ? 2 * (V < 2 ? 2 : V) : 2);
-        g.half[k] = (span + 1) / 2 + 1;
-        g.rowbuf_off[k] = off; off += 2 * g.half[k];
-        g.ring_pitch[k] = widths[k + 1] + 1;
-        g.ring_off[k] = off; off += 5 * g.ring_pitch[k];
+    *y0 = 2; *y1 = 2;
+    for (int Y1 = h[S] - 1; Y1 >= 2; --Y1) {
+        bool ok = true;
+        long long last = Y1;
+        for (int k = S - 1; k >= 0 && ok; --k) { last = 2 * last + 2; if (last > h[k] - 1) ok = false; }
+        if (ok) { *y1 = Y1 + 1; break; }
     }
-    g.lds_total = off;
+    if (*y1 < *y0) *y1 = *y0;
 }
 
-inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok, int V, DownGeom &g, bool tiny = false)
+// geometry of one launch over level-S rows [y_begin, y_end)
+inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok, int y_begin, int y_end, DownGeom &g, bool tiny = false)
 {
-    if (S < 1 || S >= MAX_CHAIN) return false;
-    g.S = S; g.T = T; g.vec = vec_ok;
+    if (S < 1 || S > 5 || y_end <= y_begin) return false;
+    g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end;
     for (int k = 0; k <= S; ++k) { g.h[k] = h[k]; g.w[k] = w[k]; }
-    // widest strip whose level-0 span fits DC_MAX_LOADS vector loads per lane and the LDS budget
-    const int max_px0 = 64 * DC_MAX_LOADS * (V < 2 ? 2 : V) - 2 * V;
-    int sw = g.w[S];
-    for (;; --sw) {
-        g.strip_w = sw;
-        down_chain_layout(g, V);
-        if (sw == 1) break;
-        if (down_chain_level0_width(S, sw) <= max_px0 && g.lds_total <= DC_LDS_BUDGET) break;
-    }
-    int strips = (g.w[S] + sw - 1) / sw;
-    sw = (g.w[S] + strips - 1) / strips;  // balance the strips
-    g.strip_w = sw; g.strips = strips;
-    down_chain_layout(g, V);
+    const int SW = S == 1 ? StripWidth<1>::SW : S == 2 ? StripWidth<2>::SW : S == 3 ? StripWidth<3>::SW
+                 : S == 4 ? StripWidth<4>::SW : StripWidth<5>::SW;
+    g.strips = (g.w[S] + SW - 1) / SW;
     // segments: enough workgroups to fill the chip (~24 waves per CU over the launch) while the vertical
     // halo (2^(S+1)-2 input rows per side) stays below ~25 % of a segment
+    const int rows = y_end - y_begin;
     int segs = 1;
     const int halo0 = (1 << (S + 1)) - 2;
-    while ((long long)T * strips * segs < 256LL * 24 && segs < g.h[S]) {
-        int seg_h = (g.h[S] + segs) / (segs + 1);
+    while ((long long)T * g.strips * segs < 256LL * 24 && segs < rows) {
+        int seg_h = (rows + segs) / (segs + 1);
         if ((seg_h << S) < 8 * halo0) break;
         ++segs;
     }
-    g.seg_h = (g.h[S] + segs - 1) / segs;
-    g.segs = (g.h[S] + g.seg_h - 1) / g.seg_h;
-    if (tiny) {  // test hook: many small strips and segments
-        g.strip_w = g.w[S] < 3 ? g.w[S] : 3; g.strips = (g.w[S] + g.strip_w - 1) / g.strip_w;
-        g.seg_h = g.h[S] < 2 ? g.h[S] : 2; g.segs = (g.h[S] + g.seg_h - 1) / g.seg_h;
-        down_chain_layout(g, V);
-    }
+    g.seg_h = (rows + segs - 1) / segs;
+    if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
+    g.segs = (rows + g.seg_h - 1) / g.seg_h;
     return true;
 }
 

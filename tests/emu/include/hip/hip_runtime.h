@@ -96,6 +96,25 @@ template <typename T> inline T __shfl_down(T v, unsigned delta, int width = 64) 
     __syncthreads();
     return r;
 }
+template <typename T> inline T __shfl(T v, int src_lane, int width = 64) {
+    unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    double *buf = hipemu::shfl_buf();
+    std::memcpy(&buf[tid], &v, sizeof(T));
+    __syncthreads();
+    unsigned lane = tid % 64, src = (unsigned)src_lane & 63u;
+    T r = v;
+    unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
+    (void)width;
+    if (tid - lane + src < nthreads) std::memcpy(&r, &buf[tid - lane + src], sizeof(T));
+    __syncthreads();
+    return r;
+}
+template <typename T> inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    unsigned lane = tid % 64;
+    (void)width;
+    return __shfl(v, lane >= delta ? (int)(lane - delta) : (int)lane);
+}
 template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) {
     unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     double *buf = hipemu::shfl_buf();
