@@ -118,6 +118,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
 
+    dbg = (ctypes.c_longlong * 4)()
+    _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
     if rank == 0:
         frames_total = world * T * a.steps
         b_alg = T * H * W * DT_BYTES[a.in_dtype] + H * W * 8  # one read of the buffer + the heatmap
@@ -148,6 +150,7 @@ def main():
             "phases_ms_per_step": {"frame_buffer_kernel": k_ms, "pyramid_rest_and_temporal": ms[1] / max(ncalls.value, 1),
                                    "collapse_passes": ms[2] / max(ncalls.value, 1), "heatmap_to_roi": ms[3] / max(ncalls.value, 1)},
             "roi": roi,
+            "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
         }
         if world == 1 and a.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(vid_u8, min(a.cpu_frames, T), a.levels, a.skip)

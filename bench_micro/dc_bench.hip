@@ -24,8 +24,7 @@ template <typename Tin> void run(int T, int H, int W, const char *name)
         for (int t = 0; t < T; ++t) CK(hipMemcpy(src + (size_t)t * H * W, hbuf.data(), hbuf.size() * sizeof(Tin), hipMemcpyHostToDevice));
     }
     DownGeom g;
-    int y0, y1;
-    down_chain_interior(S, h.data(), &y0, &y1);
+    int y0 = 0, y1 = h[S];
     make_down_geom(S, h.data(), w.data(), T, 1, y0, y1, g);
     unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g.strips * g.segs);
     size_t shmem = sizeof(double) * down_chain_lds_doubles<Tin, S>();

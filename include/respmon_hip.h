@@ -66,6 +66,11 @@ size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
 int rm_profile_enable(rm_ctx *ctx, int on);
 int rm_profile_read(rm_ctx *ctx, double *ms_host, int *n_host);
 
+/* counters of the last rm_calibrate on this context (diagnostics): out_host[0] = (frame, tile) pairs,
+ * [1] = pairs evaluated at full resolution, [2] = pairs whose values were kept for the masked sum,
+ * [3] = capacity of the value store (pairs) */
+int rm_debug_counters(rm_ctx *ctx, long long *out_host, void *stream);
+
 /* ---- dtype helpers: transforms.py:20-23 uint8_to_float, transforms.py:26-29 float_to_uint8 */
 int rm_uint8_to_float(rm_ctx *ctx, const uint8_t *src_dev, double *dst_dev, size_t n, void *stream);
 int rm_float_to_uint8(rm_ctx *ctx, const double *src_dev, uint8_t *dst_dev, size_t n, void *stream);

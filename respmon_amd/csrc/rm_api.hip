@@ -59,6 +59,7 @@ struct rm_ctx {
     int op_T = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     FlowWorkspace flow;
     // measurement hook (rm_profile_*)
+    long long dbg_pairs = 0, dbg_cap = 0;
     bool prof_on = false;
     int prof_calls = 0;
     std::vector<hipEvent_t> prof_ev[RM_PROFILE_PHASES];  // start/stop pairs per phase
@@ -171,6 +172,16 @@ extern "C" int rm_profile_read(rm_ctx *ctx, double *ms, int *n)
     }
     if (n) *n = ctx->prof_calls;
     ctx->prof_calls = 0;
+    return RM_OK;
+}
+
+extern "C" int rm_debug_counters(rm_ctx *ctx, long long *out, void *stream)
+{
+    if (!ctx || !out) return fail(RM_E_BADARG, "rm_debug_counters: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    out[0] = ctx->dbg_pairs; out[1] = ctx->h_state->n_list; out[2] = ctx->h_state->n_slots; out[3] = ctx->dbg_cap;
     return RM_OK;
 }
 
@@ -466,37 +477,24 @@ static int launch_down_chain_g(const Tin *f, int T, const DownGeom &g, double *o
     return RM_OK;
 }
 
-// interior rows with the lean instantiation, the thin top / bottom bands with the generic one
+// one launch over all level-S rows: the hot instantiation whenever every level has >= 3 rows
 template <typename Tin>
-static int launch_down_chain_t(const void *frames, int T, const std::vector<int> &h, const std::vector<int> &w, int S, int vec_ok,
+static int launch_down_chain_t(rm_ctx *ctx, const void *frames, int T, const std::vector<int> &h, const std::vector<int> &w, int S, int vec_ok,
                                double *out, hipStream_t s, bool tiny)
 {
+    (void)ctx;
     const Tin *f = (const Tin *)frames;
-    int y0, y1;
-    down_chain_interior(S, h.data(), &y0, &y1);
-    if (y1 - y0 < 4) { y0 = 0; y1 = 0; }  // image too small for a lean region: everything generic
     DownGeom g;
-    if (y1 > y0) {
-        if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, y0, y1, g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
-        RM_TRY((launch_down_chain_g<Tin, false>(f, T, g, out, s)));
-        if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, y0, g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
-        RM_TRY((launch_down_chain_g<Tin, true>(f, T, g, out, s)));
-        if (y1 < h[S]) {
-            if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, y1, h[S], g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
-            RM_TRY((launch_down_chain_g<Tin, true>(f, T, g, out, s)));
-        }
-    } else {
-        if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
-        RM_TRY((launch_down_chain_g<Tin, true>(f, T, g, out, s)));
-    }
-    return RM_OK;
+    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+    if (down_chain_hot_ok(S, h.data())) return launch_down_chain_g<Tin, false>(f, T, g, out, s);
+    return launch_down_chain_g<Tin, true>(f, T, g, out, s);
 }
 
 static int dtype_vec(int dtype) { return dtype == RM_F64 ? 2 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 8 : 16; }
 static size_t dtype_size(int dtype) { return dtype == RM_F64 ? 8 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 2 : 1; }
 
 // frames[T,H,W] -> G_S[T,h_S,w_S] in one launch
-static int launch_down_chain(const void *frames, int dtype, int T, const std::vector<int> &h, const std::vector<int> &w, int S,
+static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, const std::vector<int> &h, const std::vector<int> &w, int S,
                              double *out, hipStream_t s, bool tiny)
 {
     const int V = dtype_vec(dtype);
@@ -505,10 +503,10 @@ static int launch_down_chain(const void *frames, int dtype, int T, const std::ve
     if (S < 1 || S > 5) return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", S);
     const int vo = vec_ok ? 1 : 0;
     switch (dtype) {
-    case RM_U8: return launch_down_chain_t<uint8_t>(frames, T, h, w, S, vo, out, s, tiny);
-    case RM_F16: return launch_down_chain_t<__half>(frames, T, h, w, S, vo, out, s, tiny);
-    case RM_F32: return launch_down_chain_t<float>(frames, T, h, w, S, vo, out, s, tiny);
-    case RM_F64: return launch_down_chain_t<double>(frames, T, h, w, S, vo, out, s, tiny);
+    case RM_U8: return launch_down_chain_t<uint8_t>(ctx, frames, T, h, w, S, vo, out, s, tiny);
+    case RM_F16: return launch_down_chain_t<__half>(ctx, frames, T, h, w, S, vo, out, s, tiny);
+    case RM_F32: return launch_down_chain_t<float>(ctx, frames, T, h, w, S, vo, out, s, tiny);
+    case RM_F64: return launch_down_chain_t<double>(ctx, frames, T, h, w, S, vo, out, s, tiny);
     }
     return fail(RM_E_BADARG, "unknown dtype %d", dtype);
 }
@@ -543,7 +541,7 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
         RM_TRY(ws(ctx, "g" + std::to_string(S), (size_t)T * h[S] * w[S], &dst));
         {
             PhaseTimer pt(ctx, 0, s);
-            RM_TRY(launch_down_chain(frames, dtype, T, h, w, S, dst, s, (flags & RM_FLAG_TINY_STRIPS) != 0));
+            RM_TRY(launch_down_chain(ctx, frames, dtype, T, h, w, S, dst, s, (flags & RM_FLAG_TINY_STRIPS) != 0));
         }
         g[S] = dst; cur = dst; cur_dtype = RM_F64;
         first = S + 1;
@@ -651,6 +649,7 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         if (slot_cap < 4096) slot_cap = 4096;
         if (slot_cap > (size_t)npairs) slot_cap = (size_t)npairs;
         if (flags & RM_FLAG_TINY_STORE) slot_cap = 3;
+        ctx->dbg_pairs = npairs; ctx->dbg_cap = (long long)slot_cap;
         double *lo = nullptr, *hi = nullptr, *store = nullptr;
         unsigned int *list = nullptr;
         int *slot_of = nullptr;
@@ -664,18 +663,14 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 128)), dim3(256), 0, s, lo, hi, npairs, st);
         LAUNCH_CHECK();
         const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
-        hipLaunchKernelGGL(k_prepare_select, dim3(1), dim3(1), 0, s, st, thr);
-        LAUNCH_CHECK();
         hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 255) / 256), dim3(256), 0, s, lo, hi, npairs, st, list, slot_of,
-                           (unsigned)slot_cap, prune_ok ? 0 : 1);
+                           (unsigned)slot_cap, prune_ok ? 0 : 1, thr);
         LAUNCH_CHECK();
         size_t shmem = sizeof(double) * (size_t)g.lds_total;
         unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
         hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), shmem, s, sl.cS, g, ntiles, list, slot_of, st, store);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(64), shmem, s, sl.cS, g, T, ntiles, slot_of, store, st, heat_sum);
+        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(64), shmem, s, sl.cS, g, T, ntiles, slot_of, store, st, thr, heat_sum);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heat, st);

@@ -146,9 +146,9 @@ template <typename LL, int S, int K> struct VState : VState<LL, S, K + 1> {
 };
 template <typename LL, int S> struct VState<LL, S, S> {};
 
-// VB = false: the launch covers only level-S rows whose whole dependency cone stays inside the image
-// vertically, so the streaming vertical pass has a single, branch-free form (the hot instantiation);
-// VB = true: generic form with BORDER_REFLECT_101 on the row index (thin bands at the image top / bottom).
+// VB = false: hot instantiation, valid when every level has >= 3 rows: steady-state vertical pass plus two
+// uniform special cases at the image top and virtual (replayed) rows at the image bottom;
+// VB = true: fully generic form (any size, incl. 1- and 2-row levels), used for tiny images only.
 template <typename Tin, int S, bool VB>
 struct DownChain {
     static constexpr int SW = StripWidth<S>::SW;
@@ -225,7 +225,41 @@ struct DownChain {
             double n[L::nq(K + 2)];
             taps<K + 1>(n);
             wave_sync();  // row buffer K+1 is free again
-            step<K + 1>(y, n);
+            feed<K + 1>(y, n);
+        }
+    }
+
+    // number of VIRTUAL rows that follow the last real row of level K in the hot form: the rows that
+    // BORDER_REFLECT_101 maps back into the image are replayed from the vertical state, so the image bottom
+    // runs through the same single step() site as every other row
+    template <int K> __device__ __forceinline__ int virtual_rows(int p) const
+    {
+        if constexpr (VB) return 0;
+        return (p == g.h[K] - 1) ? ((g.h[K] & 1) ? 2 : 1) : 0;
+    }
+
+    // real row p of level K plus, after the last real row, its virtual successors (one step() site).
+    // virtual row h: even h: row h -> h-2 (= c);  odd h: row h -> h-2 (= b), then row h+1 -> h-3 (= a before).
+    // The next iteration's values are formed with value selects only (no control flow around the arrays).
+    template <int K> __device__ __forceinline__ void feed(int p, const double (&n)[L::nq(K + 1)])
+    {
+        constexpr int NQ = L::nq(K + 1);
+        VState<L, S, K> &st = vs;
+        const int nv = virtual_rows<K>(p);
+        const bool odd_h = (g.h[K] & 1) != 0;
+        double cur[NQ], held_a[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { cur[q] = n[q]; held_a[q] = 0.0; }
+#pragma nounroll
+        for (int rep = 0; rep <= nv; ++rep) {
+            step<K>(p + rep, cur);
+            const bool first = rep == 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const double from_state = odd_h ? st.b[q] : st.c[q];
+                cur[q] = first ? from_state : held_a[q];
+                held_a[q] = first ? st.a[q] : held_a[q];
+            }
         }
     }
 
@@ -236,18 +270,27 @@ struct DownChain {
         constexpr int NQ = L::nq(K + 1);
         VState<L, S, K> &st = vs;
         if constexpr (!VB) {
+            // hot form (every level has >= 3 rows).  The image top needs two uniform special cases
+            // (rows -2, -1 reflect onto 2, 1); the image bottom arrives as virtual rows (feed()).
             if (p & 1) {
+                // row 1 of the image: rows -1, -2 reflect onto 1, 2, i.e. b := n and the `+ a` term moves to row 2.
+                // Written as value selects (x + -0.0 == x bit for bit), not as control flow, so the state stays
+                // in registers.
+                const bool top = p == 1;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    st.t[q] = (st.c[q] * 6 + (st.b[q] + n[q]) * 4) + st.a[q];
-                    st.a[q] = st.c[q]; st.b[q] = n[q];
+                    const double be = top ? n[q] : st.b[q], ae = top ? -0.0 : st.a[q];
+                    st.t[q] = (st.c[q] * 6 + (be + n[q]) * 4) + ae;
                 }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { st.a[q] = st.c[q]; st.b[q] = n[q]; }
             } else {
                 const int y = (p >> 1) - 1;
                 if (y == next[K + 1] && y <= last[K + 1]) {
                     double v[NQ];
+                    const bool top = p == 2;  // row 2 of the image also stands for row -2
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) v[q] = st.t[q] + n[q];
+                    for (int q = 0; q < NQ; ++q) v[q] = (st.t[q] + n[q]) + (top ? n[q] : -0.0);
                     emit<K>(y, v);
                 }
 #pragma unroll
@@ -396,7 +439,7 @@ struct DownChain {
                     double n[NQ1];
                     hrow(regs[i], n);
                     issue(min(p + DC_PREFETCH, p_last), regs[i]);
-                    step<0>(p, n);
+                    feed<0>(p, n);
                 }
             }
         }
@@ -413,7 +456,7 @@ struct DownChain {
             double n[L::nq(1)];
             taps<0>(n);
             wave_sync();  // the row buffer is free again
-            step<0>(p, n);
+            feed<0>(p, n);
         };
         if (vec) {
             // lane-load j covers columns c0 + j*V ..; lanes past the strip re-load its last chunk (no exec masking)
@@ -520,6 +563,13 @@ inline void down_chain_interior(int S, const int *h, int *y0, int *y1)
         if (ok) { *y1 = Y1 + 1; break; }
     }
     if (*y1 < *y0) *y1 = *y0;
+}
+
+// the hot instantiation needs >= 3 rows at every level it filters
+inline bool down_chain_hot_ok(int S, const int *h)
+{
+    for (int k = 0; k < S; ++k) if (h[k] < 3) return false;
+    return true;
 }
 
 // geometry of one launch over level-S rows [y_begin, y_end)

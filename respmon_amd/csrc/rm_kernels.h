@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int s
 //        out[s,p] = amp * sum_t M[s,t] x[t,p]     (sequential in t, mul then add)
 //        block: 256 pixels x TS_CHUNK output frames; M chunk staged transposed in LDS.
 // ----------------------------------------------------------------------------------------
-constexpr int TS_CHUNK = 16;
+constexpr int TS_CHUNK = 4;
 
 __global__ __launch_bounds__(256) void k_temporal(const double *x, int T, size_t npix, const double *M, double amp,
                                                   double *out)
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_temporal(const double *x, int T, size_t
     double acc[TS_CHUNK];
 #pragma unroll
     for (int k = 0; k < TS_CHUNK; ++k) acc[k] = 0.0;
-    constexpr int U = 8;  // loads in flight per lane (the sum itself stays sequential in t)
+    constexpr int U = 16;  // loads in flight per lane (the sum itself stays sequential in t)
     for (int t0 = 0; t0 < T; t0 += U) {
         double v[U];
 #pragma unroll
@@ -331,18 +331,6 @@ __global__ __launch_bounds__(256) void k_reduce_bounds(const double *lo, const d
 
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
 
-// margin and the bounds-only upper bound of top = max - (max - min) * thr (increasing in max and min
-// for 0 <= thr <= 1)
-__global__ void k_prepare_select(CollapseState *st, double thr)
-{
-    double a = f64_unkey(st->ub_max_key), b = f64_unkey(st->lb_min_key);
-    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
-    double m = PRUNE_REL_MARGIN * (a > b ? a : b);
-    st->margin = m;
-    double mx = f64_unkey(st->ub_max_key) + m, mn = f64_unkey(st->ub_min_key) + m;
-    st->top_ub = (mx - (mx - mn) * thr) + m;
-}
-
 constexpr int SLOT_PRUNED = -1;    // every value of the pair is provably >= top: contributes `min`
 constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is full
 
@@ -350,14 +338,22 @@ constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is
 //   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max
 //   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum
 __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
-                                                      unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune)
+                                                      unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune,
+                                                      double thr)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double m = st->margin;
+    // margin and the bounds-only upper bound of top = max - (max - min) * thr (increasing in max and min
+    // for 0 <= thr <= 1); every thread derives them from the reduced bounds
     const double lb_max = f64_unkey(st->lb_max_key), ub_min = f64_unkey(st->ub_min_key);
+    const double ub_max = f64_unkey(st->ub_max_key), lb_min = f64_unkey(st->lb_min_key);
+    const double aa = ub_max < 0 ? -ub_max : ub_max, bb = lb_min < 0 ? -lb_min : lb_min;
+    const double m = PRUNE_REL_MARGIN * (aa > bb ? aa : bb);
+    const double mx_ = ub_max + m, mn_ = ub_min + m;
+    const double top_ub = (mx_ - (mx_ - mn_) * thr) + m;
+    if (i == 0) { st->margin = m; st->top_ub = top_ub; }
     bool isC = no_prune || !(hi[i] + m < lb_max - m) || !(lo[i] - m > ub_min + m);
-    bool isD = no_prune || (lo[i] - m < st->top_ub);
+    bool isD = no_prune || (lo[i] - m < top_ub);
     int slot = SLOT_PRUNED;
     if (isD) {
         unsigned sidx = atomicAdd(&st->n_slots, 1u);
@@ -454,8 +450,10 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     }
     mn = wave_min(mn); mx = wave_max(mx);
     if (lane == 0 && blockIdx.x < n) {
-        atomicMin(&st->min_key, f64_key(mn));
-        atomicMax(&st->max_key, f64_key(mx));
+        // contended same-address atomics cost ~12 ns each: skip those that cannot change the result
+        const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
+        if (kmn < *(volatile unsigned long long *)&st->min_key) atomicMin(&st->min_key, kmn);
+        if (kmx > *(volatile unsigned long long *)&st->max_key) atomicMax(&st->max_key, kmx);
     }
 }
 
@@ -473,13 +471,16 @@ constexpr int MAX_T = 4096;
 
 __global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, int ntiles,
                                                          const int *slot_of, const double *store,
-                                                         const CollapseState *st, double *heat_sum)
+                                                         CollapseState *st, double threshold, double *heat_sum)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
-    const double top = st->top, min_val = st->min_val;
+    // transforms.py:184-189: min, max, top = max - (max - min) * threshold
+    const double min_val = f64_unkey(st->min_key), max_val = f64_unkey(st->max_key);
+    const double top = max_val - (max_val - min_val) * threshold;
+    if (tile == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     TileRegion R;
     tile_regions(g, tile, R);
     for (int t = lane; t < T; t += 64) s_slot[t] = slot_of[(size_t)t * ntiles + tile];

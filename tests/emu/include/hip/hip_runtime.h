@@ -190,6 +190,12 @@ inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memcpy
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (void *)2; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (void *)1; return 0; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
