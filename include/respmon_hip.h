@@ -57,13 +57,14 @@ int rm_abi_version(void);
 /* bytes of device workspace currently held by the context */
 size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
 
-/* ---- measurement hook for bench.py: when on, rm_calibrate / rm_heatmap_to_roi bracket their phases
- *      with hipEvents on the caller's stream.  rm_profile_read waits for them and returns the summed
+/* ---- measurement hook for bench.py: mode 1 brackets only the frame-buffer kernel with hipEvents on the
+ *      caller's stream (cheap enough for the timed region), mode 2 brackets every phase of rm_calibrate /
+ *      rm_heatmap_to_roi (each bracket costs ~10 us of stream idle time), mode 0 turns it off.  rm_profile_read waits for them and returns the summed
  *      milliseconds since the last read: ms_host[0] = the kernel that reads the [T,H,W] frame buffer
  *      (the roofline kernel), [1] = remaining pyramid + temporal kernels, [2] = collapse passes,
  *      [3] = heatmap -> ROI (device part + host contour stage); *n_host = rm_calibrate calls covered. */
 #define RM_PROFILE_PHASES 4
-int rm_profile_enable(rm_ctx *ctx, int on);
+int rm_profile_enable(rm_ctx *ctx, int mode);
 int rm_profile_read(rm_ctx *ctx, double *ms_host, int *n_host);
 
 /* counters of the last rm_calibrate on this context (diagnostics): out_host[0] = (frame, tile) pairs,

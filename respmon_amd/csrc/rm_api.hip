@@ -56,10 +56,11 @@ struct rm_ctx {
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
     uint32_t *h_rowany = nullptr; size_t h_rowany_cap = 0;  // pinned
     // cached temporal operator
-    int op_T = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
+    int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     FlowWorkspace flow;
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0;
+    int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
     bool prof_on = false;
     int prof_calls = 0;
     std::vector<hipEvent_t> prof_ev[RM_PROFILE_PHASES];  // start/stop pairs per phase
@@ -77,7 +78,7 @@ struct PhaseTimer {
         else (void)hipEventCreate(&e);
         return e;
     }
-    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_on)
+    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_mode == 2 || (c_->prof_mode == 1 && phase_ == 0))
     {
         if (!on) return;
         hipEvent_t e = get(c);
@@ -149,6 +150,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
 extern "C" int rm_profile_enable(rm_ctx *ctx, int on)
 {
     if (!ctx) return fail(RM_E_BADARG, "rm_profile_enable: ctx is NULL");
+    ctx->prof_mode = on < 0 ? 0 : on > 2 ? 2 : on;
     ctx->prof_on = on != 0;
     return RM_OK;
 }
@@ -250,12 +252,15 @@ static int launch_pyr_down(const void *src, int dtype, int T, int h, int w, doub
 }
 
 static int launch_pyr_up(const double *src, int T, int sh, int sw, double *dst, int dh, int dw, int mode,
-                         const double *other, hipStream_t s)
+                         const double *other, hipStream_t s, size_t src_fs = 0, size_t dst_fs = 0, size_t other_fs = 0)
 {
+    if (!src_fs) src_fs = (size_t)sh * sw;
+    if (!dst_fs) dst_fs = (size_t)dh * dw;
+    if (!other_fs) other_fs = (size_t)dh * dw;
     if (!((dw == 2 * sw || dw == 2 * sw - 1) && (dh == 2 * sh || dh == 2 * sh - 1)))
         return fail(RM_E_BADARG, "pyrUp: dstsize (%d,%d) incompatible with source (%d,%d)", dw, dh, sw, sh);
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, T), block(256);
-    hipLaunchKernelGGL(k_pyr_up, grid, block, 0, s, src, sh, sw, dst, dh, dw, mode, other);
+    hipLaunchKernelGGL(k_pyr_up, grid, block, 0, s, src, sh, sw, src_fs, dst, dh, dw, dst_fs, mode, other, other_fs);
     LAUNCH_CHECK();
     return RM_OK;
 }
@@ -418,27 +423,94 @@ extern "C" int rm_temporal_operator(int T, double fps, double fmin, double fmax,
     return RM_OK;
 }
 
-static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax, const double **M_dev, hipStream_t s)
+// packed-rfft indices that survive the reference's mask (transforms.py:91-94), in increasing order
+static void kept_packed_indices(int n, double fps, double fmin, double fmax, std::vector<int> &kept)
 {
-    double *d = nullptr;
-    RM_TRY(ws(ctx, "temporal_M", (size_t)T * T, &d));
+    int lo, hi;
+    band_bounds(n, fps, fmin, fmax, &lo, &hi);
+    std::vector<char> keep(n, 1);
+    int start = hi, stop = (hi == 0) ? 0 : n - hi;  // python slice [hi:-hi]; -0 == 0 gives an empty slice
+    for (int k = start; k < stop; ++k) keep[k] = 0;
+    if (lo != 0) {
+        for (int k = 0; k < lo && k < n; ++k) keep[k] = 0;
+        for (int k = (n - lo > 0 ? n - lo : 0); k < n; ++k) keep[k] = 0;
+    }
+    kept.clear();
+    for (int k = 0; k < n; ++k)
+        if (keep[k]) kept.push_back(k);
+}
+
+// two-stage form of the operator: R[nk,T] = surviving rows of the packed real FFT, C[T,nk] = the columns of
+// Re(ifft) that multiply them (1/n included)
+static void two_stage_operator(int n, const std::vector<int> &kept, std::vector<double> &R, std::vector<double> &C)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    const int nk = (int)kept.size();
+    R.assign((size_t)nk * n, 0.0);
+    C.assign((size_t)n * nk, 0.0);
+    for (int i = 0; i < nk; ++i) {
+        const int k = kept[i];
+        for (int t = 0; t < n; ++t) {
+            double v;
+            if (k == 0) v = 1.0;
+            else if ((n % 2 == 0) && k == n - 1) v = (t % 2 == 0) ? 1.0 : -1.0;
+            else {
+                int j = (k + 1) / 2;
+                long long jt = ((long long)j * t) % n;  // exact argument reduction
+                double ang = two_pi * (double)jt / (double)n;
+                v = (k % 2 == 1) ? std::cos(ang) : -std::sin(ang);
+            }
+            R[(size_t)i * n + t] = v;
+        }
+        for (int sidx = 0; sidx < n; ++sidx) {
+            long long ks = ((long long)k * sidx) % n;
+            C[(size_t)sidx * nk + i] = std::cos(two_pi * (double)ks / (double)n) / (double)n;
+        }
+    }
+}
+
+struct TemporalOp { const double *R = nullptr, *C = nullptr; int nk = 0; };
+
+static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax, TemporalOp *op, hipStream_t s)
+{
     if (!(ctx->op_T == T && ctx->op_fps == fps && ctx->op_fmin == fmin && ctx->op_fmax == fmax)) {
-        std::vector<double> M((size_t)T * T);
-        RM_TRY(rm_temporal_operator(T, fps, fmin, fmax, M.data(), nullptr, nullptr));
-        HIP_TRY(hipMemcpyAsync(d, M.data(), sizeof(double) * (size_t)T * T, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));  // M is a stack-lifetime vector
+        std::vector<int> kept;
+        kept_packed_indices(T, fps, fmin, fmax, kept);
+        std::vector<double> R, C;
+        two_stage_operator(T, kept, R, C);
+        ctx->op_nk = (int)kept.size();
+        double *dR = nullptr, *dC = nullptr;
+        RM_TRY(ws(ctx, "temporal_R", R.size() + 1, &dR));
+        RM_TRY(ws(ctx, "temporal_C", C.size() + 1, &dC));
+        if (!R.empty()) {
+            HIP_TRY(hipMemcpyAsync(dR, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(dC, C.data(), sizeof(double) * C.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // R, C are stack-lifetime vectors
+        }
         ctx->op_T = T; ctx->op_fps = fps; ctx->op_fmin = fmin; ctx->op_fmax = fmax;
     }
-    *M_dev = d;
+    double *dR = nullptr, *dC = nullptr;
+    RM_TRY(ws(ctx, "temporal_R", (size_t)ctx->op_nk * T + 1, &dR));
+    RM_TRY(ws(ctx, "temporal_C", (size_t)ctx->op_nk * T + 1, &dC));
+    op->R = dR; op->C = dC; op->nk = ctx->op_nk;
     return RM_OK;
 }
 
-static int launch_temporal(const double *x, int T, size_t npix, const double *M, double amp, double *out, hipStream_t s)
+// out[T, NP] = amp * C (R x), x[T, NP]   (transforms.py:86-99)
+static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const TemporalOp &op, double amp, double *out, hipStream_t s)
 {
-    size_t shmem = sizeof(double) * (size_t)T * TS_CHUNK;
-    if (shmem > 64 * 1024) return fail(RM_E_UNSUPPORTED, "temporal filter: T=%d exceeds the LDS-staged operator (T <= 512)", T);
-    dim3 grid((unsigned)((npix + 255) / 256), (T + TS_CHUNK - 1) / TS_CHUNK), block(256);
-    hipLaunchKernelGGL(k_temporal, grid, block, shmem, s, x, T, npix, M, amp, out);
+    if (op.nk == 0) {  // nothing survives the mask
+        HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * (size_t)T * NP, s));
+        return RM_OK;
+    }
+    const size_t sh1 = sizeof(double) * (size_t)T * TF_KC, sh2 = sizeof(double) * (size_t)op.nk * TF_SC;
+    if (sh1 > 64 * 1024 || sh2 > 64 * 1024) return fail(RM_E_UNSUPPORTED, "temporal filter: T=%d exceeds the LDS-staged operator (T <= 2048)", T);
+    double *y = nullptr;
+    RM_TRY(ws(ctx, "temporal_y", (size_t)op.nk * NP, &y));
+    dim3 g1((unsigned)((NP + 63) / 64), (op.nk + TF_KC - 1) / TF_KC), g2((unsigned)((NP + 63) / 64), (T + TF_SC - 1) / TF_SC);
+    hipLaunchKernelGGL(k_temporal_fwd, g1, dim3(64), sh1, s, x, T, NP, op.R, op.nk, y);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_temporal_inv, g2, dim3(64), sh2, s, y, op.nk, NP, op.C, T, amp, out);
     LAUNCH_CHECK();
     return RM_OK;
 }
@@ -450,9 +522,9 @@ extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, 
     if (npix == 0) return RM_OK;
     if (data == out) return fail(RM_E_BADARG, "rm_temporal_bandpass_filter_fft: in-place filtering is not supported");
     hipStream_t s = (hipStream_t)stream;
-    const double *M = nullptr;
-    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &M, s));
-    return launch_temporal(data, T, npix, M, amp, out, s);
+    TemporalOp op;
+    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
+    return launch_temporal(ctx, data, T, npix, op, amp, out, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -562,21 +634,38 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
         RM_TRY(launch_to_f64(frames, dtype, (size_t)T * H * W, g0, s));
         g[0] = g0;
     }
-    const double *M = nullptr;
-    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &M, s));
+    TemporalOp op;
+    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
     PhaseTimer pt_small(ctx, 1, s);
-    // Laplacian (pyramid.py:23-26), temporal filter (transforms.py:162,169), collapse of the
-    // band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x)
-    double *c = nullptr;
-    for (int l = L - 2; l >= S; --l) {
-        size_t n = (size_t)T * h[l] * w[l];
-        double *lap = nullptr, *bp = nullptr;
-        RM_TRY(ws(ctx, "lap", (size_t)T * h[S] * w[S], &lap));
-        RM_TRY(ws(ctx, "bp" + std::to_string(l), n, &bp));
-        RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap, h[l], w[l], 1, g[l], s));
-        RM_TRY(launch_temporal(lap, T, (size_t)h[l] * w[l], M, amp, bp, s));
-        if (c) RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], bp, h[l], w[l], 2, bp, s));
-        c = bp;
+    // The filtered levels S .. L-2 live side by side in [T, NP] buffers (level S first), so the temporal
+    // filter is two launches for the whole small pyramid.
+    std::vector<size_t> off(L, 0);
+    size_t NP = 0;
+    for (int l = S; l <= L - 2; ++l) { off[l] = NP; NP += (size_t)h[l] * w[l]; }
+    double *lap = nullptr, *bp = nullptr;
+    RM_TRY(ws(ctx, "lap_all", (size_t)T * NP, &lap));
+    RM_TRY(ws(ctx, "bp_all", (size_t)T * NP, &bp));
+    // Laplacian levels (pyramid.py:23-26): L_l = G_l - pyrUp(G_{l+1})
+    for (int l = L - 2; l >= S; --l)
+        RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap + off[l], h[l], w[l], 1, g[l], s, 0, NP, 0));
+    // temporal band-pass of every level at once (transforms.py:162,169)
+    RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
+    // collapse of the band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x);
+    // the last step lands in a contiguous [T,h_S,w_S] array for the full-resolution passes
+    const double *c = bp + off[L - 2];
+    size_t c_fs = NP;
+    if (L - 2 == S) {
+        c_fs = (size_t)h[S] * w[S];  // single filtered level: NP == h_S*w_S, already contiguous
+    }
+    for (int l = L - 3; l >= S; --l) {
+        double *dst = bp + off[l];
+        size_t dst_fs = NP;
+        if (l == S) {
+            RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
+            dst_fs = (size_t)h[S] * w[S];
+        }
+        RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + off[l], s, c_fs, dst_fs, NP));
+        c = dst; c_fs = dst_fs;
     }
     out.cS = c;
     return RM_OK;
@@ -737,8 +826,8 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
 // ------------------------------------------------------------------------------------------
 __global__ void k_heat_state_init(CollapseState *st) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
 
-extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
-                                 uint8_t *binary, void *stream)
+static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
+                               uint8_t *binary, void *stream, bool have_minmax)
 {
     if (!ctx || !heat || !xywh || H < 1 || W < 1) return fail(RM_E_BADARG, "rm_heatmap_to_roi: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -763,15 +852,25 @@ extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, 
     }
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
-    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
-    LAUNCH_CHECK();
     HIP_TRY(hipMemsetAsync(row_any, 0, sizeof(uint32_t) * H, s));
-    hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
-    LAUNCH_CHECK();
+    if (!have_minmax) {  // rm_calibrate has just left the heatmap's min / max in the state
+        hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, bin, row_any, W);
     LAUNCH_CHECK();
+    // two small hops instead of one H*W copy: the row flags first, then only the rows that hold foreground
     HIP_TRY(hipMemcpyAsync(ctx->h_rowany, row_any, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(ctx->h_bin, bin, npix, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int y_lo = H, y_hi = -1;
+    for (int y = 0; y < H; ++y)
+        if (ctx->h_rowany[y]) { if (y < y_lo) y_lo = y; y_hi = y; }
+    if (y_hi >= y_lo) {
+        HIP_TRY(hipMemcpyAsync(ctx->h_bin + (size_t)y_lo * W, bin + (size_t)y_lo * W, (size_t)(y_hi - y_lo + 1) * W,
+                               hipMemcpyDeviceToHost, s));
+    }
     delete pt_roi; pt_roi = nullptr;
     HIP_TRY(hipStreamSynchronize(s));
     RoiResult r;
@@ -786,6 +885,12 @@ extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, 
     return RM_OK;
 }
 
+extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
+                                 uint8_t *binary, void *stream)
+{
+    return heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, avg_u8, binary, stream, false);
+}
+
 extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
                          double amp, int levels, int skip, double temporal_thr, int threshold, unsigned flags, int32_t *xywh,
                          void *stream)
@@ -794,7 +899,7 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     double *heat = nullptr;
     RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
     RM_TRY(rm_calibrate(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream));
-    return rm_heatmap_to_roi(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream);
+    return heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -144,60 +144,98 @@ struct GlobalImg {
 };
 
 // mode 0: dst = up(src); 1: dst = other - up(src); 2: dst = up(src) + other
-__global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int sw, double *dst, int dh, int dw,
-                                                int mode, const double *other)
+// src_fs / dst_fs / other_fs: frame strides in doubles (frames of several levels may share one [T, NP] buffer)
+__global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int sw, size_t src_fs, double *dst, int dh, int dw,
+                                                size_t dst_fs, int mode, const double *other, size_t other_fs)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     int t = blockIdx.z;
     if (x >= dw || y >= dh) return;
-    GlobalImg s{src + (size_t)t * sh * sw, sw};
+    GlobalImg s{src + (size_t)t * src_fs, sw};
     double u = up_at(s, y, x, sh, sw);
-    size_t o = ((size_t)t * dh + y) * dw + x;
-    if (mode == 1) u = other[o] - u;
-    else if (mode == 2) u = u + other[o];
-    dst[o] = u;
+    size_t o = (size_t)y * dw + x;
+    if (mode == 1) u = other[(size_t)t * other_fs + o] - u;
+    else if (mode == 2) u = u + other[(size_t)t * other_fs + o];
+    dst[(size_t)t * dst_fs + o] = u;
 }
 
 // ----------------------------------------------------------------------------------------
-// K5-K8  temporal band-pass as the explicit operator (transforms.py:82-102):
-//        out[s,p] = amp * sum_t M[s,t] x[t,p]     (sequential in t, mul then add)
-//        block: 256 pixels x TS_CHUNK output frames; M chunk staged transposed in LDS.
+// K5-K8  temporal band-pass (transforms.py:82-102): packed rfft -> index mask -> Re(ifft) -> *amp,
+//        a fixed real linear operator along T, applied in its two-stage form.
 // ----------------------------------------------------------------------------------------
-constexpr int TS_CHUNK = 4;
+// Two-stage form (the reference's own rfft -> mask -> ifft order; ~T/(2*nk) times cheaper than the dense
+// T x T product M = C R that rm_temporal_operator() exports for inspection):
+//   stage 1 (packed real FFT rows that survive the mask):  y[k,p]   = sum_t R[k,t] x[t,p]          k < nk
+//   stage 2 (Re(ifft) of the packed array, then *amp):     out[s,p] = amp * sum_k C[s,k] y[k,p]    s < T
+// One single-wave workgroup = 64 pixels x KC (resp. SC) outputs; coefficient chunks are staged in LDS and
+// read as broadcasts; the pixel loads are issued U deep.  All levels of the small pyramid sit side by side
+// in one [T, NP] buffer, so one launch per stage serves every filtered level.
+constexpr int TF_KC = 4, TF_SC = 8, TF_U = 16;
 
-__global__ __launch_bounds__(256) void k_temporal(const double *x, int T, size_t npix, const double *M, double amp,
-                                                  double *out)
+__global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y)
 {
-    HIP_DYNAMIC_SHARED(double, s_m)  // [T][TS_CHUNK]
-    const int s0 = blockIdx.y * TS_CHUNK;
-    for (int i = threadIdx.x; i < T * TS_CHUNK; i += 256) {
-        int t = i / TS_CHUNK, k = i - t * TS_CHUNK;
-        s_m[i] = (s0 + k < T) ? M[(size_t)(s0 + k) * T + t] : 0.0;
+    HIP_DYNAMIC_SHARED(double, s_r)  // [T][TF_KC]
+    const int k0 = blockIdx.y * TF_KC;
+    for (int i = threadIdx.x; i < T * TF_KC; i += 64) {
+        int t = i / TF_KC, k = i - t * TF_KC;
+        s_r[i] = (k0 + k < nk) ? R[(size_t)(k0 + k) * T + t] : 0.0;
     }
     __syncthreads();
-    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix) return;
-    double acc[TS_CHUNK];
+    size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= NP) return;
+    double acc[TF_KC];
 #pragma unroll
-    for (int k = 0; k < TS_CHUNK; ++k) acc[k] = 0.0;
-    constexpr int U = 16;  // loads in flight per lane (the sum itself stays sequential in t)
-    for (int t0 = 0; t0 < T; t0 += U) {
-        double v[U];
+    for (int k = 0; k < TF_KC; ++k) acc[k] = 0.0;
+    for (int t0 = 0; t0 < T; t0 += TF_U) {
+        double v[TF_U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (t0 + u < T) ? x[(size_t)(t0 + u) * npix + p] : 0.0;
+        for (int u = 0; u < TF_U; ++u) v[u] = (t0 + u < T) ? x[(size_t)(t0 + u) * NP + p] : 0.0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < TF_U; ++u) {
             if (t0 + u < T) {
-                const double *m = &s_m[(t0 + u) * TS_CHUNK];
+                const double *r = &s_r[(t0 + u) * TF_KC];
 #pragma unroll
-                for (int k = 0; k < TS_CHUNK; ++k) acc[k] = acc[k] + m[k] * v[u];
+                for (int k = 0; k < TF_KC; ++k) acc[k] = acc[k] + r[k] * v[u];
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < TS_CHUNK; ++k)
-        if (s0 + k < T) out[(size_t)(s0 + k) * npix + p] = acc[k] * amp;
+    for (int k = 0; k < TF_KC; ++k)
+        if (k0 + k < nk) y[(size_t)(k0 + k) * NP + p] = acc[k];
+}
+
+__global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, size_t NP, const double *C, int T, double amp,
+                                                     double *out)
+{
+    HIP_DYNAMIC_SHARED(double, s_c)  // [nk][TF_SC]
+    const int s0 = blockIdx.y * TF_SC;
+    for (int i = threadIdx.x; i < nk * TF_SC; i += 64) {
+        int k = i / TF_SC, j = i - k * TF_SC;
+        s_c[i] = (s0 + j < T) ? C[(size_t)(s0 + j) * nk + k] : 0.0;
+    }
+    __syncthreads();
+    size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= NP) return;
+    double acc[TF_SC];
+#pragma unroll
+    for (int j = 0; j < TF_SC; ++j) acc[j] = 0.0;
+    for (int k0 = 0; k0 < nk; k0 += TF_U) {
+        double v[TF_U];
+#pragma unroll
+        for (int u = 0; u < TF_U; ++u) v[u] = (k0 + u < nk) ? y[(size_t)(k0 + u) * NP + p] : 0.0;
+#pragma unroll
+        for (int u = 0; u < TF_U; ++u) {
+            if (k0 + u < nk) {
+                const double *c = &s_c[(k0 + u) * TF_SC];
+#pragma unroll
+                for (int j = 0; j < TF_SC; ++j) acc[j] = acc[j] + c[j] * v[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TF_SC; ++j)
+        if (s0 + j < T) out[(size_t)(s0 + j) * NP + p] = acc[j] * amp;
 }
 
 // ----------------------------------------------------------------------------------------
