@@ -146,6 +146,13 @@ inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) 
 }
 inline int atomicAdd(int *p, int v) { return reinterpret_cast<std::atomic<int> *>(p)->fetch_add(v); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->fetch_add(v); }
+inline unsigned atomicMax(unsigned *p, unsigned v) {
+    auto *a = reinterpret_cast<std::atomic<unsigned> *>(p);
+    unsigned o = a->load();
+    while (o < v && !a->compare_exchange_weak(o, v)) {}
+    return o;
+}
+inline int __float2int_rn(float f) { return (int)std::lrintf(f); }
 inline int atomicMax(int *p, int v) {
     auto *a = reinterpret_cast<std::atomic<int> *>(p);
     int o = a->load();

@@ -87,3 +87,51 @@ class Emu:
         rc = self.ck(self.lib.rm_locate(self.ctx, ptr(frames), DT[frames.dtype], T, H, W, fps, fmin, fmax, amp, levels, skip, thr,
                                         threshold, flags, ptr(xywh), None), "locate")
         return None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
+
+
+def _flow_methods():
+    def good_features(self, img_u8, maxCorners=100, qualityLevel=0.3, minDistance=7, blockSize=7):
+        img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        h, w = img.shape
+        cap = max(int(maxCorners), 1) if maxCorners > 0 else img.size
+        pts = np.empty((cap, 2), np.float32)
+        n = ctypes.c_int()
+        self.ck(self.lib.rm_good_features_to_track(self.ctx, ptr(img), h, w, int(maxCorners), float(qualityLevel), float(minDistance),
+                                                   int(blockSize), ptr(pts), ctypes.byref(n), None), "gftt")
+        return None if n.value == 0 else pts[:n.value].reshape(-1, 1, 2).copy()
+
+    def pyr_lk(self, prev, nxt, pts, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03)):
+        a = np.ascontiguousarray(prev, dtype=np.uint8); b = np.ascontiguousarray(nxt, dtype=np.uint8)
+        h, w = a.shape
+        p0 = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+        n = len(p0)
+        p1 = np.empty((n, 2), np.float32); st = np.empty(n, np.uint8)
+        self.ck(self.lib.rm_calc_optical_flow_pyr_lk(self.ctx, ptr(a), ptr(b), h, w, ptr(p0), n, winSize[0], winSize[1], maxLevel,
+                                                     criteria[1], float(criteria[2]), ptr(p1), ptr(st), None), "lk")
+        return p1.reshape(-1, 1, 2), st.reshape(-1, 1)
+
+    def mean_flow(self, old, new, st):
+        o = np.ascontiguousarray(old, np.float32).reshape(-1, 2); nw = np.ascontiguousarray(new, np.float32).reshape(-1, 2)
+        s = np.ascontiguousarray(st, np.uint8).reshape(-1)
+        m = np.empty(2, np.float32); ng = ctypes.c_int()
+        self.ck(self.lib.rm_mean_flow(self.ctx, ptr(o), ptr(nw), ptr(s), len(o), ptr(m), ctypes.byref(ng), None), "mean_flow")
+        return m, ng.value
+
+    def pca_reduce(self, motion):
+        m = np.ascontiguousarray(motion, np.float32).reshape(-1, 2)
+        out = ctypes.c_double()
+        self.ck(self.lib.rm_pca_reduce(self.ctx, ptr(m), len(m), ctypes.byref(out), None), "pca")
+        return out.value
+
+    def roi_mean(self, frame, x, y, w, h):
+        f = np.ascontiguousarray(frame)
+        H, W = f.shape
+        out = ctypes.c_double()
+        self.ck(self.lib.rm_roi_mean(self.ctx, ptr(f), DT[f.dtype], H, W, x, y, w, h, ctypes.byref(out), None), "roi_mean")
+        return out.value
+
+    for f in (good_features, pyr_lk, mean_flow, pca_reduce, roi_mean):
+        setattr(Emu, f.__name__, f)
+
+
+_flow_methods()

@@ -1,0 +1,98 @@
+"""GPU parity of the ROI motion-extraction path (reference base.py:354-407): Shi-Tomasi corners, pyramidal LK,
+mean flow and PCA reduction against the CPU oracle.  Bit-exact corner coordinates / status; flow vectors within
+1e-4 relative (in practice identical: the kernels keep OpenCV's accumulation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    assert torch.cuda.is_available()
+    from respmon_amd.base import _Backend
+    return _Backend()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_corners_and_flow_config3(be, oracle):
+    """BASELINE config 3: 256x256 ROI, up to 1000 Shi-Tomasi points, sub-pixel motion at 30 fps."""
+    from respmon_amd import synth
+    render = synth.synth_texture(256, 256, seed=4321)
+    a = render(0.0, 0.0)
+    pts = be.good_features_to_track(_dev(a), maxCorners=1000, qualityLevel=0.01, minDistance=7, blockSize=7)
+    ref = oracle.goodFeaturesToTrack(a, 1000, 0.01, 7, blockSize=7)
+    assert pts is not None and np.array_equal(pts, ref) and len(pts) >= 300
+    prev = a
+    cur_pts = pts
+    for t in range(1, 6):
+        dx, dy = 1.5 * np.sin(2 * np.pi * 0.4 * t / 30), 0.5 * np.sin(2 * np.pi * 0.4 * t / 30 + np.pi / 3)
+        b = render(dx, dy)
+        p1, st = be.calc_optical_flow_pyr_lk(_dev(prev), _dev(b), cur_pts, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        r1, rs, _ = oracle.calcOpticalFlowPyrLK(prev, b, cur_pts, None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        assert np.array_equal(st, rs)
+        good = rs.ravel() == 1
+        flow, rflow = (p1 - cur_pts).reshape(-1, 2)[good], (r1 - cur_pts).reshape(-1, 2)[good]
+        assert np.abs(flow - rflow).max() <= 1e-4 * max(np.abs(rflow).max(), 1e-3)   # north_star gate
+        assert np.array_equal(p1, r1)                                                # and in fact identical
+        mean, ng = be.mean_flow(cur_pts, p1, st)
+        assert ng == good.sum() and np.array_equal(mean, np.mean(cur_pts[rs == 1] - r1[rs == 1], axis=0))
+        prev, cur_pts = b, r1[rs == 1].reshape(-1, 1, 2)
+
+
+def test_small_roi_like_the_reference(be, oracle):
+    from respmon_amd import synth
+    render = synth.synth_texture(96, 112, seed=99)
+    a, b = render(0, 0)[10:61, 20:90], render(0.4, 0.2)[10:61, 20:90]   # 70x51, two LK levels
+    pts = be.good_features_to_track(_dev(a), maxCorners=100, qualityLevel=0.3, minDistance=7, blockSize=7)
+    ref = oracle.goodFeaturesToTrack(a, 100, 0.3, 7, blockSize=7)
+    assert (pts is None) == (ref is None)
+    if ref is not None:
+        assert np.array_equal(pts, ref)
+        p1, st = be.calc_optical_flow_pyr_lk(_dev(a), _dev(b), pts, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        r1, rs, _ = oracle.calcOpticalFlowPyrLK(a, b, ref, None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        assert np.array_equal(p1, r1) and np.array_equal(st, rs)
+    flat = np.full((40, 40), 9, np.uint8)
+    assert be.good_features_to_track(_dev(flat), maxCorners=10, qualityLevel=0.3, minDistance=7, blockSize=7) is None
+
+
+def test_pca_reduce_golden_and_random(be, oracle, golden):
+    g = golden("g5_extract_motion.npz")
+    md, vals = g["motion_data_f32"], g["values"]
+    for k in range(2, len(md) + 1):
+        assert abs(be.pca_reduce(md[:k]) - vals[k]) <= 1e-9 * max(1.0, abs(vals[k]))
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        n = int(rng.integers(2, 129))
+        m = (rng.standard_normal((n, 2)) * rng.uniform(0.01, 2, 2) + rng.uniform(-1, 1, 2)).astype(np.float32)
+        ref = oracle.pca_first_component([list(r) for r in m])
+        assert abs(be.pca_reduce(m) - ref) <= 1e-9 * max(1.0, abs(ref))
+
+
+def test_extract_motion_flow_state_machine(oracle):
+    """RespiratoryMonitor in 'flow' mode on a moving texture against the oracle's extract_motion restatement."""
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    render = synth.synth_texture(120, 160, seed=7)
+    T = 40
+    frames = np.stack([render(1.5 * np.sin(2 * np.pi * 0.4 * t / 10), 0.5 * np.sin(2 * np.pi * 0.4 * t / 10 + 1.0)) for t in range(T)])
+    mon = RespiratoryMonitor(capture_target=synth.FakeCapture(frames, fps=10), visualize=None, save_all_data=False,
+                             motion_extraction_method="flow", run_on_init=False)
+    mon.sync_to_fps = lambda: None
+    mon.skip_calibration(30, 20, 90, 70)
+    mon.run()
+    state = oracle.FlowState()
+    ref = []
+    for t in range(T):
+        crop = oracle.uint8_to_float(frames[t])[20:90, 30:120]
+        ref.append(oracle.extract_motion_flow(state, crop))
+    got = np.array(mon.data, dtype=np.float64)
+    ref = np.array(ref, dtype=np.float64)
+    assert len(got) == T and got[0] == 0.0 and got[1] == 0.0
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(np.array(mon.motion_data, dtype=np.float32), np.array(state.motion_data, dtype=np.float32))

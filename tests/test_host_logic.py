@@ -1,0 +1,171 @@
+"""Host-side logic without a GPU: the C-ABI library loads and exports every declared symbol, the temporal
+operator (host function) matches the golden vectors, and the RespiratoryMonitor state machine reproduces the
+reference's frame accounting (G6) when driven through a recording test double of the backend."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from respmon_amd import _capi
+    lib = _capi.load()     # no GPU needed to load; raises if the library or a symbol is missing
+    header = open(os.path.join(ROOT, "include", "respmon_hip.h")).read()
+    declared = set(re.findall(r"\b(rm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    assert lib.rm_abi_version() == 1
+    assert isinstance(lib.rm_last_error_string(), bytes)
+
+
+def test_temporal_operator_host_function(golden):
+    from respmon_amd import _capi
+    lib = _capi.load()
+    g = golden("g1_temporal_fft.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        if "M%d" % i not in g.files:
+            continue
+        n = int(n)
+        M = np.empty((n, n))
+        lo, hi = ctypes.c_int(), ctypes.c_int()
+        rc = lib.rm_temporal_operator(n, fps, fmin, fmax, ctypes.c_void_p(M.ctypes.data), ctypes.byref(lo), ctypes.byref(hi))
+        assert rc == 0 and np.abs(M - g["M%d" % i]).max() < 1e-15
+        assert np.allclose((M @ g["x%d" % i].reshape(n, -1)) * amp, g["y%d" % i].reshape(n, -1), rtol=0, atol=1e-9)
+    assert lib.rm_temporal_operator(0, 10.0, 0.1, 1.0, None, None, None) < 0       # bad argument -> negative code
+    assert b"rm_temporal_operator" in lib.rm_last_error_string()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from respmon_amd import _capi, transforms
+    with pytest.raises(_capi.RespmonError):
+        transforms.uint8_to_float(np.zeros(4, np.uint8))
+    from respmon_amd.base import RespiratoryMonitor
+    with pytest.raises(_capi.RespmonError):
+        RespiratoryMonitor.locate(np.zeros((4, 8, 8)), 10)
+
+
+class RecordingBackend:
+    """Test double: records the calls the state machine makes and answers with fixed values."""
+
+    def __init__(self, roi=(12, 22, 28, 26), fail_first=0):
+        self.roi, self.fail_first = roi, fail_first
+        self.locate_calls, self.stored = [], []
+
+    def alloc_buffer(self, T, H, W, dtype):
+        return np.zeros((T, H, W))
+
+    def bgr_to_gray(self, frame):
+        return np.ascontiguousarray(frame[..., 0])
+
+    def store_frame(self, buf, idx, gray):
+        buf[idx] = gray * (1. / 255)
+        self.stored.append(idx)
+
+    def locate(self, buf, fps, fmin, fmax, amp, levels, skip, tthr, thr, flags=0):
+        self.locate_calls.append((fps, fmin, fmax, amp, levels, skip, tthr, thr, float(buf.sum())))
+        if len(self.locate_calls) <= self.fail_first:
+            return None
+        return self.roi
+
+    def roi_mean(self, gray, x, y, w, h):
+        return float(np.average(gray[y:y + h, x:x + w] * (1. / 255)))
+
+
+def _monitor(frames, fps, backend, **kw):
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    mon = RespiratoryMonitor(capture_target=synth.FakeCapture(frames, fps=fps), visualize=None, save_all_data=False,
+                             run_on_init=False, backend=backend, **kw)
+    mon.sync_to_fps = lambda: None
+    return mon
+
+
+def test_state_machine_frame_accounting_matches_reference_trace(golden):
+    from respmon_amd import synth
+    g = golden("g6_run_trace.npz")
+    vid = synth.synth_breathing(150, 48, 64, seed=11)
+    roi = tuple(int(v) for v in g["c2_roi"])
+    be = RecordingBackend(roi=roi)
+    mon = _monitor(vid, 30, be, motion_extraction_method="average")
+    trace = []
+    real_next = mon.next_frame
+
+    def traced():
+        trace.append((["initialize", "calibration", "measure", "error"].index(mon.state), mon.calibration_buffer_idx))
+        return real_next()
+    mon.next_frame = traced
+    mon.run()
+    assert np.array_equal(np.array(trace, dtype=np.int32), g["c2_trace"])     # same (state, buffer index) per frame
+    assert be.stored == list(range(128))                                      # frames 1..128 fill the buffer
+    fps, fmin, fmax, amp, levels, skip, tthr, thr, _ = be.locate_calls[0]
+    assert [fps, fmin, fmax, tthr, thr] == [float(v) for v in g["c2_locate_kw"]]   # fps clamped to fps_limit = 10
+    assert (amp, levels, skip) == (500, 9, 4)                                 # locate()'s defaults (base.py:549-550)
+    assert (mon.x, mon.y, mon.w, mon.h) == roi and mon.fps == 10
+    assert np.allclose(np.array(mon.data), g["c2_data"], rtol=1e-13, atol=0)
+    assert np.array_equal(np.array(mon.t), g["c2_t"])
+
+
+def test_state_machine_retries_when_locate_returns_none():
+    from respmon_amd import synth
+    vid = synth.synth_breathing(300, 24, 32, seed=3)
+    be = RecordingBackend(fail_first=1)
+    mon = _monitor(vid, 10, be)
+    mon.run()
+    assert len(be.locate_calls) == 2                    # base.py:451-454: buffer index reset, buffer refilled, retry
+    assert be.stored == list(range(128)) * 2
+    assert mon.state == 'measure' and len(mon.data) == 300 - (1 + 128 + 1 + 128 + 1)
+
+
+def test_skip_calibration_config1_and_deque_cap(golden):
+    from respmon_amd import synth
+    g = golden("g6_run_trace.npz")
+    frames = synth.synth_brightness_video(64, 240, 320)
+    mon = _monitor(frames, 10, RecordingBackend())
+    mon.skip_calibration(100, 80, 70, 51)
+    assert mon.state == 'measure' and mon.peak_minimum_sample_distance == int(g["c1_peak_min_dist"])
+    mon.run()
+    assert np.allclose(np.array(mon.data), g["c1_data"], rtol=1e-13, atol=0) and np.array_equal(np.array(mon.t), g["c1_t"])
+    # the measurement deques are capped at measure_buffer_length = 128 (base.py:473-475)
+    mon2 = _monitor(synth.synth_brightness_video(200, 24, 32), 10, RecordingBackend())
+    mon2.skip_calibration(2, 2, 8, 8)
+    mon2.run()
+    assert len(mon2.data) == 128 and len(mon2.t) == 128
+
+
+def test_constructor_argument_contract():
+    import pytest
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    cap = synth.FakeCapture(synth.synth_brightness_video(2, 8, 8), fps=10)
+    for bad in (dict(fps_limit=0), dict(save_calibration_image=1), dict(visualize="matplotlib"), dict(fig_size=(1,)),
+                dict(error_reset_delay=-1), dict(save_all_data=None), dict(motion_extraction_method="median")):
+        with pytest.raises(AssertionError):
+            RespiratoryMonitor(capture_target=cap, run_on_init=False, backend=RecordingBackend(), **bad)
+
+
+def test_tools_and_peaks(golden):
+    from respmon_amd import peaks, tools
+    g = golden("g7_misc.npz")
+    for c, r in zip(g["rbb_in"], g["rbb_out"]):
+        x, y, w, h, a = c
+        assert tuple(tools.reduce_bounding_box(int(x), int(y), int(w), int(h), a)) == tuple(int(v) for v in r)
+    from respmon_amd.transforms import butter_lowpass_filter
+    assert np.array_equal(butter_lowpass_filter(g["sig"], 0.5, 10, 3), g["filt"])
+    t = np.arange(128) / 10.0
+    sig = np.sin(2 * np.pi * 0.3 * t)
+    idx = peaks.indexes(sig, min_dist=10)
+    assert len(idx) >= 3 and np.allclose(np.diff(t[idx]), 1 / 0.3, atol=0.11)
+    p = peaks.gaussian_fit(t[20:40], peaks.gaussian(t[20:40], 2.0, 3.0, 0.5))
+    assert np.allclose(p, [2.0, 3.0, 0.5], atol=1e-6)
+    b = tools.Benchmarker(); b.add_tag("x"); b.tick_start("x"); b.tick_end("x")
+    assert b.has_tag("x") and "x, " in b.get_report()

@@ -1,0 +1,72 @@
+"""Analytic known-answer tests for the oracle's restatement of cv2.goodFeaturesToTrack and
+cv2.calcOpticalFlowPyrLK (cv2 is absent: parity unpinned; these anchor oracle/cvref_flow.c)."""
+import numpy as np
+
+from respmon_amd import synth
+
+
+def test_lk_recovers_known_subpixel_shift(oracle):
+    render = synth.synth_texture(128, 144, seed=4321)
+    a = render(0.0, 0.0)
+    pts = oracle.goodFeaturesToTrack(a, 150, 0.02, 7, blockSize=7)
+    assert pts is not None and len(pts) >= 50
+    for (dx, dy) in [(0.7, -0.4), (-1.5, 0.5), (2.25, 1.75), (0.0, 0.0)]:
+        b = render(dx, dy)
+        p1, st, _ = oracle.calcOpticalFlowPyrLK(a, b, pts, None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        good = st.ravel() == 1
+        assert good.mean() > 0.9
+        flow = (p1 - pts).reshape(-1, 2)[good]
+        assert np.abs(np.median(flow, axis=0) - [dx, dy]).max() < 2e-2
+        assert np.abs(flow.mean(axis=0) - [dx, dy]).max() < 5e-2
+
+
+def test_lk_pyramid_depth_and_status(oracle):
+    # 70x51 ROI: levels 0,1 only (35x26 ok, 18x13 <= 15 stops) -- SURVEY App. B5
+    import ctypes
+    lib = oracle._lib()
+    assert lib.rmo_lk_max_level(51, 70, 15, 15, 2) == 1
+    assert lib.rmo_lk_max_level(256, 256, 15, 15, 2) == 2
+    assert lib.rmo_lk_max_level(20, 20, 15, 15, 2) == 0
+    # a flat image has no trackable texture: every point loses status (minEig < 1e-4)
+    flat = np.full((64, 64), 120, np.uint8)
+    pts = np.array([[[20.0, 20.0]], [[40.5, 30.25]]], np.float32)
+    p1, st, _ = oracle.calcOpticalFlowPyrLK(flat, flat, pts, None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+    assert st.ravel().tolist() == [0, 0]
+
+
+def test_gftt_checkerboard_corners(oracle):
+    img = np.zeros((80, 80), np.uint8)
+    for by in range(4):
+        for bx in range(4):
+            if (bx + by) % 2 == 0:
+                img[by * 20:(by + 1) * 20, bx * 20:(bx + 1) * 20] = 220
+    img[img == 0] = 30
+    pts = oracle.goodFeaturesToTrack(img, 50, 0.3, 7, blockSize=7)
+    assert pts is not None
+    got = pts.reshape(-1, 2)
+    # every detection sits within the 7x7 block of an inner checkerboard crossing (multiples of 20) and every
+    # crossing is detected (the block-summed response peaks on the two diagonal sides of a crossing)
+    crossings = np.array([[x, y] for y in (20, 40, 60) for x in (20, 40, 60)], np.float32)
+    d = np.abs(got[:, None, :] - crossings[None]).max(axis=2)
+    assert (d.min(axis=1) <= 3).all()
+    assert len({int(i) for i in d.argmin(axis=1)}) == len(crossings)
+    # minimum-distance rule
+    dd = np.sqrt(((got[:, None] - got[None]) ** 2).sum(-1)) + np.eye(len(got)) * 1e9
+    assert dd.min() >= 7
+    # nothing to track in a flat image: cv2 returns None (base.py:367 then raises TypeError in the reference)
+    assert oracle.goodFeaturesToTrack(np.full((40, 40), 9, np.uint8), 10, 0.3, 7, blockSize=7) is None
+
+
+def test_min_eigen_val_matches_independent_float64(oracle):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(2)
+    img = (ndi.gaussian_filter(rng.random((48, 56)), 1.5) * 255).astype(np.uint8)
+    e = oracle.cornerMinEigenVal(img, 7)
+    f = img.astype(np.float64)
+    sc = 1.0 / (4 * 7 * 255.0)
+    dx = ndi.correlate1d(ndi.correlate1d(f, [-1, 0, 1], axis=1, mode="mirror"), [1, 2, 1], axis=0, mode="mirror") * sc
+    dy = ndi.correlate1d(ndi.correlate1d(f, [1, 2, 1], axis=1, mode="mirror"), [-1, 0, 1], axis=0, mode="mirror") * sc
+    box = lambda a: ndi.uniform_filter(a, 7, mode="mirror") * 49
+    a, b, c = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
+    ref = (a + c) - np.sqrt((a - c) ** 2 + b * b)
+    assert np.abs(e - ref).max() <= 2e-5 * np.abs(ref).max()
