@@ -91,7 +91,12 @@ def main():
     flags = _capi.RM_FLAG_NO_PRUNE if a.no_prune else 0
     kw = dict(pyramid_levels=a.levels, skip_levels_at_top=a.skip, flags=flags)
 
+    from respmon_amd.base import _Backend
+    backend = _Backend()
+
     def step():
+        if world == 1:   # exactly RespiratoryMonitor.locate: one rm_locate call
+            return backend.locate(buf, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
         return rdist.locate_streams(buf, 10, threshold=20, **kw)
 
     def barrier():

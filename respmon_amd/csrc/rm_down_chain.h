@@ -581,16 +581,19 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
     const int SW = S == 1 ? StripWidth<1>::SW : S == 2 ? StripWidth<2>::SW : S == 3 ? StripWidth<3>::SW
                  : S == 4 ? StripWidth<4>::SW : StripWidth<5>::SW;
     g.strips = (g.w[S] + SW - 1) / SW;
-    // segments: enough workgroups to fill the chip (~24 waves per CU over the launch) while the vertical
-    // halo (2^(S+1)-2 input rows per side) stays below ~25 % of a segment
+    // segments: ONE resident round of waves (12 per CU at ~147 VGPRs = 3072 on the chip).  Every extra segment
+    // re-reads 2*(2^(S+1)-2) input rows from HBM (measured: 4 segments = 1.23x the algorithmic bytes at 1080p),
+    // so take the fewest segments that fill the machine, and never let the halo exceed ~25 % of a segment.
     const int rows = y_end - y_begin;
-    int segs = 1;
     const int halo0 = (1 << (S + 1)) - 2;
-    while ((long long)T * g.strips * segs < 256LL * 24 && segs < rows) {
-        int seg_h = (rows + segs) / (segs + 1);
-        if ((seg_h << S) < 8 * halo0) break;
-        ++segs;
-    }
+    const long long per_seg = (long long)T * g.strips;
+    int segs = (int)((3072 + per_seg / 2) / per_seg);
+    if (segs < 1) segs = 1;
+    if (segs > rows) segs = rows;
+    while (segs > 1 && ((((rows + segs - 1) / segs) << S) < 8 * halo0)) --segs;
+#ifdef RM_DC_SEGS  // developer experiment
+    segs = RM_DC_SEGS;
+#endif
     g.seg_h = (rows + segs - 1) / segs;
     if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
     g.segs = (rows + g.seg_h - 1) / g.seg_h;

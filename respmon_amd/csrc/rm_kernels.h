@@ -258,21 +258,24 @@ struct ChainGeom {
     int tiles_x, tiles_y;
 };
 
-struct TileRegion { int y0[MAX_CHAIN], y1[MAX_CHAIN], x0[MAX_CHAIN], x1[MAX_CHAIN]; };  // inclusive
+struct Region { int y0, y1, x0, x1; };  // inclusive
 
 __device__ __forceinline__ int floordiv2(int a) { return a >> 1; }  // arithmetic shift == floor for negatives
 
-__device__ __forceinline__ void tile_regions(const ChainGeom &g, int tile, TileRegion &R)
+// footprint of `tile` at level k (0 = the tile itself): scalars only, so nothing lands in scratch
+__device__ __forceinline__ Region tile_region(const ChainGeom &g, int tile, int k)
 {
     int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
-    R.y0[0] = ty * CT_H; R.y1[0] = min(R.y0[0] + CT_H, g.h[0]) - 1;
-    R.x0[0] = tx * CT_W; R.x1[0] = min(R.x0[0] + CT_W, g.w[0]) - 1;
-    for (int k = 1; k <= g.S; ++k) {
-        R.y0[k] = max(0, floordiv2(R.y0[k - 1]) - 1);
-        R.y1[k] = min(g.h[k] - 1, floordiv2(R.y1[k - 1]) + 1);
-        R.x0[k] = max(0, floordiv2(R.x0[k - 1]) - 1);
-        R.x1[k] = min(g.w[k] - 1, floordiv2(R.x1[k - 1]) + 1);
+    Region R;
+    R.y0 = ty * CT_H; R.y1 = min(R.y0 + CT_H, g.h[0]) - 1;
+    R.x0 = tx * CT_W; R.x1 = min(R.x0 + CT_W, g.w[0]) - 1;
+    for (int i = 1; i <= k; ++i) {
+        R.y0 = max(0, floordiv2(R.y0) - 1);
+        R.y1 = min(g.h[i] - 1, floordiv2(R.y1) + 1);
+        R.x0 = max(0, floordiv2(R.x0) - 1);
+        R.x1 = min(g.w[i] - 1, floordiv2(R.x1) + 1);
     }
+    return R;
 }
 
 // worst-case tile-buffer extent of level k (host + device agree on the LDS layout)
@@ -311,14 +314,14 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom
     int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= ntiles * T) return;
     int t = idx / ntiles, tile = idx - t * ntiles;
-    TileRegion R;
-    tile_regions(g, tile, R);
     const int S = g.S;
-    const double *p = cS + (size_t)t * g.h[S] * g.w[S];
-    double mn = p[(size_t)R.y0[S] * g.w[S] + R.x0[S]], mx = mn;
-    for (int y = R.y0[S]; y <= R.y1[S]; ++y)
-        for (int x = R.x0[S]; x <= R.x1[S]; ++x) {
-            double v = p[(size_t)y * g.w[S] + x];
+    const Region R = tile_region(g, tile, S);
+    const int wS = g.w[S];
+    const double *p = cS + (size_t)t * g.h[S] * wS;
+    double mn = p[(size_t)R.y0 * wS + R.x0], mx = mn;
+    for (int y = R.y0; y <= R.y1; ++y)
+        for (int x = R.x0; x <= R.x1; ++x) {
+            double v = p[(size_t)y * wS + x];
             mn = (v < mn) ? v : mn;
             mx = (v > mx) ? v : mx;
         }
@@ -402,39 +405,42 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
 }
 
 // stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
-__device__ __forceinline__ void chain_to_level1(const ChainGeom &g, const TileRegion &R, const double *cS_t,
-                                                double *lds)
+__device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, const double *cS_t, double *lds)
 {
     const int lane = threadIdx.x;
     const int S = g.S;
+    Region Rk = tile_region(g, tile, S);
     {
         double *d = lds + g.lds_off[S];
-        int nw = R.x1[S] - R.x0[S] + 1, n = (R.y1[S] - R.y0[S] + 1) * nw;
+        const int nw = Rk.x1 - Rk.x0 + 1, n = (Rk.y1 - Rk.y0 + 1) * nw, wS = g.w[S];
         for (int i = lane; i < n; i += 64) {
             int r = i / nw, c = i - r * nw;
-            d[i] = cS_t[(size_t)(R.y0[S] + r) * g.w[S] + R.x0[S] + c];
+            d[i] = cS_t[(size_t)(Rk.y0 + r) * wS + Rk.x0 + c];
         }
     }
     __syncthreads();
     for (int k = S; k >= 2; --k) {
-        LdsImg s{lds + g.lds_off[k], R.y0[k], R.x0[k], R.x1[k] - R.x0[k] + 1};
+        const Region Rd = tile_region(g, tile, k - 1);
+        LdsImg s{lds + g.lds_off[k], Rk.y0, Rk.x0, Rk.x1 - Rk.x0 + 1};
         double *d = lds + g.lds_off[k - 1];
-        int nw = R.x1[k - 1] - R.x0[k - 1] + 1, n = (R.y1[k - 1] - R.y0[k - 1] + 1) * nw;
+        const int nw = Rd.x1 - Rd.x0 + 1, n = (Rd.y1 - Rd.y0 + 1) * nw;
+        const int hk = g.h[k], wk = g.w[k];
         for (int i = lane; i < n; i += 64) {
             int r = i / nw, c = i - r * nw;
-            d[i] = up_at(s, R.y0[k - 1] + r, R.x0[k - 1] + c, g.h[k], g.w[k]);
+            d[i] = up_at(s, Rd.y0 + r, Rd.x0 + c, hk, wk);
         }
         __syncthreads();
+        Rk = Rd;
     }
 }
 
 // level 1 (LDS) -> level 0 for this lane's column; out[j] = raw[t, y0+j, x]
-__device__ __forceinline__ void level0_column(const ChainGeom &g, const TileRegion &R, const double *lds, int x,
+__device__ __forceinline__ void level0_column(const ChainGeom &g, const Region &R0, const Region &R1, const double *lds, int x,
                                               double (&out)[CT_H])
 {
-    LdsImg s{lds + g.lds_off[1], R.y0[1], R.x0[1], R.x1[1] - R.x0[1] + 1};
+    LdsImg s{lds + g.lds_off[1], R1.y0, R1.x0, R1.x1 - R1.x0 + 1};
     const int sh = g.h[1], sw = g.w[1];
-    const int y0 = R.y0[0];  // multiple of CT_H (even)
+    const int y0 = R0.y0;  // multiple of CT_H (even)
     // horizontal values of source rows i0-1 .. i0+CT_H/2 (border rules applied by row index)
     const int i0 = y0 >> 1;
     double hv[CT_H / 2 + 2];
@@ -466,15 +472,14 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
         unsigned idx = list[c];
         int t = idx / ntiles, tile = idx - t * ntiles;
-        TileRegion R;
-        tile_regions(g, tile, R);
-        chain_to_level1(g, R, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
-        int x = R.x0[0] + lane;
+        const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
+        chain_to_level1(g, tile, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
+        int x = R0.x0 + lane;
         int slot = slot_of[idx];
-        if (x <= R.x1[0]) {
+        if (x <= R0.x1) {
             double v[CT_H];
-            level0_column(g, R, lds, x, v);
-            int rows = R.y1[0] - R.y0[0] + 1;
+            level0_column(g, R0, R1, lds, x, v);
+            int rows = R0.y1 - R0.y0 + 1;
 #pragma unroll
             for (int j = 0; j < CT_H; ++j)
                 if (j < rows) { mn = (v[j] < mn) ? v[j] : mn; mx = (v[j] > mx) ? v[j] : mx; }
@@ -504,7 +509,8 @@ __global__ void k_finish_minmax(CollapseState *st, double threshold)
 }
 
 // pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order,
-// base.py:562).  Pruned pairs add `min`; kept pairs read their values back from `store`.
+// base.py:562).  Pruned pairs add `min`; kept pairs read their values back from `store`, one kept frame
+// ahead of the accumulation so the load latency hides behind the runs of pruned frames.
 constexpr int MAX_T = 4096;
 
 __global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, int ntiles,
@@ -513,51 +519,67 @@ __global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, Chain
 {
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
+    __shared__ short s_kept_t[MAX_T];
+    __shared__ int s_nkept;
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(st->min_key), max_val = f64_unkey(st->max_key);
     const double top = max_val - (max_val - min_val) * threshold;
     if (tile == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
-    TileRegion R;
-    tile_regions(g, tile, R);
+    const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
     for (int t = lane; t < T; t += 64) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
     __syncthreads();
-    const int x = R.x0[0] + lane;
-    const int rows = R.y1[0] - R.y0[0] + 1;
-    const bool active = x <= R.x1[0];
-    double acc[CT_H];
+    if (lane == 0) {  // compact, ordered list of the frames that are not pruned
+        int n = 0;
+        for (int t = 0; t < T; ++t)
+            if (s_slot[t] != SLOT_PRUNED) s_kept_t[n++] = (short)t;
+        s_nkept = n;
+    }
+    __syncthreads();
+    const int nkept = s_nkept;
+    const int x = R0.x0 + lane;
+    const int rows = R0.y1 - R0.y0 + 1;
+    const bool active = x <= R0.x1;
+    double acc[CT_H], nxt[CT_H];
 #pragma unroll
-    for (int j = 0; j < CT_H; ++j) acc[j] = 0.0;
-    for (int t = 0; t < T; ++t) {
-        const int slot = s_slot[t];
-        if (slot == SLOT_PRUNED) {
+    for (int j = 0; j < CT_H; ++j) { acc[j] = 0.0; nxt[j] = 0.0; }
+    auto fetch = [&](int i, double (&v)[CT_H]) __attribute__((always_inline)) {
+        const int slot = (i < nkept) ? s_slot[s_kept_t[i]] : -1;
+        if (slot >= 0 && active) {
+            const double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
+#pragma unroll
+            for (int j = 0; j < CT_H; ++j) v[j] = d[j * CT_W];
+        }
+    };
+    fetch(0, nxt);
+    int t_done = 0;
+    for (int i = 0; i <= nkept; ++i) {
+        const int t_stop = (i < nkept) ? s_kept_t[i] : T;  // frames [t_done, t_stop) are pruned
+        double cur[CT_H];
+#pragma unroll
+        for (int j = 0; j < CT_H; ++j) cur[j] = nxt[j];
+        fetch(i + 1, nxt);
+        for (int t = t_done; t < t_stop; ++t) {
 #pragma unroll
             for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + min_val;
-        } else if (slot >= 0) {
-            if (active) {
-                const double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
-                double v[CT_H];
-#pragma unroll
-                for (int j = 0; j < CT_H; ++j) v[j] = d[j * CT_W];
-#pragma unroll
-                for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
-            }
-        } else {
-            chain_to_level1(g, R, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
-            if (active) {
-                double v[CT_H];
-                level0_column(g, R, lds, x, v);
-#pragma unroll
-                for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
-            }
+        }
+        if (i == nkept) break;
+        if (s_slot[t_stop] < 0) {  // SLOT_ON_THE_FLY: the value store was full, evaluate here
+            chain_to_level1(g, tile, cS + (size_t)t_stop * g.h[g.S] * g.w[g.S], lds);
+            if (active) level0_column(g, R0, R1, lds, x, cur);
             __syncthreads();
         }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + ((cur[j] >= top) ? min_val : cur[j]);
+        }
+        t_done = t_stop + 1;
     }
     if (active)
 #pragma unroll
         for (int j = 0; j < CT_H; ++j)
-            if (j < rows) heat_sum[(size_t)(R.y0[0] + j) * g.w[0] + x] = acc[j];
+            if (j < rows) heat_sum[(size_t)(R0.y0 + j) * g.w[0] + x] = acc[j];
 }
 
 // ----------------------------------------------------------------------------------------
