@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=9)
     ap.add_argument("--skip", type=int, default=4)
     ap.add_argument("--no-prune", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T frames if host memory allows, else 64)")
     return ap.parse_args()
 
 
@@ -164,8 +164,15 @@ def main():
             "roi": roi,
             "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
         }
-        if world == 1 and a.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(vid_u8, min(a.cpu_frames, T), a.levels, a.skip)
+        if world == 1 and a.cpu_frames != 0:
+            n_cpu = a.cpu_frames
+            if n_cpu < 0:
+                import psutil
+                need = 6.0 * T * H * W * 8   # the materialising algorithm holds ~5-6 float64 [T,H,W] arrays
+                n_cpu = T if psutil.virtual_memory().available > 1.3 * need else 64
+            out["cpu_baseline"] = cpu_baseline(vid_u8, min(n_cpu, T), a.levels, a.skip)
+            if min(n_cpu, T) == T:
+                out["cpu_baseline"]["roi_equals_gpu"] = list(out["cpu_baseline"]["roi"] or []) == list(roi or [])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
