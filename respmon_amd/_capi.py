@@ -14,6 +14,7 @@ RM_FLAG_NO_PRUNE = 1
 RM_FLAG_UNFUSED_DOWN = 2
 RM_FLAG_TINY_STORE = 4
 RM_FLAG_TINY_STRIPS = 8
+RM_FLAG_UNFUSED_SMALL = 16
 
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint

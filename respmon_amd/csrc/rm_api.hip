@@ -60,6 +60,8 @@ struct rm_ctx {
     FlowWorkspace flow;
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0;
+    unsigned int *h_slots_seen = nullptr;  // pinned: n_slots of the previous rm_calibrate (async readback)
+    int slots_seen_pairs = 0;              // npairs that readback belongs to
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
     bool prof_on = false;
     int prof_calls = 0;
@@ -126,6 +128,8 @@ extern "C" int rm_ctx_create(int device, rm_ctx **out)
     c->device = device;
     HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(CollapseState)));
     HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(CollapseState), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_slots_seen, sizeof(unsigned int), hipHostMallocDefault));
+    *c->h_slots_seen = 0;
     *out = c;
     return RM_OK;
 }
@@ -138,6 +142,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_slots_seen) (void)hipHostFree(ctx->h_slots_seen);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
     if (ctx->h_rowany) (void)hipHostFree(ctx->h_rowany);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
@@ -618,15 +623,35 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
         g[S] = dst; cur = dst; cur_dtype = RM_F64;
         first = S + 1;
     }
-    for (int l = first; l < L; ++l) {
-        double *dst = nullptr;
-        if (l < S) RM_TRY(ws(ctx, (l & 1) ? "g_ping" : "g_pong", (size_t)T * h[l] * w[l], &dst));
-        else RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &dst));
-        {
-            PhaseTimer pt(ctx, (l == 1) ? 0 : 1, s);
-            RM_TRY(launch_pyr_down(cur, cur_dtype, T, h[l - 1], w[l - 1], dst, s));
+    // small pyramid geometry: levels S..L-1 of one frame side by side
+    std::vector<size_t> off(L, 0);
+    size_t NP = 0;
+    for (int l = S; l <= L - 2; ++l) { off[l] = NP; NP += (size_t)h[l] * w[l]; }
+    size_t lds_levels = 0;  // doubles needed to hold G_S..G_{L-1} of one frame
+    for (int l = S; l < L; ++l) lds_levels += (size_t)h[l] * w[l];
+    const size_t LDS_LIMIT = 150 * 1024;
+    const bool fuse_small = g[S] != nullptr && !(flags & RM_FLAG_UNFUSED_SMALL) && L <= SMALL_MAX_LEVELS &&
+                            lds_levels * sizeof(double) <= LDS_LIMIT && NP * sizeof(double) <= LDS_LIMIT;
+    SmallGeom sg;
+    if (fuse_small) {
+        sg.S = S; sg.L = L; sg.NP = (int)NP;
+        int o = 0;
+        for (int l = 0; l < L; ++l) {
+            sg.h[l] = h[l]; sg.w[l] = w[l];
+            sg.g_off[l] = 0; sg.np_off[l] = (int)off[l];
+            if (l >= S) { sg.g_off[l] = o; o += h[l] * w[l]; }
         }
-        g[l] = dst; cur = dst; cur_dtype = RM_F64;
+    } else {
+        for (int l = first; l < L; ++l) {
+            double *dst = nullptr;
+            if (l < S) RM_TRY(ws(ctx, (l & 1) ? "g_ping" : "g_pong", (size_t)T * h[l] * w[l], &dst));
+            else RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &dst));
+            {
+                PhaseTimer pt(ctx, (l == 1) ? 0 : 1, s);
+                RM_TRY(launch_pyr_down(cur, cur_dtype, T, h[l - 1], w[l - 1], dst, s));
+            }
+            g[l] = dst; cur = dst; cur_dtype = RM_F64;
+        }
     }
     if (S == 0) {
         double *g0 = nullptr;
@@ -639,33 +664,49 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
     PhaseTimer pt_small(ctx, 1, s);
     // The filtered levels S .. L-2 live side by side in [T, NP] buffers (level S first), so the temporal
     // filter is two launches for the whole small pyramid.
-    std::vector<size_t> off(L, 0);
-    size_t NP = 0;
-    for (int l = S; l <= L - 2; ++l) { off[l] = NP; NP += (size_t)h[l] * w[l]; }
     double *lap = nullptr, *bp = nullptr;
     RM_TRY(ws(ctx, "lap_all", (size_t)T * NP, &lap));
     RM_TRY(ws(ctx, "bp_all", (size_t)T * NP, &bp));
-    // Laplacian levels (pyramid.py:23-26): L_l = G_l - pyrUp(G_{l+1})
-    for (int l = L - 2; l >= S; --l)
-        RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap + off[l], h[l], w[l], 1, g[l], s, 0, NP, 0));
+    if (fuse_small) {
+        // Gaussian levels S+1..L-1 and all Laplacians in one launch, one workgroup per frame, in LDS
+        const size_t shmem = lds_levels * sizeof(double);
+        if (shmem > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_small_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k_small_pyramid, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)g[S], sg, lap);
+        LAUNCH_CHECK();
+    } else {
+        // Laplacian levels (pyramid.py:23-26): L_l = G_l - pyrUp(G_{l+1})
+        for (int l = L - 2; l >= S; --l)
+            RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap + off[l], h[l], w[l], 1, g[l], s, 0, NP, 0));
+    }
     // temporal band-pass of every level at once (transforms.py:162,169)
     RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
     // collapse of the band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x);
-    // the last step lands in a contiguous [T,h_S,w_S] array for the full-resolution passes
+    // the result is a contiguous [T,h_S,w_S] array for the full-resolution passes
     const double *c = bp + off[L - 2];
-    size_t c_fs = NP;
     if (L - 2 == S) {
-        c_fs = (size_t)h[S] * w[S];  // single filtered level: NP == h_S*w_S, already contiguous
-    }
-    for (int l = L - 3; l >= S; --l) {
-        double *dst = bp + off[l];
-        size_t dst_fs = NP;
-        if (l == S) {
-            RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
-            dst_fs = (size_t)h[S] * w[S];
+        // single filtered level: NP == h_S*w_S, bp_all is already C_S
+    } else if (fuse_small) {
+        double *dst = nullptr;
+        RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
+        const size_t shmem = NP * sizeof(double);
+        if (shmem > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, sg, dst);
+        LAUNCH_CHECK();
+        c = dst;
+    } else {
+        size_t c_fs = NP;
+        for (int l = L - 3; l >= S; --l) {
+            double *dst = bp + off[l];
+            size_t dst_fs = NP;
+            if (l == S) {
+                RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
+                dst_fs = (size_t)h[S] * w[S];
+            }
+            RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + off[l], s, c_fs, dst_fs, NP));
+            c = dst; c_fs = dst_fs;
         }
-        RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + off[l], s, c_fs, dst_fs, NP));
-        c = dst; c_fs = dst_fs;
     }
     out.cS = c;
     return RM_OK;
@@ -734,7 +775,11 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         const int npairs = ntiles * T;
         // value store for the pairs the masked sum needs: 1/8 of all pairs (>= 4096 slots); pairs beyond
         // the capacity are re-evaluated inside the sum kernel, so the size is a speed knob, not a limit
+        // The store adapts without a host sync: every call leaves its slot demand in pinned memory
+        // (asynchronous copy); the next call with the same geometry sizes the store from it (+25 %).
         size_t slot_cap = (size_t)npairs / 8;
+        if (ctx->slots_seen_pairs == npairs && (size_t)*ctx->h_slots_seen > slot_cap)
+            slot_cap = (size_t)*ctx->h_slots_seen + (size_t)*ctx->h_slots_seen / 4;
         if (slot_cap < 4096) slot_cap = 4096;
         if (slot_cap > (size_t)npairs) slot_cap = (size_t)npairs;
         if (flags & RM_FLAG_TINY_STORE) slot_cap = 3;
@@ -759,8 +804,10 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
         hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), shmem, s, sl.cS, g, ntiles, list, slot_of, st, store);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(64), shmem, s, sl.cS, g, T, ntiles, slot_of, store, st, thr, heat_sum);
+        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(256), shmem, s, sl.cS, g, T, ntiles, slot_of, store, st, thr, heat_sum);
         LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(ctx->h_slots_seen, &st->n_slots, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        ctx->slots_seen_pairs = npairs;
     }
     hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
     LAUNCH_CHECK();

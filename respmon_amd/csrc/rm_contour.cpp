@@ -29,15 +29,35 @@ struct Tracer {
     int step = 0;
     int nbr[16];
 
+    int rows_dirty_h = 0;            // geometry of the previous image (the buffer is kept between calls)
+    std::vector<char> dirty;         // rows of the working copy that are not all-background
+
     void prepare(const uint8_t *bin, int H, int W, const uint32_t *row_any)
     {
-        step = W + 2;
-        buf.assign((size_t)step * (H + 2), BG);
+        const int new_step = W + 2;
+        if (new_step != step || rows_dirty_h != H) {
+            step = new_step; rows_dirty_h = H;
+            buf.assign((size_t)step * (H + 2), BG);
+            dirty.assign(H, 0);
+        }
         for (int y = 0; y < H; ++y) {
-            if (row_any && !row_any[y]) continue;
-            const uint8_t *s = bin + (size_t)y * W;
             signed char *d = buf.data() + (size_t)(y + 1) * step + 1;
-            for (int x = 0; x < W; ++x) d[x] = s[x] ? FG : BG;
+            const bool any = row_any ? row_any[y] != 0 : true;
+            if (!any) {
+                if (dirty[y]) { std::memset(d, BG, (size_t)W); dirty[y] = 0; }  // only rows the last image touched
+                continue;
+            }
+            dirty[y] = 1;
+            const uint8_t *s = bin + (size_t)y * W;
+            int x = 0;
+            // foreground = non-zero byte, 8 pixels per step: bit 7 of ((b & 0x7f) + 0x7f) | b is set iff b != 0
+            for (; x + 8 <= W; x += 8) {
+                unsigned long long v;
+                std::memcpy(&v, s + x, 8);
+                v = ((((v & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | v) & 0x8080808080808080ull) >> 7;
+                std::memcpy(d + x, &v, 8);
+            }
+            for (; x < W; ++x) d[x] = s[x] ? FG : BG;
         }
         const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
         const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
@@ -91,7 +111,7 @@ int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *r
     out->found = 0; out->n_contours = 0; out->area = 0.0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
-    Tracer tr;
+    static thread_local Tracer tr;   // working copy reused across calls (one context drives one thread at a time)
     tr.prepare(bin, H, W, row_any);
     const int step = tr.step;
     double best = -1.0;

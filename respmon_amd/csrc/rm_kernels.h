@@ -239,6 +239,94 @@ __global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, si
 }
 
 // ----------------------------------------------------------------------------------------
+// Small pyramid, one workgroup per frame, everything in LDS (levels S..L-1 of a 1080p frame are 87 KB):
+//   k_small_pyramid : G_S[t] -> G_{S+1..L-1} (cv2.pyrDown, pyramid.py:14) -> L_l = G_l - pyrUp(G_{l+1})
+//                     for l = L-2..S (pyramid.py:23-26), written side by side into lap_all[t, :]
+//   k_small_collapse: band-passed levels bp_all[t, :] -> c = bp_{L-2}; c = pyrUp(c) + bp_l for l = L-3..S
+//                     (pyramid.py:51-57) -> C_S[t]
+// Same per-pixel arithmetic as k_pyr_down / k_pyr_up (bit-identical); they replace ~13 tiny launches.
+// ----------------------------------------------------------------------------------------
+constexpr int SMALL_MAX_LEVELS = 16;
+constexpr int SMALL_NT = 1024;     // one workgroup per frame and per CU: 16 waves hide the LDS / global latencies
+struct SmallGeom {
+    int S, L;                        // levels S .. L-1 take part
+    int h[SMALL_MAX_LEVELS], w[SMALL_MAX_LEVELS];
+    int g_off[SMALL_MAX_LEVELS];     // LDS offset (doubles) of Gaussian level l
+    int np_off[SMALL_MAX_LEVELS];    // offset of level l inside a [NP] frame of lap_all / bp_all
+    int NP;
+};
+
+struct LdsPlain {
+    const double *p; int w;
+    __device__ __forceinline__ double operator()(int r, int c) const { return p[r * w + c]; }
+};
+
+__global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int S = g.S, L = g.L;
+    {
+        const int n = g.h[S] * g.w[S];
+        const double *src = gS + (size_t)t * n;
+        for (int i = tid; i < n; i += SMALL_NT) lds[g.g_off[S] + i] = src[i];
+    }
+    __syncthreads();
+    for (int l = S + 1; l < L; ++l) {
+        const int sh = g.h[l - 1], sw = g.w[l - 1], dh = g.h[l], dw = g.w[l];
+        const double *s = lds + g.g_off[l - 1];
+        double *d = lds + g.g_off[l];
+        for (int i = tid; i < dh * dw; i += SMALL_NT) {
+            const int y = i / dw, x = i - y * dw;
+            const int c0 = reflect101(2 * x - 2, sw), c1 = reflect101(2 * x - 1, sw), c2 = reflect101(2 * x, sw);
+            const int c3 = reflect101(2 * x + 1, sw), c4 = reflect101(2 * x + 2, sw);
+            double r[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double *row = s + reflect101(2 * y - 2 + k, sh) * sw;
+                r[k] = row[c2] * 6 + (row[c1] + row[c3]) * 4 + row[c0] + row[c4];
+            }
+            d[i] = (r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]) * (1.0 / 256);
+        }
+        __syncthreads();
+    }
+    double *out = lap_all + (size_t)t * g.NP;
+    for (int l = L - 2; l >= S; --l) {
+        const int dh = g.h[l], dw = g.w[l], sh = g.h[l + 1], sw = g.w[l + 1];
+        LdsPlain up{lds + g.g_off[l + 1], sw};
+        const double *base = lds + g.g_off[l];
+        double *o = out + g.np_off[l];
+        for (int i = tid; i < dh * dw; i += SMALL_NT) {
+            const int y = i / dw, x = i - y * dw;
+            o[i] = base[i] - up_at(up, y, x, sh, sw);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_all, SmallGeom g, double *cS)
+{
+    HIP_DYNAMIC_SHARED(double, lds)   // the [NP] frame, levels laid out as in bp_all
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int S = g.S, L = g.L;
+    const double *src = bp_all + (size_t)t * g.NP;
+    for (int i = tid; i < g.NP; i += SMALL_NT) lds[i] = src[i];
+    __syncthreads();
+    for (int l = L - 3; l >= S; --l) {
+        const int dh = g.h[l], dw = g.w[l], sh = g.h[l + 1], sw = g.w[l + 1];
+        LdsPlain c{lds + g.np_off[l + 1], sw};
+        double *d = lds + g.np_off[l];
+        for (int i = tid; i < dh * dw; i += SMALL_NT) {
+            const int y = i / dw, x = i - y * dw;
+            d[i] = up_at(c, y, x, sh, sw) + d[i];
+        }
+        __syncthreads();
+    }
+    const int n = g.h[S] * g.w[S];
+    double *o = cS + (size_t)t * n;
+    for (int i = tid; i < n; i += SMALL_NT) o[i] = lds[g.np_off[S] + i];
+}
+
+// ----------------------------------------------------------------------------------------
 // Fused collapse from level S to full resolution (pyramid.py:51-69 for the levels below
 // skip_levels_at_top, which are all-zero in the band-passed pyramid: transforms.py:150-160).
 //
@@ -407,13 +495,13 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
 // stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
 __device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, const double *cS_t, double *lds)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, nthr = blockDim.x;
     const int S = g.S;
     Region Rk = tile_region(g, tile, S);
     {
         double *d = lds + g.lds_off[S];
         const int nw = Rk.x1 - Rk.x0 + 1, n = (Rk.y1 - Rk.y0 + 1) * nw, wS = g.w[S];
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += nthr) {
             int r = i / nw, c = i - r * nw;
             d[i] = cS_t[(size_t)(Rk.y0 + r) * wS + Rk.x0 + c];
         }
@@ -425,7 +513,7 @@ __device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, co
         double *d = lds + g.lds_off[k - 1];
         const int nw = Rd.x1 - Rd.x0 + 1, n = (Rd.y1 - Rd.y0 + 1) * nw;
         const int hk = g.h[k], wk = g.w[k];
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += nthr) {
             int r = i / nw, c = i - r * nw;
             d[i] = up_at(s, Rd.y0 + r, Rd.x0 + c, hk, wk);
         }
@@ -434,25 +522,25 @@ __device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, co
     }
 }
 
-// level 1 (LDS) -> level 0 for this lane's column; out[j] = raw[t, y0+j, x]
-__device__ __forceinline__ void level0_column(const ChainGeom &g, const Region &R0, const Region &R1, const double *lds, int x,
-                                              double (&out)[CT_H])
+// level 1 (LDS) -> level 0 for this lane's column: out[j] = raw[t, y0 + j0 + j, x], j < NR (j0, NR even)
+template <int NR>
+__device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0, const Region &R1, const double *lds, int x, int j0,
+                                            double (&out)[NR])
 {
     LdsImg s{lds + g.lds_off[1], R1.y0, R1.x0, R1.x1 - R1.x0 + 1};
     const int sh = g.h[1], sw = g.w[1];
-    const int y0 = R0.y0;  // multiple of CT_H (even)
-    // horizontal values of source rows i0-1 .. i0+CT_H/2 (border rules applied by row index)
-    const int i0 = y0 >> 1;
-    double hv[CT_H / 2 + 2];
+    // horizontal values of source rows i0-1 .. i0+NR/2 (border rules applied by row index)
+    const int i0 = (R0.y0 + j0) >> 1;  // R0.y0 is a multiple of CT_H, j0 is even
+    double hv[NR / 2 + 2];
 #pragma unroll
-    for (int k = 0; k < CT_H / 2 + 2; ++k) {
+    for (int k = 0; k < NR / 2 + 2; ++k) {
         int i = i0 - 1 + k;
         int r = (i < 0) ? (sh > 1 ? 1 : 0) : (i > sh - 1 ? sh - 1 : i);
         hv[k] = up_h(s, r, x, sw);
     }
 #pragma unroll
-    for (int j = 0; j < CT_H; ++j) {
-        int k = (j >> 1) + 1;  // hv index of source row i = (y0+j)/2
+    for (int j = 0; j < NR; ++j) {
+        int k = (j >> 1) + 1;  // hv index of source row i = (y0+j0+j)/2
         if (j & 1) out[j] = ((hv[k] + hv[k + 1]) * 4) * (1.0 / 64);
         else out[j] = (hv[k - 1] + hv[k] * 6 + hv[k + 1]) * (1.0 / 64);
     }
@@ -478,7 +566,7 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
         int slot = slot_of[idx];
         if (x <= R0.x1) {
             double v[CT_H];
-            level0_column(g, R0, R1, lds, x, v);
+            level0_rows<CT_H>(g, R0, R1, lds, x, 0, v);
             int rows = R0.y1 - R0.y0 + 1;
 #pragma unroll
             for (int j = 0; j < CT_H; ++j)
@@ -508,29 +596,33 @@ __global__ void k_finish_minmax(CollapseState *st, double threshold)
     st->top = mx - (mx - mn) * threshold;
 }
 
-// pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order,
-// base.py:562).  Pruned pairs add `min`; kept pairs read their values back from `store`, one kept frame
-// ahead of the accumulation so the load latency hides behind the runs of pruned frames.
+// pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order, base.py:562).
+// Pruned pairs add `min`; kept pairs read their values back from `store`.  A 256-thread workgroup owns a
+// tile (wave w: rows 4w..4w+3 of every column) and walks the ordered list of kept frames in batches of
+// MS_B whose loads are issued one batch ahead, so a tile with hundreds of kept frames is not a chain of
+// exposed memory latencies.
 constexpr int MAX_T = 4096;
+constexpr int MS_B = 8;               // kept frames per batch
+constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 
-__global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, int ntiles,
-                                                         const int *slot_of, const double *store,
-                                                         CollapseState *st, double threshold, double *heat_sum)
+__global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, int ntiles,
+                                                          const int *slot_of, const double *store,
+                                                          CollapseState *st, double threshold, double *heat_sum)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
-    __shared__ short s_kept_t[MAX_T];
+    __shared__ short s_kept_t[MAX_T + MS_B];
     __shared__ int s_nkept;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, j0 = (tid >> 6) * MS_R;
     const int tile = blockIdx.x;
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(st->min_key), max_val = f64_unkey(st->max_key);
     const double top = max_val - (max_val - min_val) * threshold;
-    if (tile == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    if (tile == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
-    for (int t = lane; t < T; t += 64) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
+    for (int t = tid; t < T; t += 256) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
     __syncthreads();
-    if (lane == 0) {  // compact, ordered list of the frames that are not pruned
+    if (tid == 0) {  // compact, ordered list of the frames that are not pruned
         int n = 0;
         for (int t = 0; t < T; ++t)
             if (s_slot[t] != SLOT_PRUNED) s_kept_t[n++] = (short)t;
@@ -541,45 +633,64 @@ __global__ __launch_bounds__(64) void k_masked_sum_tiles(const double *cS, Chain
     const int x = R0.x0 + lane;
     const int rows = R0.y1 - R0.y0 + 1;
     const bool active = x <= R0.x1;
-    double acc[CT_H], nxt[CT_H];
+    double acc[MS_R];
 #pragma unroll
-    for (int j = 0; j < CT_H; ++j) { acc[j] = 0.0; nxt[j] = 0.0; }
-    auto fetch = [&](int i, double (&v)[CT_H]) __attribute__((always_inline)) {
-        const int slot = (i < nkept) ? s_slot[s_kept_t[i]] : -1;
-        if (slot >= 0 && active) {
-            const double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
+    for (int j = 0; j < MS_R; ++j) acc[j] = 0.0;
+    double nxt[MS_B][MS_R];
 #pragma unroll
-            for (int j = 0; j < CT_H; ++j) v[j] = d[j * CT_W];
+    for (int b = 0; b < MS_B; ++b)
+#pragma unroll
+        for (int j = 0; j < MS_R; ++j) nxt[b][j] = 0.0;
+    auto fetch = [&](int ib, double (&v)[MS_B][MS_R]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < MS_B; ++b) {
+            const int i = ib + b;
+            const int slot = (i < nkept) ? s_slot[s_kept_t[i]] : -1;
+            if (slot >= 0 && active) {
+                const double *d = store + (size_t)slot * (CT_H * CT_W) + (size_t)j0 * CT_W + lane;
+#pragma unroll
+                for (int j = 0; j < MS_R; ++j) v[b][j] = d[j * CT_W];
+            }
         }
     };
     fetch(0, nxt);
     int t_done = 0;
-    for (int i = 0; i <= nkept; ++i) {
-        const int t_stop = (i < nkept) ? s_kept_t[i] : T;  // frames [t_done, t_stop) are pruned
-        double cur[CT_H];
+    for (int ib = 0; ib < nkept; ib += MS_B) {
+        double cur[MS_B][MS_R];
 #pragma unroll
-        for (int j = 0; j < CT_H; ++j) cur[j] = nxt[j];
-        fetch(i + 1, nxt);
-        for (int t = t_done; t < t_stop; ++t) {
+        for (int b = 0; b < MS_B; ++b)
 #pragma unroll
-            for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + min_val;
-        }
-        if (i == nkept) break;
-        if (s_slot[t_stop] < 0) {  // SLOT_ON_THE_FLY: the value store was full, evaluate here
-            chain_to_level1(g, tile, cS + (size_t)t_stop * g.h[g.S] * g.w[g.S], lds);
-            if (active) level0_column(g, R0, R1, lds, x, cur);
-            __syncthreads();
-        }
-        if (active) {
+            for (int j = 0; j < MS_R; ++j) cur[b][j] = nxt[b][j];
+        fetch(ib + MS_B, nxt);
 #pragma unroll
-            for (int j = 0; j < CT_H; ++j) acc[j] = acc[j] + ((cur[j] >= top) ? min_val : cur[j]);
+        for (int b = 0; b < MS_B; ++b) {
+            if (ib + b < nkept) {
+                const int t_stop = s_kept_t[ib + b];  // frames [t_done, t_stop) are pruned
+                for (int t = t_done; t < t_stop; ++t) {
+#pragma unroll
+                    for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + min_val;
+                }
+                if (s_slot[t_stop] < 0) {  // SLOT_ON_THE_FLY: the value store was full, evaluate here
+                    __syncthreads();
+                    chain_to_level1(g, tile, cS + (size_t)t_stop * g.h[g.S] * g.w[g.S], lds);
+                    if (active) level0_rows<MS_R>(g, R0, R1, lds, x, j0, cur[b]);
+                }
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + ((cur[b][j] >= top) ? min_val : cur[b][j]);
+                }
+                t_done = t_stop + 1;
+            }
         }
-        t_done = t_stop + 1;
+    }
+    for (int t = t_done; t < T; ++t) {
+#pragma unroll
+        for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + min_val;
     }
     if (active)
 #pragma unroll
-        for (int j = 0; j < CT_H; ++j)
-            if (j < rows) heat_sum[(size_t)(R0.y0 + j) * g.w[0] + x] = acc[j];
+        for (int j = 0; j < MS_R; ++j)
+            if (j0 + j < rows) heat_sum[(size_t)(R0.y0 + j0 + j) * g.w[0] + x] = acc[j];
 }
 
 // ----------------------------------------------------------------------------------------

@@ -62,6 +62,8 @@ def test_emu_eulerian_and_fused_calibrate_match_golden(emu, golden):
         assert np.array_equal(mm, mm2)                                 # fused == materialised min/max
         heat_np, mm3 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S), flags=1)
         assert np.array_equal(heat, heat_np) and np.array_equal(mm2, mm3)  # pruning never changes a bit
+        heat_us, mm5 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S), flags=16)
+        assert np.array_equal(heat, heat_us) and np.array_equal(mm2, mm5)  # LDS-resident small pyramid == per-level launches
         heat_ts, mm4 = emu.calibrate(vid8, fps, levels=int(L), skip=int(S), flags=4)
         assert np.array_equal(heat, heat_ts) and np.array_equal(mm2, mm4)  # value-store overflow path
         assert np.array_equal(np.average(masked, axis=0), heat)        # fused == materialised heatmap

@@ -109,6 +109,7 @@ def test_fused_down_chain_equals_per_level(hip):
             per_level = dist.hip_calibrate(buf, 10, flags=2, **kw)
             assert torch.equal(dist.hip_calibrate(buf, 10, **kw), per_level), (dt, T, H, W, L, S)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=8, **kw), per_level), (dt, T, H, W, L, S)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=16, **kw), per_level), (dt, T, H, W, L, S)
 
 
 def test_locate_golden_roi_bit_exact(hip, golden):
@@ -162,6 +163,7 @@ def test_full_size_properties_1080p(hip, oracle):
     heat_np = dist.hip_calibrate(buf, 10, flags=1)
     assert torch.equal(heat, heat_np)                         # pruned == exhaustive, bit for bit
     assert torch.equal(heat, dist.hip_calibrate(buf, 10, flags=2))   # fused pyrDown chain == per-level kernels
+    assert torch.equal(heat, dist.hip_calibrate(buf, 10, flags=16))  # LDS-resident small pyramid == per-level launches
     assert torch.equal(heat, dist.hip_calibrate(buf, 10))     # deterministic
     roi = dist.hip_heatmap_to_roi(heat, 20)
     # the host contour stage against the oracle's, on the GPU's own heatmap
