@@ -17,6 +17,7 @@
 #include "rm_contour.h"
 #include "rm_kernels.h"
 #include "rm_down_chain.h"
+#include "rm_down_chain_u8.h"
 #include "rm_flow.h"
 
 using namespace rm;
@@ -579,6 +580,23 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
     const bool vec_ok = (w[0] % V == 0) && (((size_t)h[0] * w[0] * esz) % 16 == 0) && (((uintptr_t)frames) % 16 == 0);
     if (S < 1 || S > 5) return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", S);
     const int vo = vec_ok ? 1 : 0;
+    if (dtype == RM_U8 && vec_ok) {
+        // all-register variant for uint8 buffers (rm_down_chain_u8.h)
+        DownGeom g8;
+        if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny)) {
+            const size_t fs = (size_t)h[0] * w[0];
+            const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
+            const uint8_t *f = (const uint8_t *)frames;
+            switch (S) {
+            case 1: hipLaunchKernelGGL((k_down_chain_u8<1>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+            case 2: hipLaunchKernelGGL((k_down_chain_u8<2>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+            case 3: hipLaunchKernelGGL((k_down_chain_u8<3>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+            default: hipLaunchKernelGGL((k_down_chain_u8<4>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+            }
+            LAUNCH_CHECK();
+            return RM_OK;
+        }
+    }
     switch (dtype) {
     case RM_U8: return launch_down_chain_t<uint8_t>(ctx, frames, T, h, w, S, vo, out, s, tiny);
     case RM_F16: return launch_down_chain_t<__half>(ctx, frames, T, h, w, S, vo, out, s, tiny);

@@ -115,7 +115,7 @@ def test_emu_fused_down_chain_equals_per_level(emu):
     for dt in (np.float64, np.uint8, np.float32, np.float16):
         for (T, H, W, L, S) in [(3, 64, 96, 4, 2), (2, 67, 131, 5, 3), (2, 48, 64, 3, 1), (2, 135, 240, 6, 4),
                                 (9, 32, 48, 4, 2), (2, 33, 47, 4, 2), (1, 200, 320, 7, 5), (1, 40, 800, 4, 2),
-                                (1, 48, 704, 6, 4), (1, 36, 401, 5, 3)]:
+                                (1, 48, 704, 6, 4), (1, 36, 401, 5, 3), (2, 70, 1936, 6, 4)]:
             v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
             per_level, _ = emu.calibrate(v, 10.0, levels=L, skip=S, flags=2)
             fused, _ = emu.calibrate(v, 10.0, levels=L, skip=S)

@@ -102,7 +102,8 @@ def test_fused_down_chain_equals_per_level(hip):
     rng = np.random.default_rng(3)
     for dt in (np.float64, np.uint8, np.float32, np.float16):
         for (T, H, W, L, S) in [(3, 64, 96, 4, 2), (2, 67, 131, 5, 3), (2, 135, 240, 6, 4), (9, 32, 48, 4, 2),
-                                (1, 200, 320, 7, 5), (16, 270, 480, 9, 4), (8, 360, 640, 4, 2)]:
+                                (1, 200, 320, 7, 5), (16, 270, 480, 9, 4), (8, 360, 640, 4, 2), (4, 540, 1936, 8, 4),
+                                (3, 300, 2000, 6, 3)]:
             v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
             buf = torch.from_numpy(v).cuda()
             kw = dict(pyramid_levels=L, skip_levels_at_top=S)
