@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=9)
     ap.add_argument("--skip", type=int, default=4)
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T frames if host memory allows, else 64)")
     return ap.parse_args()
 
@@ -67,8 +68,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one rank per GPU; the modulo only matters for the single-GPU dry run of this path
+        # (RESPMON_BENCH_BACKEND=gloo, several ranks on one device), never for the 8-GPU node
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        backend_name = os.environ.get("RESPMON_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend_name)
     else:
         torch.cuda.set_device(0)
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
@@ -125,6 +133,23 @@ def main():
     torch.cuda.synchronize()
     _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
     _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+    # same video kept as uint8 in HBM (what a camera delivers; kernels apply uint8_to_float on the fly):
+    # bit-identical ROI at 1/8 of the frame-buffer bytes.  Reported beside the headline, never as `value`.
+    alt = None
+    if world == 1 and a.in_dtype != "u8" and not a.no_u8_alt:
+        buf8 = torch.from_numpy(vid_u8).cuda()
+        roi8 = None
+        for _ in range(a.warmup):
+            roi8 = backend.locate(buf8, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        for _ in range(a.steps):
+            roi8 = backend.locate(buf8, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
+        torch.cuda.synchronize()
+        e8 = time.perf_counter() - t8
+        alt = {"frame_buffer_dtype": "u8", "value": T * a.steps / e8, "unit": "frames/s", "ms_per_step": e8 / a.steps * 1e3,
+               "roi": roi8, "roi_equals_headline": list(roi8 or []) == list(roi or [])}
+        del buf8
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,6 +187,7 @@ def main():
             "phases_ms_per_step": {"frame_buffer_kernel": ms[0] / max(ncalls.value, 1), "pyramid_rest_and_temporal": ms[1] / max(ncalls.value, 1),
                                    "collapse_passes": ms[2] / max(ncalls.value, 1), "heatmap_to_roi": ms[3] / max(ncalls.value, 1)},
             "roi": roi,
+            "alt_uint8_buffer": alt,
             "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
         }
         if world == 1 and a.cpu_frames != 0:
