@@ -253,12 +253,14 @@ struct DownChain {
 #pragma nounroll
         for (int rep = 0; rep <= nv; ++rep) {
             step<K>(p + rep, cur);
-            const bool first = rep == 0;
+            if (rep < nv) {  // only the last real row of a level has successors to prepare
+                const bool first = rep == 0;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const double from_state = odd_h ? st.b[q] : st.c[q];
-                cur[q] = first ? from_state : held_a[q];
-                held_a[q] = first ? st.a[q] : held_a[q];
+                for (int q = 0; q < NQ; ++q) {
+                    const double from_state = odd_h ? st.b[q] : st.c[q];
+                    cur[q] = first ? from_state : held_a[q];
+                    held_a[q] = first ? st.a[q] : held_a[q];
+                }
             }
         }
     }

@@ -91,12 +91,14 @@ struct RegChain {
 #pragma nounroll
         for (int rep = 0; rep <= nv; ++rep) {
             step<K>(p + rep, cur);
-            const bool first = rep == 0;
+            if (rep < nv) {  // only the last real row of a level has successors to prepare
+                const bool first = rep == 0;
 #pragma unroll
-            for (int j = 0; j < NO; ++j) {
-                const double from_state = odd_h ? st.b[j] : st.c[j];
-                cur[j] = first ? from_state : held_a[j];
-                held_a[j] = first ? st.a[j] : held_a[j];
+                for (int j = 0; j < NO; ++j) {
+                    const double from_state = odd_h ? st.b[j] : st.c[j];
+                    cur[j] = first ? from_state : held_a[j];
+                    held_a[j] = first ? st.a[j] : held_a[j];
+                }
             }
         }
     }
@@ -107,20 +109,30 @@ struct RegChain {
         constexpr int NO = (16 >> K) / 2;
         VStateU8<S, K> &st = vs;
         if (p & 1) {
-            const bool top = p == 1;
+            // row 1 of the image: rows -1, -2 reflect onto 1, 2, i.e. b := n and the `+ a` term moves to row 2
+            // (x + -0.0 == x bit for bit)
+            double be[NO], ae[NO];
+#pragma unroll
+            for (int j = 0; j < NO; ++j) { be[j] = st.b[j]; ae[j] = st.a[j]; }
+            if (p == 1) {
+#pragma unroll
+                for (int j = 0; j < NO; ++j) { be[j] = n[j]; ae[j] = -0.0; }
+            }
 #pragma unroll
             for (int j = 0; j < NO; ++j) {
-                const double be = top ? n[j] : st.b[j], ae = top ? -0.0 : st.a[j];
-                st.t[j] = (st.c[j] * 6 + (be + n[j]) * 4) + ae;
+                st.t[j] = (st.c[j] * 6 + (be[j] + n[j]) * 4) + ae[j];
                 st.a[j] = st.c[j]; st.b[j] = n[j];
             }
         } else {
             const int y = (p >> 1) - 1;
             if (y == next[K + 1] && y <= last[K + 1]) {
                 double v[NO];
-                const bool top = p == 2;
 #pragma unroll
-                for (int j = 0; j < NO; ++j) v[j] = (st.t[j] + n[j]) + (top ? n[j] : -0.0);
+                for (int j = 0; j < NO; ++j) v[j] = st.t[j] + n[j];
+                if (p == 2) {  // row 2 of the image also stands for row -2
+#pragma unroll
+                    for (int j = 0; j < NO; ++j) v[j] = v[j] + n[j];
+                }
                 emit<K>(y, v);
             }
 #pragma unroll
