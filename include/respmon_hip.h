@@ -134,6 +134,32 @@ int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int 
               int skip_levels_at_top, double temporal_threshold, int threshold, unsigned flags,
               int32_t *xywh_host, void *stream);
 
+/* ---- frame-sharded calibration (one [T,H,W] buffer split by frame index over the GPUs of a node; SURVEY 8e
+ *      "Mode A", BASELINE north_star).  Same arithmetic as rm_calibrate (transforms.py:144-198, base.py:562),
+ *      cut at the three points where frames meet; the caller runs a collective at each cut
+ *      (respmon_amd/dist.py::locate_sharded uses torch.distributed / RCCL):
+ *        rm_shard_pyramid   frames[t0:t1] -> lap_local[(t1-t0), NP]   Laplacian levels skip..L-2 (pyramid.py:20-48)
+ *          -- all-gather lap_local -> lap_all[T, NP] --
+ *        rm_shard_collapse  temporal band-pass + collapse of every frame (cheap, identical on every rank),
+ *                           full-resolution evaluation of this rank's frames [t0,t1) only;
+ *                           negmin_max_dev[2] (DEVICE) = { -min, max } of raw over those frames
+ *          -- all-reduce(MAX) of negmin_max_dev --
+ *        rm_shard_heat      heat_sum_dev[H*W] = sum_{t in [t0,t1)} (raw >= top ? min : raw)   (transforms.py:184-192)
+ *          -- all-reduce(SUM) of heat_sum_dev: the single [H,W] heatmap collective --
+ *        rm_shard_finish    heatmap = heat_sum / T (base.py:562), then base.py:563-575 -> xywh_host (may be NULL).
+ *      With one rank (t0 = 0, t1 = T) the result equals rm_calibrate / rm_locate bit for bit; with several
+ *      ranks the time sum is associated per shard (<= 1e-15 relative on the heatmap).
+ *      rm_shard_layout returns NP (0 when no level is filtered).  Requires skip_levels_at_top >= 1. */
+int rm_shard_layout(int H, int W, int pyramid_levels, int skip_levels_at_top, size_t *np_out);
+int rm_shard_pyramid(rm_ctx *ctx, const void *frames_local_dev, int dtype, int T_local, int H, int W, int pyramid_levels,
+                     int skip_levels_at_top, unsigned flags, double *lap_local_dev, void *stream);
+int rm_shard_collapse(rm_ctx *ctx, const double *lap_all_dev, int T, int t0, int t1, int H, int W, double fps,
+                      double freq_min, double freq_max, double amplification, int pyramid_levels, int skip_levels_at_top,
+                      double temporal_threshold, unsigned flags, double *negmin_max_dev, void *stream);
+int rm_shard_heat(rm_ctx *ctx, const double *negmin_max_dev, double temporal_threshold, double *heat_sum_dev, void *stream);
+int rm_shard_finish(rm_ctx *ctx, const double *heat_sum_dev, int T, int H, int W, int threshold, double *heatmap_dev,
+                    int32_t *xywh_host, void *stream);
+
 /* ---- base.py:355-358 + 471: extract_motion('average') = np.average(frame[y:y+h, x:x+w]) -- */
 int rm_roi_mean(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h,
                 double *out_host, void *stream);

@@ -41,6 +41,11 @@ SIGNATURES = {
     "rm_calibrate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _u, _vp, _vp, _vp]),
     "rm_heatmap_to_roi": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rm_locate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
+    "rm_shard_layout": (_i, [_i, _i, _i, _i, _c.POINTER(_sz)]),
+    "rm_shard_pyramid": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _vp]),
+    "rm_shard_collapse": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _u, _vp, _vp]),
+    "rm_shard_heat": (_i, [_vp, _vp, _d, _vp, _vp]),
+    "rm_shard_finish": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rm_roi_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rm_roi_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rm_good_features_to_track": (_i, [_vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),

@@ -49,6 +49,20 @@ static int fail(int code, const char *fmt, ...)
 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
+// what the collapse passes share (see collapse_eval / collapse_sum below)
+struct CollapsePlan {
+    ChainGeom g;
+    int ntiles = 0, npairs = 0;
+    double *lo = nullptr, *hi = nullptr, *store = nullptr;
+    unsigned int *list = nullptr;
+    int *slot_of = nullptr;
+    size_t shmem = 0;
+    const double *cS = nullptr;
+    int T = 0, t0 = 0, t1 = 0, H = 0, W = 0, S = 0;
+    bool valid = false;
+};
+
+
 struct rm_ctx {
     int device = 0;
     std::map<std::string, DevBuf> bufs;
@@ -59,6 +73,7 @@ struct rm_ctx {
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     FlowWorkspace flow;
+    CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0;
     unsigned int *h_slots_seen = nullptr;  // pinned: n_slots of the previous rm_calibrate (async readback)
@@ -540,11 +555,12 @@ template <typename Tin, bool VB>
 static int launch_down_chain_g(const Tin *f, int T, const DownGeom &g, double *out, hipStream_t s)
 {
     const size_t fs = (size_t)g.h[0] * g.w[0];
-    const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g.strips * g.segs);
+    (void)T;
+    const unsigned grid = down_chain_grid(g), block = down_chain_block(g);
 #define RM_DC_CASE(SS)                                                                                         \
     case SS:                                                                                                   \
-        hipLaunchKernelGGL((k_down_chain<Tin, SS, VB>), dim3(grid), dim3(64), (sizeof(double) * down_chain_lds_doubles<Tin, SS>()), s, \
-                           f, fs, g, out);                                                                     \
+        hipLaunchKernelGGL((k_down_chain<Tin, SS, VB>), dim3(grid), dim3(block),                               \
+                           (sizeof(double) * down_chain_lds_doubles<Tin, SS>() * g.wpg), s, f, fs, g, out);    \
         break;
     switch (g.S) {
         RM_DC_CASE(1) RM_DC_CASE(2) RM_DC_CASE(3) RM_DC_CASE(4) RM_DC_CASE(5)
@@ -607,7 +623,10 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
 }
 
 // ------------------------------------------------------------------------------------------
-// shared front half of calibration: frames -> collapsed band-passed level S  (C_S [T,hS,wS])
+// front half of calibration in two steps:
+//   front_pyramid: frames[T,H,W] -> Laplacian levels S..L-2 side by side, lap[T,NP]     (per frame)
+//   front_filter : lap[T,NP]     -> collapsed band-passed level S, C_S[T,hS,wS]         (needs every frame)
+// rm_calibrate runs them back to back; the frame-sharded path (rm_shard_*) all-gathers lap in between.
 // ------------------------------------------------------------------------------------------
 struct SmallLevels {
     std::vector<int> h, w;
@@ -616,21 +635,58 @@ struct SmallLevels {
     bool all_zero = false;  // no level is filtered: the band-passed pyramid is all zeros
 };
 
-static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
-                      double amp, int levels, int skip, unsigned flags, SmallLevels &out, hipStream_t s)
+struct PyrGeom {
+    std::vector<int> h, w;
+    std::vector<size_t> off;   // offset of level l inside a [NP] frame of the small pyramid (levels S..L-2)
+    size_t NP = 0;             // filtered pixels per frame
+    size_t lds_levels = 0;     // doubles needed to hold G_S..G_{L-1} of one frame
+    int S = 0, L = 0;
+    bool all_zero = false;
+    bool chain = false;        // the fused pyrDown chain builds G_S
+    bool fuse_small = false;   // per-frame LDS kernels build / collapse the small pyramid
+    SmallGeom sg;
+};
+
+static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom &pg)
 {
-    level_sizes(H, W, levels, out.h, out.w);
-    const std::vector<int> &h = out.h, &w = out.w;
-    const int L = levels;
-    if (skip >= L - 1) { out.all_zero = true; out.S = 0; return RM_OK; }
-    const int S = skip;
-    out.S = S;
+    level_sizes(H, W, levels, pg.h, pg.w);
+    const int L = levels, S = skip;
+    pg.L = L; pg.S = S;
+    pg.all_zero = skip >= L - 1;
+    if (pg.all_zero) { pg.S = 0; return; }
+    pg.chain = S >= 1 && S <= 5 && !(flags & RM_FLAG_UNFUSED_DOWN);
+    pg.off.assign(L, 0);
+    pg.NP = 0;
+    for (int l = S; l <= L - 2; ++l) { pg.off[l] = pg.NP; pg.NP += (size_t)pg.h[l] * pg.w[l]; }
+    pg.lds_levels = 0;
+    for (int l = S; l < L; ++l) pg.lds_levels += (size_t)pg.h[l] * pg.w[l];
+    const size_t LDS_LIMIT = 150 * 1024;
+    pg.fuse_small = pg.chain && !(flags & RM_FLAG_UNFUSED_SMALL) && L <= SMALL_MAX_LEVELS &&
+                    pg.lds_levels * sizeof(double) <= LDS_LIMIT && pg.NP * sizeof(double) <= LDS_LIMIT;
+    if (pg.fuse_small) {
+        SmallGeom &sg = pg.sg;
+        sg.S = S; sg.L = L; sg.NP = (int)pg.NP;
+        int o = 0;
+        for (int l = 0; l < L; ++l) {
+            sg.h[l] = pg.h[l]; sg.w[l] = pg.w[l];
+            sg.g_off[l] = 0; sg.np_off[l] = (int)pg.off[l];
+            if (l >= S) { sg.g_off[l] = o; o += pg.h[l] * pg.w[l]; }
+        }
+    }
+}
+
+static int front_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, const PyrGeom &pg, unsigned flags,
+                         double *lap, hipStream_t s)
+{
+    const std::vector<int> &h = pg.h, &w = pg.w;
+    const int L = pg.L, S = pg.S;
+    const size_t NP = pg.NP;
     // Gaussian chain (pyramid.py:9-17).  Levels < S are stepping stones (ping-pong scratch);
     // levels S..L-1 are kept for the Laplacians.
     std::vector<double *> g(L, nullptr);
     const void *cur = frames; int cur_dtype = dtype;
     int first = 1;
-    if (S >= 1 && S <= 5 && !(flags & RM_FLAG_UNFUSED_DOWN)) {
+    if (pg.chain) {
         // one launch reads the frame buffer once and writes only G_S
         double *dst = nullptr;
         RM_TRY(ws(ctx, "g" + std::to_string(S), (size_t)T * h[S] * w[S], &dst));
@@ -641,25 +697,7 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
         g[S] = dst; cur = dst; cur_dtype = RM_F64;
         first = S + 1;
     }
-    // small pyramid geometry: levels S..L-1 of one frame side by side
-    std::vector<size_t> off(L, 0);
-    size_t NP = 0;
-    for (int l = S; l <= L - 2; ++l) { off[l] = NP; NP += (size_t)h[l] * w[l]; }
-    size_t lds_levels = 0;  // doubles needed to hold G_S..G_{L-1} of one frame
-    for (int l = S; l < L; ++l) lds_levels += (size_t)h[l] * w[l];
-    const size_t LDS_LIMIT = 150 * 1024;
-    const bool fuse_small = g[S] != nullptr && !(flags & RM_FLAG_UNFUSED_SMALL) && L <= SMALL_MAX_LEVELS &&
-                            lds_levels * sizeof(double) <= LDS_LIMIT && NP * sizeof(double) <= LDS_LIMIT;
-    SmallGeom sg;
-    if (fuse_small) {
-        sg.S = S; sg.L = L; sg.NP = (int)NP;
-        int o = 0;
-        for (int l = 0; l < L; ++l) {
-            sg.h[l] = h[l]; sg.w[l] = w[l];
-            sg.g_off[l] = 0; sg.np_off[l] = (int)off[l];
-            if (l >= S) { sg.g_off[l] = o; o += h[l] * w[l]; }
-        }
-    } else {
+    if (!pg.fuse_small) {
         for (int l = first; l < L; ++l) {
             double *dst = nullptr;
             if (l < S) RM_TRY(ws(ctx, (l & 1) ? "g_ping" : "g_pong", (size_t)T * h[l] * w[l], &dst));
@@ -677,57 +715,80 @@ static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, 
         RM_TRY(launch_to_f64(frames, dtype, (size_t)T * H * W, g0, s));
         g[0] = g0;
     }
-    TemporalOp op;
-    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
     PhaseTimer pt_small(ctx, 1, s);
     // The filtered levels S .. L-2 live side by side in [T, NP] buffers (level S first), so the temporal
     // filter is two launches for the whole small pyramid.
-    double *lap = nullptr, *bp = nullptr;
-    RM_TRY(ws(ctx, "lap_all", (size_t)T * NP, &lap));
-    RM_TRY(ws(ctx, "bp_all", (size_t)T * NP, &bp));
-    if (fuse_small) {
+    if (pg.fuse_small) {
         // Gaussian levels S+1..L-1 and all Laplacians in one launch, one workgroup per frame, in LDS
-        const size_t shmem = lds_levels * sizeof(double);
+        const size_t shmem = pg.lds_levels * sizeof(double);
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_small_pyramid, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)g[S], sg, lap);
+        hipLaunchKernelGGL(k_small_pyramid, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)g[S], pg.sg, lap);
         LAUNCH_CHECK();
     } else {
         // Laplacian levels (pyramid.py:23-26): L_l = G_l - pyrUp(G_{l+1})
         for (int l = L - 2; l >= S; --l)
-            RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap + off[l], h[l], w[l], 1, g[l], s, 0, NP, 0));
+            RM_TRY(launch_pyr_up(g[l + 1], T, h[l + 1], w[l + 1], lap + pg.off[l], h[l], w[l], 1, g[l], s, 0, NP, 0));
     }
+    return RM_OK;
+}
+
+static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg, double fps, double fmin, double fmax, double amp,
+                        SmallLevels &out, hipStream_t s)
+{
+    const std::vector<int> &h = pg.h, &w = pg.w;
+    const int L = pg.L, S = pg.S;
+    const size_t NP = pg.NP;
+    out.h = pg.h; out.w = pg.w; out.S = S; out.all_zero = false;
+    TemporalOp op;
+    RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
+    PhaseTimer pt_small(ctx, 1, s);
+    double *bp = nullptr;
+    RM_TRY(ws(ctx, "bp_all", (size_t)T * NP, &bp));
     // temporal band-pass of every level at once (transforms.py:162,169)
     RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
     // collapse of the band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x);
     // the result is a contiguous [T,h_S,w_S] array for the full-resolution passes
-    const double *c = bp + off[L - 2];
+    const double *c = bp + pg.off[L - 2];
     if (L - 2 == S) {
         // single filtered level: NP == h_S*w_S, bp_all is already C_S
-    } else if (fuse_small) {
+    } else if (pg.fuse_small) {
         double *dst = nullptr;
         RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
         const size_t shmem = NP * sizeof(double);
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, sg, dst);
+        hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst);
         LAUNCH_CHECK();
         c = dst;
     } else {
         size_t c_fs = NP;
         for (int l = L - 3; l >= S; --l) {
-            double *dst = bp + off[l];
+            double *dst = bp + pg.off[l];
             size_t dst_fs = NP;
             if (l == S) {
                 RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
                 dst_fs = (size_t)h[S] * w[S];
             }
-            RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + off[l], s, c_fs, dst_fs, NP));
+            RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + pg.off[l], s, c_fs, dst_fs, NP));
             c = dst; c_fs = dst_fs;
         }
     }
     out.cS = c;
     return RM_OK;
+}
+
+static int front_half(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
+                      double amp, int levels, int skip, unsigned flags, SmallLevels &out, hipStream_t s)
+{
+    PyrGeom pg;
+    pyr_geom(H, W, levels, skip, flags, pg);
+    out.h = pg.h; out.w = pg.w;
+    if (pg.all_zero) { out.all_zero = true; out.S = 0; return RM_OK; }
+    double *lap = nullptr;
+    RM_TRY(ws(ctx, "lap_all", (size_t)T * pg.NP, &lap));
+    RM_TRY(front_pyramid(ctx, frames, dtype, T, H, W, pg, flags, lap, s));
+    return front_filter(ctx, lap, T, pg, fps, fmin, fmax, amp, out, s);
 }
 
 static int make_geom(const SmallLevels &sl, ChainGeom &g)
@@ -748,11 +809,101 @@ static int make_geom(const SmallLevels &sl, ChainGeom &g)
     return RM_OK;
 }
 
+static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
+                               uint8_t *binary, void *stream, bool have_minmax);
+__global__ void k_heat_state_init(CollapseState *st);
+
+// nothing is filtered (skip >= levels - 1): the band-passed pyramid, raw and the heatmap are all zeros.  The
+// heatmap extrema (0, 0) go into the state like after a real calibration, so rm_locate normalises 0/0 -> NaN
+// -> uint8 0 -> no contour, as the reference does (base.py:563-570).
 static int zero_result(rm_ctx *ctx, size_t npix, double *heat, double *minmax_host, hipStream_t s)
 {
-    (void)ctx;
     HIP_TRY(hipMemsetAsync(heat, 0, sizeof(double) * npix, s));
+    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, ctx->d_state);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_heat_minmax, dim3(1), dim3(256), 0, s, (const double *)heat, (size_t)1, ctx->d_state);
+    LAUNCH_CHECK();
     if (minmax_host) { minmax_host[0] = 0.0; minmax_host[1] = 0.0; HIP_TRY(hipStreamSynchronize(s)); }
+    return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// back half: C_S -> exact raw.min()/raw.max() -> masked time sum, for the frames [t0, t1) of the buffer.
+// The bounds and the pruning decisions always cover all T frames (they are cheap and every rank of a
+// frame-sharded run must agree on them); full-resolution evaluation and the sum touch only [t0, t1).
+// ------------------------------------------------------------------------------------------
+static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, double thr, unsigned flags, CollapsePlan &cp,
+                         hipStream_t s)
+{
+    CollapseState *st = ctx->d_state;
+    cp.valid = false;
+    cp.cS = sl.cS; cp.T = T; cp.t0 = t0; cp.t1 = t1; cp.H = sl.h[0]; cp.W = sl.w[0]; cp.S = sl.S;
+    const size_t npix = (size_t)cp.H * cp.W;
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
+    LAUNCH_CHECK();
+    const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
+    if (sl.S == 0) {
+        if (t0 != 0 || t1 != T) return fail(RM_E_UNSUPPORTED, "frame-sharded calibration needs skip_levels_at_top >= 1");
+        size_t n = (size_t)T * npix;
+        hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, sl.cS, n, st);
+        LAUNCH_CHECK();
+        cp.valid = true;
+        return RM_OK;
+    }
+    ChainGeom &g = cp.g;
+    RM_TRY(make_geom(sl, g));
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const int npairs = ntiles * T;
+    cp.ntiles = ntiles; cp.npairs = npairs;
+    // value store for the pairs the masked sum needs: 1/8 of all pairs (>= 4096 slots); pairs beyond
+    // the capacity are re-evaluated inside the sum kernel, so the size is a speed knob, not a limit
+    // The store adapts without a host sync: every call leaves its slot demand in pinned memory
+    // (asynchronous copy); the next call with the same geometry sizes the store from it (+25 %).
+    size_t slot_cap = (size_t)npairs / 8;
+    if (ctx->slots_seen_pairs == npairs && (size_t)*ctx->h_slots_seen > slot_cap)
+        slot_cap = (size_t)*ctx->h_slots_seen + (size_t)*ctx->h_slots_seen / 4;
+    if (slot_cap < 4096) slot_cap = 4096;
+    if (slot_cap > (size_t)npairs) slot_cap = (size_t)npairs;
+    if (flags & RM_FLAG_TINY_STORE) slot_cap = 3;
+    ctx->dbg_pairs = npairs; ctx->dbg_cap = (long long)slot_cap;
+    RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &cp.lo));
+    RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &cp.hi));
+    RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
+    RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
+    RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
+    hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 128)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st);
+    LAUNCH_CHECK();
+    const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
+    hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 255) / 256), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
+                       (unsigned)slot_cap, prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles);
+    LAUNCH_CHECK();
+    cp.shmem = sizeof(double) * (size_t)g.lds_total;
+    unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
+    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list, cp.slot_of, st, cp.store);
+    LAUNCH_CHECK();
+    cp.valid = true;
+    return RM_OK;
+}
+
+// heat_sum[H*W] = sum over t in [t0, t1) of (raw >= top ? min : raw), with min/max as they stand in the state
+static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_sum, hipStream_t s)
+{
+    CollapseState *st = ctx->d_state;
+    const size_t npix = (size_t)cp.H * cp.W;
+    if (cp.S == 0) {
+        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_masked_sum_plain, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, cp.cS, cp.T, npix, st, heat_sum);
+        LAUNCH_CHECK();
+        return RM_OK;
+    }
+    hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
+                       cp.store, st, thr, heat_sum);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(ctx->h_slots_seen, &st->n_slots, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    ctx->slots_seen_pairs = cp.npairs;
     return RM_OK;
 }
 
@@ -775,58 +926,9 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     RM_TRY(ws(ctx, "heat_sum", npix, &heat_sum));
     PhaseTimer *pt_collapse = new PhaseTimer(ctx, 2, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_collapse};
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
-    LAUNCH_CHECK();
-    const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
-    if (sl.S == 0) {
-        size_t n = (size_t)T * npix;
-        hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, sl.cS, n, st);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_masked_sum_plain, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, sl.cS, T, npix, st, heat_sum);
-        LAUNCH_CHECK();
-    } else {
-        ChainGeom g;
-        RM_TRY(make_geom(sl, g));
-        const int ntiles = g.tiles_x * g.tiles_y;
-        const int npairs = ntiles * T;
-        // value store for the pairs the masked sum needs: 1/8 of all pairs (>= 4096 slots); pairs beyond
-        // the capacity are re-evaluated inside the sum kernel, so the size is a speed knob, not a limit
-        // The store adapts without a host sync: every call leaves its slot demand in pinned memory
-        // (asynchronous copy); the next call with the same geometry sizes the store from it (+25 %).
-        size_t slot_cap = (size_t)npairs / 8;
-        if (ctx->slots_seen_pairs == npairs && (size_t)*ctx->h_slots_seen > slot_cap)
-            slot_cap = (size_t)*ctx->h_slots_seen + (size_t)*ctx->h_slots_seen / 4;
-        if (slot_cap < 4096) slot_cap = 4096;
-        if (slot_cap > (size_t)npairs) slot_cap = (size_t)npairs;
-        if (flags & RM_FLAG_TINY_STORE) slot_cap = 3;
-        ctx->dbg_pairs = npairs; ctx->dbg_cap = (long long)slot_cap;
-        double *lo = nullptr, *hi = nullptr, *store = nullptr;
-        unsigned int *list = nullptr;
-        int *slot_of = nullptr;
-        RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
-        RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
-        RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &list));
-        RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &slot_of));
-        RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &store));
-        hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, lo, hi);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 128)), dim3(256), 0, s, lo, hi, npairs, st);
-        LAUNCH_CHECK();
-        const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
-        hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 255) / 256), dim3(256), 0, s, lo, hi, npairs, st, list, slot_of,
-                           (unsigned)slot_cap, prune_ok ? 0 : 1, thr);
-        LAUNCH_CHECK();
-        size_t shmem = sizeof(double) * (size_t)g.lds_total;
-        unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
-        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), shmem, s, sl.cS, g, ntiles, list, slot_of, st, store);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(ntiles), dim3(256), shmem, s, sl.cS, g, T, ntiles, slot_of, store, st, thr, heat_sum);
-        LAUNCH_CHECK();
-        HIP_TRY(hipMemcpyAsync(ctx->h_slots_seen, &st->n_slots, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-        ctx->slots_seen_pairs = npairs;
-    }
+    CollapsePlan cp;
+    RM_TRY(collapse_eval(ctx, sl, T, 0, T, thr, flags, cp, s));
+    RM_TRY(collapse_sum(ctx, cp, thr, heat_sum, s));
     hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
     LAUNCH_CHECK();
     delete pt_collapse; pt_collapse = nullptr;
@@ -837,6 +939,92 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         minmax_host[1] = ctx->h_state->max_val;
     }
     return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// frame-sharded calibration (SURVEY 8e "Mode A"): ONE [T,H,W] buffer split by frame index over the ranks.
+// The library does the per-rank stages; the caller (respmon_amd/dist.py) runs the three collectives between
+// them with torch.distributed (RCCL): all-gather of the small pyramid, all-reduce(MAX) of {-min, max},
+// all-reduce(SUM) of the [H,W] heat sum.
+// ------------------------------------------------------------------------------------------
+extern "C" int rm_shard_layout(int H, int W, int levels, int skip, size_t *np_out)
+{
+    if (!np_out || H < 1 || W < 1 || levels < 1 || skip < 0) return fail(RM_E_BADARG, "rm_shard_layout: bad argument");
+    PyrGeom pg;
+    pyr_geom(H, W, levels, skip, 0, pg);
+    *np_out = pg.all_zero ? 0 : pg.NP;
+    return RM_OK;
+}
+
+extern "C" int rm_shard_pyramid(rm_ctx *ctx, const void *frames, int dtype, int Tl, int H, int W, int levels, int skip,
+                                unsigned flags, double *lap_local, void *stream)
+{
+    if (!ctx || !frames || !lap_local || Tl < 1 || H < 1 || W < 1 || levels < 1 || skip < 1 || !valid_dtype(dtype))
+        return fail(RM_E_BADARG, "rm_shard_pyramid: bad argument (frame-sharded calibration needs skip_levels_at_top >= 1)");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PyrGeom pg;
+    pyr_geom(H, W, levels, skip, flags, pg);
+    if (pg.all_zero) return RM_OK;  // nothing is filtered: rm_shard_layout reported NP = 0
+    return front_pyramid(ctx, frames, dtype, Tl, H, W, pg, flags, lap_local, s);
+}
+
+extern "C" int rm_shard_collapse(rm_ctx *ctx, const double *lap_all, int T, int t0, int t1, int H, int W, double fps, double fmin,
+                                 double fmax, double amp, int levels, int skip, double thr, unsigned flags, double *negmin_max_dev,
+                                 void *stream)
+{
+    if (!ctx || !negmin_max_dev || T < 1 || t0 < 0 || t1 < t0 || t1 > T || H < 1 || W < 1 || levels < 1 || skip < 1 || !(fps > 0))
+        return fail(RM_E_BADARG, "rm_shard_collapse: bad argument");
+    if (T > MAX_T) return fail(RM_E_UNSUPPORTED, "rm_shard_collapse: T=%d > %d", T, MAX_T);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PyrGeom pg;
+    pyr_geom(H, W, levels, skip, flags, pg);
+    CollapsePlan &cp = ctx->shard_plan;
+    cp.valid = false;
+    if (ctx->prof_on) ctx->prof_calls++;
+    if (pg.all_zero) {  // band-passed pyramid is all zeros: min = max = 0, heat sum = 0
+        cp.T = T; cp.t0 = t0; cp.t1 = t1; cp.H = H; cp.W = W; cp.S = -1; cp.valid = true;
+        HIP_TRY(hipMemsetAsync(negmin_max_dev, 0, 2 * sizeof(double), s));
+        return RM_OK;
+    }
+    if (!lap_all) return fail(RM_E_BADARG, "rm_shard_collapse: lap_all is NULL");
+    SmallLevels sl;
+    RM_TRY(front_filter(ctx, lap_all, T, pg, fps, fmin, fmax, amp, sl, s));
+    PhaseTimer pt(ctx, 2, s);
+    RM_TRY(collapse_eval(ctx, sl, T, t0, t1, thr, flags, cp, s));
+    hipLaunchKernelGGL(k_export_minmax, dim3(1), dim3(1), 0, s, ctx->d_state, negmin_max_dev);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+extern "C" int rm_shard_heat(rm_ctx *ctx, const double *negmin_max_dev, double thr, double *heat_sum, void *stream)
+{
+    if (!ctx || !negmin_max_dev || !heat_sum) return fail(RM_E_BADARG, "rm_shard_heat: bad argument");
+    const CollapsePlan &cp = ctx->shard_plan;
+    if (!cp.valid) return fail(RM_E_BADARG, "rm_shard_heat: no rm_shard_collapse result on this context");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (cp.S < 0) { HIP_TRY(hipMemsetAsync(heat_sum, 0, sizeof(double) * (size_t)cp.H * cp.W, s)); return RM_OK; }
+    PhaseTimer pt(ctx, 2, s);
+    hipLaunchKernelGGL(k_import_minmax, dim3(1), dim3(1), 0, s, ctx->d_state, negmin_max_dev);
+    LAUNCH_CHECK();
+    return collapse_sum(ctx, cp, thr, heat_sum, s);
+}
+
+extern "C" int rm_shard_finish(rm_ctx *ctx, const double *heat_sum, int T, int H, int W, int threshold, double *heatmap,
+                               int32_t *xywh, void *stream)
+{
+    if (!ctx || !heat_sum || !heatmap || T < 1 || H < 1 || W < 1) return fail(RM_E_BADARG, "rm_shard_finish: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)H * W;
+    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, ctx->d_state);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heatmap, ctx->d_state);
+    LAUNCH_CHECK();
+    if (!xywh) return RM_OK;
+    return heatmap_to_roi_impl(ctx, heatmap, H, W, threshold, xywh, nullptr, nullptr, stream, true);
 }
 
 extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps,

@@ -21,6 +21,7 @@
 // Workgroups of one frame are placed on one XCD (blockIdx % 8) so halo lines are shared in its L2.
 #pragma once
 #include "rm_kernels.h"
+#include <cstdlib>
 
 namespace rm {
 
@@ -35,6 +36,7 @@ struct DownGeom {
     int seg_h;                       // segment size in level-S rows
     int y_begin, y_end;              // level-S rows [y_begin, y_end) covered by this launch
     int strips, segs;                // per frame
+    int wpg;                         // waves (= adjacent strips of one segment) per workgroup, marching in lockstep
     int T;
     int vec;                         // 1: 16-byte aligned vector loads are legal for this buffer
 };
@@ -172,7 +174,17 @@ struct DownChain {
     bool lane_ok1;               // this lane's level-1 elements are real (DPP front end: lanes 1..62)
     VState<L, S, 0> vs;
 
-    __device__ __forceinline__ DownChain(const DownGeom &g_, double *lds_) : g(g_), lds(lds_), lane(threadIdx.x) {}
+    __device__ __forceinline__ DownChain(const DownGeom &g_, double *lds_) : g(g_), lds(lds_), lane(threadIdx.x & 63) {}
+
+    // The waves of a workgroup are the adjacent strips of one (frame, segment): a barrier per prefetch round
+    // keeps them on the same input rows, so the columns two strips share are fetched from HBM once and hit
+    // in L2 for the neighbour.  Raw s_barrier: no waitcnt, the prefetched rows stay in flight across it.
+    __device__ __forceinline__ void lockstep() const
+    {
+#ifndef RM_HIPEMU
+        if (g.wpg > 1) __builtin_amdgcn_s_barrier();
+#endif
+    }
 
     // index of column c inside row buffer K (columns c0-2 .. are stored de-interleaved)
     template <int K> __device__ __forceinline__ int rb_index(int c) const
@@ -434,6 +446,7 @@ struct DownChain {
 #pragma unroll
         for (int i = 0; i < DC_PREFETCH; ++i) issue(min(p_first + i, p_last), regs[i]);
         for (int base = p_first; base <= p_last; base += DC_PREFETCH) {
+            lockstep();
 #pragma unroll
             for (int i = 0; i < DC_PREFETCH; ++i) {
                 const int p = base + i;
@@ -489,6 +502,7 @@ struct DownChain {
 #pragma unroll
             for (int i = 0; i < DC_PREFETCH; ++i) issue(min(p_first + i, p_last), regs[i]);
             for (int base = p_first; base <= p_last; base += DC_PREFETCH) {
+                lockstep();
 #pragma unroll
                 for (int i = 0; i < DC_PREFETCH; ++i) {
                     const int p = base + i;
@@ -535,24 +549,40 @@ struct DownChain {
     }
 };
 
+template <typename Tin, int S> __host__ __device__ constexpr int down_chain_lds_doubles() { return DCLayout<S, StripWidth<S>::SW, VecTraits<Tin>::V>::total(); }
+
+constexpr int DC_MAX_WPG = 2;  // waves per workgroup (launch bound).  Measured in bench.py, 1080p x 256 f64: 1 -> 0.816 ms, 2 -> 0.788 ms, 3 -> 1.06 ms (a stalled wave stalls its whole group: fewer independent contexts per CU)
+
 template <typename Tin, int S, bool VB>
-__global__ __launch_bounds__(64) void k_down_chain(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
+__global__ __launch_bounds__(64 * DC_MAX_WPG) void k_down_chain(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
 {
-    HIP_DYNAMIC_SHARED(double, lds)
+    HIP_DYNAMIC_SHARED(double, lds_all)
     // XCD-aware mapping: block b runs on XCD b % 8; give each XCD whole frames so the strips and
-    // segments of a frame share halo lines in one L2
-    const int per_frame = g.strips * g.segs;
+    // segments of a frame share halo lines in one L2.  A workgroup = g.wpg adjacent strips of one segment,
+    // one wave each (private LDS slice, no data exchanged between the waves).
+    const int groups = (g.strips + g.wpg - 1) / g.wpg;
+    const int per_frame = groups * g.segs;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int t = (j / per_frame) * 8 + xcd;
     if (t >= g.T) return;
     const int inner = j % per_frame;
-    const int seg = inner / g.strips, strip = inner - seg * g.strips;
+    const int seg = inner / groups, grp = inner - seg * groups;
+#ifdef RM_HIPEMU
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep the geometry in SGPRs
+#endif
+    const int strip = grp * g.wpg + wave;
+    if (strip >= g.strips) return;  // a terminated wave no longer counts at s_barrier
+    double *lds = lds_all + wave * down_chain_lds_doubles<Tin, S>();
     DownChain<Tin, S, VB> dc(g, lds);
     dc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }
 
 // host-side geometry
-template <typename Tin, int S> inline int down_chain_lds_doubles() { return DCLayout<S, StripWidth<S>::SW, VecTraits<Tin>::V>::total(); }
+
+inline unsigned down_chain_grid(const DownGeom &g) { return (unsigned)(((g.T + 7) / 8) * 8 * ((g.strips + g.wpg - 1) / g.wpg) * g.segs); }
+inline unsigned down_chain_block(const DownGeom &g) { return 64u * (unsigned)g.wpg; }
 
 // level-S row range [y0, y1) whose dependency cone needs no vertical border handling at any level
 inline void down_chain_interior(int S, const int *h, int *y0, int *y1)
@@ -599,6 +629,19 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
     g.seg_h = (rows + segs - 1) / segs;
     if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
     g.segs = (rows + g.seg_h - 1) / g.seg_h;
+    // workgroup = up to DC_MAX_WPG adjacent strips in lockstep, split evenly when a row has more strips
+    const int ngroups = (g.strips + DC_MAX_WPG - 1) / DC_MAX_WPG;
+    g.wpg = (g.strips + ngroups - 1) / ngroups;
+#ifdef RM_DC_WPG  // developer experiment
+    g.wpg = RM_DC_WPG;
+#endif
+    if (const char *e = getenv("RM_DC_WPG")) {  // developer experiment (A/B on one box)
+        const int v = atoi(e);
+        if (v >= 1 && v <= DC_MAX_WPG) g.wpg = v;
+    }
+#ifdef RM_HIPEMU
+    g.wpg = 1;
+#endif
     return true;
 }
 

@@ -468,7 +468,7 @@ constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is
 //   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum
 __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
                                                       unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune,
-                                                      double thr)
+                                                      double thr, int first_pair, int end_pair)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -481,6 +481,9 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
     const double mx_ = ub_max + m, mn_ = ub_min + m;
     const double top_ub = (mx_ - (mx_ - mn_) * thr) + m;
     if (i == 0) { st->margin = m; st->top_ub = top_ub; }
+    // frame shard (pairs are [t][tile]): the bounds above cover every frame, the evaluation only this
+    // rank's frames [first_pair, end_pair) / ntiles
+    if (i < first_pair || i >= end_pair) { slot_of[i] = SLOT_PRUNED; return; }
     bool isC = no_prune || !(hi[i] + m < lb_max - m) || !(lo[i] - m > ub_min + m);
     bool isD = no_prune || (lo[i] - m < top_ub);
     int slot = SLOT_PRUNED;
@@ -596,6 +599,20 @@ __global__ void k_finish_minmax(CollapseState *st, double threshold)
     st->top = mx - (mx - mn) * threshold;
 }
 
+// frame-sharded calibration: the exact extrema of this rank's frames leave as {-min, max} (one all-reduce(MAX)
+// serves both) and the global pair comes back the same way
+__global__ void k_export_minmax(const CollapseState *st, double *negmin_max)
+{
+    const double inf = __builtin_huge_val();
+    negmin_max[0] = (st->min_key == ~0ull) ? -inf : -f64_unkey(st->min_key);
+    negmin_max[1] = (st->max_key == 0ull) ? -inf : f64_unkey(st->max_key);
+}
+__global__ void k_import_minmax(CollapseState *st, const double *negmin_max)
+{
+    st->min_key = f64_key(-negmin_max[0]);
+    st->max_key = f64_key(negmin_max[1]);
+}
+
 // pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order, base.py:562).
 // Pruned pairs add `min`; kept pairs read their values back from `store`.  A 256-thread workgroup owns a
 // tile (wave w: rows 4w..4w+3 of every column) and walks the ordered list of kept frames in batches of
@@ -605,7 +622,7 @@ constexpr int MAX_T = 4096;
 constexpr int MS_B = 8;               // kept frames per batch
 constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 
-__global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int T, int ntiles,
+__global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum)
 {
@@ -620,11 +637,12 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
     const double top = max_val - (max_val - min_val) * threshold;
     if (tile == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
-    for (int t = tid; t < T; t += 256) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
+    // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks)
+    for (int t = t_first + tid; t < t_end; t += 256) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
     __syncthreads();
     if (tid == 0) {  // compact, ordered list of the frames that are not pruned
         int n = 0;
-        for (int t = 0; t < T; ++t)
+        for (int t = t_first; t < t_end; ++t)
             if (s_slot[t] != SLOT_PRUNED) s_kept_t[n++] = (short)t;
         s_nkept = n;
     }
@@ -654,7 +672,7 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
         }
     };
     fetch(0, nxt);
-    int t_done = 0;
+    int t_done = t_first;
     for (int ib = 0; ib < nkept; ib += MS_B) {
         double cur[MS_B][MS_R];
 #pragma unroll
@@ -683,7 +701,7 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
             }
         }
     }
-    for (int t = t_done; t < T; ++t) {
+    for (int t = t_done; t < t_end; ++t) {
 #pragma unroll
         for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + min_val;
     }

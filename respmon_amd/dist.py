@@ -4,8 +4,10 @@ Mode B (BASELINE config 4, the weak-scaling figure): every rank calibrates its O
 (no data-path collective -- streams are independent units), then ONE all-reduce(sum) of the
 float64 [H,W] heatmap gives the fused multi-stream heatmap every rank turns into the same ROI.
 
-Mode A (one buffer sharded by frame index) is documented in DESIGN.md; its building blocks are
-`all_reduce_heatmap` and `all_reduce_minmax`.
+Mode A (`locate_sharded`, BASELINE north_star): ONE [T,H,W] buffer split by frame index; rank r holds frames
+shard_frames(T, r, world).  Three collectives, at the three points where frames meet:
+  all-gather of the small Laplacian pyramid ([T, NP] float64, <= 22 MB at 1080p x 256),
+  all-reduce(MAX) of {-min, max} (16 bytes), all-reduce(SUM) of the [H,W] heat sum (the heatmap collective).
 
 The functions take a `calibrate_fn` / `roi_fn` pair so that the collective sequencing can be tested
 on CPU with gloo and a test double (tests/test_dist_gloo.py); on the GPU they default to the HIP path."""
@@ -74,3 +76,136 @@ def shard_frames(T, rank, world):
     base, rem = divmod(T, world)
     t0 = rank * base + min(rank, rem)
     return t0, t0 + base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Mode A: one buffer sharded by frame index
+# ---------------------------------------------------------------------------------------------------
+def _world(group=None):
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _staged(tensor, group):
+    """gloo moves host memory: stage device tensors through the host for it (single-GPU dry runs and tests);
+    RCCL ("nccl") works on the device tensor itself."""
+    dist = _dist()
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(tensor, op, group=None):
+    dist = _dist()
+    if _world(group)[1] == 1:
+        return tensor
+    if _staged(tensor, group):
+        host = tensor.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        tensor.copy_(host)
+    else:
+        dist.all_reduce(tensor, op=op, group=group)
+    return tensor
+
+
+def all_gather_frames(local, T, group=None):
+    """[T_local, NP] rows of every rank -> [T, NP] in frame order (shards are contiguous and ordered by rank)."""
+    import torch
+    dist = _dist()
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    spans = [shard_frames(T, r, world) for r in range(world)]
+    counts = [b - a for a, b in spans]
+    width = local.shape[1]
+    cmax = max(counts)
+    work = local
+    if _staged(local, group):
+        work = local.cpu()
+    if cmax != counts[rank]:   # uneven shards: pad to the longest, compact afterwards
+        pad = work.new_zeros((cmax, width))
+        pad[:counts[rank]] = work
+        work = pad
+    out = work.new_empty((world * cmax, width))
+    dist.all_gather_into_tensor(out, work.contiguous(), group=group)
+    if any(c != cmax for c in counts):
+        out = torch.cat([out[r * cmax:r * cmax + counts[r]] for r in range(world)], dim=0)
+    return out.to(local.device) if out.device != local.device else out
+
+
+class HipShardStages:
+    """The per-rank stages of the frame-sharded calibration on the current HIP device (include/respmon_hip.h
+    rm_shard_*).  tests/test_dist_gloo.py substitutes an oracle-based double to check the collective sequencing
+    on CPU."""
+
+    def __init__(self):
+        from . import _capi, device
+        self._capi, self._device = _capi, device
+        self.t = device.require_gpu()
+        self.lib = _capi.load()
+
+    def layout(self, H, W, levels, skip):
+        import ctypes
+        n = ctypes.c_size_t()
+        self._capi.check(self.lib, self.lib.rm_shard_layout(H, W, levels, skip, ctypes.byref(n)), "rm_shard_layout")
+        return int(n.value)
+
+    def pyramid(self, buf_local, levels, skip, flags, NP):
+        d, t = self._device, self.t
+        Tl, H, W = buf_local.shape
+        lap = t.empty((Tl, NP), dtype=t.float64, device=buf_local.device)
+        if NP:
+            self._capi.check(self.lib, self.lib.rm_shard_pyramid(d.ctx(), d.ptr(buf_local), d.dtype_code(buf_local), Tl, H, W, levels,
+                                                                 skip, int(flags), d.ptr(lap), d.stream_ptr()), "rm_shard_pyramid")
+        return lap
+
+    def collapse(self, lap_all, T, t0, t1, H, W, fps, fmin, fmax, amp, levels, skip, thr, flags):
+        d, t = self._device, self.t
+        mm = t.empty(2, dtype=t.float64, device=lap_all.device)
+        self._capi.check(self.lib, self.lib.rm_shard_collapse(d.ctx(), d.ptr(lap_all) if lap_all.numel() else None, T, t0, t1, H, W,
+                                                              float(fps), float(fmin), float(fmax), float(amp), levels, skip, float(thr),
+                                                              int(flags), d.ptr(mm), d.stream_ptr()), "rm_shard_collapse")
+        return mm
+
+    def heat(self, negmin_max, thr, H, W):
+        d, t = self._device, self.t
+        hs = t.empty((H, W), dtype=t.float64, device=negmin_max.device)
+        self._capi.check(self.lib, self.lib.rm_shard_heat(d.ctx(), d.ptr(negmin_max), float(thr), d.ptr(hs), d.stream_ptr()),
+                         "rm_shard_heat")
+        return hs
+
+    def finish(self, heat_sum, T, threshold):
+        import ctypes
+        d, t = self._device, self.t
+        H, W = heat_sum.shape
+        heat = t.empty((H, W), dtype=t.float64, device=heat_sum.device)
+        xywh = (ctypes.c_int32 * 4)()
+        rc = self._capi.check(self.lib, self.lib.rm_shard_finish(d.ctx(), d.ptr(heat_sum), T, H, W, int(threshold), d.ptr(heat), xywh,
+                                                                 d.stream_ptr()), "rm_shard_finish")
+        roi = None if rc == self._capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
+        return roi, heat
+
+
+def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4,
+                   temporal_threshold=0.7, threshold=20, flags=0, group=None, stages=None, return_heatmap=False):
+    """Mode A step: RespiratoryMonitor.locate (base.py:547-601) of ONE [T,H,W] calibration buffer whose frames
+    shard_frames(T, rank, world) live on this rank as `buf_local`.  Every rank returns the same ROI."""
+    dist = _dist()
+    rank, world = _world(group)
+    t0, t1 = shard_frames(T, rank, world)
+    if buf_local.shape[0] != t1 - t0:
+        raise ValueError("rank %d holds %d frames, shard_frames(%d, %d, %d) says %d" % (rank, buf_local.shape[0], T, rank, world, t1 - t0))
+    if t1 - t0 < 1:
+        raise ValueError("every rank needs at least one frame (T=%d, world=%d)" % (T, world))
+    st = stages if stages is not None else HipShardStages()
+    _, H, W = buf_local.shape
+    L, S = int(pyramid_levels), int(skip_levels_at_top)
+    NP = st.layout(H, W, L, S)
+    lap_local = st.pyramid(buf_local, L, S, flags, NP)
+    lap_all = all_gather_frames(lap_local, T, group) if NP else lap_local
+    mm = st.collapse(lap_all, T, t0, t1, H, W, fps, freq_min, freq_max, amplification, L, S, temporal_threshold, flags)
+    _all_reduce(mm, dist.ReduceOp.MAX, group)
+    heat_sum = st.heat(mm, temporal_threshold, H, W)
+    _all_reduce(heat_sum, dist.ReduceOp.SUM, group)
+    roi, heat = st.finish(heat_sum, T, threshold)
+    return (roi, heat) if return_heatmap else roi

@@ -89,6 +89,58 @@ class Emu:
         return None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
 
 
+def _shard_methods():
+    def new_ctx(self):
+        h = ctypes.c_void_p()
+        self.ck(self.lib.rm_ctx_create(0, ctypes.byref(h)), "ctx_create")
+        return h
+
+    def locate_sharded(self, frames, world, fps=10.0, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, threshold=20, flags=0):
+        """The rm_shard_* stages for `world` emulated ranks (a context each), collectives done with numpy."""
+        frames = np.ascontiguousarray(frames)
+        T, H, W = frames.shape
+        n = ctypes.c_size_t()
+        self.ck(self.lib.rm_shard_layout(H, W, levels, skip, ctypes.byref(n)), "shard_layout")
+        NP = int(n.value)
+        spans = []
+        base, rem = divmod(T, world)
+        for r in range(world):
+            t0 = r * base + min(r, rem)
+            spans.append((t0, t0 + base + (1 if r < rem else 0)))
+        ctxs = [self.new_ctx() for _ in range(world)]
+        lap_all = np.zeros((T, max(NP, 1)))[:, :NP].copy()
+        for c, (t0, t1) in zip(ctxs, spans):
+            local = np.ascontiguousarray(frames[t0:t1])
+            lap = np.empty((t1 - t0, NP))
+            if NP:
+                self.ck(self.lib.rm_shard_pyramid(c, ptr(local), DT[local.dtype], t1 - t0, H, W, levels, skip, flags, ptr(lap), None),
+                        "shard_pyramid")
+            lap_all[t0:t1] = lap
+        mms = []
+        for c, (t0, t1) in zip(ctxs, spans):
+            mm = np.empty(2)
+            self.ck(self.lib.rm_shard_collapse(c, ptr(lap_all) if NP else None, T, t0, t1, H, W, fps, fmin, fmax, amp, levels, skip,
+                                               thr, flags, ptr(mm), None), "shard_collapse")
+            mms.append(mm)
+        mm = np.max(np.stack(mms), axis=0)
+        total = np.zeros((H, W))
+        for c in ctxs:
+            hs = np.empty((H, W))
+            self.ck(self.lib.rm_shard_heat(c, ptr(mm), thr, ptr(hs), None), "shard_heat")
+            total = total + hs
+        heat = np.empty((H, W)); xywh = np.zeros(4, np.int32)
+        rc = self.ck(self.lib.rm_shard_finish(ctxs[0], ptr(total), T, H, W, threshold, ptr(heat), ptr(xywh), None), "shard_finish")
+        for c in ctxs:
+            self.lib.rm_ctx_destroy(c)
+        return (None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)), heat, (-mm[0], mm[1])
+
+    for f in (new_ctx, locate_sharded):
+        setattr(Emu, f.__name__, f)
+
+
+_shard_methods()
+
+
 def _flow_methods():
     def good_features(self, img_u8, maxCorners=100, qualityLevel=0.3, minDistance=7, blockSize=7):
         img = np.ascontiguousarray(img_u8, dtype=np.uint8)

@@ -122,3 +122,24 @@ def test_emu_fused_down_chain_equals_per_level(emu):
             tiny, _ = emu.calibrate(v, 10.0, levels=L, skip=S, flags=8)
             assert np.array_equal(fused, per_level), (dt, T, H, W, L, S)
             assert np.array_equal(tiny, per_level), (dt, T, H, W, L, S)
+
+
+def test_emu_frame_sharded_stages(emu, oracle):
+    """rm_shard_* (Mode A): one rank == rm_calibrate bit for bit; several emulated ranks give the same ROI and
+    extrema, the heatmap up to the association of the time sum."""
+    cases = [(24, 40, 56, 5, 2, 3), (17, 33, 47, 4, 1, 4)]
+    for (T, H, W, L, S, seed) in cases:
+        frames = oracle.uint8_to_float(synth.synth_breathing(T, H, W, seed=seed))
+        heat_ref, mm_ref = emu.calibrate(frames, 10.0, levels=L, skip=S)
+        roi_ref = emu.locate(frames, 10.0, levels=L, skip=S)
+        assert roi_ref == oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
+        roi1, heat1, mm1 = emu.locate_sharded(frames, 1, levels=L, skip=S)
+        assert roi1 == roi_ref and np.array_equal(heat1, heat_ref) and tuple(mm1) == tuple(mm_ref)
+        for world in (2, 3):
+            roi, heat, mm = emu.locate_sharded(frames, world, levels=L, skip=S)
+            assert roi == roi_ref and tuple(mm) == tuple(mm_ref)
+            assert np.abs(heat - heat_ref).max() <= 1e-12 * np.abs(heat_ref).max()
+    # nothing filtered (skip >= levels - 1): all-zero heatmap, no contour -- same as rm_locate
+    frames = oracle.uint8_to_float(synth.synth_breathing(8, 16, 16, seed=1))
+    roi, heat, mm = emu.locate_sharded(frames, 2, levels=3, skip=2)
+    assert roi is None and not heat.any() and emu.locate(frames, 10.0, levels=3, skip=2) is None

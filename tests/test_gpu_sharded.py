@@ -1,0 +1,155 @@
+"""Frame-sharded calibration (Mode A, include/respmon_hip.h rm_shard_*) on the MI355X:
+  * one rank: the staged path equals rm_locate / rm_calibrate bit for bit;
+  * several ranks emulated in ONE process (a library context per rank, the three collectives done by hand):
+    same ROI as the unsharded path and as the CPU oracle, heatmap within the association error of the time sum;
+  * two real processes on the one GPU of the test box (gloo stages the tensors through the host; on the
+    8-GPU node the same code runs over RCCL): dist.locate_sharded end to end."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from respmon_amd import _capi
+    return _capi.load()
+
+
+def _buffer(oracle, T, H, W, seed):
+    import torch
+    from respmon_amd import synth
+    frames = oracle.uint8_to_float(synth.synth_breathing(T, H, W, seed=seed))
+    return frames, torch.from_numpy(frames).cuda()
+
+
+def test_one_rank_equals_locate_bit_for_bit(hip, oracle):
+    import torch
+    from respmon_amd import dist as rdist
+    from respmon_amd.base import RespiratoryMonitor
+    for (T, H, W, L, S, seed) in [(64, 135, 241, 8, 3, 5), (48, 270, 480, 9, 4, 6), (40, 64, 64, 5, 1, 24)]:
+        frames, buf = _buffer(oracle, T, H, W, seed)
+        roi, heat = rdist.locate_sharded(buf, T, 10, pyramid_levels=L, skip_levels_at_top=S, return_heatmap=True)
+        assert roi == RespiratoryMonitor.locate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
+        assert torch.equal(heat, rdist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S))
+        assert roi == oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
+    # nothing filtered (skip >= levels - 1): zero heatmap -> NaN after normalisation -> no contour -> None (base.py:569-570)
+    frames, buf = _buffer(oracle, 16, 32, 48, 9)
+    assert oracle.locate(frames, 10, pyramid_levels=3, skip_levels_at_top=2) is None
+    assert RespiratoryMonitor.locate(buf, 10, pyramid_levels=3, skip_levels_at_top=2) is None
+    assert rdist.locate_sharded(buf, 16, 10, pyramid_levels=3, skip_levels_at_top=2) is None
+
+
+class _Rank:
+    """One emulated rank: its own library context, so the per-rank state of rm_shard_* is really separate."""
+
+    def __init__(self, lib):
+        from respmon_amd import _capi
+        self.lib, self._capi = lib, _capi
+        self.ctx = ctypes.c_void_p()
+        _capi.check(lib, lib.rm_ctx_create(0, ctypes.byref(self.ctx)), "rm_ctx_create")
+
+    def close(self):
+        self.lib.rm_ctx_destroy(self.ctx)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_emulated_ranks_match_unsharded(hip, oracle, world):
+    import torch
+    from respmon_amd import _capi, device, dist as rdist
+    from respmon_amd.base import RespiratoryMonitor
+    lib = hip
+    T, H, W, L, S = 67, 180, 320, 8, 3          # 67 frames: uneven shards for every world size
+    frames, buf = _buffer(oracle, T, H, W, 31)
+    sp = device.stream_ptr()
+    n = ctypes.c_size_t()
+    _capi.check(lib, lib.rm_shard_layout(H, W, L, S, ctypes.byref(n)), "rm_shard_layout")
+    NP = int(n.value)
+    ranks = [_Rank(lib) for _ in range(world)]
+    try:
+        spans = [rdist.shard_frames(T, r, world) for r in range(world)]
+        lap_all = torch.empty((T, NP), dtype=torch.float64, device="cuda")
+        for rk, (t0, t1) in zip(ranks, spans):        # stage 1 + "all-gather"
+            local = buf[t0:t1].contiguous()
+            _capi.check(lib, lib.rm_shard_pyramid(rk.ctx, device.ptr(local), _capi.RM_F64, t1 - t0, H, W, L, S, 0,
+                                                  ctypes.c_void_p(lap_all[t0:t1].data_ptr()), sp), "rm_shard_pyramid")
+        mms = []
+        for rk, (t0, t1) in zip(ranks, spans):        # stage 2
+            mm = torch.empty(2, dtype=torch.float64, device="cuda")
+            _capi.check(lib, lib.rm_shard_collapse(rk.ctx, device.ptr(lap_all), T, t0, t1, H, W, 10.0, 0.1, 1.0, 500.0, L, S, 0.7, 0,
+                                                   device.ptr(mm), sp), "rm_shard_collapse")
+            mms.append(mm)
+        mm = torch.stack(mms).max(dim=0).values        # "all-reduce(MAX)"
+        total = torch.zeros((H, W), dtype=torch.float64, device="cuda")
+        for rk in ranks:                               # stage 3 + "all-reduce(SUM)" in rank order
+            hs = torch.empty((H, W), dtype=torch.float64, device="cuda")
+            _capi.check(lib, lib.rm_shard_heat(rk.ctx, device.ptr(mm), 0.7, device.ptr(hs), sp), "rm_shard_heat")
+            total += hs
+        heat = torch.empty((H, W), dtype=torch.float64, device="cuda")
+        xywh = (ctypes.c_int32 * 4)()
+        rc = _capi.check(lib, lib.rm_shard_finish(ranks[0].ctx, device.ptr(total), T, H, W, 20, device.ptr(heat), xywh, sp),
+                         "rm_shard_finish")
+        roi = None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
+    finally:
+        for rk in ranks:
+            rk.close()
+    ref_heat = rdist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
+    assert roi == RespiratoryMonitor.locate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
+    assert roi == oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
+    err = float((heat - ref_heat).abs().max() / ref_heat.abs().max())
+    assert err <= 1e-12, err
+    # the exact extrema found by the shards are the global ones
+    masked, raw = oracle.eulerian_magnification_bandpass(frames, 10, 0.1, 1.0, 500, pyramid_levels=L, skip_levels_at_top=S)
+    got_min, got_max = -float(mm[0]), float(mm[1])
+    assert abs(got_min - raw.min()) <= 1e-9 * abs(raw.min()) and abs(got_max - raw.max()) <= 1e-9 * abs(raw.max())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, T, H, W, L, S):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import dist as rdist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = oracle.uint8_to_float(synth.synth_breathing(T, H, W, seed=41))
+    t0, t1 = rdist.shard_frames(T, rank, world)
+    local = torch.from_numpy(frames[t0:t1].copy()).cuda()
+    roi, heat = rdist.locate_sharded(local, T, 10, pyramid_levels=L, skip_levels_at_top=S, return_heatmap=True)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), roi=np.array(roi if roi is not None else (-1, -1, -1, -1)),
+             heat=heat.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_locate_sharded(hip, oracle, tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    from respmon_amd import dist as rdist
+    T, H, W, L, S = 65, 135, 240, 8, 3
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), T, H, W, L, S), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["roi"], r1["roi"]) and np.array_equal(r0["heat"], r1["heat"])
+    frames, buf = _buffer(oracle, T, H, W, 41)
+    assert tuple(int(v) for v in r0["roi"]) == oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
+    ref = rdist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S).cpu().numpy()
+    assert np.abs(r0["heat"] - ref).max() <= 1e-12 * np.abs(ref).max()
