@@ -626,6 +626,10 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
 #ifdef RM_DC_SEGS  // developer experiment
     segs = RM_DC_SEGS;
 #endif
+    if (const char *e = getenv("RM_DC_SEGS")) {  // developer experiment (A/B on one box)
+        const int v = atoi(e);
+        if (v >= 1 && v <= rows) segs = v;
+    }
     g.seg_h = (rows + segs - 1) / segs;
     if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
     g.segs = (rows + g.seg_h - 1) / g.seg_h;

@@ -218,3 +218,57 @@ def test_state_machine_full_calibration_trace(hip, golden):
         assert mon.fps == int(g["c2_fps"])
         assert np.allclose(np.array(mon.data), g["c2_data"], rtol=1e-13, atol=0)
         assert np.array_equal(np.array(mon.t), g["c2_t"])
+
+
+def test_config_q_720p_full_size_vs_oracle(hip, oracle):
+    """BASELINE config 2 at full size: 128 x 720p, 4-level pyramid, skip 2 (the module defaults of
+    eulerian_magnification_bandpass, transforms.py:145) -- bit-exact ROI against the oracle's materialising run."""
+    import torch
+    from respmon_amd import synth, dist
+    from respmon_amd.base import RespiratoryMonitor
+    T, H, W, L, S = 128, 720, 1280, 4, 2
+    v8 = synth.synth_breathing(T, H, W, seed=1234)
+    frames = oracle.uint8_to_float(v8)
+    ref, mid = oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
+    buf = torch.from_numpy(frames).cuda()
+    assert RespiratoryMonitor.locate(buf, 10, pyramid_levels=L, skip_levels_at_top=S) == ref
+    heat = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
+    assert _rel(heat.cpu().numpy(), mid["avg_frame"]) <= 1e-12          # north_star gate is 1e-4
+    assert torch.equal(heat, dist.hip_calibrate(torch.from_numpy(v8).cuda(), 10, pyramid_levels=L, skip_levels_at_top=S))
+    assert torch.equal(heat, dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=1))   # pruned == exhaustive
+
+
+def test_config_r_fp16_buffer(hip, oracle):
+    """BASELINE config 5 (6-level pyramid, skip 2, float16 frame buffer): the library widens the stored halves
+    exactly, so against the oracle fed the SAME rounded values the ROI is bit-exact; against the float64 video
+    the float16 storage error is reported (north_star: 'f16 config reports its own error and ROI match')."""
+    import torch
+    from respmon_amd import synth, dist
+    from respmon_amd.base import RespiratoryMonitor
+    L, S = 6, 2
+    v8 = synth.synth_breathing(64, 270, 480, seed=55)
+    f64 = oracle.uint8_to_float(v8)
+    f16 = f64.astype(np.float16)
+    ref16, mid16 = oracle.locate(f16.astype(np.float64), 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
+    ref64, mid64 = oracle.locate(f64, 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
+    buf16 = torch.from_numpy(f16).cuda()
+    assert RespiratoryMonitor.locate(buf16, 10, pyramid_levels=L, skip_levels_at_top=S) == ref16
+    heat = dist.hip_calibrate(buf16, 10, pyramid_levels=L, skip_levels_at_top=S).cpu().numpy()
+    assert _rel(heat, mid16["avg_frame"]) <= 1e-12
+    storage_err = _rel(mid16["avg_frame"], mid64["avg_frame"])
+    print("config R float16 storage: heatmap rel. error vs float64 video %.3e, ROI f16 %s / f64 %s" % (storage_err, ref16, ref64))
+    assert storage_err < 0.2     # the half-precision frame buffer perturbs, but does not destroy, the heatmap
+    # 4K frames (full width / height of config 5, fewer frames): size-independent properties
+    T, H, W = 32, 2160, 3840
+    v8 = synth.synth_breathing(T, H, W, seed=1234)
+    dev8 = torch.from_numpy(v8).cuda()
+    b16 = torch.empty((T, H, W), dtype=torch.float16, device="cuda")
+    for t0 in range(0, T, 8):
+        b16[t0:t0 + 8] = (dev8[t0:t0 + 8].to(torch.float64) * (1.0 / 255)).to(torch.float16)
+    h0 = dist.hip_calibrate(b16, 10, pyramid_levels=L, skip_levels_at_top=S)
+    assert torch.equal(h0, dist.hip_calibrate(b16, 10, pyramid_levels=L, skip_levels_at_top=S, flags=1))   # pruned == exhaustive
+    assert torch.equal(h0, dist.hip_calibrate(b16, 10, pyramid_levels=L, skip_levels_at_top=S, flags=2))   # fused chain == per level
+    assert torch.equal(h0, dist.hip_calibrate(b16.to(torch.float64), 10, pyramid_levels=L, skip_levels_at_top=S))  # exact widening
+    roi = dist.hip_heatmap_to_roi(h0, 20)
+    a = h0.cpu().numpy()
+    assert roi == oracle.roi_from_heatmap_u8(oracle.float_to_uint8((a - a.min()) / (a.max() - a.min())), 20)
