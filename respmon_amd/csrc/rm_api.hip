@@ -69,7 +69,6 @@ struct rm_ctx {
     CollapseState *d_state = nullptr;
     CollapseState *h_state = nullptr;  // pinned
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
-    uint32_t *h_rowany = nullptr; size_t h_rowany_cap = 0;  // pinned
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     FlowWorkspace flow;
@@ -160,7 +159,6 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_slots_seen) (void)hipHostFree(ctx->h_slots_seen);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
-    if (ctx->h_rowany) (void)hipHostFree(ctx->h_rowany);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -839,7 +837,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     cp.valid = false;
     cp.cS = sl.cS; cp.T = T; cp.t0 = t0; cp.t1 = t1; cp.H = sl.h[0]; cp.W = sl.w[0]; cp.S = sl.S;
     const size_t npix = (size_t)cp.H * cp.W;
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
     LAUNCH_CHECK();
     const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
     if (sl.S == 0) {
@@ -871,10 +869,18 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
     RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
-    hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_bounds, dim3(nblk(npairs, 256, 128)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st);
-    LAUNCH_CHECK();
+    {
+        // per-frame separable form when its row-extrema table fits LDS, else the per-pair kernel
+        const size_t tbl = 2 * sizeof(double) * (size_t)g.h[g.S] * g.tiles_x;
+        if (tbl <= 150 * 1024 && ntiles < 65536) {
+            if (tbl > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)k_frame_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbl));
+            hipLaunchKernelGGL(k_frame_bounds, dim3(T), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st);
+        } else {
+            hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi, st);
+        }
+        LAUNCH_CHECK();
+    }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 255) / 256), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
                        (unsigned)slot_cap, prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles);
@@ -893,7 +899,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     CollapseState *st = ctx->d_state;
     const size_t npix = (size_t)cp.H * cp.W;
     if (cp.S == 0) {
-        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
+        hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(NSTRIPE), 0, s, st, thr);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_masked_sum_plain, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, cp.cS, cp.T, npix, st, heat_sum);
         LAUNCH_CHECK();
@@ -993,7 +999,7 @@ extern "C" int rm_shard_collapse(rm_ctx *ctx, const double *lap_all, int T, int 
     RM_TRY(front_filter(ctx, lap_all, T, pg, fps, fmin, fmax, amp, sl, s));
     PhaseTimer pt(ctx, 2, s);
     RM_TRY(collapse_eval(ctx, sl, T, t0, t1, thr, flags, cp, s));
-    hipLaunchKernelGGL(k_export_minmax, dim3(1), dim3(1), 0, s, ctx->d_state, negmin_max_dev);
+    hipLaunchKernelGGL(k_export_minmax, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state, negmin_max_dev);
     LAUNCH_CHECK();
     return RM_OK;
 }
@@ -1007,7 +1013,7 @@ extern "C" int rm_shard_heat(rm_ctx *ctx, const double *negmin_max_dev, double t
     HIP_TRY(hipSetDevice(ctx->device));
     if (cp.S < 0) { HIP_TRY(hipMemsetAsync(heat_sum, 0, sizeof(double) * (size_t)cp.H * cp.W, s)); return RM_OK; }
     PhaseTimer pt(ctx, 2, s);
-    hipLaunchKernelGGL(k_import_minmax, dim3(1), dim3(1), 0, s, ctx->d_state, negmin_max_dev);
+    hipLaunchKernelGGL(k_import_minmax, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state, negmin_max_dev);
     LAUNCH_CHECK();
     return collapse_sum(ctx, cp, thr, heat_sum, s);
 }
@@ -1058,11 +1064,11 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
     }
     if (sl.S == 0) HIP_TRY(hipMemcpyAsync(raw_buf, sl.cS, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     CollapseState *st = ctx->d_state;
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, s, st);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, raw_buf, n, st);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(1), 0, s, st, thr);
+    hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(NSTRIPE), 0, s, st, thr);
     LAUNCH_CHECK();
     if (masked) {
         hipLaunchKernelGGL(k_mask_plain, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, raw_buf, n, st, masked);
@@ -1087,49 +1093,33 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
     CollapseState *st = ctx->d_state;
-    uint8_t *bin = binary;
-    if (!bin) RM_TRY(ws(ctx, "binary", npix, &bin));
-    uint32_t *row_any = nullptr;
-    RM_TRY(ws(ctx, "row_any", (size_t)H, &row_any));
-    if (ctx->h_bin_cap < npix) {
+    // the thresholded image goes to the host bit-packed (npix / 8 bytes, pinned) in one copy
+    const size_t nwords = (npix + 63) / 64;
+    unsigned long long *bits = nullptr;
+    RM_TRY(ws(ctx, "binary_bits", nwords, &bits));
+    if (ctx->h_bin_cap < nwords * 8) {
         if (ctx->h_bin) HIP_TRY(hipHostFree(ctx->h_bin));
         ctx->h_bin = nullptr; ctx->h_bin_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, npix, hipHostMallocDefault));
-        ctx->h_bin_cap = npix;
-    }
-    if (ctx->h_rowany_cap < (size_t)H) {
-        if (ctx->h_rowany) HIP_TRY(hipHostFree(ctx->h_rowany));
-        ctx->h_rowany = nullptr; ctx->h_rowany_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&ctx->h_rowany, sizeof(uint32_t) * H, hipHostMallocDefault));
-        ctx->h_rowany_cap = H;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, nwords * 8, hipHostMallocDefault));
+        ctx->h_bin_cap = nwords * 8;
     }
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
-    HIP_TRY(hipMemsetAsync(row_any, 0, sizeof(uint32_t) * H, s));
     if (!have_minmax) {  // rm_calibrate has just left the heatmap's min / max in the state
         hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, bin, row_any, W);
+    hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, binary, bits);
     LAUNCH_CHECK();
-    // two small hops instead of one H*W copy: the row flags first, then only the rows that hold foreground
-    HIP_TRY(hipMemcpyAsync(ctx->h_rowany, row_any, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    int y_lo = H, y_hi = -1;
-    for (int y = 0; y < H; ++y)
-        if (ctx->h_rowany[y]) { if (y < y_lo) y_lo = y; y_hi = y; }
-    if (y_hi >= y_lo) {
-        HIP_TRY(hipMemcpyAsync(ctx->h_bin + (size_t)y_lo * W, bin + (size_t)y_lo * W, (size_t)(y_hi - y_lo + 1) * W,
-                               hipMemcpyDeviceToHost, s));
-    }
+    HIP_TRY(hipMemcpyAsync(ctx->h_bin, bits, nwords * 8, hipMemcpyDeviceToHost, s));
     delete pt_roi; pt_roi = nullptr;
     HIP_TRY(hipStreamSynchronize(s));
     RoiResult r;
     {
         auto t0 = std::chrono::steady_clock::now();
-        largest_external_contour(ctx->h_bin, H, W, ctx->h_rowany, &r);
+        largest_external_contour_bits((const uint64_t *)ctx->h_bin, H, W, &r);
         if (ctx->prof_on)
             ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

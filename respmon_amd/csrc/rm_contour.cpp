@@ -64,6 +64,66 @@ struct Tracer {
         for (int i = 0; i < 8; ++i) nbr[i] = nbr[i + 8] = dy[i] * step + dx[i];
     }
 
+    std::vector<uint32_t> own_row_any;
+
+    // 64 pixels starting at bit position `pos` of the packed image (bits past `end` read as background)
+    static inline uint64_t get64(const uint64_t *bits, size_t pos, size_t end)
+    {
+        const size_t wi = pos >> 6, sh = pos & 63, last = (end - 1) >> 6;
+        uint64_t v = bits[wi] >> sh;
+        if (sh && wi + 1 <= last) v |= bits[wi + 1] << (64 - sh);
+        const size_t left = end - pos;
+        if (left < 64) v &= (~0ull) >> (64 - left);
+        return v;
+    }
+
+    void prepare_bits(const uint64_t *bits, int H, int W)
+    {
+        static uint64_t lut[256];
+        static bool lut_ok = false;
+        if (!lut_ok) {  // byte of 8 pixel bits -> 8 bytes FG / BG
+            for (int b = 0; b < 256; ++b) {
+                uint64_t v = 0;
+                for (int k = 0; k < 8; ++k) v |= (uint64_t)((b >> k) & 1) << (8 * k);
+                lut[b] = v;
+            }
+            lut_ok = true;
+        }
+        const int new_step = W + 2;
+        if (new_step != step || rows_dirty_h != H) {
+            step = new_step; rows_dirty_h = H;
+            buf.assign((size_t)step * (H + 2), BG);
+            dirty.assign(H, 0);
+        }
+        own_row_any.assign(H, 0);
+        const size_t end = (size_t)H * W;
+        for (int y = 0; y < H; ++y) {
+            signed char *d = buf.data() + (size_t)(y + 1) * step + 1;
+            const size_t r0 = (size_t)y * W;
+            uint64_t any = 0;
+            for (int x = 0; x < W && !any; x += 64) any |= get64(bits, r0 + x, r0 + W);
+            if (!any) {
+                if (dirty[y]) { std::memset(d, BG, (size_t)W); dirty[y] = 0; }  // only rows the last image touched
+                continue;
+            }
+            dirty[y] = 1; own_row_any[y] = 1;
+            for (int x = 0; x < W; x += 64) {
+                const uint64_t v = get64(bits, r0 + x, r0 + W);
+                const int n = (W - x < 64) ? W - x : 64;
+                if (!v) { std::memset(d + x, BG, (size_t)n); continue; }
+                if (n == 64) {
+                    for (int k = 0; k < 8; ++k) { const uint64_t e = lut[(v >> (8 * k)) & 0xff]; std::memcpy(d + x + 8 * k, &e, 8); }
+                } else {
+                    for (int k = 0; k < n; ++k) d[x + k] = (signed char)((v >> k) & 1);
+                }
+            }
+        }
+        (void)end;
+        const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+        const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+        for (int i = 0; i < 8; ++i) nbr[i] = nbr[i + 8] = dy[i] * step + dx[i];
+    }
+
     // follow the outer border that starts at `start` (padded coords px,py); returns twice the signed area
     long long follow(signed char *start, int px, int py, int &minx, int &miny, int &maxx, int &maxy)
     {
@@ -106,13 +166,30 @@ struct Tracer {
 };
 }  // namespace
 
+static thread_local Tracer g_tracer;   // working copy reused across calls (one context drives one thread at a time)
+
+static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out);
+
 int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out)
 {
     out->found = 0; out->n_contours = 0; out->area = 0.0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
-    static thread_local Tracer tr;   // working copy reused across calls (one context drives one thread at a time)
-    tr.prepare(bin, H, W, row_any);
+    g_tracer.prepare(bin, H, W, row_any);
+    return scan_prepared(g_tracer, H, row_any, out);
+}
+
+int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult *out)
+{
+    out->found = 0; out->n_contours = 0; out->area = 0.0;
+    out->x = out->y = out->w = out->h = 0;
+    if (H <= 0 || W <= 0) return 0;
+    g_tracer.prepare_bits(bits, H, W);
+    return scan_prepared(g_tracer, H, g_tracer.own_row_any.data(), out);
+}
+
+static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out)
+{
     const int step = tr.step;
     double best = -1.0;
     for (int y = 0; y < H; ++y) {

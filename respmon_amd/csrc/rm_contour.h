@@ -11,4 +11,6 @@ struct RoiResult {
 };
 // bin: H*W bytes (non-zero = foreground); row_any (nullable): per-row "has foreground" flags
 int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out);
+// the same on a bit-packed image: bit (p & 63) of word (p >> 6) = pixel p = y*W + x; words beyond H*W bits are not read
+int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult *out);
 }  // namespace rm

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int s
 // in one [T, NP] buffer, so one launch per stage serves every filtered level.
 constexpr int TF_KC = 4, TF_SC = 8, TF_U = 16;
 
+// (Splitting T over 4 waves per workgroup with an LDS reduction was measured slower: 48 us vs 42 us.)
 __global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y)
 {
     HIP_DYNAMIC_SHARED(double, s_r)  // [T][TF_KC]
@@ -392,37 +393,45 @@ __device__ __forceinline__ void block_minmax(double &mn, double &mx)
     __syncthreads();
 }
 
+// i -> (i / nw, i % nw) for the small element counts of a tile buffer (i < 2^16, 1 <= nw <= 2^10): one multiply
+// by the reciprocal instead of the ~35-instruction integer division; (i + 0.5) / nw is at least 0.5 / nw away
+// from an integer, far more than the float rounding error at these magnitudes, so the floor is exact
+__device__ __forceinline__ void split_rc(int i, int nw, float inv_nw, int &r, int &c)
+{
+    r = (int)(((float)i + 0.5f) * inv_nw);
+    c = i - r * nw;
+}
+
+// wave-uniform value into a scalar register (index math derived from it then runs on the scalar unit)
+__device__ __forceinline__ int uniform(int v)
+{
+#ifdef RM_HIPEMU
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // per (frame, tile) bounds of the level-S footprint: every full-resolution value of the tile
 // is a convex combination of these, so  lo - margin <= raw <= hi + margin.
 // Layout [t][tile]: consecutive lanes take consecutive tiles of one frame (overlapping, x-contiguous
 // footprints -> coalesced reads).
-__global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
-                                                     double *lo, double *hi)
-{
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= ntiles * T) return;
-    int t = idx / ntiles, tile = idx - t * ntiles;
-    const int S = g.S;
-    const Region R = tile_region(g, tile, S);
-    const int wS = g.w[S];
-    const double *p = cS + (size_t)t * g.h[S] * wS;
-    double mn = p[(size_t)R.y0 * wS + R.x0], mx = mn;
-    for (int y = R.y0; y <= R.y1; ++y)
-        for (int x = R.x0; x <= R.x1; ++x) {
-            double v = p[(size_t)y * wS + x];
-            mn = (v < mn) ? v : mn;
-            mx = (v > mx) ? v : mx;
-        }
-    lo[idx] = mn; hi[idx] = mx;
-}
-
+// (k_tile_bounds follows the CollapseState it reduces into)
 // device-side scalars shared by the collapse passes
+// Thousands of workgroups finish at about the same time and all want to fold their extremum into ONE word:
+// same-address atomics serialise at ~5-12 ns each (100+ us for the evaluation pass).  Each reduction target is
+// therefore striped over NSTRIPE words (workgroup b uses stripe b % NSTRIPE); readers fold the stripes with one
+// load per lane and a wave reduction.
+constexpr int NSTRIPE = 64;
+
 struct CollapseState {
     unsigned long long lb_max_key;  // max over pairs of lo  (lower bound of raw.max())
     unsigned long long ub_min_key;  // min over pairs of hi  (upper bound of raw.min())
     unsigned long long ub_max_key;  // max over pairs of hi  (upper bound of raw.max())
     unsigned long long lb_min_key;  // min over pairs of lo  (lower bound of raw.min())
     unsigned long long min_key, max_key;  // exact raw.min() / raw.max()
+    unsigned long long lb_max_keys[NSTRIPE], ub_min_keys[NSTRIPE], ub_max_keys[NSTRIPE], lb_min_keys[NSTRIPE];
+    unsigned long long min_keys[NSTRIPE], max_keys[NSTRIPE];  // stripes of the six words above
     unsigned int n_list;            // (frame, tile) pairs that must be evaluated
     unsigned int n_slots;           // pairs whose values are kept for the masked time sum
     double margin;                  // absolute safety margin of the bounds
@@ -431,30 +440,123 @@ struct CollapseState {
     unsigned long long heat_min_key, heat_max_key;
 };
 
-__global__ void k_state_init(CollapseState *st)
+__global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st)
 {
+    const int i = threadIdx.x;
+    st->lb_max_keys[i] = 0ull; st->ub_min_keys[i] = ~0ull; st->ub_max_keys[i] = 0ull; st->lb_min_keys[i] = ~0ull;
+    st->min_keys[i] = ~0ull; st->max_keys[i] = 0ull;
+    if (i != 0) return;
     st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->ub_max_key = 0ull; st->lb_min_key = ~0ull;
     st->min_key = ~0ull; st->max_key = 0ull; st->n_list = 0; st->n_slots = 0;
     st->margin = 0; st->top_ub = 0; st->min_val = 0; st->max_val = 0; st->top = 0;
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
 }
 
-__global__ __launch_bounds__(256) void k_reduce_bounds(const double *lo, const double *hi, int n, CollapseState *st)
+// fold the stripes of one target (plus its unstriped word); every lane of the wave gets the result
+__device__ __forceinline__ unsigned long long fold_min_keys(const unsigned long long *stripes, unsigned long long word)
+{
+    unsigned long long v = stripes[threadIdx.x & (NSTRIPE - 1)];
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = (o < v) ? o : v; }
+    return (word < v) ? word : v;
+}
+__device__ __forceinline__ unsigned long long fold_max_keys(const unsigned long long *stripes, unsigned long long word)
+{
+    unsigned long long v = stripes[threadIdx.x & (NSTRIPE - 1)];
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = (o > v) ? o : v; }
+    return (word > v) ? word : v;
+}
+
+// The four extrema of the bounds (over ALL pairs) are reduced here as well: block-level min/max, then striped
+// atomics that are skipped when they cannot change the result.
+__global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
+                                                     double *lo, double *hi, CollapseState *st)
 {
     const double inf = __builtin_huge_val();
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    double mn = inf, mx = -inf;
+    if (idx < ntiles * T) {
+        int t = idx / ntiles, tile = idx - t * ntiles;
+        const int S = g.S;
+        const Region R = tile_region(g, tile, S);
+        const int wS = g.w[S];
+        const double *p = cS + (size_t)t * g.h[S] * wS;
+        mn = p[(size_t)R.y0 * wS + R.x0]; mx = mn;
+        for (int y = R.y0; y <= R.y1; ++y)
+            for (int x = R.x0; x <= R.x1; ++x) {
+                double v = p[(size_t)y * wS + x];
+                mn = (v < mn) ? v : mn;
+                mx = (v > mx) ? v : mx;
+            }
+        lo[idx] = mn; hi[idx] = mx;
+    }
+    // lanes past the end hold (+inf, -inf): neutral for min-of-lo / max-of-hi; for max-of-lo / min-of-hi they must
+    // not take part, so those two use the swapped neutral elements
+    double lo_mn = mn, lo_mx = (idx < ntiles * T) ? mn : -inf;
+    double hi_mx = mx, hi_mn = (idx < ntiles * T) ? mx : inf;
+    block_minmax(lo_mn, lo_mx);
+    block_minmax(hi_mn, hi_mx);
+    if (threadIdx.x == 0) {
+        const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
+        const int sp = blockIdx.x & (NSTRIPE - 1);
+        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+    }
+}
+
+// The same bounds, one workgroup per frame: the level-S footprint of a tile is a rectangle, so its min / max is
+// the min / max over the footprint rows of per-row extrema over the footprint columns (exact: min and max are
+// associative).  Row extrema for every (row, tile column) go to LDS first; ~3.6x fewer loads than k_tile_bounds
+// and no per-thread 2-D loop over global memory.  Used when the [h_S][tiles_x] x 2 table fits LDS.
+__global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi,
+                                                      CollapseState *st)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const double inf = __builtin_huge_val();
+    const int S = g.S, hS = g.h[S], wS = g.w[S], ntx = g.tiles_x;
+    const int t = blockIdx.x;
+    double *rmin = lds, *rmax = lds + (size_t)hS * ntx;
+    const double *p = cS + (size_t)t * hS * wS;
+    const float inv_ntx = 1.0f / (float)ntx;
+    for (int i = threadIdx.x; i < hS * ntx; i += 256) {
+        int y, tx;
+        split_rc(i, ntx, inv_ntx, y, tx);
+        const Region R = tile_region(g, tx, S);   // tile tx of the first tile row: same column range as every tile below it
+        const double *row = p + (size_t)y * wS;
+        double mn = row[R.x0], mx = mn;
+        for (int x = R.x0 + 1; x <= R.x1; ++x) {
+            const double v = row[x];
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
+        }
+        rmin[i] = mn; rmax[i] = mx;
+    }
+    __syncthreads();
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        double l = lo[i], h = hi[i];
-        lo_mn = (l < lo_mn) ? l : lo_mn; lo_mx = (l > lo_mx) ? l : lo_mx;
-        hi_mn = (h < hi_mn) ? h : hi_mn; hi_mx = (h > hi_mx) ? h : hi_mx;
+    for (int tile = threadIdx.x; tile < ntiles; tile += 256) {
+        int ty, tx;
+        split_rc(tile, ntx, inv_ntx, ty, tx);
+        const Region R = tile_region(g, tile, S);
+        double mn = rmin[R.y0 * ntx + tx], mx = rmax[R.y0 * ntx + tx];
+        for (int y = R.y0 + 1; y <= R.y1; ++y) {
+            const double a = rmin[y * ntx + tx], b = rmax[y * ntx + tx];
+            mn = (a < mn) ? a : mn;
+            mx = (b > mx) ? b : mx;
+        }
+        lo[(size_t)t * ntiles + tile] = mn; hi[(size_t)t * ntiles + tile] = mx;
+        lo_mn = (mn < lo_mn) ? mn : lo_mn; lo_mx = (mn > lo_mx) ? mn : lo_mx;
+        hi_mn = (mx < hi_mn) ? mx : hi_mn; hi_mx = (mx > hi_mx) ? mx : hi_mx;
     }
     block_minmax(lo_mn, lo_mx);
     block_minmax(hi_mn, hi_mx);
     if (threadIdx.x == 0) {
-        atomicMax(&st->lb_max_key, f64_key(lo_mx));
-        atomicMin(&st->lb_min_key, f64_key(lo_mn));
-        atomicMax(&st->ub_max_key, f64_key(hi_mx));
-        atomicMin(&st->ub_min_key, f64_key(hi_mn));
+        const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
+        const int sp = blockIdx.x & (NSTRIPE - 1);
+        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
     }
 }
 
@@ -470,12 +572,14 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
                                                       unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune,
                                                       double thr, int first_pair, int end_pair)
 {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = i < n;
     // margin and the bounds-only upper bound of top = max - (max - min) * thr (increasing in max and min
     // for 0 <= thr <= 1); every thread derives them from the reduced bounds
-    const double lb_max = f64_unkey(st->lb_max_key), ub_min = f64_unkey(st->ub_min_key);
-    const double ub_max = f64_unkey(st->ub_max_key), lb_min = f64_unkey(st->lb_min_key);
+    const unsigned long long k_lb_max = fold_max_keys(st->lb_max_keys, st->lb_max_key), k_ub_min = fold_min_keys(st->ub_min_keys, st->ub_min_key);
+    const unsigned long long k_ub_max = fold_max_keys(st->ub_max_keys, st->ub_max_key), k_lb_min = fold_min_keys(st->lb_min_keys, st->lb_min_key);
+    const double lb_max = f64_unkey(k_lb_max), ub_min = f64_unkey(k_ub_min);
+    const double ub_max = f64_unkey(k_ub_max), lb_min = f64_unkey(k_lb_min);
     const double aa = ub_max < 0 ? -ub_max : ub_max, bb = lb_min < 0 ? -lb_min : lb_min;
     const double m = PRUNE_REL_MARGIN * (aa > bb ? aa : bb);
     const double mx_ = ub_max + m, mn_ = ub_min + m;
@@ -483,16 +587,32 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
     if (i == 0) { st->margin = m; st->top_ub = top_ub; }
     // frame shard (pairs are [t][tile]): the bounds above cover every frame, the evaluation only this
     // rank's frames [first_pair, end_pair) / ntiles
-    if (i < first_pair || i >= end_pair) { slot_of[i] = SLOT_PRUNED; return; }
-    bool isC = no_prune || !(hi[i] + m < lb_max - m) || !(lo[i] - m > ub_min + m);
-    bool isD = no_prune || (lo[i] - m < top_ub);
+    const bool mine = in_range && i >= first_pair && i < end_pair;
+    bool isC = false, isD = false;
+    if (mine) {
+        const double l = lo[i], h = hi[i];
+        isC = no_prune || !(h + m < lb_max - m) || !(l - m > ub_min + m);
+        isD = no_prune || (l - m < top_ub);
+    }
+    // one atomic per wave and counter (ballot + prefix popcount), not one per selected pair
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long mD = __ballot(isD);
+    unsigned base_slot = 0;
+    if (lane == 0 && mD) base_slot = atomicAdd(&st->n_slots, (unsigned)__popcll(mD));
+    base_slot = (unsigned)__shfl((int)base_slot, 0);
     int slot = SLOT_PRUNED;
     if (isD) {
-        unsigned sidx = atomicAdd(&st->n_slots, 1u);
+        const unsigned sidx = base_slot + (unsigned)__popcll(mD & below);
         slot = (sidx < slot_cap) ? (int)sidx : SLOT_ON_THE_FLY;
     }
-    slot_of[i] = slot;
-    if (isC || slot >= 0) list[atomicAdd(&st->n_list, 1u)] = (unsigned)i;
+    if (in_range) slot_of[i] = slot;
+    const bool listed = isC || slot >= 0;
+    const unsigned long long mL = __ballot(listed);
+    unsigned base_list = 0;
+    if (lane == 0 && mL) base_list = atomicAdd(&st->n_list, (unsigned)__popcll(mL));
+    base_list = (unsigned)__shfl((int)base_list, 0);
+    if (listed) list[base_list + (unsigned)__popcll(mL & below)] = (unsigned)i;
 }
 
 // stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
@@ -504,8 +624,10 @@ __device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, co
     {
         double *d = lds + g.lds_off[S];
         const int nw = Rk.x1 - Rk.x0 + 1, n = (Rk.y1 - Rk.y0 + 1) * nw, wS = g.w[S];
+        const float inv_nw = 1.0f / (float)nw;
         for (int i = lane; i < n; i += nthr) {
-            int r = i / nw, c = i - r * nw;
+            int r, c;
+            split_rc(i, nw, inv_nw, r, c);
             d[i] = cS_t[(size_t)(Rk.y0 + r) * wS + Rk.x0 + c];
         }
     }
@@ -516,8 +638,10 @@ __device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, co
         double *d = lds + g.lds_off[k - 1];
         const int nw = Rd.x1 - Rd.x0 + 1, n = (Rd.y1 - Rd.y0 + 1) * nw;
         const int hk = g.h[k], wk = g.w[k];
+        const float inv_nw = 1.0f / (float)nw;
         for (int i = lane; i < n; i += nthr) {
-            int r = i / nw, c = i - r * nw;
+            int r, c;
+            split_rc(i, nw, inv_nw, r, c);
             d[i] = up_at(s, Rd.y0 + r, Rd.x0 + c, hk, wk);
         }
         __syncthreads();
@@ -561,12 +685,12 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     const double inf = __builtin_huge_val();
     double mn = inf, mx = -inf;
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
-        unsigned idx = list[c];
-        int t = idx / ntiles, tile = idx - t * ntiles;
+        const unsigned idx = (unsigned)uniform((int)list[c]);   // wave-uniform: the tile geometry stays in scalar registers
+        const int t = idx / ntiles, tile = idx - t * ntiles;
         const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
         chain_to_level1(g, tile, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
         int x = R0.x0 + lane;
-        int slot = slot_of[idx];
+        const int slot = uniform(slot_of[idx]);
         if (x <= R0.x1) {
             double v[CT_H];
             level0_rows<CT_H>(g, R0, R1, lds, x, 0, v);
@@ -584,31 +708,38 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     }
     mn = wave_min(mn); mx = wave_max(mx);
     if (lane == 0 && blockIdx.x < n) {
-        // contended same-address atomics cost ~12 ns each: skip those that cannot change the result
+        // striped, and skipped when they cannot change the result
         const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
-        if (kmn < *(volatile unsigned long long *)&st->min_key) atomicMin(&st->min_key, kmn);
-        if (kmx > *(volatile unsigned long long *)&st->max_key) atomicMax(&st->max_key, kmx);
+        const int sp = blockIdx.x & (NSTRIPE - 1);
+        if (kmn < *(volatile unsigned long long *)&st->min_keys[sp]) atomicMin(&st->min_keys[sp], kmn);
+        if (kmx > *(volatile unsigned long long *)&st->max_keys[sp]) atomicMax(&st->max_keys[sp], kmx);
     }
 }
 
 // transforms.py:184-189: min, max, top = max - (max - min) * threshold
-__global__ void k_finish_minmax(CollapseState *st, double threshold)
+__global__ __launch_bounds__(NSTRIPE) void k_finish_minmax(CollapseState *st, double threshold)
 {
-    double mn = f64_unkey(st->min_key), mx = f64_unkey(st->max_key);
+    const unsigned long long kmn = fold_min_keys(st->min_keys, st->min_key), kmx = fold_max_keys(st->max_keys, st->max_key);
+    if (threadIdx.x != 0) return;
+    double mn = f64_unkey(kmn), mx = f64_unkey(kmx);
     st->min_val = mn; st->max_val = mx;
     st->top = mx - (mx - mn) * threshold;
 }
 
 // frame-sharded calibration: the exact extrema of this rank's frames leave as {-min, max} (one all-reduce(MAX)
 // serves both) and the global pair comes back the same way
-__global__ void k_export_minmax(const CollapseState *st, double *negmin_max)
+__global__ __launch_bounds__(NSTRIPE) void k_export_minmax(const CollapseState *st, double *negmin_max)
 {
     const double inf = __builtin_huge_val();
-    negmin_max[0] = (st->min_key == ~0ull) ? -inf : -f64_unkey(st->min_key);
-    negmin_max[1] = (st->max_key == 0ull) ? -inf : f64_unkey(st->max_key);
+    const unsigned long long kmn = fold_min_keys(st->min_keys, st->min_key), kmx = fold_max_keys(st->max_keys, st->max_key);
+    if (threadIdx.x != 0) return;
+    negmin_max[0] = (kmn == ~0ull) ? -inf : -f64_unkey(kmn);
+    negmin_max[1] = (kmx == 0ull) ? -inf : f64_unkey(kmx);
 }
-__global__ void k_import_minmax(CollapseState *st, const double *negmin_max)
+__global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, const double *negmin_max)
 {
+    st->min_keys[threadIdx.x] = ~0ull; st->max_keys[threadIdx.x] = 0ull;   // the global pair replaces this rank's stripes
+    if (threadIdx.x != 0) return;
     st->min_key = f64_key(-negmin_max[0]);
     st->max_key = f64_key(negmin_max[1]);
 }
@@ -617,7 +748,8 @@ __global__ void k_import_minmax(CollapseState *st, const double *negmin_max)
 // Pruned pairs add `min`; kept pairs read their values back from `store`.  A 256-thread workgroup owns a
 // tile (wave w: rows 4w..4w+3 of every column) and walks the ordered list of kept frames in batches of
 // MS_B whose loads are issued one batch ahead, so a tile with hundreds of kept frames is not a chain of
-// exposed memory latencies.
+// exposed memory latencies.  (Measured alternatives: quarter tiles with one row per lane and 32-frame batches
+// shorten the chain of the few heavy tiles but quadruple the fixed cost of the ~2000 light ones: 105 us vs 75 us.)
 constexpr int MAX_T = 4096;
 constexpr int MS_B = 8;               // kept frames per batch
 constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
@@ -629,25 +761,32 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
     __shared__ short s_kept_t[MAX_T + MS_B];
-    __shared__ int s_nkept;
-    const int tid = threadIdx.x, lane = tid & 63, j0 = (tid >> 6) * MS_R;
+    __shared__ int s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j0 = wave * MS_R;
     const int tile = blockIdx.x;
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
-    const double min_val = f64_unkey(st->min_key), max_val = f64_unkey(st->max_key);
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;
     if (tile == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
-    // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks)
-    for (int t = t_first + tid; t < t_end; t += 256) s_slot[t] = slot_of[(size_t)t * ntiles + tile];
-    __syncthreads();
-    if (tid == 0) {  // compact, ordered list of the frames that are not pruned
-        int n = 0;
-        for (int t = t_first; t < t_end; ++t)
-            if (s_slot[t] != SLOT_PRUNED) s_kept_t[n++] = (short)t;
-        s_nkept = n;
+    // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks).
+    // Ordered compaction of the frames that are not pruned: ballot + prefix popcount, 256 frames per round.
+    int nkept = 0;
+    for (int c0 = t_first; c0 < t_end; c0 += 256) {
+        const int t = c0 + tid;
+        const int slot = (t < t_end) ? slot_of[(size_t)t * ntiles + tile] : SLOT_PRUNED;
+        if (t < t_end) s_slot[t] = slot;
+        const bool kept = slot != SLOT_PRUNED;
+        const unsigned long long m = __ballot(kept);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = nkept, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
+        if (kept) s_kept_t[off + __popcll(m & ((1ull << lane) - 1ull))] = (short)t;
+        nkept += tot;
+        __syncthreads();
     }
-    __syncthreads();
-    const int nkept = s_nkept;
     const int x = R0.x0 + lane;
     const int rows = R0.y1 - R0.y0 + 1;
     const bool active = x <= R0.x1;
@@ -790,19 +929,28 @@ __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t 
     }
 }
 
+// `bits` receives the thresholded image bit-packed (bit p & 63 of word p >> 6 = pixel p, row-major): 1/8 of a
+// byte per pixel, so the host contour stage gets the whole image in ONE small device-to-host copy.
 __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, const CollapseState *st,
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
-                                                    unsigned int *row_any, int W)
+                                                    unsigned long long *bits)
 {
     const double mn = f64_unkey(st->heat_min_key), mx = f64_unkey(st->heat_max_key);
     const double range = mx - mn;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
-        double nrm = (heat[i] - mn) / range;          // base.py:563 (NaN when the heatmap is flat)
-        uint8_t u = f64_to_u8_trunc(nrm * 255);       // transforms.py:26-29
-        uint8_t b = (u > threshold) ? 255 : 0;        // cv2.threshold THRESH_BINARY, base.py:566
-        if (avg_u8) avg_u8[i] = u;
-        binary[i] = b;
-        if (b && row_any) row_any[i / W] = 1u;
+    const int lane = threadIdx.x & 63;
+    // `base` is the first pixel of this wave's 64-pixel group: the same for all lanes, so the ballot is complete
+    for (size_t base = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u); base < npix; base += (size_t)gridDim.x * 256) {
+        const size_t i = base + lane;
+        uint8_t b = 0;
+        if (i < npix) {
+            double nrm = (heat[i] - mn) / range;          // base.py:563 (NaN when the heatmap is flat)
+            uint8_t u = f64_to_u8_trunc(nrm * 255);       // transforms.py:26-29
+            b = (u > threshold) ? 255 : 0;                // cv2.threshold THRESH_BINARY, base.py:566
+            if (avg_u8) avg_u8[i] = u;
+            if (binary) binary[i] = b;
+        }
+        const unsigned long long m = __ballot(b != 0);
+        if (lane == 0 && bits) bits[base >> 6] = m;
     }
 }
 

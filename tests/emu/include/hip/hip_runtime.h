@@ -109,6 +109,19 @@ template <typename T> inline T __shfl(T v, int src_lane, int width = 64) {
     __syncthreads();
     return r;
 }
+inline unsigned long long __ballot(int pred) {
+    unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    double *buf = hipemu::shfl_buf();
+    buf[tid] = pred ? 1.0 : 0.0;
+    __syncthreads();
+    unsigned lane = tid % 64, nthreads = blockDim.x * blockDim.y * blockDim.z;
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64; ++l)
+        if (tid - lane + l < nthreads && buf[tid - lane + l] != 0.0) m |= 1ull << l;
+    __syncthreads();
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 template <typename T> inline T __shfl_up(T v, unsigned delta, int width = 64) {
     unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     unsigned lane = tid % 64;

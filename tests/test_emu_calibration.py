@@ -98,10 +98,13 @@ def test_emu_ragged_shapes_and_degenerate_levels(emu, oracle):
 def test_emu_contour_stage_matches_oracle(emu, oracle):
     import scipy.ndimage as ndi
     rng = np.random.default_rng(9)
-    for k in range(12):
-        heat = ndi.gaussian_filter(rng.standard_normal((37, 61)), 2.5)
+    shapes = [(37, 61), (37, 61), (37, 61), (20, 64), (9, 128), (33, 130), (40, 7), (5, 200), (64, 65), (3, 63), (1, 70), (31, 1)]
+    for k in range(12):   # widths around the 64-pixel words of the bit-packed binary image, rows straddling words
+        heat = ndi.gaussian_filter(rng.standard_normal(shapes[k]), 2.5 if min(shapes[k]) > 8 else 0.8)
         if k % 3 == 0:
             heat[:, 0] = heat.max()      # blobs touching the frame
+        if k % 4 == 1:
+            heat[-1, :] = heat.max(); heat[:, -1] = heat.max()
         roi, u8, binary = emu.heatmap_to_roi(heat, threshold=150)
         ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
         assert np.array_equal(u8, ref_u8)
