@@ -201,7 +201,7 @@ extern "C" int rm_debug_counters(rm_ctx *ctx, long long *out, void *stream)
     if (!ctx || !out) return fail(RM_E_BADARG, "rm_debug_counters: bad argument");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
     out[0] = ctx->dbg_pairs; out[1] = ctx->h_state->n_list; out[2] = ctx->h_state->n_slots; out[3] = ctx->dbg_cap;
     return RM_OK;
 }
@@ -504,7 +504,7 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
         if (!R.empty()) {
             HIP_TRY(hipMemcpyAsync(dR, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(dC, C.data(), sizeof(double) * C.size(), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));  // R, C are stack-lifetime vectors
+            HIP_TRY(stream_wait(s));  // R, C are stack-lifetime vectors
         }
         ctx->op_T = T; ctx->op_fps = fps; ctx->op_fmin = fmin; ctx->op_fmax = fmax;
     }
@@ -809,7 +809,7 @@ static int make_geom(const SmallLevels &sl, ChainGeom &g)
 
 static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
                                uint8_t *binary, void *stream, bool have_minmax);
-__global__ void k_heat_state_init(CollapseState *st);
+__global__ __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st);
 
 // nothing is filtered (skip >= levels - 1): the band-passed pyramid, raw and the heatmap are all zeros.  The
 // heatmap extrema (0, 0) go into the state like after a real calibration, so rm_locate normalises 0/0 -> NaN
@@ -817,11 +817,11 @@ __global__ void k_heat_state_init(CollapseState *st);
 static int zero_result(rm_ctx *ctx, size_t npix, double *heat, double *minmax_host, hipStream_t s)
 {
     HIP_TRY(hipMemsetAsync(heat, 0, sizeof(double) * npix, s));
-    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, ctx->d_state);
+    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_heat_minmax, dim3(1), dim3(256), 0, s, (const double *)heat, (size_t)1, ctx->d_state);
     LAUNCH_CHECK();
-    if (minmax_host) { minmax_host[0] = 0.0; minmax_host[1] = 0.0; HIP_TRY(hipStreamSynchronize(s)); }
+    if (minmax_host) { minmax_host[0] = 0.0; minmax_host[1] = 0.0; HIP_TRY(stream_wait(s)); }
     return RM_OK;
 }
 
@@ -894,19 +894,26 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
 }
 
 // heat_sum[H*W] = sum over t in [t0, t1) of (raw >= top ? min : raw), with min/max as they stand in the state
-static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_sum, hipStream_t s)
+// avg_T > 0: the sum covers the whole buffer, write heat = sum / avg_T and leave the heatmap's min / max in the state
+static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_sum, hipStream_t s, int avg_T = 0)
 {
     CollapseState *st = ctx->d_state;
     const size_t npix = (size_t)cp.H * cp.W;
     if (cp.S == 0) {
         hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(NSTRIPE), 0, s, st, thr);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_masked_sum_plain, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, cp.cS, cp.T, npix, st, heat_sum);
+        double *sum = heat_sum;
+        if (avg_T > 0) RM_TRY(ws(ctx, "heat_sum", npix, &sum));
+        hipLaunchKernelGGL(k_masked_sum_plain, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, cp.cS, cp.T, npix, st, sum);
         LAUNCH_CHECK();
+        if (avg_T > 0) {
+            hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, sum, npix, avg_T, heat_sum, st);
+            LAUNCH_CHECK();
+        }
         return RM_OK;
     }
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
-                       cp.store, st, thr, heat_sum);
+                       cp.store, st, thr, heat_sum, avg_T);
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(ctx->h_slots_seen, &st->n_slots, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     ctx->slots_seen_pairs = cp.npairs;
@@ -928,19 +935,15 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     if (ctx->prof_on) ctx->prof_calls++;
     if (sl.all_zero) return zero_result(ctx, npix, heat, minmax_host, s);
     CollapseState *st = ctx->d_state;
-    double *heat_sum = nullptr;
-    RM_TRY(ws(ctx, "heat_sum", npix, &heat_sum));
     PhaseTimer *pt_collapse = new PhaseTimer(ctx, 2, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_collapse};
     CollapsePlan cp;
     RM_TRY(collapse_eval(ctx, sl, T, 0, T, thr, flags, cp, s));
-    RM_TRY(collapse_sum(ctx, cp, thr, heat_sum, s));
-    hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heat, st);
-    LAUNCH_CHECK();
+    RM_TRY(collapse_sum(ctx, cp, thr, heat, s, T));   // time average and heatmap extrema ride the sum kernel
     delete pt_collapse; pt_collapse = nullptr;
     if (minmax_host) {
         HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_wait(s));
         minmax_host[0] = ctx->h_state->min_val;
         minmax_host[1] = ctx->h_state->max_val;
     }
@@ -1025,7 +1028,7 @@ extern "C" int rm_shard_finish(rm_ctx *ctx, const double *heat_sum, int T, int H
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
-    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, ctx->d_state);
+    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heatmap, ctx->d_state);
     LAUNCH_CHECK();
@@ -1048,7 +1051,7 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
         if (masked) HIP_TRY(hipMemsetAsync(masked, 0, sizeof(double) * n, s));
         if (raw) HIP_TRY(hipMemsetAsync(raw, 0, sizeof(double) * n, s));
         if (minmax_host) { minmax_host[0] = minmax_host[1] = 0.0; }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_wait(s));
         return RM_OK;
     }
     double *raw_buf = raw;
@@ -1075,7 +1078,7 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
         LAUNCH_CHECK();
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
     if (minmax_host) { minmax_host[0] = ctx->h_state->min_val; minmax_host[1] = ctx->h_state->max_val; }
     return RM_OK;
 }
@@ -1083,7 +1086,11 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
 // ------------------------------------------------------------------------------------------
 // heatmap -> ROI  (base.py:563-575)
 // ------------------------------------------------------------------------------------------
-__global__ void k_heat_state_init(CollapseState *st) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
+__global__ __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st)
+{
+    st->heat_min_keys[threadIdx.x] = ~0ull; st->heat_max_keys[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
+}
 
 static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
                                uint8_t *binary, void *stream, bool have_minmax)
@@ -1106,7 +1113,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
     if (!have_minmax) {  // rm_calibrate has just left the heatmap's min / max in the state
-        hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(1), 0, s, st);
+        hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
         LAUNCH_CHECK();
@@ -1115,7 +1122,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(ctx->h_bin, bits, nwords * 8, hipMemcpyDeviceToHost, s));
     delete pt_roi; pt_roi = nullptr;
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
     RoiResult r;
     {
         auto t0 = std::chrono::steady_clock::now();
@@ -1165,7 +1172,7 @@ extern "C" int rm_roi_mean(rm_ctx *ctx, const void *frame, int dtype, int H, int
     }
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(out, d, sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
     return RM_OK;
 }
 

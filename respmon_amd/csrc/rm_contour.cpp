@@ -48,6 +48,7 @@ struct Tracer {
                 continue;
             }
             dirty[y] = 1;
+            if ((int)clr_x0.size() == H) { clr_x0[y] = 0; clr_x1[y] = W - 1; }
             const uint8_t *s = bin + (size_t)y * W;
             int x = 0;
             // foreground = non-zero byte, 8 pixels per step: bit 7 of ((b & 0x7f) + 0x7f) | b is set iff b != 0
@@ -65,6 +66,8 @@ struct Tracer {
     }
 
     std::vector<uint32_t> own_row_any;
+    std::vector<int> row_x0, row_x1;   // first / last foreground column of each dirty row (image coordinates)
+    std::vector<int> clr_x0, clr_x1;   // column range of a dirty row that is not background
 
     // 64 pixels starting at bit position `pos` of the packed image (bits past `end` read as background)
     static inline uint64_t get64(const uint64_t *bits, size_t pos, size_t end)
@@ -95,30 +98,48 @@ struct Tracer {
             buf.assign((size_t)step * (H + 2), BG);
             dirty.assign(H, 0);
         }
+        if ((int)clr_x0.size() != H) { clr_x0.assign(H, 0); clr_x1.assign(H, W - 1); }
         own_row_any.assign(H, 0);
-        const size_t end = (size_t)H * W;
+        row_x0.assign(H, 0); row_x1.assign(H, -1);
         for (int y = 0; y < H; ++y) {
             signed char *d = buf.data() + (size_t)(y + 1) * step + 1;
             const size_t r0 = (size_t)y * W;
-            uint64_t any = 0;
-            for (int x = 0; x < W && !any; x += 64) any |= get64(bits, r0 + x, r0 + W);
-            if (!any) {
-                if (dirty[y]) { std::memset(d, BG, (size_t)W); dirty[y] = 0; }  // only rows the last image touched
-                continue;
+            // the part of the working row the previous image (and its border marks) touched is cleared; only the
+            // 64-pixel groups that hold foreground are written afterwards
+            if (dirty[y]) { std::memset(d + clr_x0[y], BG, (size_t)(clr_x1[y] - clr_x0[y] + 1)); dirty[y] = 0; }
+            // most rows are empty: test the row's words in place (edge words masked) before any unpacking
+            const size_t b0 = r0, b1 = r0 + W - 1, w0 = b0 >> 6, w1 = b1 >> 6;
+            const uint64_t m0 = ~0ull << (b0 & 63), m1 = ~0ull >> (63 - (b1 & 63));
+            size_t wf = w1 + 1, wl = w0;   // first / last word of the row that holds foreground
+            if (w0 == w1) { if (bits[w0] & m0 & m1) { wf = w0; wl = w0; } }
+            else {
+                if (bits[w0] & m0) { wf = w0; wl = w0; }
+                for (size_t wq = w0 + 1; wq < w1; ++wq)
+                    if (bits[wq]) { if (wf > w1) wf = wq; wl = wq; }
+                if (bits[w1] & m1) { if (wf > w1) wf = w1; wl = w1; }
             }
-            dirty[y] = 1; own_row_any[y] = 1;
-            for (int x = 0; x < W; x += 64) {
+            if (wf > w1) continue;
+            // 64-pixel groups of this row (group k = columns 64k..64k+63) that can hold those words
+            const int xa = (int)(((wf << 6) > b0 ? (wf << 6) - b0 : 0) / 64) * 64;
+            const size_t last_bit = ((wl << 6) + 63 < b1 ? (wl << 6) + 63 : b1) - b0;
+            const int xb = (int)(last_bit / 64) * 64;
+            int x0 = -1, x1 = -1;
+            for (int x = xa; x <= xb; x += 64) {
                 const uint64_t v = get64(bits, r0 + x, r0 + W);
+                if (!v) continue;
+                if (x0 < 0) x0 = x + __builtin_ctzll(v);
+                x1 = x + 63 - __builtin_clzll(v);
                 const int n = (W - x < 64) ? W - x : 64;
-                if (!v) { std::memset(d + x, BG, (size_t)n); continue; }
                 if (n == 64) {
                     for (int k = 0; k < 8; ++k) { const uint64_t e = lut[(v >> (8 * k)) & 0xff]; std::memcpy(d + x + 8 * k, &e, 8); }
                 } else {
                     for (int k = 0; k < n; ++k) d[x + k] = (signed char)((v >> k) & 1);
                 }
             }
+            if (x0 < 0) continue;
+            dirty[y] = 1; own_row_any[y] = 1; row_x0[y] = x0; row_x1[y] = x1;
+            clr_x0[y] = x0 & ~63; clr_x1[y] = ((x1 | 63) < W - 1) ? (x1 | 63) : W - 1;   // whole groups were written
         }
-        (void)end;
         const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
         const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
         for (int i = 0; i < 8; ++i) nbr[i] = nbr[i + 8] = dy[i] * step + dx[i];
@@ -168,7 +189,7 @@ struct Tracer {
 
 static thread_local Tracer g_tracer;   // working copy reused across calls (one context drives one thread at a time)
 
-static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out);
+static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out, bool have_ranges);
 
 int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out)
 {
@@ -176,7 +197,7 @@ int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *r
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare(bin, H, W, row_any);
-    return scan_prepared(g_tracer, H, row_any, out);
+    return scan_prepared(g_tracer, H, row_any, out, false);
 }
 
 int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult *out)
@@ -185,19 +206,22 @@ int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult 
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare_bits(bits, H, W);
-    return scan_prepared(g_tracer, H, g_tracer.own_row_any.data(), out);
+    return scan_prepared(g_tracer, H, g_tracer.own_row_any.data(), out, true);
 }
 
-static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out)
+// `have_ranges`: pixels left of row_x0 / right of row_x1 are background without marks (borders only visit
+// foreground pixels), so the raster scan of a row may start at its first and stop after its last foreground pixel
+static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out, bool have_ranges)
 {
-    const int step = tr.step;
+    const int full_step = tr.step;
     double best = -1.0;
     for (int y = 0; y < H; ++y) {
         if (row_any && !row_any[y]) continue;
-        signed char *row = tr.buf.data() + (size_t)(y + 1) * step;
+        signed char *row = tr.buf.data() + (size_t)(y + 1) * full_step;
         int prev = BG;
         int last_border_x = 0;  // column 0 is the zero frame: "outside"
-        int x = 1;
+        int x = have_ranges ? tr.row_x0[y] + 1 : 1;                       // padded coordinates: pixel c sits at c + 1
+        const int step = have_ranges ? tr.row_x1[y] + 3 : full_step;      // one background pixel past the last foreground
         while (x < step) {
             // skip to the next transition, 8 pixels at a time
             {

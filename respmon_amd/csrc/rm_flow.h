@@ -162,7 +162,7 @@ inline int flow_good_features(FlowWorkspace &ws, const uint8_t *img, int h, int 
     FLOW_HIP(hipGetLastError());
     unsigned host_scal[2];
     FLOW_HIP(hipMemcpyAsync(host_scal, scal, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    FLOW_HIP(hipStreamSynchronize(s));
+    FLOW_HIP(stream_wait(s));
     unsigned key = host_scal[0];
     key = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
     float max_val_f;
@@ -172,7 +172,7 @@ inline int flow_good_features(FlowWorkspace &ws, const uint8_t *img, int h, int 
     hipLaunchKernelGGL(k_gftt_candidates, dim3(grid), dim3(256), 0, s, eig, h, w, thr, cval, cidx, (int *)(scal + 1), (int)n);
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(host_scal, scal, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    FLOW_HIP(hipStreamSynchronize(s));
+    FLOW_HIP(stream_wait(s));
     int nc = (int)host_scal[1];
     if (nc > (int)n) nc = (int)n;
     std::vector<float> hv(nc);
@@ -180,7 +180,7 @@ inline int flow_good_features(FlowWorkspace &ws, const uint8_t *img, int h, int 
     if (nc) {
         FLOW_HIP(hipMemcpyAsync(hv.data(), cval, sizeof(float) * nc, hipMemcpyDeviceToHost, s));
         FLOW_HIP(hipMemcpyAsync(hi.data(), cidx, sizeof(int) * nc, hipMemcpyDeviceToHost, s));
-        FLOW_HIP(hipStreamSynchronize(s));
+        FLOW_HIP(stream_wait(s));
     }
     // sort by value descending, ties by raster index descending (OpenCV >= 3.4 greaterThanPtr), then the
     // greedy minimum-distance acceptance -- sequential by definition
@@ -429,7 +429,7 @@ inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *ne
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(pts_out, d_out, sizeof(float) * 2 * npts, hipMemcpyDeviceToHost, s));
     FLOW_HIP(hipMemcpyAsync(status, d_st, npts, hipMemcpyDeviceToHost, s));
-    FLOW_HIP(hipStreamSynchronize(s));
+    FLOW_HIP(stream_wait(s));
     return max_level;
 }
 
@@ -466,7 +466,7 @@ inline int flow_mean(FlowWorkspace &ws, const float *old_pts, const float *new_p
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(mean_xy, d_m, sizeof(float) * 2, hipMemcpyDeviceToHost, s));
     FLOW_HIP(hipMemcpyAsync(n_good, d_c, sizeof(int), hipMemcpyDeviceToHost, s));
-    FLOW_HIP(hipStreamSynchronize(s));
+    FLOW_HIP(stream_wait(s));
     return RM_OK;
 }
 
@@ -579,7 +579,7 @@ inline int flow_pca(FlowWorkspace &ws, const float *motion, int n, double *out, 
     hipLaunchKernelGGL(k_pca_reduce, dim3(1), dim3(64), 0, s, d_m, n, d_o);
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(out, d_o, sizeof(double), hipMemcpyDeviceToHost, s));
-    FLOW_HIP(hipStreamSynchronize(s));
+    FLOW_HIP(stream_wait(s));
     return RM_OK;
 }
 

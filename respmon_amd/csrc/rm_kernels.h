@@ -15,7 +15,23 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <chrono>
+
 namespace rm {
+
+// Host wait for a result on `s`.  hipStreamSynchronize sleeps on an interrupt (tens of microseconds to wake up);
+// the calls that return host results are latency-critical (one per locate(), one per measured frame), so poll
+// first and only fall back to the blocking wait when the stream is still busy after a few milliseconds.
+inline hipError_t stream_wait(hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) return hipStreamSynchronize(s);
+    }
+}
+
 
 // ----------------------------------------------------------------------------------------
 // small helpers
@@ -432,6 +448,7 @@ struct CollapseState {
     unsigned long long min_key, max_key;  // exact raw.min() / raw.max()
     unsigned long long lb_max_keys[NSTRIPE], ub_min_keys[NSTRIPE], ub_max_keys[NSTRIPE], lb_min_keys[NSTRIPE];
     unsigned long long min_keys[NSTRIPE], max_keys[NSTRIPE];  // stripes of the six words above
+    unsigned long long heat_min_keys[NSTRIPE], heat_max_keys[NSTRIPE];  // stripes of heat_min_key / heat_max_key
     unsigned int n_list;            // (frame, tile) pairs that must be evaluated
     unsigned int n_slots;           // pairs whose values are kept for the masked time sum
     double margin;                  // absolute safety margin of the bounds
@@ -445,6 +462,7 @@ __global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st)
     const int i = threadIdx.x;
     st->lb_max_keys[i] = 0ull; st->ub_min_keys[i] = ~0ull; st->ub_max_keys[i] = 0ull; st->lb_min_keys[i] = ~0ull;
     st->min_keys[i] = ~0ull; st->max_keys[i] = 0ull;
+    st->heat_min_keys[i] = ~0ull; st->heat_max_keys[i] = 0ull;
     if (i != 0) return;
     st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->ub_max_key = 0ull; st->lb_min_key = ~0ull;
     st->min_key = ~0ull; st->max_key = 0ull; st->n_list = 0; st->n_slots = 0;
@@ -756,7 +774,7 @@ constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 
 __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
                                                           const int *slot_of, const double *store,
-                                                          CollapseState *st, double threshold, double *heat_sum)
+                                                          CollapseState *st, double threshold, double *heat_sum, int avg_T)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
@@ -844,10 +862,29 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
 #pragma unroll
         for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + min_val;
     }
-    if (active)
+    // avg_T > 0 (the whole buffer is summed here): write np.average = sum / T (base.py:562) and reduce the
+    // heatmap's min / max for the normalisation (base.py:563) on the way out
+    const double cnt = (double)avg_T;
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+    if (active) {
 #pragma unroll
         for (int j = 0; j < MS_R; ++j)
-            if (j0 + j < rows) heat_sum[(size_t)(R0.y0 + j0 + j) * g.w[0] + x] = acc[j];
+            if (j0 + j < rows) {
+                const double v = avg_T > 0 ? acc[j] / cnt : acc[j];
+                heat_sum[(size_t)(R0.y0 + j0 + j) * g.w[0] + x] = v;
+                hmn = (v < hmn) ? v : hmn;
+                hmx = (v > hmx) ? v : hmx;
+            }
+    }
+    if (avg_T > 0) {
+        block_minmax(hmn, hmx);
+        if (tid == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp = blockIdx.x & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -935,7 +972,8 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
                                                     unsigned long long *bits)
 {
-    const double mn = f64_unkey(st->heat_min_key), mx = f64_unkey(st->heat_max_key);
+    const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
+    const double mx = f64_unkey(fold_max_keys(st->heat_max_keys, st->heat_max_key));
     const double range = mx - mn;
     const int lane = threadIdx.x & 63;
     // `base` is the first pixel of this wave's 64-pixel group: the same for all lanes, so the ballot is complete

@@ -209,6 +209,8 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStrea
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipErrorNotReady 600
+inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2

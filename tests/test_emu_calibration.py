@@ -111,6 +111,24 @@ def test_emu_contour_stage_matches_oracle(emu, oracle):
         assert roi == oracle.roi_from_heatmap_u8(ref_u8, 150)
 
 
+def test_emu_contour_stage_reuses_its_working_copy(emu, oracle):
+    """Same geometry, different images back to back: the host tracer keeps its working copy between calls and
+    clears only what the previous image (and its border marks) touched."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(21)
+    for k in range(10):
+        heat = ndi.gaussian_filter(rng.standard_normal((45, 203)), 1.5 + 0.4 * (k % 4))
+        if k == 4:
+            heat[:] = 0.0                       # flat heatmap in between: NaN -> no contour
+        if k == 7:
+            heat[10:30, 60:190] = heat.max() + 1.0   # one big rectangle
+        roi, u8, binary = emu.heatmap_to_roi(heat, threshold=120 + 10 * (k % 3))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
+        assert np.array_equal(u8, ref_u8)
+        assert roi == oracle.roi_from_heatmap_u8(ref_u8, 120 + 10 * (k % 3)), k
+
+
 def test_emu_fused_down_chain_equals_per_level(emu):
     """The marching fused pyrDown chain (rm_down_chain.h) must equal the per-level kernel bit for bit,
     for every frame dtype, vector and scalar load paths, and many-strip / many-segment decompositions."""
