@@ -35,6 +35,12 @@ def parse():
                     "f64 is the reference's calibration_buffer dtype (base.py:119)")
     ap.add_argument("--levels", type=int, default=9)
     ap.add_argument("--skip", type=int, default=4)
+    ap.add_argument("--prewarm-steps", type=int, default=600, help="untimed steps run BEFORE the W warmup steps (a fixed count so that "
+                    "all ranks issue the same collectives): a fresh box starts in a low power state and its clocks take a few hundred ms "
+                    "of load to settle -- measured 1.18 -> 1.14 ms/step (reported as pre_warm_steps; 0 disables)")
+    ap.add_argument("--mode", default="streams", choices=["streams", "sharded"], help="N>1 only.  streams (default, BASELINE config 4): one "
+                    "independent [T,H,W] stream per GPU + one heatmap all-reduce, weak scaling.  sharded: ONE [T,H,W] buffer split by frame "
+                    "index over the GPUs (respmon_amd.dist.locate_sharded), strong scaling")
     ap.add_argument("--no-prune", action="store_true")
     ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T frames if host memory allows, else 64)")
@@ -82,14 +88,19 @@ def main():
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
 
     T, H, W = a.frames, a.height, a.width
-    vid_u8 = synth.synth_breathing(T, H, W, seed=1234 + rank)  # config 4: independent stream per GPU
+    sharded = world > 1 and a.mode == "sharded"
+    # config 4: an independent stream per GPU; sharded mode: the same buffer everywhere, each rank keeps its frame shard
+    vid_u8 = synth.synth_breathing(T, H, W, seed=1234 + (0 if sharded else rank))
+    if sharded:
+        t_lo, t_hi = rdist.shard_frames(T, rank, world)
+        vid_u8 = vid_u8[t_lo:t_hi]
     tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[a.in_dtype]
     dev_u8 = torch.from_numpy(vid_u8).cuda()
     if a.in_dtype == "u8":
         buf = dev_u8
     else:
-        buf = torch.empty((T, H, W), dtype=tdt, device="cuda")
-        for t0 in range(0, T, 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype
+        buf = torch.empty(tuple(dev_u8.shape), dtype=tdt, device="cuda")
+        for t0 in range(0, buf.shape[0], 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype
             buf[t0:t0 + 16] = (dev_u8[t0:t0 + 16].to(torch.float64) * (1.0 / 255)).to(tdt)
         del dev_u8
     torch.cuda.synchronize()
@@ -105,6 +116,8 @@ def main():
     def step():
         if world == 1:   # exactly RespiratoryMonitor.locate: one rm_locate call
             return backend.locate(buf, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
+        if sharded:
+            return rdist.locate_sharded(buf, T, 10, threshold=20, **kw)
         return rdist.locate_streams(buf, 10, threshold=20, **kw)
 
     def barrier():
@@ -113,6 +126,9 @@ def main():
         torch.cuda.synchronize()
 
     roi = None
+    pre_steps = max(0, a.prewarm_steps)
+    for _ in range(pre_steps):   # clock ramp of a fresh box; not part of W or K
+        roi = step()
     for _ in range(a.warmup):
         roi = step()
     barrier()
@@ -158,8 +174,9 @@ def main():
     dbg = (ctypes.c_longlong * 4)()
     _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
     if rank == 0:
-        frames_total = world * T * a.steps
-        b_alg = T * H * W * DT_BYTES[a.in_dtype] + H * W * 8  # one read of the buffer + the heatmap
+        frames_total = (1 if sharded else world) * T * a.steps
+        # one read of the (rank-local) frame buffer + the heatmap
+        b_alg = int(buf.shape[0]) * H * W * DT_BYTES[a.in_dtype] + H * W * 8
         k_ms = k_ms_total / max(k_calls, 1)
         achieved = b_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         traffic = None
@@ -167,18 +184,19 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "%s_%dx%dx%d" % (a.in_dtype, T, H, W)
+                key = "%s_%dx%dx%d" % (a.in_dtype, int(buf.shape[0]), H, W)
                 traffic = tj.get(key, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
             "metric": "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s",
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / a.steps * 1e3, "pre_warm_steps": pre_steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Eulerian calibration + ROI (locate) on a %dx%dx%d frame buffer, %d-level Laplacian pyramid, "
-                                   "skip %d, temporal FFT band-pass 0.1-1.0 Hz @10 fps; one independent stream per GPU + one RCCL "
-                                   "heatmap all-reduce" % (T, H, W, a.levels, a.skip),
+                                   "skip %d, temporal FFT band-pass 0.1-1.0 Hz @10 fps; %s" % (T, H, W, a.levels, a.skip,
+                                   "ONE buffer sharded by frame index over the GPUs: all-gather of the small pyramid, min/max all-reduce, "
+                                   "one RCCL heatmap all-reduce" if sharded else "one independent stream per GPU + one RCCL heatmap all-reduce"),
                        "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "prune": not a.no_prune},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

@@ -23,7 +23,7 @@ def all_reduce_heatmap(heat, group=None):
     """In-place sum of the [H,W] float64 heatmap over ranks (the single data collective of Mode B)."""
     dist = _dist()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(heat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(heat, dist.ReduceOp.SUM, group)
     return heat
 
 
