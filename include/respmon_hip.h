@@ -106,6 +106,20 @@ int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data_dev, int T, 
 int rm_temporal_operator(int T, double fps, double freq_min, double freq_max, double *M_host,
                          int *bound_low, int *bound_high);
 
+/* ---- transforms.py:72-79 temporal_bandpass_filter, transforms.py:53-55 butter_bandpass_filter_fast:
+ *      out = scipy.signal.lfilter(b, a, data, axis=0) * scale on data[T, npix] float64 (transposed direct form II,
+ *      the operation order of scipy's C loop).  b_host / a_host: ncoef coefficients each (ncoef <= 16; the
+ *      reference's order-6 Butterworth band-pass has 13), designed on the host with scipy.signal.butter exactly
+ *      as transforms.py:38-44 does.  SURVEY 8f row f4. */
+int rm_lfilter(rm_ctx *ctx, const double *data_dev, int T, size_t npix, const double *b_host, const double *a_host,
+               int ncoef, double scale, double *out_dev, void *stream);
+
+/* ---- transforms.py:184-192 on a materialised array: minmax_host = {raw.min(), raw.max()} (may be NULL);
+ *      masked_dev (may be NULL) = raw with every value >= max - (max - min) * threshold replaced by min.
+ *      Lets eulerian_magnification_bandpass run with ANY temporal_filter_function (transforms.py:146). */
+int rm_threshold_mask(rm_ctx *ctx, const double *raw_dev, size_t n, double threshold, double *masked_dev,
+                      double *minmax_host, void *stream);
+
 /* ---- transforms.py:144-198 eulerian_magnification_bandpass (materialised outputs) ------ */
 /* masked_dev / raw_dev: [T,H,W] float64 (either may be NULL); minmax_host[2] = {min, max} of raw. */
 int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W,

@@ -10,7 +10,7 @@ arithmetic itself stays "parity unpinned" (see oracle/respmon_oracle.py header).
 
 Fixture ids follow SURVEY.md section 8c: G1 temporal FFT filter, G2 uint8<->float LUT,
 G3 eulerian_magnification_bandpass, G4 locate, G5 extract_motion (scripted LK), G6 run()
-frame accounting, G7 reduce_bounding_box / butter_lowpass_filter.
+frame accounting, G7 reduce_bounding_box / butter_lowpass_filter, G8 IIR temporal_bandpass_filter (row f4).
 """
 import hashlib
 import os
@@ -244,10 +244,36 @@ def g7(R):
                         rbb_out=np.array(res, dtype=np.int64), sig=sig, filt=filt)
 
 
+def g8(R):
+    """the IIR alternative temporal_bandpass_filter (transforms.py:72-79) -- authentic scipy --
+    and eulerian_magnification_bandpass(temporal_filter_function=temporal_bandpass_filter)."""
+    out = {}
+    cases = [(128, 10.0, 0.1, 1.0, 500.0), (64, 30.0, 0.833, 1.0, 50.0), (200, 10.0, 0.4, 2.0, 20.0)]
+    for i, (n, fps, fmin, fmax, amp) in enumerate(cases):
+        rng = np.random.Generator(np.random.PCG64(300 + i))
+        x = rng.standard_normal((n, 4, 6))
+        out["x%d" % i] = x
+        out["y%d" % i] = R.transforms.temporal_bandpass_filter(x.copy(), fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+        out["meta%d" % i] = np.array([n, fps, fmin, fmax, amp])
+    out["ncases"] = np.array(len(cases))
+    vid_u8 = synth.synth_breathing(48, 36, 44, seed=78, amplitude=0.25)
+    vid = R.transforms.uint8_to_float(vid_u8)
+    masked, raw = R.transforms.eulerian_magnification_bandpass(vid.copy(), 10.0, 0.1, 1.0, 500, pyramid_levels=5, skip_levels_at_top=2,
+                                                               temporal_filter_function=R.transforms.temporal_bandpass_filter)
+    out["e_vid_u8"] = vid_u8
+    out["e_raw"] = raw
+    out["e_avg"] = np.average(masked, axis=0)
+    out["e_meta"] = np.array([5, 2, 10.0])
+    np.savez_compressed(os.path.join(OUT, "g8_iir.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load()
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+        if only and fn.__name__ not in only:
+            continue
         fn(R)
         print("wrote", fn.__name__)
 

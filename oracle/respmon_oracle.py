@@ -305,6 +305,16 @@ def temporal_bandpass_filter_fft(data, fps, freq_min=0.833, freq_max=1, axis=0, 
     return out
 
 
+def temporal_bandpass_filter(data, fps, freq_min=0.833, freq_max=1, axis=0, amplification_factor=50):
+    """transforms.py:72-79 (with 38-44, 53-55): order-6 Butterworth band-pass, lfilter along `axis`, *amplification."""
+    import scipy.signal
+    nyq = 0.5 * fps
+    b, a = scipy.signal.butter(6, [freq_min / nyq, freq_max / nyq], btype='band', output='ba')
+    result = scipy.signal.lfilter(b, a, np.asarray(data, dtype=np.float64), axis=axis)
+    result *= amplification_factor
+    return result
+
+
 def temporal_operator(n, fps, freq_min, freq_max):
     """The filter above as an explicit real n x n matrix (WITHOUT the amplification):
     out = M @ x along time.  Built by applying transforms.py:86-98 literally to the identity."""
@@ -316,14 +326,15 @@ def temporal_operator(n, fps, freq_min, freq_max):
 # transforms.py:144-198  eulerian_magnification_bandpass
 # --------------------------------------------------------------------------- #
 def eulerian_magnification_bandpass(vid_data, fps, freq_min, freq_max, amplification,
-                                    pyramid_levels=4, skip_levels_at_top=2, threshold=0.7):
+                                    pyramid_levels=4, skip_levels_at_top=2, threshold=0.7, temporal_filter_function=None):
+    temporal_filter_function = temporal_filter_function or temporal_bandpass_filter_fft        # :146
     vid_pyramid = create_laplacian_video_pyramid(vid_data, pyramid_levels)          # :148
     bandpassed = [np.zeros(l.shape) for l in vid_pyramid]                            # :150-152
     for i, vid in enumerate(vid_pyramid):                                            # :156
         if i < skip_levels_at_top or i >= len(vid_pyramid) - 1:                      # :157
             continue
-        bandpassed[i] += temporal_bandpass_filter_fft(vid, fps, freq_min=freq_min, freq_max=freq_max,
-                                                      amplification_factor=amplification)   # :162,169
+        bandpassed[i] += temporal_filter_function(vid, fps, freq_min=freq_min, freq_max=freq_max,
+                                                  amplification_factor=amplification)       # :162,169
     raw = collapse_laplacian_video_pyramid(bandpassed)                               # :182
     min_val = raw.min()                                                              # :185
     max_val = raw.max()                                                              # :187

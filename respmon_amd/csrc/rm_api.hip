@@ -546,6 +546,53 @@ extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, 
     return launch_temporal(ctx, data, T, npix, op, amp, out, s);
 }
 
+extern "C" int rm_lfilter(rm_ctx *ctx, const double *data, int T, size_t npix, const double *b_host, const double *a_host, int ncoef,
+                          double scale, double *out, void *stream)
+{
+    if (!ctx || !data || !out || !b_host || !a_host || T < 1 || ncoef < 1) return fail(RM_E_BADARG, "rm_lfilter: bad argument");
+    if (ncoef > IIR_MAX) return fail(RM_E_UNSUPPORTED, "rm_lfilter: %d coefficients > %d", ncoef, IIR_MAX);
+    if (a_host[0] == 0.0) return fail(RM_E_BADARG, "rm_lfilter: a[0] must not be zero");
+    if (npix == 0) return RM_OK;
+    if (data == out) return fail(RM_E_BADARG, "rm_lfilter: in-place filtering is not supported");
+    IirCoef c;
+    c.n = ncoef;
+    for (int i = 0; i < IIR_MAX; ++i) {  // scipy normalises both polynomials by a[0] first
+        c.b[i] = i < ncoef ? b_host[i] / a_host[0] : 0.0;
+        c.a[i] = i < ncoef ? a_host[i] / a_host[0] : 0.0;
+    }
+    hipLaunchKernelGGL(k_lfilter, dim3((unsigned)((npix + 63) / 64)), dim3(64), 0, (hipStream_t)stream, data, T, npix, c, scale, out);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+// transforms.py:184-192 on a materialised [n] array: min, max, top = max - (max - min) * threshold,
+// masked = raw with every value >= top replaced by min
+extern "C" int rm_threshold_mask(rm_ctx *ctx, const double *raw, size_t n, double threshold, double *masked, double *minmax_host,
+                                 void *stream)
+{
+    if (!ctx || !raw || n == 0) return fail(RM_E_BADARG, "rm_threshold_mask: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    CollapseState *st = ctx->d_state;
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, raw, n, st);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finish_minmax, dim3(1), dim3(NSTRIPE), 0, s, st, threshold);
+    LAUNCH_CHECK();
+    if (masked) {
+        hipLaunchKernelGGL(k_mask_plain, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, raw, n, st, masked);
+        LAUNCH_CHECK();
+    }
+    if (minmax_host) {
+        HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(stream_wait(s));
+        minmax_host[0] = ctx->h_state->min_val;
+        minmax_host[1] = ctx->h_state->max_val;
+    }
+    return RM_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // fused Gaussian chain (rm_down_chain.h)
 // ------------------------------------------------------------------------------------------

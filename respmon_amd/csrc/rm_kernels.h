@@ -256,6 +256,41 @@ __global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, si
 }
 
 // ----------------------------------------------------------------------------------------
+// transforms.py:72-79 temporal_bandpass_filter (the IIR alternative to the FFT filter, selectable through
+// eulerian_magnification_bandpass(temporal_filter_function=...)): scipy.signal.lfilter(b, a, data, axis=0) * amp.
+// One lane per pixel column, the recurrence runs sequentially in t in scipy's transposed direct form II
+//   y = z[0] + b[0] x ;  z[i] = z[i+1] + b[i+1] x - a[i+1] y ;  z[n-2] = b[n-1] x - a[n-1] y
+// (b, a already divided by a[0], as scipy does), so every value is the same sequence of float64 operations.
+// Coefficients are wave-uniform (constant memory through the kernel argument), loads are coalesced across pixels.
+// ----------------------------------------------------------------------------------------
+constexpr int IIR_MAX = 16;  // coefficients per polynomial (a band-pass of order 6 has 13)
+struct IirCoef { double b[IIR_MAX], a[IIR_MAX]; int n; };
+
+__global__ __launch_bounds__(64) void k_lfilter(const double *x, int T, size_t NP, IirCoef c, double scale, double *y)
+{
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= NP) return;
+    double z[IIR_MAX];
+#pragma unroll
+    for (int i = 0; i < IIR_MAX; ++i) z[i] = 0.0;
+    double nxt = x[p];
+    for (int t = 0; t < T; ++t) {
+        const double v = nxt;
+        if (t + 1 < T) nxt = x[(size_t)(t + 1) * NP + p];   // one sample ahead of the recurrence
+        const double out = z[0] + c.b[0] * v;
+#pragma unroll
+        for (int i = 0; i < IIR_MAX - 2; ++i)
+            if (i < c.n - 2) z[i] = (z[i + 1] + c.b[i + 1] * v) - c.a[i + 1] * out;
+        if (c.n >= 2) {
+#pragma unroll
+            for (int i = 0; i < IIR_MAX - 1; ++i)
+                if (i == c.n - 2) z[i] = c.b[i + 1] * v - c.a[i + 1] * out;
+        }
+        y[(size_t)t * NP + p] = out * scale;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // Small pyramid, one workgroup per frame, everything in LDS (levels S..L-1 of a 1080p frame are 87 KB):
 //   k_small_pyramid : G_S[t] -> G_{S+1..L-1} (cv2.pyrDown, pyramid.py:14) -> L_l = G_l - pyrUp(G_{l+1})
 //                     for l = L-2..S (pyramid.py:23-26), written side by side into lap_all[t, :]

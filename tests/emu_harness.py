@@ -51,6 +51,23 @@ class Emu:
         self.ck(self.lib.rm_temporal_bandpass_filter_fft(self.ctx, ptr(data), T, npix, fps, fmin, fmax, amp, ptr(out), None), "temporal")
         return out
 
+    def lfilter(self, b, a, data, scale=1.0):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        T = data.shape[0]
+        npix = data[0].size
+        out = np.empty_like(data)
+        b = np.ascontiguousarray(b, dtype=np.float64); a = np.ascontiguousarray(a, dtype=np.float64)
+        n = max(len(b), len(a))
+        b = np.concatenate([b, np.zeros(n - len(b))]); a = np.concatenate([a, np.zeros(n - len(a))])
+        self.ck(self.lib.rm_lfilter(self.ctx, ptr(data), T, npix, ptr(b), ptr(a), n, float(scale), ptr(out), None), "lfilter")
+        return out
+
+    def threshold_mask(self, raw, thr=0.7):
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        masked = np.empty_like(raw); mm = np.empty(2)
+        self.ck(self.lib.rm_threshold_mask(self.ctx, ptr(raw), raw.size, thr, ptr(masked), ptr(mm), None), "threshold_mask")
+        return masked, mm
+
     def operator(self, T, fps, fmin, fmax):
         M = np.empty((T, T))
         lo, hi = ctypes.c_int(), ctypes.c_int()

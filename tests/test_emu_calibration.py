@@ -164,3 +164,25 @@ def test_emu_frame_sharded_stages(emu, oracle):
     frames = oracle.uint8_to_float(synth.synth_breathing(8, 16, 16, seed=1))
     roi, heat, mm = emu.locate_sharded(frames, 2, levels=3, skip=2)
     assert roi is None and not heat.any() and emu.locate(frames, 10.0, levels=3, skip=2) is None
+
+
+def test_emu_iir_filter_and_threshold_mask(emu, oracle, golden):
+    """rm_lfilter == scipy.signal.lfilter in the reference's temporal_bandpass_filter (G8, authentic
+    scipy), and rm_threshold_mask == transforms.py:184-192."""
+    import scipy.signal
+    g = golden("g8_iir.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        b, a = scipy.signal.butter(6, [fmin / (0.5 * fps), fmax / (0.5 * fps)], btype='band', output='ba')
+        y = emu.lfilter(b, a, g["x%d" % i], scale=amp)
+        ref = g["y%d" % i]
+        assert np.abs(y - ref).max() <= 1e-9 * np.abs(ref).max()      # north_star gate: 1e-4 relative
+    rng = np.random.default_rng(4)
+    for (b, a) in [([0.5], [2.0]), ([1.0, -0.3], [1.0]), ([0.2, 0.1, 0.05], [1.5, -0.4, 0.1]), ([1.0], [1.0, -0.9])]:
+        x = rng.standard_normal((50, 7))
+        assert np.abs(emu.lfilter(b, a, x) - scipy.signal.lfilter(b, a, x, axis=0)).max() < 1e-12
+    raw = rng.standard_normal((5, 9, 11))
+    masked, mm = emu.threshold_mask(raw, 0.7)
+    top = raw.max() - (raw.max() - raw.min()) * 0.7
+    assert tuple(mm) == (raw.min(), raw.max())
+    assert np.array_equal(masked, np.where(raw >= top, raw.min(), raw))

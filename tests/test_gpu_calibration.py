@@ -272,3 +272,55 @@ def test_config_r_fp16_buffer(hip, oracle):
     roi = dist.hip_heatmap_to_roi(h0, 20)
     a = h0.cpu().numpy()
     assert roi == oracle.roi_from_heatmap_u8(oracle.float_to_uint8((a - a.min()) / (a.max() - a.min())), 20)
+
+
+def test_image_pyramid_functions(hip, oracle):
+    """pyramid.py:9-28, 51-57: the per-image forms, bit-exact against the oracle."""
+    from respmon_amd import pyramid
+    rng = np.random.default_rng(12)
+    for shape, L in [((64, 96), 5), ((33, 47), 4), ((135, 240), 6), ((5, 8), 3)]:
+        img = rng.random(shape)
+        for a, b in zip(pyramid.create_gaussian_image_pyramid(img, L), oracle.create_gaussian_image_pyramid(img, L)):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        lap = pyramid.create_laplacian_image_pyramid(img, L)
+        lap_ref = oracle.create_laplacian_image_pyramid(img, L)
+        for a, b in zip(lap, lap_ref):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        assert np.array_equal(pyramid.collapse_laplacian_pyramid(lap), oracle.collapse_laplacian_pyramid(lap_ref))
+    u8 = (rng.random((21, 30)) * 255).astype(np.uint8)       # the reference copies any dtype into float64 (pyramid.py:10-11)
+    assert np.array_equal(pyramid.create_gaussian_image_pyramid(u8, 3)[2], oracle.create_gaussian_image_pyramid(u8, 3)[2])
+
+
+def test_iir_temporal_filter_golden(hip, oracle, golden):
+    """temporal_bandpass_filter (order-6 Butterworth lfilter along T, transforms.py:72-79) and
+    eulerian_magnification_bandpass(temporal_filter_function=temporal_bandpass_filter) against the reference's outputs."""
+    import torch
+    from respmon_amd import transforms
+    g = golden("g8_iir.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        y = transforms.temporal_bandpass_filter(g["x%d" % i].copy(), fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+        assert _rel(y, g["y%d" % i]) <= 1e-9        # north_star gate: 1e-4 relative
+    L, S, fps = g["e_meta"]
+    vid = transforms.uint8_to_float(g["e_vid_u8"])
+    masked, raw = transforms.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L), skip_levels_at_top=int(S),
+                                                             temporal_filter_function=transforms.temporal_bandpass_filter)
+    assert _rel(raw, g["e_raw"]) <= 1e-9
+    assert _rel(np.average(masked, axis=0), g["e_avg"]) <= 1e-9
+    # any callable with the reference's filter signature works (transforms.py:146): here the FFT filter passed explicitly
+    # through the general path must equal the fused default
+    def fft_again(vid, fps, freq_min, freq_max, amplification_factor, **_):
+        return transforms.temporal_bandpass_filter_fft(vid, fps, freq_min=freq_min, freq_max=freq_max, amplification_factor=amplification_factor)
+    m1, r1 = transforms.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L), skip_levels_at_top=int(S),
+                                                        temporal_filter_function=fft_again)
+    m0, r0 = transforms.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L), skip_levels_at_top=int(S))
+    assert np.array_equal(r1, r0) and np.array_equal(m1, m0)
+    # device tensors stay on the device
+    xt = torch.from_numpy(g["x0"]).cuda()
+    yt = transforms.temporal_bandpass_filter(xt, 10.0, freq_min=0.1, freq_max=1.0, amplification_factor=500.0)
+    assert yt.is_cuda and _rel(yt.cpu().numpy(), g["y0"]) <= 1e-9
+    # 1-D host signals go to scipy like the reference (transforms.py:47-50)
+    sig = np.sin(np.arange(200) * 0.3)
+    import scipy.signal
+    b, a = transforms.butter_bandpass(0.5, 2.0, 10.0, order=3)
+    assert np.array_equal(transforms.butter_bandpass_filter(sig, 0.5, 2.0, 10.0, order=3), scipy.signal.lfilter(b, a, sig))

@@ -103,3 +103,19 @@ def test_g7_misc(oracle, golden):
         x, y, w, h, a = c
         assert tuple(oracle.reduce_bounding_box(int(x), int(y), int(w), int(h), a)) == tuple(int(v) for v in r)
     assert np.array_equal(oracle.butter_lowpass_filter(g["sig"], 0.5, 10, 3), g["filt"])
+
+
+def test_g8_iir_filter_and_eulerian(oracle, golden):
+    """Row f4: the oracle's temporal_bandpass_filter and eulerian_magnification_bandpass(temporal_filter_function=...)
+    against outputs of the reference itself."""
+    g = golden("g8_iir.npz")
+    for i in range(int(g["ncases"])):
+        n, fps, fmin, fmax, amp = g["meta%d" % i]
+        y = oracle.temporal_bandpass_filter(g["x%d" % i], fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+        assert np.array_equal(y, g["y%d" % i])
+    L, S, fps = g["e_meta"]
+    vid = oracle.uint8_to_float(g["e_vid_u8"])
+    masked, raw = oracle.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L), skip_levels_at_top=int(S),
+                                                         temporal_filter_function=oracle.temporal_bandpass_filter)
+    assert np.array_equal(raw, g["e_raw"])
+    assert np.array_equal(np.average(masked, axis=0), g["e_avg"])
