@@ -29,6 +29,7 @@ extern "C" {
 
 #define RM_OK 0
 #define RM_NO_CONTOUR 1
+#define RM_SPARSE_FALLBACK 2 /* rm_heat_sparse_merge_roi: a packet overflowed, use the dense all-reduce instead */
 #define RM_E_BADARG (-1)
 #define RM_E_HIP (-2)
 #define RM_E_NOMEM (-3)
@@ -141,6 +142,23 @@ int rm_calibrate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, i
  *      the uint8 heatmap and the thresholded image.  Returns RM_OK + xywh_host[4], or RM_NO_CONTOUR. */
 int rm_heatmap_to_roi(rm_ctx *ctx, const double *heatmap_dev, int H, int W, int threshold,
                       int32_t *xywh_host, uint8_t *avg_u8_dev, uint8_t *binary_dev, void *stream);
+
+/* ---- sparse exchange of per-stream heatmaps between GPUs (one stream per GPU, respmon_amd/dist.py::locate_streams).
+ *      Not a reference function: it replaces the dense all-reduce(sum) of the [H,W] float64 heatmaps (16.6 MB per GPU
+ *      at 1080p) by ONE all-gather of small packets.  The heatmap rm_calibrate leaves behind is a single constant (the
+ *      time average of `min`, transforms.py:190-192 + base.py:562) in every 64x16 tile whose frames were all masked,
+ *      so a packet holds that constant plus the values of the tiles that differ from it (cap_tiles of them at most).
+ *        rm_heat_sparse_packet_doubles(cap)  packet length in doubles
+ *        rm_heat_sparse_pack      packet_dev <- heatmap of the LAST rm_calibrate on this context
+ *          -- all-gather the packets: packets_dev[world][packet] --
+ *        rm_heat_sparse_merge_roi fused_dev[H*W] = sum over ranks, in rank order, of the per-rank heatmaps, then
+ *                                 base.py:563-575 on it -> xywh_host.  Returns RM_OK / RM_NO_CONTOUR, or
+ *                                 RM_SPARSE_FALLBACK when some rank needed more than cap_tiles tiles (every rank sees
+ *                                 the same packets, so every rank falls back to the dense all-reduce together). */
+size_t rm_heat_sparse_packet_doubles(int cap_tiles);
+int rm_heat_sparse_pack(rm_ctx *ctx, const double *heat_dev, int H, int W, int cap_tiles, double *packet_dev, void *stream);
+int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets_dev, int world, int H, int W, int cap_tiles, int threshold,
+                             double *fused_dev, int32_t *xywh_host, void *stream);
 
 /* ---- base.py:547-601 RespiratoryMonitor.locate = rm_calibrate + rm_heatmap_to_roi ------- */
 int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W, double fps,

@@ -9,6 +9,7 @@ import os
 
 RM_OK = 0
 RM_NO_CONTOUR = 1
+RM_SPARSE_FALLBACK = 2
 RM_U8, RM_F16, RM_F32, RM_F64 = 0, 1, 2, 3
 RM_FLAG_NO_PRUNE = 1
 RM_FLAG_UNFUSED_DOWN = 2
@@ -42,6 +43,9 @@ SIGNATURES = {
     "rm_eulerian_magnification_bandpass": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _vp, _vp, _vp, _vp]),
     "rm_calibrate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _u, _vp, _vp, _vp]),
     "rm_heatmap_to_roi": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rm_heat_sparse_packet_doubles": (_sz, [_i]),
+    "rm_heat_sparse_pack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rm_heat_sparse_merge_roi": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rm_locate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
     "rm_shard_layout": (_i, [_i, _i, _i, _i, _c.POINTER(_sz)]),
     "rm_shard_pyramid": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _vp]),

@@ -73,6 +73,8 @@ struct rm_ctx {
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
+    int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
+    int *h_flag = nullptr;          // pinned: overflow flag of the sparse heatmap merge
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0;
     unsigned int *h_slots_seen = nullptr;  // pinned: n_slots of the previous rm_calibrate (async readback)
@@ -159,6 +161,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_slots_seen) (void)hipHostFree(ctx->h_slots_seen);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -959,9 +962,12 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         }
         return RM_OK;
     }
+    int *tile_nkept = nullptr;
+    RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
-                       cp.store, st, thr, heat_sum, avg_T);
+                       cp.store, st, thr, heat_sum, avg_T, tile_nkept);
     LAUNCH_CHECK();
+    if (avg_T > 0) { ctx->nkept_H = cp.H; ctx->nkept_W = cp.W; }   // the whole-buffer heatmap's constant tiles are known
     HIP_TRY(hipMemcpyAsync(ctx->h_slots_seen, &st->n_slots, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     ctx->slots_seen_pairs = cp.npairs;
     return RM_OK;
@@ -977,6 +983,7 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
+    ctx->nkept_H = ctx->nkept_W = 0;   // set again by collapse_sum when the tile bookkeeping of this call exists
     SmallLevels sl;
     RM_TRY(front_half(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, flags, sl, s));
     if (ctx->prof_on) ctx->prof_calls++;
@@ -1180,6 +1187,69 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
     xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;
     return RM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse heatmap exchange (kernels: k_sparse_*)
+// ------------------------------------------------------------------------------------------
+extern "C" size_t rm_heat_sparse_packet_doubles(int cap_tiles)
+{
+    return cap_tiles < 1 ? 0 : (size_t)SP_HDR + (size_t)cap_tiles + (size_t)cap_tiles * CT_H * CT_W;
+}
+
+extern "C" int rm_heat_sparse_pack(rm_ctx *ctx, const double *heat, int H, int W, int cap_tiles, double *packet, void *stream)
+{
+    if (!ctx || !heat || !packet || H < 1 || W < 1 || cap_tiles < 1) return fail(RM_E_BADARG, "rm_heat_sparse_pack: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(packet, 0, sizeof(double) * SP_HDR, s));
+    const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, ntiles = tiles_x * tiles_y;
+    if (ctx->nkept_H != H || ctx->nkept_W != W) {
+        // no pruning bookkeeping for this heatmap (skip 0, zero result, foreign heatmap): report overflow -> dense exchange
+        const unsigned int over = (unsigned int)cap_tiles + 1u;
+        HIP_TRY(hipMemcpyAsync(packet, &over, sizeof over, hipMemcpyHostToDevice, s));
+        return RM_OK;
+    }
+    int *tile_nkept = nullptr;
+    RM_TRY(ws(ctx, "tile_nkept", (size_t)ntiles, &tile_nkept));
+    hipLaunchKernelGGL(k_sparse_background, dim3(1), dim3(256), 0, s, heat, W, tiles_x, ntiles, tile_nkept, cap_tiles, packet);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sparse_pack, dim3(ntiles), dim3(256), 0, s, heat, H, W, tiles_x, tile_nkept, cap_tiles, packet);
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
+static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
+                               uint8_t *binary, void *stream, bool have_minmax);
+
+extern "C" int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets, int world, int H, int W, int cap_tiles, int threshold,
+                                        double *fused, int32_t *xywh, void *stream)
+{
+    if (!ctx || !packets || !fused || !xywh || world < 1 || H < 1 || W < 1 || cap_tiles < 1)
+        return fail(RM_E_BADARG, "rm_heat_sparse_merge_roi: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, ntiles = tiles_x * tiles_y;
+    const size_t pd = rm_heat_sparse_packet_doubles(cap_tiles);
+    int *map = nullptr, *flag = nullptr;
+    RM_TRY(ws(ctx, "sparse_map", (size_t)world * ntiles + 1, &map));
+    flag = map + (size_t)world * ntiles;
+    if (!ctx->h_flag) HIP_TRY(hipHostMalloc((void **)&ctx->h_flag, sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(map, 0xFF, sizeof(int) * (size_t)world * ntiles, s));
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_sparse_index, dim3(world), dim3(256), 0, s, packets, pd, world, cap_tiles, ntiles, map, flag);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sparse_merge, dim3(ntiles), dim3(256), 0, s, packets, pd, world, cap_tiles, H, W, tiles_x, ntiles, map, fused,
+                       ctx->d_state);
+    LAUNCH_CHECK();
+    // the ROI stage synchronises the stream; the overflow flag is in pinned memory by then
+    const int rc = heatmap_to_roi_impl(ctx, fused, H, W, threshold, xywh, nullptr, nullptr, stream, true);
+    if (rc < 0) return rc;
+    if (*ctx->h_flag) return RM_SPARSE_FALLBACK;
+    return rc;
 }
 
 extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,

@@ -157,6 +157,12 @@ inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
 inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) {
     return reinterpret_cast<std::atomic<unsigned long long> *>(p)->fetch_or(v);
 }
+inline int atomicMin(int *p, int v) {
+    auto *a = reinterpret_cast<std::atomic<int> *>(p);
+    int cur = a->load();
+    while (v < cur && !a->compare_exchange_weak(cur, v)) {}
+    return cur;
+}
 inline int atomicAdd(int *p, int v) { return reinterpret_cast<std::atomic<int> *>(p)->fetch_add(v); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->fetch_add(v); }
 inline unsigned atomicMax(unsigned *p, unsigned v) {

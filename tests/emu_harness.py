@@ -151,7 +151,32 @@ def _shard_methods():
             self.lib.rm_ctx_destroy(c)
         return (None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)), heat, (-mm[0], mm[1])
 
-    for f in (new_ctx, locate_sharded):
+    def sparse_exchange(self, videos, cap, fps=10.0, levels=9, skip=4, threshold=20):
+        """Mode B heatmap exchange for emulated ranks: calibrate + pack per rank (a context each), packets concatenated by
+        hand (the all-gather), merge + ROI on rank 0.  Returns (rc, roi, fused, heats, counts)."""
+        heats, packets = [], []
+        pd = int(self.lib.rm_heat_sparse_packet_doubles(cap))
+        ctxs = [self.new_ctx() for _ in videos]
+        for c, v in zip(ctxs, videos):
+            v = np.ascontiguousarray(v)
+            T, H, W = v.shape
+            heat = np.empty((H, W))
+            self.ck(self.lib.rm_calibrate(c, ptr(v), DT[v.dtype], T, H, W, fps, 0.1, 1.0, 500.0, levels, skip, 0.7, 0, ptr(heat), None, None),
+                    "calibrate")
+            pk = np.zeros(pd)
+            self.ck(self.lib.rm_heat_sparse_pack(c, ptr(heat), H, W, cap, ptr(pk), None), "sparse_pack")
+            heats.append(heat); packets.append(pk)
+        allp = np.concatenate(packets)
+        fused = np.empty((H, W)); xywh = np.zeros(4, np.int32)
+        rc = self.ck(self.lib.rm_heat_sparse_merge_roi(ctxs[0], ptr(allp), len(videos), H, W, cap, threshold, ptr(fused), ptr(xywh), None),
+                     "sparse_merge")
+        for c in ctxs:
+            self.lib.rm_ctx_destroy(c)
+        counts = [int(pk[:1].view(np.uint32)[0]) for pk in packets]
+        roi = tuple(int(v) for v in xywh) if rc == _capi.RM_OK else None
+        return rc, roi, fused, heats, counts
+
+    for f in (new_ctx, locate_sharded, sparse_exchange):
         setattr(Emu, f.__name__, f)
 
 

@@ -186,3 +186,34 @@ def test_emu_iir_filter_and_threshold_mask(emu, oracle, golden):
     top = raw.max() - (raw.max() - raw.min()) * 0.7
     assert tuple(mm) == (raw.min(), raw.max())
     assert np.array_equal(masked, np.where(raw >= top, raw.min(), raw))
+
+
+def test_emu_sparse_heatmap_exchange(emu, oracle):
+    """rm_heat_sparse_pack / rm_heat_sparse_merge_roi (Mode B between GPUs): the fused heatmap is the rank-ordered sum
+    of the per-rank heatmaps bit for bit whenever the packets hold their tiles, and the call says so when they do not.
+    At sizes the emulator can run the pruning keeps every tile (it needs 1080p-scale footprints to bite), so this
+    exercises the packet / index / fallback plumbing; the sparse path proper is covered on the GPU
+    (tests/test_gpu_sharded.py, 128 x 1080p)."""
+    from respmon_amd import _capi
+    rng = np.random.default_rng(8)
+    H, W, T = 70, 200, 24            # 5 x 4 tiles, the last row / column of tiles partial
+
+    def video(seed, blob):
+        v = np.full((T, H, W), 0.5) + 0.001 * np.random.default_rng(seed).standard_normal((T, H, W))
+        y0, x0 = blob
+        v[:, y0:y0 + 12, x0:x0 + 30] += 0.2 * np.sin(2 * np.pi * 0.4 * np.arange(T) / 10.0)[:, None, None]
+        return v
+    vids = [video(1, (10, 20)), video(2, (40, 150)), video(3, (55, 90))]
+    rc, roi, fused, heats, counts = emu.sparse_exchange(vids, cap=20, levels=5, skip=2)
+    dense = heats[0] + heats[1] + heats[2]
+    if rc == _capi.RM_SPARSE_FALLBACK:
+        assert max(counts) > 20
+    else:
+        assert np.array_equal(fused, dense), counts
+        u8 = oracle.float_to_uint8((dense - dense.min()) / (dense.max() - dense.min()))
+        assert roi == oracle.roi_from_heatmap_u8(u8, 20)
+    rc2, _, _, _, counts2 = emu.sparse_exchange(vids, cap=1, levels=5, skip=2)
+    assert rc2 == _capi.RM_SPARSE_FALLBACK or max(counts2) <= 1
+    # no pruning bookkeeping (skip 0 takes the plain path) -> fallback
+    rc3, _, _, _, counts3 = emu.sparse_exchange([v[:6, :20, :24] for v in vids], cap=8, levels=2, skip=0)
+    assert rc3 == _capi.RM_SPARSE_FALLBACK

@@ -153,3 +153,88 @@ def test_two_processes_locate_sharded(hip, oracle, tmp_path):
     assert tuple(int(v) for v in r0["roi"]) == oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
     ref = rdist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S).cpu().numpy()
     assert np.abs(r0["heat"] - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Mode B (one stream per GPU): sparse heatmap exchange == dense sum of the per-stream heatmaps
+# ---------------------------------------------------------------------------------------------------
+def test_sparse_heatmap_exchange_emulated_ranks(hip, oracle):
+    """rm_heat_sparse_pack / rm_heat_sparse_merge_roi with the all-gather done by hand: the fused heatmap equals the
+    rank-ordered dense sum bit for bit, the ROI equals the dense path's; overflow and missing bookkeeping fall back."""
+    import torch
+    from respmon_amd import _capi, device, dist as rdist
+    lib = hip
+    from respmon_amd import synth
+    T, H, W, L, S = 128, 1080, 1920, 9, 4          # the pruning needs a long buffer to bite (cf. DESIGN.md 4.3)
+    world, cap = 3, rdist.SPARSE_CAP_TILES
+    sp = device.stream_ptr()
+    pd = int(lib.rm_heat_sparse_packet_doubles(cap))
+    heats, packets = [], []
+    for r in range(world):
+        buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=60 + r)).cuda()   # uint8 frame buffer (bit-identical results)
+        heat = rdist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
+        pk = torch.empty(pd, dtype=torch.float64, device="cuda")
+        _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(heat), H, W, cap, device.ptr(pk), sp), "pack")
+        heats.append(heat); packets.append(pk)
+    allp = torch.cat(packets)
+    fused = torch.empty((H, W), dtype=torch.float64, device="cuda")
+    xywh = (ctypes.c_int32 * 4)()
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(allp), world, H, W, cap, 20, device.ptr(fused), xywh, sp), "merge")
+    dense = heats[0].clone()
+    for h in heats[1:]:
+        dense = dense + h                                   # rank order, like the merge kernel
+    counts = [int(pk[:1].view(torch.int32)[0]) for pk in packets]
+    assert rc in (_capi.RM_OK, _capi.RM_NO_CONTOUR), counts
+    assert torch.equal(fused, dense)
+    roi = None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
+    assert roi == rdist.hip_heatmap_to_roi(dense, 20)
+    assert all(0 < c <= cap for c in counts), counts           # the sparse path was really taken
+    # a packet that cannot hold its tiles -> every rank is told to fall back
+    small = 2
+    pd2 = int(lib.rm_heat_sparse_packet_doubles(small))
+    pk2 = torch.empty(pd2, dtype=torch.float64, device="cuda")
+    _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(heats[-1]), H, W, small, device.ptr(pk2), sp), "pack")
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(pk2), 1, H, W, small, 20, device.ptr(fused), xywh, sp), "merge")
+    assert rc == _capi.RM_SPARSE_FALLBACK
+    # a heatmap the context has no pruning bookkeeping for (other geometry) -> fall back as well
+    other = torch.rand((64, 96), dtype=torch.float64, device="cuda")
+    pk3 = torch.empty(pd, dtype=torch.float64, device="cuda")
+    _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(other), 64, 96, cap, device.ptr(pk3), sp), "pack")
+    f3 = torch.empty((64, 96), dtype=torch.float64, device="cuda")
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(pk3), 1, 64, 96, cap, 20, device.ptr(f3), xywh, sp), "merge")
+    assert rc == _capi.RM_SPARSE_FALLBACK
+
+
+def _worker_streams(rank, world, port, out_dir, T, H, W):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import dist as rdist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=90 + rank)).cuda()   # uint8 frame buffer
+    roi_s, fused_s = rdist.locate_streams(buf, 10, threshold=20, return_heatmap=True)                 # sparse exchange
+    taken = rdist.hip_sparse_exchange_roi(rdist.hip_calibrate(buf, 10), 20)[0]
+    roi_d, fused_d = rdist.locate_streams(buf, 10, threshold=20, sparse=False, return_heatmap=True)  # dense all-reduce
+    local = rdist.hip_calibrate(buf, 10)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), roi_s=np.array(roi_s or (-1,) * 4), roi_d=np.array(roi_d or (-1,) * 4),
+             fused_s=fused_s.cpu().numpy(), fused_d=fused_d.cpu().numpy(), local=local.cpu().numpy(), sparse_taken=np.array(taken))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_locate_streams_sparse_equals_dense(hip, oracle, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_streams, args=(2, port, str(tmp_path), 128, 1080, 1920), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["fused_s"], r1["fused_s"]) and np.array_equal(r0["roi_s"], r1["roi_s"])
+    assert np.array_equal(r0["fused_s"], r0["local"] + r1["local"])          # rank-ordered sum of the per-stream heatmaps
+    assert np.array_equal(r0["fused_s"], r0["fused_d"])                      # two ranks: the dense sum has only one order
+    assert np.array_equal(r0["roi_s"], r0["roi_d"]) and r0["roi_s"][2] > 0
+    assert bool(r0["sparse_taken"]) and bool(r1["sparse_taken"])
