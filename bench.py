@@ -4,8 +4,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one locate() (calibration + ROI) over one [T,H,W] frame buffer already resident in HBM.
-N>1: one process per GPU, each with its own stream (weak scaling, Mode B of respmon_amd/dist.py) and
-one RCCL all-reduce(sum) of the [H,W] heatmap per step.  Rank 0 prints ONE JSON line.
+N>1: one process per GPU, each with its own stream (weak scaling, Mode B of respmon_amd/dist.py) and one RCCL
+exchange of the [H,W] heatmaps per step (an all-gather of sparse packets; dense all-reduce(sum) as the fallback);
+--mode sharded: ONE buffer split by frame index over the GPUs (Mode A, strong scaling).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -196,7 +197,7 @@ def main():
             "config": {"workload": "Eulerian calibration + ROI (locate) on a %dx%dx%d frame buffer, %d-level Laplacian pyramid, "
                                    "skip %d, temporal FFT band-pass 0.1-1.0 Hz @10 fps; %s" % (T, H, W, a.levels, a.skip,
                                    "ONE buffer sharded by frame index over the GPUs: all-gather of the small pyramid, min/max all-reduce, "
-                                   "one RCCL heatmap all-reduce" if sharded else "one independent stream per GPU + one RCCL heatmap all-reduce"),
+                                   "one RCCL heatmap all-reduce" if sharded else "one independent stream per GPU + one RCCL exchange of the heatmaps"),
                        "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "prune": not a.no_prune},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -205,6 +206,10 @@ def main():
             "phases_ms_per_step": {"frame_buffer_kernel": ms[0] / max(ncalls.value, 1), "pyramid_rest_and_temporal": ms[1] / max(ncalls.value, 1),
                                    "collapse_passes": ms[2] / max(ncalls.value, 1), "heatmap_to_roi": ms[3] / max(ncalls.value, 1)},
             "roi": roi,
+            "heatmap_exchange": (rdist.LAST_EXCHANGE and {"sparse": "one all-gather of sparse packets (%d-tile cap, %.2f MB per rank)"
+                                                          % (rdist.SPARSE_CAP_TILES, 8e-6 * (4 + rdist.SPARSE_CAP_TILES * 1025)),
+                                                          "dense": "all-reduce(sum) of the [H,W] float64 heatmap"}[rdist.LAST_EXCHANGE])
+                                if world > 1 and not sharded else None,
             "alt_uint8_buffer": alt,
             "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
         }

@@ -65,6 +65,7 @@ def hip_heatmap_to_roi(heat, threshold=20):
     return None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
 
 
+LAST_EXCHANGE = None      # "sparse" / "dense": how the last locate_streams summed the heatmaps (bench.py reports it)
 SPARSE_CAP_TILES = 128   # tiles (64x16 px) a packet can carry: 1 MB per rank; the synthetic 1080p x 256 stream needs ~80
 
 
@@ -111,13 +112,16 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
     The sum travels as ONE all-gather of sparse packets (a stream's heatmap is a single constant outside the few
     tiles that survive the pruning: 1 MB per rank instead of a 16.6 MB all-reduce at 1080p, summed in rank order);
     `sparse=False`, a test double for the calibration, or a packet overflow uses the dense all-reduce(sum)."""
+    global LAST_EXCHANGE
     heat = calibrate_fn(buf, fps, **kw)
     if sparse is None:
         sparse = calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and _world(group)[1] > 1
     if sparse:
         ok, roi, fused = hip_sparse_exchange_roi(heat, threshold, group)
         if ok:
+            LAST_EXCHANGE = "sparse"
             return (roi, fused) if return_heatmap else roi
+    LAST_EXCHANGE = "dense"
     all_reduce_heatmap(heat, group)
     roi = roi_fn(heat, threshold)
     return (roi, heat) if return_heatmap else roi
