@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int s
 // in one [T, NP] buffer, so one launch per stage serves every filtered level.
 constexpr int TF_KC = 4, TF_SC = 8, TF_U = 16;
 
-// (Splitting T over 4 waves per workgroup with an LDS reduction was measured slower: 48 us vs 42 us.)
+// Measured and rejected: splitting T over 4 waves per workgroup with an LDS reduction (48 us vs 42 us for stage 1);
+// one fused kernel per 64 pixel columns that reads x once, keeps all y[k] in registers and takes the
+// coefficients through the scalar cache (128 us vs 64 us for both stages: one workgroup per CU exposes every
+// scalar-load and global-load latency, the two-stage form has 8-20 waves per CU to hide them).
 __global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y)
 {
     HIP_DYNAMIC_SHARED(double, s_r)  // [T][TF_KC]
