@@ -626,9 +626,9 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
 #ifdef RM_DC_SEGS  // developer experiment
     segs = RM_DC_SEGS;
 #endif
-    if (const char *e = getenv("RM_DC_SEGS")) {  // developer experiment (A/B on one box)
-        const int v = atoi(e);
-        if (v >= 1 && v <= rows) segs = v;
+    {   // developer A/B knob, read once: RM_DC_SEGS=<n> overrides the segment count
+        static const int env_segs = [] { const char *e = getenv("RM_DC_SEGS"); return e ? atoi(e) : 0; }();
+        if (env_segs >= 1 && env_segs <= rows) segs = env_segs;
     }
     g.seg_h = (rows + segs - 1) / segs;
     if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
@@ -639,9 +639,9 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
 #ifdef RM_DC_WPG  // developer experiment
     g.wpg = RM_DC_WPG;
 #endif
-    if (const char *e = getenv("RM_DC_WPG")) {  // developer experiment (A/B on one box)
-        const int v = atoi(e);
-        if (v >= 1 && v <= DC_MAX_WPG) g.wpg = v;
+    {   // developer A/B knob, read once: RM_DC_WPG=<n> overrides the waves per workgroup
+        static const int env_wpg = [] { const char *e = getenv("RM_DC_WPG"); return e ? atoi(e) : 0; }();
+        if (env_wpg >= 1 && env_wpg <= DC_MAX_WPG) g.wpg = env_wpg;
     }
 #ifdef RM_HIPEMU
     g.wpg = 1;

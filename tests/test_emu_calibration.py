@@ -217,3 +217,45 @@ def test_emu_sparse_heatmap_exchange(emu, oracle):
     # no pruning bookkeeping (skip 0 takes the plain path) -> fallback
     rc3, _, _, _, counts3 = emu.sparse_exchange([v[:6, :20, :24] for v in vids], cap=8, levels=2, skip=0)
     assert rc3 == _capi.RM_SPARSE_FALLBACK
+
+
+def test_emu_error_conventions(emu):
+    """include/respmon_hip.h conventions: bad arguments give a negative code plus a message, nothing aborts, and
+    unsupported shapes say so (checked on the host-emulated build: the argument checks are host code)."""
+    from tests.emu_harness import ptr
+    from respmon_amd import _capi
+    lib, ctx = emu.lib, emu.ctx
+    f = np.zeros((4, 8, 8))
+    heat = np.zeros((8, 8)); xywh = np.zeros(4, np.int32); mm = np.zeros(2); pk = np.zeros(64)
+    bad = [
+        ("rm_calibrate T=0", lib.rm_calibrate(ctx, ptr(f), _capi.RM_F64, 0, 8, 8, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 0, ptr(heat), None, None)),
+        ("rm_calibrate NULL frames", lib.rm_calibrate(ctx, None, _capi.RM_F64, 4, 8, 8, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 0, ptr(heat), None, None)),
+        ("rm_calibrate dtype", lib.rm_calibrate(ctx, ptr(f), 9, 4, 8, 8, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 0, ptr(heat), None, None)),
+        ("rm_calibrate fps", lib.rm_calibrate(ctx, ptr(f), _capi.RM_F64, 4, 8, 8, 0.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 0, ptr(heat), None, None)),
+        ("rm_locate NULL out", lib.rm_locate(ctx, ptr(f), _capi.RM_F64, 4, 8, 8, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 20, 0, None, None)),
+        ("rm_pyr_up dstsize", lib.rm_pyr_up(ctx, ptr(f), 4, 8, 8, ptr(np.zeros((4, 20, 20))), 20, 20, 0, None, None)),
+        ("rm_pyr_up mode", lib.rm_pyr_up(ctx, ptr(f), 4, 8, 8, ptr(np.zeros((4, 16, 16))), 16, 16, 5, None, None)),
+        ("rm_heatmap_to_roi NULL", lib.rm_heatmap_to_roi(ctx, None, 8, 8, 20, ptr(xywh), None, None, None)),
+        ("rm_roi_mean outside", lib.rm_roi_mean(ctx, ptr(heat), _capi.RM_F64, 8, 8, 4, 4, 8, 8, ptr(mm), None)),
+        ("rm_temporal in place", lib.rm_temporal_bandpass_filter_fft(ctx, ptr(f), 4, 64, 10.0, 0.1, 1.0, 50.0, ptr(f), None)),
+        ("rm_lfilter a0", lib.rm_lfilter(ctx, ptr(f), 4, 64, ptr(np.ones(2)), ptr(np.zeros(2)), 2, 1.0, ptr(np.zeros((4, 8, 8))), None)),
+        ("rm_lfilter ncoef", lib.rm_lfilter(ctx, ptr(f), 4, 64, ptr(np.ones(40)), ptr(np.ones(40)), 40, 1.0, ptr(np.zeros((4, 8, 8))), None)),
+        ("rm_shard_pyramid skip 0", lib.rm_shard_pyramid(ctx, ptr(f), _capi.RM_F64, 4, 8, 8, 3, 0, 0, ptr(np.zeros((4, 64))), None)),
+        ("rm_shard_collapse range", lib.rm_shard_collapse(ctx, ptr(np.zeros((4, 16))), 4, 3, 2, 8, 8, 10.0, 0.1, 1.0, 500.0, 3, 1, 0.7, 0, ptr(mm), None)),
+        ("rm_heat_sparse_pack cap", lib.rm_heat_sparse_pack(ctx, ptr(heat), 8, 8, 0, ptr(pk), None)),
+        ("rm_threshold_mask n=0", lib.rm_threshold_mask(ctx, ptr(heat), 0, 0.7, ptr(heat), ptr(mm), None)),
+        ("rm_ctx_create NULL", lib.rm_ctx_create(0, None)),
+    ]
+    for what, rc in bad:
+        assert rc < 0, what
+        assert len(lib.rm_last_error_string()) > 0, what
+    # rm_shard_heat before any rm_shard_collapse on a fresh context
+    c2 = emu.new_ctx()
+    assert lib.rm_shard_heat(c2, ptr(mm), 0.7, ptr(heat), None) < 0 and b"rm_shard_collapse" in lib.rm_last_error_string()
+    lib.rm_ctx_destroy(c2)
+    assert lib.rm_ctx_destroy(None) == 0                      # destroying nothing is not an error
+    # a flat buffer: NaN after normalisation -> no contour is a RESULT (positive code), not an error (base.py:569-570)
+    flat = np.full((8, 16, 16), 0.25)
+    assert lib.rm_locate(ctx, ptr(flat), _capi.RM_F64, 8, 16, 16, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 20, 0, ptr(xywh), None) == _capi.RM_NO_CONTOUR
+    # T beyond the supported maximum is reported, not truncated
+    assert lib.rm_calibrate(ctx, ptr(f), _capi.RM_F64, 5000, 8, 8, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 0, ptr(heat), None, None) == -4
