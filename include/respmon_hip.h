@@ -107,6 +107,10 @@ int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data_dev, int T, 
 int rm_temporal_operator(int T, double fps, double freq_min, double freq_max, double *M_host,
                          int *bound_low, int *bound_high);
 
+/* ---- np.average(video, axis=0) (base.py:562, 579, 587, 589: heatmap and the panels of the calibration image):
+ *      out_dev[npix] float64 = (sum over t, in t order, of data[t, :]) / T for a [T, npix] array of any frame dtype. */
+int rm_time_average(rm_ctx *ctx, const void *data_dev, int dtype, int T, size_t npix, double *out_dev, void *stream);
+
 /* ---- transforms.py:72-79 temporal_bandpass_filter, transforms.py:53-55 butter_bandpass_filter_fast:
  *      out = scipy.signal.lfilter(b, a, data, axis=0) * scale on data[T, npix] float64 (transposed direct form II,
  *      the operation order of scipy's C loop).  b_host / a_host: ncoef coefficients each (ncoef <= 16; the

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rm_collapse_laplacian_video_pyramid": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _vp]),
     "rm_temporal_bandpass_filter_fft": (_i, [_vp, _vp, _i, _sz, _d, _d, _d, _d, _vp, _vp]),
     "rm_temporal_operator": (_i, [_i, _d, _d, _d, _vp, _c.POINTER(_i), _c.POINTER(_i)]),
+    "rm_time_average": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp]),
     "rm_lfilter": (_i, [_vp, _vp, _i, _sz, _vp, _vp, _i, _d, _vp, _vp]),
     "rm_threshold_mask": (_i, [_vp, _vp, _sz, _d, _vp, _vp, _vp]),
     "rm_eulerian_magnification_bandpass": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _vp, _vp, _vp, _vp]),

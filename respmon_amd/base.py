@@ -393,12 +393,17 @@ class RespiratoryMonitor:
         and no [T,H,W] intermediate is written (rm_locate)."""
         if threshold_type != THRESH_BINARY:
             raise NotImplementedError("only cv2.THRESH_BINARY is used by the reference (base.py:448,551)")
-        if save_calibration_image:
-            logging.info("save_calibration_image: the debug montage (base.py:577-596) is not produced by this build")
         logging.info("Beginning processing calibration frames...")
         buf = device.to_device(calibration_video_data)
         roi = _Backend().locate(buf, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
                                 temporal_threshold, threshold)
+        if save_calibration_image and roi is not None:     # base.py:577-596 (the reference returns before it when no contour)
+            from . import montage
+            logging.info('Creating calibration image.')
+            path, _ = montage.save_calibration_image(buf, fps, freq_min=freq_min, freq_max=freq_max, amplification=amplification,
+                                                     pyramid_levels=pyramid_levels, skip_levels_at_top=skip_levels_at_top,
+                                                     temporal_threshold=temporal_threshold, threshold=threshold)
+            logging.info('Calibration image saved: %s', path)
         if verbose and roi is not None:
             print('x:{0}, y:{1}, w:{2}, h:{3}'.format(*roi))
         return roi
@@ -477,5 +482,12 @@ class RespiratoryMonitor:
     def _locate_buffer(self):
         """the locate() call of run(), base.py:444-448: threshold = int(round(0.08*255)) = 20; pyramid_levels=9,
         skip_levels_at_top=4, amplification=500 are locate's defaults."""
-        return self._backend.locate(self.calibration_buffer, self.fps, self.freq_min, self.freq_max, 500, 9, 4,
-                                    self.temporal_threshold, int(np.round(self.threshold * 255)))
+        thr = int(np.round(self.threshold * 255))
+        roi = self._backend.locate(self.calibration_buffer, self.fps, self.freq_min, self.freq_max, 500, 9, 4,
+                                   self.temporal_threshold, thr)
+        if self.save_calibration_image and roi is not None:     # base.py:448 passes the flag on; montage at base.py:577-596
+            from . import montage
+            path, _ = montage.save_calibration_image(self.calibration_buffer, self.fps, freq_min=self.freq_min, freq_max=self.freq_max,
+                                                     temporal_threshold=self.temporal_threshold, threshold=thr)
+            logging.info('Calibration image saved: %s', path)
+        return roi

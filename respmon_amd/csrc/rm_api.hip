@@ -549,6 +549,22 @@ extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, 
     return launch_temporal(ctx, data, T, npix, op, amp, out, s);
 }
 
+extern "C" int rm_time_average(rm_ctx *ctx, const void *data, int dtype, int T, size_t npix, double *out, void *stream)
+{
+    if (!ctx || !data || !out || T < 1 || !valid_dtype(dtype)) return fail(RM_E_BADARG, "rm_time_average: bad argument");
+    if (npix == 0) return RM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+    switch (dtype) {
+    case RM_U8: hipLaunchKernelGGL((k_time_average<uint8_t>), grid, block, 0, s, (const uint8_t *)data, T, npix, out); break;
+    case RM_F16: hipLaunchKernelGGL((k_time_average<__half>), grid, block, 0, s, (const __half *)data, T, npix, out); break;
+    case RM_F32: hipLaunchKernelGGL((k_time_average<float>), grid, block, 0, s, (const float *)data, T, npix, out); break;
+    default: hipLaunchKernelGGL((k_time_average<double>), grid, block, 0, s, (const double *)data, T, npix, out); break;
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
 extern "C" int rm_lfilter(rm_ctx *ctx, const double *data, int T, size_t npix, const double *b_host, const double *a_host, int ncoef,
                           double scale, double *out, void *stream)
 {

@@ -969,6 +969,18 @@ __global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int
     heat_sum[p] = acc;
 }
 
+// np.average(video, axis=0) of a [T, npix] array of any frame dtype (base.py:562, 579, 587, 589): float64 sum in t
+// order, then / T -- the order numpy's pairwise-free axis-0 reduction uses.
+template <typename Tin>
+__global__ __launch_bounds__(256) void k_time_average(const Tin *v, int T, size_t npix, double *out)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    double acc = 0.0;
+    for (int t = 0; t < T; ++t) acc = acc + load_px(v, (size_t)t * npix + p);
+    out[p] = acc / (double)T;
+}
+
 // ----------------------------------------------------------------------------------------
 // base.py:562-566: avg = sum / T ; normalise ; float_to_uint8 ; threshold
 // ----------------------------------------------------------------------------------------

@@ -324,3 +324,44 @@ def test_iir_temporal_filter_golden(hip, oracle, golden):
     import scipy.signal
     b, a = transforms.butter_bandpass(0.5, 2.0, 10.0, order=3)
     assert np.array_equal(transforms.butter_bandpass_filter(sig, 0.5, 2.0, 10.0, order=3), scipy.signal.lfilter(b, a, sig))
+
+
+def test_calibration_image_panels(hip, oracle, tmp_path):
+    """SURVEY 8f row f1, base.py:577-596: the data of the six panels (time averages, normalisation, float_to_uint8,
+    threshold) bit-exact against the oracle; the montage is written as calibration<i>.png like the reference does."""
+    import os
+    from respmon_amd import montage, synth
+    from respmon_amd.base import RespiratoryMonitor
+    v8 = synth.synth_breathing(48, 96, 128, seed=5)
+    frames = oracle.uint8_to_float(v8)
+    L, S = 6, 2
+    panels, roi = montage.calibration_panels(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
+    masked, raw = oracle.eulerian_magnification_bandpass(frames, 10, 0.1, 1.0, 500, pyramid_levels=L, skip_levels_at_top=S)
+
+    def norm_u8(a):
+        return oracle.float_to_uint8((a - a.min()) / (a.max() - a.min()))
+    avg = norm_u8(np.average(masked, axis=0))
+    assert np.array_equal(panels["avg"], avg)
+    assert np.array_equal(panels["avg_raw"], norm_u8(np.average(raw, axis=0)))
+    assert np.array_equal(panels["avg_original"], oracle.float_to_uint8(np.average(frames, axis=0)))
+    assert np.array_equal(panels["thresh"], np.where(avg > 20, 255, 0).astype(np.uint8))
+    assert roi == oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S) and roi is not None
+    x, y, w, h = roi
+    total = oracle.float_to_uint8(np.average(frames, axis=0))
+    assert np.all(panels["drawn"][y, x:x + w + 1] == 255)                       # the ROI rectangle is drawn on (mean + avg)
+    inside = panels["drawn"][y + 3:y + h - 2, x + 3:x + w - 2]
+    assert np.array_equal(inside, (total + avg).astype(np.uint8)[y + 3:y + h - 2, x + 3:x + w - 2])
+    assert (panels["contour_img"] != total).any() and np.all(panels["contour_img"][panels["contour_img"] != total] == 0)
+    # time average of other frame dtypes
+    assert np.array_equal(montage.time_average(v8).cpu().numpy(), np.average(frames, axis=0))
+    # locate(save_calibration_image=True) writes calibration0.png, then calibration1.png, ... into the working directory
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        for i in range(2):
+            assert RespiratoryMonitor.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S, save_calibration_image=True) == roi
+            assert os.path.exists("calibration%d.png" % i)
+        img = montage.read_png_gray("calibration1.png")
+    finally:
+        os.chdir(cwd)
+    assert img.shape == (2 * 96, 3 * 128) and np.array_equal(img, montage.montage(panels))
