@@ -44,6 +44,7 @@ def parse():
                     "index over the GPUs (respmon_amd.dist.locate_sharded), strong scaling")
     ap.add_argument("--no-prune", action="store_true")
     ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
+    ap.add_argument("--no-roi-flow", action="store_true", help="skip the per-frame ROI optical-flow measurement")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T frames if host memory allows, else 64)")
     return ap.parse_args()
 
@@ -167,6 +168,36 @@ def main():
         alt = {"frame_buffer_dtype": "u8", "value": T * a.steps / e8, "unit": "frames/s", "ms_per_step": e8 / a.steps * 1e3,
                "roi": roi8, "roi_equals_headline": list(roi8 or []) == list(roi or [])}
         del buf8
+    # BASELINE config 4 is "calibration + ROI flow": the per-frame motion extraction (base.py:354-407, 'flow' method) on the
+    # ROI just found -- Shi-Tomasi corners once, then pyramidal LK + mean flow + PCA per frame.  Latency bound
+    # (no roofline fraction is meaningful); reported beside the headline, never part of `value`.
+    roi_flow = None
+    if world == 1 and roi is not None and not a.no_roi_flow:
+        x, y, w, h = roi
+        n_fl = min(T - 1, 60)
+        crops = [backend.roi_to_uint8(torch.from_numpy(vid_u8[i]).cuda(), x, y, w, h) for i in range(n_fl + 1)]
+        pts = backend.good_features_to_track(crops[0], 100, 0.3, 7, 7)      # base.py:91-94
+        if pts is not None:
+            motion = []
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            p = pts
+            for i in range(n_fl):
+                if len(p) == 0:
+                    break
+                p1, st = backend.calc_optical_flow_pyr_lk(crops[i], crops[i + 1], p, (15, 15), 2, (3, 10, 0.03))   # base.py:96-98
+                mean, n_good = backend.mean_flow(p, p1, st)
+                p = p1[st == 1].reshape(-1, 1, 2)
+                if n_good:
+                    motion.append([mean[0], mean[1]])
+                if len(motion) >= 2:
+                    backend.pca_reduce(np.array(motion, dtype=np.float32))
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - tf) / max(n_fl, 1)
+            roi_flow = {"roi": [x, y, w, h], "corners": int(len(pts)), "frames": n_fl, "ms_per_frame": dtf * 1e3,
+                        "frames_per_s": 1.0 / dtf if dtf > 0 else None, "budget_ms_at_30fps": 33.3}
+        else:
+            roi_flow = {"roi": [x, y, w, h], "corners": 0}
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -211,6 +242,7 @@ def main():
                                                           "dense": "all-reduce(sum) of the [H,W] float64 heatmap"}[rdist.LAST_EXCHANGE])
                                 if world > 1 and not sharded else None,
             "alt_uint8_buffer": alt,
+            "roi_flow": roi_flow,
             "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
         }
         if world == 1 and a.cpu_frames != 0:
