@@ -660,19 +660,24 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
     const bool vec_ok = (w[0] % V == 0) && (((size_t)h[0] * w[0] * esz) % 16 == 0) && (((uintptr_t)frames) % 16 == 0);
     if (S < 1 || S > 5) return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", S);
     const int vo = vec_ok ? 1 : 0;
-    if (dtype == RM_U8 && vec_ok) {
-        // all-register variant for uint8 buffers (rm_down_chain_u8.h)
+    static const unsigned flags_dev = [] { const char *e = getenv("RM_DC_LDS_FRONT_END"); return (unsigned)(e ? atoi(e) : 0); }();  // developer A/B knob
+    if ((dtype == RM_U8 || dtype == RM_F16 || dtype == RM_F32) && vec_ok && !(flags_dev & 1u)) {
+        // all-register variant for narrow frame buffers (rm_down_chain_u8.h): a lane owns 16 adjacent pixels
         DownGeom g8;
         if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny)) {
             const size_t fs = (size_t)h[0] * w[0];
             const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
-            const uint8_t *f = (const uint8_t *)frames;
-            switch (S) {
-            case 1: hipLaunchKernelGGL((k_down_chain_u8<1>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
-            case 2: hipLaunchKernelGGL((k_down_chain_u8<2>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
-            case 3: hipLaunchKernelGGL((k_down_chain_u8<3>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
-            default: hipLaunchKernelGGL((k_down_chain_u8<4>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+#define RM_REG_CASE(SS, TT, ptr) case SS: hipLaunchKernelGGL((k_down_chain_u8<SS, TT>), dim3(grid), dim3(64), 0, s, ptr, fs, g8, out); break;
+#define RM_REG_SWITCH(TT)                                                                                   \
+            {                                                                                               \
+                const TT *f = (const TT *)frames;                                                           \
+                switch (S) { RM_REG_CASE(1, TT, f) RM_REG_CASE(2, TT, f) RM_REG_CASE(3, TT, f) default: hipLaunchKernelGGL((k_down_chain_u8<4, TT>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break; } \
             }
+            if (dtype == RM_U8) RM_REG_SWITCH(uint8_t)
+            else if (dtype == RM_F16) RM_REG_SWITCH(__half)
+            else RM_REG_SWITCH(float)
+#undef RM_REG_SWITCH
+#undef RM_REG_CASE
             LAUNCH_CHECK();
             return RM_OK;
         }

@@ -1,5 +1,10 @@
-// respmon_amd/csrc/rm_down_chain_u8.h -- fused Gaussian pyramid chain for uint8 frame buffers
-// frames[T,H,W] uint8 (W % 16 == 0) -> G_S[T,h_S,w_S] float64, S <= 4           (pyramid.py:9-17)
+// respmon_amd/csrc/rm_down_chain_u8.h -- fused Gaussian pyramid chain for NARROW frame buffers (uint8, float16, float32)
+// frames[T,H,W] (W % 16 == 0) -> G_S[T,h_S,w_S] float64, S <= 4                   (pyramid.py:9-17)
+//
+// Written for uint8 first (the text below); float16 / float32 buffers use the same register-resident chain with
+// 2 / 4 sixteen-byte loads per lane and row instead of one (a lane still owns 16 adjacent pixels), and their
+// values widen exactly to float64.  float64 buffers keep the 2-pixels-per-lane DPP front end of rm_down_chain.h:
+// 128 contiguous bytes per lane would make every load instruction touch 64 cache lines.
 //
 // uint8 is what a camera delivers and 1/8 of the HBM bytes of the reference's float64 buffer; the kernels
 // apply uint8_to_float's  k * (1./255)  (transforms.py:20-23) on the fly, so results are bit-identical to
@@ -27,9 +32,15 @@ template <int S, int K> struct VStateU8 : VStateU8<S, K + 1> {
 };
 template <int S> struct VStateU8<S, S> {};
 
-template <int S>
+template <typename Tin> struct RegTraits;   // NLD: 16-byte loads per lane and row; PF: rows in flight
+template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8_PREFETCH; };
+template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = 3; };
+template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = 2; };
+
+template <int S, typename Tin = uint8_t>
 struct RegChain {
     static_assert(S >= 1 && S <= 4, "a lane owns 16 >> K columns of level K");
+    static constexpr int NLD = RegTraits<Tin>::NLD, PF = RegTraits<Tin>::PF, VPER = 16 / NLD;  // VPER pixels per 16-byte load
     const DownGeom &g;
     const int lane;
     int next[S + 1], last[S + 1];
@@ -140,7 +151,7 @@ struct RegChain {
         }
     }
 
-    __device__ __forceinline__ void run(const uint8_t *frame, double *out_t, int strip, int seg)
+    __device__ __forceinline__ void run(const Tin *frame, double *out_t, int strip, int seg)
     {
         out_frame = out_t;
         const int W = g.w[0];
@@ -153,20 +164,25 @@ struct RegChain {
         last_lane = (c_first + 15 == W - 1);
         store_ok = lane >= 2 && lane <= 61;
         col_S = c_first >> S;                                  // exact: P and 16*lane are multiples of 16 >= 2^S
-        const uint8_t *src = frame + min(max(c_first, 0), W - 16);
+        const Tin *src = frame + min(max(c_first, 0), W - 16);
         const int p_first = next[0], p_last = last[0];
-        Raw16 regs[RM_U8_PREFETCH];
+        Raw16 regs[PF][NLD];
+        auto issue = [&](int row, Raw16 (&r)[NLD]) __attribute__((always_inline)) {
+            const Tin *rp = src + (size_t)row * W;
 #pragma unroll
-        for (int i = 0; i < RM_U8_PREFETCH; ++i) regs[i] = *reinterpret_cast<const Raw16 *>(src + (size_t)min(p_first + i, p_last) * W);
-        for (int base = p_first; base <= p_last; base += RM_U8_PREFETCH) {
+            for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(rp + j * VPER);
+        };
 #pragma unroll
-            for (int i = 0; i < RM_U8_PREFETCH; ++i) {
+        for (int i = 0; i < PF; ++i) issue(min(p_first + i, p_last), regs[i]);
+        for (int base = p_first; base <= p_last; base += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
                 const int p = base + i;
                 if (p <= p_last) {
                     double v[16], n[8];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = unpack_px<uint8_t>(regs[i], e);
-                    regs[i] = *reinterpret_cast<const Raw16 *>(src + (size_t)min(p + RM_U8_PREFETCH, p_last) * W);
+                    for (int e = 0; e < 16; ++e) v[e] = unpack_px<Tin>(regs[i][e / VPER], e % VPER);
+                    issue(min(p + PF, p_last), regs[i]);
                     hfilter<0>(v, n);
                     feed<0>(p, n);
                 }
@@ -175,8 +191,8 @@ struct RegChain {
     }
 };
 
-template <int S>
-__global__ __launch_bounds__(64) void k_down_chain_u8(const uint8_t *frames, size_t frame_stride, DownGeom g, double *out)
+template <int S, typename Tin = uint8_t>
+__global__ __launch_bounds__(64) void k_down_chain_u8(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
 {
     const int per_frame = g.strips * g.segs;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(64) void k_down_chain_u8(const uint8_t *frames, siz
     if (t >= g.T) return;
     const int inner = j % per_frame;
     const int seg = inner / g.strips, strip = inner - seg * g.strips;
-    RegChain<S> rc(g);
+    RegChain<S, Tin> rc(g);
     rc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }
 
