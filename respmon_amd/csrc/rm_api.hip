@@ -985,11 +985,12 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
+    unsigned int *slots_seen_dev = nullptr;   // the slot demand of this call goes straight to pinned host memory
+    HIP_TRY(hipHostGetDevicePointer((void **)&slots_seen_dev, ctx->h_slots_seen, 0));
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
-                       cp.store, st, thr, heat_sum, avg_T, tile_nkept);
+                       cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev);
     LAUNCH_CHECK();
     if (avg_T > 0) { ctx->nkept_H = cp.H; ctx->nkept_W = cp.W; }   // the whole-buffer heatmap's constant tiles are known
-    HIP_TRY(hipMemcpyAsync(ctx->h_slots_seen, &st->n_slots, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     ctx->slots_seen_pairs = cp.npairs;
     return RM_OK;
 }
@@ -1175,16 +1176,18 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
     CollapseState *st = ctx->d_state;
-    // the thresholded image goes to the host bit-packed (npix / 8 bytes, pinned) in one copy
+    // the thresholded image goes to the host bit-packed (npix / 8 bytes): the kernel stores its ballot words straight
+    // into pinned, device-mapped host memory (one 8-byte store per 64 pixels rides the kernel; a separate
+    // device-to-host copy costs ~15 us of copy-engine start-up on this path)
     const size_t nwords = (npix + 63) / 64;
-    unsigned long long *bits = nullptr;
-    RM_TRY(ws(ctx, "binary_bits", nwords, &bits));
     if (ctx->h_bin_cap < nwords * 8) {
         if (ctx->h_bin) HIP_TRY(hipHostFree(ctx->h_bin));
         ctx->h_bin = nullptr; ctx->h_bin_cap = 0;
         HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, nwords * 8, hipHostMallocDefault));
         ctx->h_bin_cap = nwords * 8;
     }
+    unsigned long long *bits = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&bits, ctx->h_bin, 0));
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
     if (!have_minmax) {  // rm_calibrate has just left the heatmap's min / max in the state
@@ -1195,7 +1198,6 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     }
     hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, binary, bits);
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(ctx->h_bin, bits, nwords * 8, hipMemcpyDeviceToHost, s));
     delete pt_roi; pt_roi = nullptr;
     HIP_TRY(stream_wait(s));
     RoiResult r;

@@ -813,7 +813,7 @@ constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
-                                                          int *tile_nkept)
+                                                          int *tile_nkept, unsigned int *slots_seen_host)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
@@ -824,7 +824,10 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;
-    if (tile == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    if (tile == 0 && tid == 0) {
+        st->min_val = min_val; st->max_val = max_val; st->top = top;
+        if (slots_seen_host) *slots_seen_host = st->n_slots;   // pinned host word: the next call sizes the value store from it
+    }
     const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
     // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks).
     // Ordered compaction of the frames that are not pruned: ballot + prefix popcount, 256 frames per round.

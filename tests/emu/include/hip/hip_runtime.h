@@ -211,6 +211,7 @@ inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 2
 inline hipError_t hipFree(void *p) { free(p); return 0; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return 0; }
+inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
