@@ -68,6 +68,7 @@ struct Tracer {
     std::vector<uint32_t> own_row_any;
     std::vector<int> row_x0, row_x1;   // first / last foreground column of each dirty row (image coordinates)
     std::vector<int> clr_x0, clr_x1;   // column range of a dirty row that is not background
+    std::vector<int> grp_a, grp_b;     // first / last 64-pixel group of a row that holds foreground
 
     // 64 pixels starting at bit position `pos` of the packed image (bits past `end` read as background)
     static inline uint64_t get64(const uint64_t *bits, size_t pos, size_t end)
@@ -101,6 +102,7 @@ struct Tracer {
         if ((int)clr_x0.size() != H) { clr_x0.assign(H, 0); clr_x1.assign(H, W - 1); }
         own_row_any.assign(H, 0);
         row_x0.assign(H, 0); row_x1.assign(H, -1);
+        grp_a.assign(H, 0); grp_b.assign(H, -1);
         for (int y = 0; y < H; ++y) {
             signed char *d = buf.data() + (size_t)(y + 1) * step + 1;
             const size_t r0 = (size_t)y * W;
@@ -137,7 +139,7 @@ struct Tracer {
                 }
             }
             if (x0 < 0) continue;
-            dirty[y] = 1; own_row_any[y] = 1; row_x0[y] = x0; row_x1[y] = x1;
+            dirty[y] = 1; own_row_any[y] = 1; row_x0[y] = x0; row_x1[y] = x1; grp_a[y] = xa; grp_b[y] = xb;
             clr_x0[y] = x0 & ~63; clr_x1[y] = ((x1 | 63) < W - 1) ? (x1 | 63) : W - 1;   // whole groups were written
         }
         const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
@@ -200,13 +202,66 @@ int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *r
     return scan_prepared(g_tracer, H, row_any, out, false);
 }
 
+// Raster scan for border starts driven by the PACKED image: the foreground runs of a row come from bit tricks on
+// the 64-pixel groups, so background pixels are never touched, and the marks the border follower leaves (only ever
+// on foreground pixels) are read back per run.  Same decisions as scan_prepared():
+//   a run starts a new outer border iff its first pixel is still unmarked and the last marked pixel to its left in
+//   this row is not a SEEN (entering) border, i.e. we are not inside an already traced component (RETR_EXTERNAL);
+//   the "last marked pixel" then moves to the last marked pixel of this run, if it has one.
+static int scan_runs(Tracer &tr, const uint64_t *bits, int H, int W, RoiResult *out)
+{
+    const int step = tr.step;
+    double best = -1.0;
+    for (int y = 0; y < H; ++y) {
+        if (!tr.own_row_any[y]) continue;
+        signed char *row = tr.buf.data() + (size_t)(y + 1) * step + 1;   // row[c] = pixel c
+        const size_t r0 = (size_t)y * W;
+        int last_mark = BG;      // value of the last marked pixel seen in this row (BG: none, the zero frame)
+        int run_start = -1;
+        uint64_t prev_bit = 0;
+        auto handle_run = [&](int a, int b) {   // pixels [a, b) are foreground in the image
+            if (row[a] == FG && !(last_mark > 0)) {
+                int minx, miny, maxx, maxy;
+                long long a2 = tr.follow(row + a, a + 1, y + 1, minx, miny, maxx, maxy);
+                double area = 0.5 * (double)(a2 < 0 ? -a2 : a2);
+                ++out->n_contours;
+                if (area >= best) {
+                    best = area;
+                    out->found = 1;
+                    out->x = minx - 1; out->y = miny - 1;
+                    out->w = maxx - minx + 1; out->h = maxy - miny + 1;
+                    out->area = area;
+                }
+            }
+            for (int x = b - 1; x >= a; --x)
+                if (row[x] & -2) { last_mark = row[x]; break; }
+        };
+        for (int x = tr.grp_a[y]; x <= tr.grp_b[y]; x += 64) {
+            const uint64_t v = Tracer::get64(bits, r0 + x, r0 + W);
+            uint64_t t = v ^ ((v << 1) | prev_bit);   // bit k set: pixel x+k differs from pixel x+k-1
+            prev_bit = v >> 63;
+            while (t) {
+                const int pos = x + __builtin_ctzll(t);
+                t &= t - 1;
+                if (run_start < 0) run_start = pos;
+                else { handle_run(run_start, pos); run_start = -1; }
+            }
+        }
+        if (run_start >= 0) {   // the run reaches the end of the last group that holds foreground
+            const int end = (tr.grp_b[y] + 64 < W) ? tr.grp_b[y] + 64 : W;
+            handle_run(run_start, end);
+        }
+    }
+    return 0;
+}
+
 int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult *out)
 {
     out->found = 0; out->n_contours = 0; out->area = 0.0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare_bits(bits, H, W);
-    return scan_prepared(g_tracer, H, g_tracer.own_row_any.data(), out, true);
+    return scan_runs(g_tracer, bits, H, W, out);
 }
 
 // `have_ranges`: pixels left of row_x0 / right of row_x1 are background without marks (borders only visit

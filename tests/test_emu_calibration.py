@@ -259,3 +259,25 @@ def test_emu_error_conventions(emu):
     assert lib.rm_locate(ctx, ptr(flat), _capi.RM_F64, 8, 16, 16, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 20, 0, ptr(xywh), None) == _capi.RM_NO_CONTOUR
     # T beyond the supported maximum is reported, not truncated
     assert lib.rm_calibrate(ctx, ptr(f), _capi.RM_F64, 5000, 8, 8, 10.0, 0.1, 1.0, 500.0, 4, 2, 0.7, 0, ptr(heat), None, None) == -4
+
+
+def test_emu_contour_stage_many_components_and_nesting(emu, oracle):
+    """The run-based raster scan of the host contour stage (rm_contour.cpp scan_runs) on images with thousands of
+    components, holes, and components nested inside holes (RETR_EXTERNAL must skip those), against the oracle's
+    independent findContours restatement."""
+    rng = np.random.default_rng(33)
+    masks = []
+    for (h, w, dens) in [(40, 131, 0.15), (64, 64, 0.35), (57, 200, 0.5), (33, 129, 0.62), (20, 70, 0.05), (48, 192, 0.45)]:
+        masks.append(rng.random((h, w)) < dens)
+    ring = np.zeros((60, 150), bool)                      # ring with an island in its hole, twice nested, plus noise outside
+    ring[5:55, 10:90] = True; ring[12:48, 20:80] = False; ring[20:40, 30:70] = True; ring[25:35, 40:60] = False
+    ring[28:32, 45:55] = True
+    ring[:, 100:] = rng.random((60, 50)) < 0.3
+    masks.append(ring)
+    full = np.ones((17, 66), bool); full[8, 33] = False   # everything foreground but one pixel; touches all four frame edges
+    masks.append(full)
+    for m in masks:
+        heat = m.astype(np.float64)
+        roi, u8, binary = emu.heatmap_to_roi(heat, threshold=20)
+        assert np.array_equal(binary != 0, m)
+        assert roi == oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20), m.shape
