@@ -85,6 +85,11 @@ def load():
     """Load the gfx950 HIP library.  Fails loudly: there is no other implementation to fall back to."""
     global _LIB
     if _LIB is None:
+        # PyTorch-ROCm ships its own HIP / HSA runtime libraries (torch/lib) under the same SONAMEs as /opt/rocm's.
+        # They must be in the process BEFORE this library is opened, so that its libamdhip64.so.7 dependency resolves
+        # to the runtime that owns torch's device memory and streams; loaded the other way round the process ends
+        # up with two runtimes and the second one finds "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RespmonError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
                                "g.build()'` or `make -C respmon_amd/csrc`)" % LIB_PATH)

@@ -2,6 +2,7 @@
 the CPU oracle and the committed golden vectors.  Bit-exact for ROI coordinates and the uint8 heatmap;
 float magnitudes within 1e-4 relative (north_star) -- in practice ~1e-15."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -365,3 +366,18 @@ def test_calibration_image_panels(hip, oracle, tmp_path):
     finally:
         os.chdir(cwd)
     assert img.shape == (2 * 96, 3 * 128) and np.array_equal(img, montage.montage(panels))
+
+
+def test_library_first_then_torch_in_a_fresh_process(hip):
+    """`build()` opens the HIP library before anything touches the GPU; `smoke()` may follow in the same process.
+    PyTorch bundles its own HIP runtime under the same SONAME, so the loader must see torch first (_capi.load)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from respmon_amd import _capi\n"
+            "lib = _capi.load(); assert lib.rm_abi_version() == 1\n"
+            "import __graft_entry__ as g\n"
+            "g.build(); g.smoke(); print('ok')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
