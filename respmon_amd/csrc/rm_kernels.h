@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int s
 // in one [T, NP] buffer, so one launch per stage serves every filtered level.
 constexpr int TF_KC = 4, TF_SC = 8, TF_U = 16;
 
-// Measured and rejected: splitting T over 4 waves per workgroup with an LDS reduction (48 us vs 42 us for stage 1);
+// Measured and rejected (1080p x 256, both stages 0.064 ms as written): splitting T over 4 waves per workgroup with an
+// LDS reduction (stage 1 48 us vs 42 us); splitting T over 2 / 4 workgroups with partial y buffers (+11 / +56 us);
+// 8 / 12 / 16 rows of R per workgroup instead of 4, i.e. fewer re-reads of x through L2 but fewer waves (+10 / +25 /
+// +34 us); 16 output rows per workgroup in stage 2 (no change);
 // one fused kernel per 64 pixel columns that reads x once, keeps all y[k] in registers and takes the
 // coefficients through the scalar cache (128 us vs 64 us for both stages: one workgroup per CU exposes every
 // scalar-load and global-load latency, the two-stage form has 8-20 waves per CU to hide them).
