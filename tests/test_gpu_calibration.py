@@ -381,3 +381,14 @@ def test_library_first_then_torch_in_a_fresh_process(hip):
             "g.build(); g.smoke(); print('ok')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_long_buffers(hip, oracle):
+    """Long calibration buffers (T = 512 and 1024: 92 / 184 surviving rfft rows, several 256-frame rounds in the
+    kept-frame compaction) against the oracle."""
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    for (T, H, W, L, S) in [(512, 48, 80, 5, 2), (1024, 40, 64, 5, 2)]:
+        frames = oracle.uint8_to_float(synth.synth_breathing(T, H, W, seed=T))
+        ref = oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
+        assert RespiratoryMonitor.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S) == ref, (T, H, W)
