@@ -53,7 +53,7 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 struct CollapsePlan {
     ChainGeom g;
     int ntiles = 0, npairs = 0;
-    double *lo = nullptr, *hi = nullptr, *store = nullptr;
+    double *lo = nullptr, *hi = nullptr, *store = nullptr, *slot_min = nullptr;
     unsigned int *list = nullptr;
     int *slot_of = nullptr;
     size_t shmem = 0;
@@ -940,6 +940,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
     RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
+    RM_TRY(ws(ctx, "slot_min", slot_cap, &cp.slot_min));
     {
         // per-frame separable form when its row-extrema table fits LDS, else the per-pair kernel
         const size_t tbl = 2 * sizeof(double) * (size_t)g.h[g.S] * g.tiles_x;
@@ -958,7 +959,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
     unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
-    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list, cp.slot_of, st, cp.store);
+    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list, cp.slot_of, st, cp.store, cp.slot_min);
     LAUNCH_CHECK();
     cp.valid = true;
     return RM_OK;
@@ -988,7 +989,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     unsigned int *slots_seen_dev = nullptr;   // the slot demand of this call goes straight to pinned host memory
     HIP_TRY(hipHostGetDevicePointer((void **)&slots_seen_dev, ctx->h_slots_seen, 0));
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
-                       cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev);
+                       cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev, cp.slot_min);
     LAUNCH_CHECK();
     if (avg_T > 0) { ctx->nkept_H = cp.H; ctx->nkept_W = cp.W; }   // the whole-buffer heatmap's constant tiles are known
     ctx->slots_seen_pairs = cp.npairs;

@@ -736,7 +736,7 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
 // Exact raw.min()/raw.max() (transforms.py:185,187) come from here; values of pairs that can fall
 // below `top` are parked in `store` ([slot][row][lane], coalesced) for the masked time sum.
 __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list,
-                                                   const int *slot_of, CollapseState *st, double *store)
+                                                   const int *slot_of, CollapseState *st, double *store, double *slot_min)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     const unsigned n = st->n_list;
@@ -750,18 +750,24 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
         chain_to_level1(g, tile, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
         int x = R0.x0 + lane;
         const int slot = uniform(slot_of[idx]);
+        double pmn = inf;   // minimum of this pair's tile: the sum pass skips kept frames that turn out fully masked
         if (x <= R0.x1) {
             double v[CT_H];
             level0_rows<CT_H>(g, R0, R1, lds, x, 0, v);
             int rows = R0.y1 - R0.y0 + 1;
 #pragma unroll
             for (int j = 0; j < CT_H; ++j)
-                if (j < rows) { mn = (v[j] < mn) ? v[j] : mn; mx = (v[j] > mx) ? v[j] : mx; }
+                if (j < rows) { pmn = (v[j] < pmn) ? v[j] : pmn; mx = (v[j] > mx) ? v[j] : mx; }
             if (slot >= 0) {
                 double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
 #pragma unroll
                 for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
             }
+        }
+        mn = (pmn < mn) ? pmn : mn;
+        if (slot >= 0) {   // wave-uniform
+            pmn = wave_min(pmn);
+            if (lane == 0) slot_min[slot] = pmn;
         }
         __syncthreads();
     }
@@ -816,7 +822,7 @@ constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
-                                                          int *tile_nkept, unsigned int *slots_seen_host)
+                                                          int *tile_nkept, unsigned int *slots_seen_host, const double *slot_min)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_slot[MAX_T];
@@ -837,7 +843,10 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
     int nkept = 0;
     for (int c0 = t_first; c0 < t_end; c0 += 256) {
         const int t = c0 + tid;
-        const int slot = (t < t_end) ? slot_of[(size_t)t * ntiles + tile] : SLOT_PRUNED;
+        int slot = (t < t_end) ? slot_of[(size_t)t * ntiles + tile] : SLOT_PRUNED;
+        // a kept frame whose whole tile is >= top adds `min` to every pixel, exactly like a pruned one: drop it here
+        // (its exact minimum was recorded by the evaluation pass) instead of loading its 8 KB of values
+        if (slot >= 0 && slot_min[slot] >= top) slot = SLOT_PRUNED;
         if (t < t_end) s_slot[t] = slot;
         const bool kept = slot != SLOT_PRUNED;
         const unsigned long long m = __ballot(kept);
