@@ -742,6 +742,7 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     const unsigned n = st->n_list;
     const int lane = threadIdx.x;
     const double inf = __builtin_huge_val();
+    const double top_ub = st->top_ub;   // upper bound of `top` from the tile bounds (k_select_pairs)
     double mn = inf, mx = -inf;
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
         const unsigned idx = (unsigned)uniform((int)list[c]);   // wave-uniform: the tile geometry stays in scalar registers
@@ -751,23 +752,25 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
         int x = R0.x0 + lane;
         const int slot = uniform(slot_of[idx]);
         double pmn = inf;   // minimum of this pair's tile: the sum pass skips kept frames that turn out fully masked
+        double v[CT_H];
+        const int rows = R0.y1 - R0.y0 + 1;
         if (x <= R0.x1) {
-            double v[CT_H];
             level0_rows<CT_H>(g, R0, R1, lds, x, 0, v);
-            int rows = R0.y1 - R0.y0 + 1;
 #pragma unroll
             for (int j = 0; j < CT_H; ++j)
                 if (j < rows) { pmn = (v[j] < pmn) ? v[j] : pmn; mx = (v[j] > mx) ? v[j] : mx; }
-            if (slot >= 0) {
-                double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
-#pragma unroll
-                for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
-            }
         }
         mn = (pmn < mn) ? pmn : mn;
         if (slot >= 0) {   // wave-uniform
             pmn = wave_min(pmn);
-            if (lane == 0) slot_min[slot] = pmn;
+            // nothing of this tile can fall below top (top <= top_ub): no values to park, the sum pass treats it as pruned
+            const bool masked_for_sure = pmn >= top_ub;
+            if (lane == 0) slot_min[slot] = masked_for_sure ? inf : pmn;
+            if (!masked_for_sure && x <= R0.x1) {
+                double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
+#pragma unroll
+                for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
+            }
         }
         __syncthreads();
     }
