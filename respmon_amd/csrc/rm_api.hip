@@ -872,6 +872,14 @@ static int make_geom(const SmallLevels &sl, ChainGeom &g)
         g.lds_off[k] = off;
         off += (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k) + 1);
     }
+    // scratch of the separable pyrUp steps: every source row of level k at the destination columns of level k-1
+    int hb = 0;
+    for (int k = 2; k <= S; ++k) {
+        const int n = (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k - 1) + 1);
+        if (n > hb) hb = n;
+    }
+    g.lds_hbuf = off;
+    off += hb;
     g.lds_total = off;
     g.tiles_x = (sl.w[0] + CT_W - 1) / CT_W;
     g.tiles_y = (sl.h[0] + CT_H - 1) / CT_H;

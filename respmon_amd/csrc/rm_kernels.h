@@ -400,6 +400,7 @@ struct ChainGeom {
     int S;                       // number of pyrUp steps (== skip_levels_at_top), 1..MAX_CHAIN-1
     int h[MAX_CHAIN], w[MAX_CHAIN];  // level sizes, index 0 = full resolution
     int lds_off[MAX_CHAIN];      // offset (doubles) of level k's tile buffer in LDS, k = 1..S
+    int lds_hbuf;                // offset of the scratch buffer of the horizontal pass (chain_step)
     int lds_total;               // doubles
     int tiles_x, tiles_y;
 };
@@ -674,38 +675,94 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
     if (listed) list[base_list + (unsigned)__popcll(mL & below)] = (unsigned)i;
 }
 
-// stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
-__device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, const double *cS_t, double *lds)
+// ---- pyrUp inside LDS, separable and branch-free -------------------------------------------------------------
+// up_h() above chooses between five differently shaped expressions per column (interior / left / right border,
+// even / odd), which on a wavefront means divergent branches and every shape executed.  The same values, bit for
+// bit, come out of ONE shape with per-column operands and weights fixed once per level:
+//     h(x) = (A*wa + B*wb) + C*wc
+//   even interior  A=s[j-1] B=s[j] C=s[j+1]  w = 1,6,1    == s[j-1] + s[j]*6 + s[j+1]
+//   even left      B=s[0]   C=s[1]           w = 0,6,2    == s[0]*6 + s[1]*2          (0 + x is exact)
+//   even right     A=s[j-1] B=s[j]           w = 1,7,0    == s[j-1] + s[j]*7          (x + 0 is exact)
+//   odd  interior  B=s[j]   C=s[j+1]         w = 0,4,4    == (s[j] + s[j+1])*4        (scaling by 4 commutes with rounding)
+//   odd  right / single column  B=C=s[j]     w = 0,4,4    == s[j]*8
+// (only the sign of an exact zero can differ, which no later operation observes).  The vertical pass needs no such
+// trick: OpenCV's border rules are index clamps there, and row parity is uniform across a wavefront.
+struct HTap { int ia, ib, ic; double wa, wb, wc; };
+
+__device__ __forceinline__ HTap make_htap(int x, int sw)   // destination column x of a pyrUp from a source row of width sw
 {
-    const int lane = threadIdx.x, nthr = blockDim.x;
+    HTap t;
+    const int j = x >> 1;
+    const bool odd = (x & 1) != 0, single = sw == 1, left = j == 0, right = j == sw - 1;
+    const bool four = odd || single;                      // the (B + C) * 4 shapes
+    t.ib = j;
+    t.ia = (four || left) ? j : j - 1;                   // unused (weight 0) in those shapes: any valid index
+    t.ic = (single || right) ? j : j + 1;
+    t.wa = (four || left) ? 0.0 : 1.0;
+    t.wb = four ? 4.0 : (right ? 7.0 : 6.0);
+    t.wc = four ? 4.0 : (left ? 2.0 : (right ? 0.0 : 1.0));
+    return t;
+}
+
+// stage the level-S footprint of `tile` for frame t
+__device__ __forceinline__ Region chain_stage(const ChainGeom &g, int tile, const double *cS_t, double *lds)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int S = g.S;
-    Region Rk = tile_region(g, tile, S);
-    {
-        double *d = lds + g.lds_off[S];
-        const int nw = Rk.x1 - Rk.x0 + 1, n = (Rk.y1 - Rk.y0 + 1) * nw, wS = g.w[S];
-        const float inv_nw = 1.0f / (float)nw;
-        for (int i = lane; i < n; i += nthr) {
-            int r, c;
-            split_rc(i, nw, inv_nw, r, c);
-            d[i] = cS_t[(size_t)(Rk.y0 + r) * wS + Rk.x0 + c];
+    const Region Rk = tile_region(g, tile, S);
+    double *d = lds + g.lds_off[S];
+    const int nw = Rk.x1 - Rk.x0 + 1, n = (Rk.y1 - Rk.y0 + 1) * nw, wS = g.w[S];
+    const float inv_nw = 1.0f / (float)nw;
+    for (int i = tid; i < n; i += nthr) {
+        int r, c;
+        split_rc(i, nw, inv_nw, r, c);
+        d[i] = cS_t[(size_t)(Rk.y0 + r) * wS + Rk.x0 + c];
+    }
+    __syncthreads();
+    return Rk;
+}
+
+// one pyrUp step inside LDS, level k (footprint Rk) -> level k-1: horizontal pass into the scratch buffer (every
+// source row at the destination columns), then the vertical pass.  Wave w takes rows w, w + nwaves, ...; lane = column.
+__device__ __forceinline__ Region chain_step(const ChainGeom &g, int tile, double *lds, int k, const Region &Rk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    const Region Rd = tile_region(g, tile, k - 1);
+    const double *src = lds + g.lds_off[k];
+    double *hb = lds + g.lds_hbuf, *dst = lds + g.lds_off[k - 1];
+    const int sp = Rk.x1 - Rk.x0 + 1, srows = Rk.y1 - Rk.y0 + 1;      // source pitch / rows
+    const int dw = Rd.x1 - Rd.x0 + 1, drows = Rd.y1 - Rd.y0 + 1;
+    const int sh = g.h[k], sw = g.w[k];
+    for (int c = lane; c < dw; c += 64) {
+        const HTap t = make_htap(Rd.x0 + c, sw);
+        const int oa = t.ia - Rk.x0, ob = t.ib - Rk.x0, oc = t.ic - Rk.x0;
+        for (int r = wave; r < srows; r += nwaves) {
+            const double *row = src + r * sp;
+            hb[r * dw + c] = (row[oa] * t.wa + row[ob] * t.wb) + row[oc] * t.wc;
         }
     }
     __syncthreads();
-    for (int k = S; k >= 2; --k) {
-        const Region Rd = tile_region(g, tile, k - 1);
-        LdsImg s{lds + g.lds_off[k], Rk.y0, Rk.x0, Rk.x1 - Rk.x0 + 1};
-        double *d = lds + g.lds_off[k - 1];
-        const int nw = Rd.x1 - Rd.x0 + 1, n = (Rd.y1 - Rd.y0 + 1) * nw;
-        const int hk = g.h[k], wk = g.w[k];
-        const float inv_nw = 1.0f / (float)nw;
-        for (int i = lane; i < n; i += nthr) {
-            int r, c;
-            split_rc(i, nw, inv_nw, r, c);
-            d[i] = up_at(s, Rd.y0 + r, Rd.x0 + c, hk, wk);
+    for (int r = wave; r < drows; r += nwaves) {
+        const int y = Rd.y0 + r, i = y >> 1;                          // uniform per wave: no divergence
+        const int r2 = ((i == sh - 1) ? i : i + 1) - Rk.y0;
+        const int r1 = i - Rk.y0;
+        if (y & 1) {
+            for (int c = lane; c < dw; c += 64) dst[r * dw + c] = ((hb[r1 * dw + c] + hb[r2 * dw + c]) * 4) * (1.0 / 64);
+        } else {
+            const int r0 = ((i == 0) ? (sh > 1 ? 1 : 0) : i - 1) - Rk.y0;
+            for (int c = lane; c < dw; c += 64)
+                dst[r * dw + c] = (hb[r0 * dw + c] + hb[r1 * dw + c] * 6 + hb[r2 * dw + c]) * (1.0 / 64);
         }
-        __syncthreads();
-        Rk = Rd;
     }
+    __syncthreads();
+    return Rd;
+}
+
+// stage the level-S footprint of `tile` for frame t, then run the chain S -> 1 inside LDS
+__device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, const double *cS_t, double *lds)
+{
+    Region Rk = chain_stage(g, tile, cS_t, lds);
+    for (int k = g.S; k >= 2; --k) Rk = chain_step(g, tile, lds, k, Rk);
 }
 
 // level 1 (LDS) -> level 0 for this lane's column: out[j] = raw[t, y0 + j0 + j, x], j < NR (j0, NR even)
@@ -713,8 +770,11 @@ template <int NR>
 __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0, const Region &R1, const double *lds, int x, int j0,
                                             double (&out)[NR])
 {
-    LdsImg s{lds + g.lds_off[1], R1.y0, R1.x0, R1.x1 - R1.x0 + 1};
+    const double *src = lds + g.lds_off[1];
+    const int sp = R1.x1 - R1.x0 + 1;
     const int sh = g.h[1], sw = g.w[1];
+    const HTap t = make_htap(x, sw);
+    const int oa = t.ia - R1.x0, ob = t.ib - R1.x0, oc = t.ic - R1.x0;
     // horizontal values of source rows i0-1 .. i0+NR/2 (border rules applied by row index)
     const int i0 = (R0.y0 + j0) >> 1;  // R0.y0 is a multiple of CT_H, j0 is even
     double hv[NR / 2 + 2];
@@ -722,7 +782,8 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
     for (int k = 0; k < NR / 2 + 2; ++k) {
         int i = i0 - 1 + k;
         int r = (i < 0) ? (sh > 1 ? 1 : 0) : (i > sh - 1 ? sh - 1 : i);
-        hv[k] = up_h(s, r, x, sw);
+        const double *row = src + (r - R1.y0) * sp;
+        hv[k] = (row[oa] * t.wa + row[ob] * t.wb) + row[oc] * t.wc;
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
