@@ -949,6 +949,14 @@ __global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, Chai
     };
     fetch(0, nxt);
     int t_done = t_first;
+    {   // every row starts with the same run of pruned frames: one chain of `+ min` instead of one per row
+        const int t_lead = (nkept > 0) ? (int)s_kept_t[0] : t_end;
+        double lead = 0.0;
+        for (int t = t_first; t < t_lead; ++t) lead = lead + min_val;
+#pragma unroll
+        for (int j = 0; j < MS_R; ++j) acc[j] = lead;
+        t_done = t_lead;
+    }
     for (int ib = 0; ib < nkept; ib += MS_B) {
         double cur[MS_B][MS_R];
 #pragma unroll
