@@ -240,7 +240,7 @@ def main():
             "heatmap_exchange": (rdist.LAST_EXCHANGE and {"sparse": "one all-gather of sparse packets (%d-tile cap, %.2f MB per rank)"
                                                           % (rdist.SPARSE_CAP_TILES, 8e-6 * (4 + rdist.SPARSE_CAP_TILES * 1025)),
                                                           "dense": "all-reduce(sum) of the [H,W] float64 heatmap"}[rdist.LAST_EXCHANGE])
-                                if world > 1 and not sharded else None,
+                                if world > 1 else None,
             "alt_uint8_buffer": alt,
             "roi_flow": roi_flow,
             "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},

@@ -155,14 +155,16 @@ int rm_heatmap_to_roi(rm_ctx *ctx, const double *heatmap_dev, int H, int W, int 
  *        rm_heat_sparse_packet_doubles(cap)  packet length in doubles
  *        rm_heat_sparse_pack      packet_dev <- heatmap of the LAST rm_calibrate on this context
  *          -- all-gather the packets: packets_dev[world][packet] --
- *        rm_heat_sparse_merge_roi fused_dev[H*W] = sum over ranks, in rank order, of the per-rank heatmaps, then
+ *        rm_heat_sparse_merge_roi fused_dev[H*W] = sum over ranks, in rank order, of the per-rank heatmaps (avg_T = 0),
+ *                                 or of the partial heat sums of a frame-sharded buffer divided by avg_T (rm_shard_heat
+ *                                 outputs: the sparse form of the heat-sum all-reduce + rm_shard_finish), then
  *                                 base.py:563-575 on it -> xywh_host.  Returns RM_OK / RM_NO_CONTOUR, or
  *                                 RM_SPARSE_FALLBACK when some rank needed more than cap_tiles tiles (every rank sees
  *                                 the same packets, so every rank falls back to the dense all-reduce together). */
 size_t rm_heat_sparse_packet_doubles(int cap_tiles);
 int rm_heat_sparse_pack(rm_ctx *ctx, const double *heat_dev, int H, int W, int cap_tiles, double *packet_dev, void *stream);
 int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets_dev, int world, int H, int W, int cap_tiles, int threshold,
-                             double *fused_dev, int32_t *xywh_host, void *stream);
+                             int avg_T, double *fused_dev, int32_t *xywh_host, void *stream);
 
 /* ---- base.py:547-601 RespiratoryMonitor.locate = rm_calibrate + rm_heatmap_to_roi ------- */
 int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W, double fps,

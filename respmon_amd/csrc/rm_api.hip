@@ -999,7 +999,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
                        cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev, cp.slot_min);
     LAUNCH_CHECK();
-    if (avg_T > 0) { ctx->nkept_H = cp.H; ctx->nkept_W = cp.W; }   // the whole-buffer heatmap's constant tiles are known
+    ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;   // the constant tiles of this heatmap (or partial heat sum of a frame shard) are known
     ctx->slots_seen_pairs = cp.npairs;
     return RM_OK;
 }
@@ -1076,6 +1076,7 @@ extern "C" int rm_shard_collapse(rm_ctx *ctx, const double *lap_all, int T, int 
     pyr_geom(H, W, levels, skip, flags, pg);
     CollapsePlan &cp = ctx->shard_plan;
     cp.valid = false;
+    ctx->nkept_H = ctx->nkept_W = 0;
     if (ctx->prof_on) ctx->prof_calls++;
     if (pg.all_zero) {  // band-passed pyramid is all zeros: min = max = 0, heat sum = 0
         cp.T = T; cp.t0 = t0; cp.t1 = t1; cp.H = H; cp.W = W; cp.S = -1; cp.valid = true;
@@ -1255,7 +1256,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
                                uint8_t *binary, void *stream, bool have_minmax);
 
 extern "C" int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets, int world, int H, int W, int cap_tiles, int threshold,
-                                        double *fused, int32_t *xywh, void *stream)
+                                        int avg_T, double *fused, int32_t *xywh, void *stream)
 {
     if (!ctx || !packets || !fused || !xywh || world < 1 || H < 1 || W < 1 || cap_tiles < 1)
         return fail(RM_E_BADARG, "rm_heat_sparse_merge_roi: bad argument");
@@ -1275,7 +1276,7 @@ extern "C" int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets, int 
     hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sparse_merge, dim3(ntiles), dim3(256), 0, s, packets, pd, world, cap_tiles, H, W, tiles_x, ntiles, map, fused,
-                       ctx->d_state);
+                       ctx->d_state, avg_T);
     LAUNCH_CHECK();
     // the ROI stage synchronises the stream; the overflow flag is in pinned memory by then
     const int rc = heatmap_to_roi_impl(ctx, fused, H, W, threshold, xywh, nullptr, nullptr, stream, true);

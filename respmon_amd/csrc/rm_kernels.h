@@ -1209,8 +1209,10 @@ __global__ __launch_bounds__(256) void k_sparse_index(const double *packets, siz
 }
 
 // fused[p] = sum over ranks (in rank order) of heat_r[p]; also the fused heatmap's min / max (striped)
+// avg_T > 0: the packets hold partial time SUMS of a frame-sharded buffer; the fused value is their sum / avg_T
 __global__ __launch_bounds__(256) void k_sparse_merge(const double *packets, size_t packet_doubles, int world, int cap, int H, int W,
-                                                      int tiles_x, int ntiles, const int *map, double *fused, CollapseState *st)
+                                                      int tiles_x, int ntiles, const int *map, double *fused, CollapseState *st,
+                                                      int avg_T)
 {
     const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * CT_H, x0 = tx * CT_W;
@@ -1225,6 +1227,7 @@ __global__ __launch_bounds__(256) void k_sparse_merge(const double *packets, siz
             const double v = slot >= 0 ? pk[SP_HDR + cap + (size_t)slot * (CT_H * CT_W) + i] : pk[1];
             acc = (r == 0) ? v : acc + v;
         }
+        if (avg_T > 0) acc = acc / (double)avg_T;   // np.average = sum / T (base.py:562)
         fused[(size_t)y * W + x] = acc;
         mn = (acc < mn) ? acc : mn;
         mx = (acc > mx) ? acc : mx;

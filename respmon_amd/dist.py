@@ -69,10 +69,11 @@ LAST_EXCHANGE = None      # "sparse" / "dense": how the last locate_streams summ
 SPARSE_CAP_TILES = 128   # tiles (64x16 px) a packet can carry: 1 MB per rank; the synthetic 1080p x 256 stream needs ~80
 
 
-def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TILES):
+def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TILES, avg_T=0):
     """All ranks' heatmaps summed in rank order through ONE all-gather of sparse packets (include/respmon_hip.h
     rm_heat_sparse_*), then the ROI stage.  Returns (status, roi, fused): status False = a packet overflowed on some
-    rank (every rank sees that) and the caller must use the dense all-reduce."""
+    rank (every rank sees that) and the caller must use the dense all-reduce.
+    avg_T > 0: `heat` is this rank's partial time SUM of a frame-sharded buffer (rm_shard_heat); fused = sum / avg_T."""
     import ctypes
     from . import _capi, device
     t = device.require_gpu()
@@ -98,7 +99,8 @@ def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TI
     fused = t.empty((H, W), dtype=t.float64, device=heat.device)
     xywh = (ctypes.c_int32 * 4)()
     rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(allp), world, H, W, cap_tiles, int(threshold),
-                                                       device.ptr(fused), xywh, device.stream_ptr()), "rm_heat_sparse_merge_roi")
+                                                       int(avg_T), device.ptr(fused), xywh, device.stream_ptr()),
+                     "rm_heat_sparse_merge_roi")
     if rc == _capi.RM_SPARSE_FALLBACK:
         return False, None, None
     roi = None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
@@ -243,7 +245,7 @@ class HipShardStages:
 
 
 def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4,
-                   temporal_threshold=0.7, threshold=20, flags=0, group=None, stages=None, return_heatmap=False):
+                   temporal_threshold=0.7, threshold=20, flags=0, group=None, stages=None, return_heatmap=False, sparse=None):
     """Mode A step: RespiratoryMonitor.locate (base.py:547-601) of ONE [T,H,W] calibration buffer whose frames
     shard_frames(T, rank, world) live on this rank as `buf_local`.  Every rank returns the same ROI."""
     dist = _dist()
@@ -262,6 +264,15 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
     mm = st.collapse(lap_all, T, t0, t1, H, W, fps, freq_min, freq_max, amplification, L, S, temporal_threshold, flags)
     _all_reduce(mm, dist.ReduceOp.MAX, group)
     heat_sum = st.heat(mm, temporal_threshold, H, W)
+    if sparse is None:
+        sparse = stages is None and world > 1
+    global LAST_EXCHANGE
+    if sparse:   # the partial heat sums are one constant outside a few tiles too: sparse all-gather instead of a 16.6 MB all-reduce
+        ok, roi, heat = hip_sparse_exchange_roi(heat_sum, threshold, group, avg_T=T)
+        if ok:
+            LAST_EXCHANGE = "sparse"
+            return (roi, heat) if return_heatmap else roi
+    LAST_EXCHANGE = "dense"
     _all_reduce(heat_sum, dist.ReduceOp.SUM, group)
     roi, heat = st.finish(heat_sum, T, threshold)
     return (roi, heat) if return_heatmap else roi

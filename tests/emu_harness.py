@@ -168,7 +168,7 @@ def _shard_methods():
             heats.append(heat); packets.append(pk)
         allp = np.concatenate(packets)
         fused = np.empty((H, W)); xywh = np.zeros(4, np.int32)
-        rc = self.ck(self.lib.rm_heat_sparse_merge_roi(ctxs[0], ptr(allp), len(videos), H, W, cap, threshold, ptr(fused), ptr(xywh), None),
+        rc = self.ck(self.lib.rm_heat_sparse_merge_roi(ctxs[0], ptr(allp), len(videos), H, W, cap, threshold, 0, ptr(fused), ptr(xywh), None),
                      "sparse_merge")
         for c in ctxs:
             self.lib.rm_ctx_destroy(c)

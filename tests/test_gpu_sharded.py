@@ -179,7 +179,7 @@ def test_sparse_heatmap_exchange_emulated_ranks(hip, oracle):
     allp = torch.cat(packets)
     fused = torch.empty((H, W), dtype=torch.float64, device="cuda")
     xywh = (ctypes.c_int32 * 4)()
-    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(allp), world, H, W, cap, 20, device.ptr(fused), xywh, sp), "merge")
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(allp), world, H, W, cap, 20, 0, device.ptr(fused), xywh, sp), "merge")
     dense = heats[0].clone()
     for h in heats[1:]:
         dense = dense + h                                   # rank order, like the merge kernel
@@ -194,14 +194,14 @@ def test_sparse_heatmap_exchange_emulated_ranks(hip, oracle):
     pd2 = int(lib.rm_heat_sparse_packet_doubles(small))
     pk2 = torch.empty(pd2, dtype=torch.float64, device="cuda")
     _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(heats[-1]), H, W, small, device.ptr(pk2), sp), "pack")
-    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(pk2), 1, H, W, small, 20, device.ptr(fused), xywh, sp), "merge")
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(pk2), 1, H, W, small, 20, 0, device.ptr(fused), xywh, sp), "merge")
     assert rc == _capi.RM_SPARSE_FALLBACK
     # a heatmap the context has no pruning bookkeeping for (other geometry) -> fall back as well
     other = torch.rand((64, 96), dtype=torch.float64, device="cuda")
     pk3 = torch.empty(pd, dtype=torch.float64, device="cuda")
     _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(other), 64, 96, cap, device.ptr(pk3), sp), "pack")
     f3 = torch.empty((64, 96), dtype=torch.float64, device="cuda")
-    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(pk3), 1, 64, 96, cap, 20, device.ptr(f3), xywh, sp), "merge")
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(pk3), 1, 64, 96, cap, 20, 0, device.ptr(f3), xywh, sp), "merge")
     assert rc == _capi.RM_SPARSE_FALLBACK
 
 
@@ -238,3 +238,47 @@ def test_two_processes_locate_streams_sparse_equals_dense(hip, oracle, tmp_path)
     assert np.array_equal(r0["fused_s"], r0["fused_d"])                      # two ranks: the dense sum has only one order
     assert np.array_equal(r0["roi_s"], r0["roi_d"]) and r0["roi_s"][2] > 0
     assert bool(r0["sparse_taken"]) and bool(r1["sparse_taken"])
+
+
+def _worker_sharded_big(rank, world, port, out_dir, T, H, W):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from respmon_amd import dist as rdist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    v8 = synth.synth_breathing(T, H, W, seed=123)
+    t0, t1 = rdist.shard_frames(T, rank, world)
+    local = torch.from_numpy(v8[t0:t1].copy()).cuda()          # uint8 frame shard
+    roi, heat = rdist.locate_sharded(local, T, 10, return_heatmap=True)
+    how = rdist.LAST_EXCHANGE
+    roi_d, heat_d = rdist.locate_sharded(local, T, 10, return_heatmap=True, sparse=False)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), roi=np.array(roi or (-1,) * 4), heat=heat.cpu().numpy(),
+             roi_d=np.array(roi_d or (-1,) * 4), heat_d=heat_d.cpu().numpy(), sparse=np.array(how == "sparse"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_locate_sharded_1080p_sparse_heat_sum(hip, tmp_path):
+    """Mode A at a size where the pruning bites: the partial heat sums travel as sparse packets (summed in rank order,
+    then / T) and give the same heatmap as the dense all-reduce and -- up to the association of the time sum -- as
+    the unsharded calibration."""
+    import torch
+    import torch.multiprocessing as mp
+    from respmon_amd import dist as rdist, synth
+    T, H, W = 128, 1080, 1920
+    port = _free_port()
+    mp.spawn(_worker_sharded_big, args=(2, port, str(tmp_path), T, H, W), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert bool(r0["sparse"]) and bool(r1["sparse"])
+    assert np.array_equal(r0["heat"], r1["heat"]) and np.array_equal(r0["roi"], r1["roi"])
+    assert np.array_equal(r0["heat"], r0["heat_d"]) and np.array_equal(r0["roi"], r0["roi_d"])   # two ranks: one summation order
+    buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=123)).cuda()
+    ref = rdist.hip_calibrate(buf, 10)
+    assert tuple(int(v) for v in r0["roi"]) == rdist.hip_heatmap_to_roi(ref, 20)
+    ref = ref.cpu().numpy()
+    assert np.abs(r0["heat"] - ref).max() <= 1e-12 * np.abs(ref).max()
