@@ -1235,10 +1235,10 @@ extern "C" int rm_heat_sparse_pack(rm_ctx *ctx, const double *heat, int H, int W
     if (!ctx || !heat || !packet || H < 1 || W < 1 || cap_tiles < 1) return fail(RM_E_BADARG, "rm_heat_sparse_pack: bad argument");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(packet, 0, sizeof(double) * SP_HDR, s));
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, ntiles = tiles_x * tiles_y;
     if (ctx->nkept_H != H || ctx->nkept_W != W) {
         // no pruning bookkeeping for this heatmap (skip 0, zero result, foreign heatmap): report overflow -> dense exchange
+        HIP_TRY(hipMemsetAsync(packet, 0, sizeof(double) * SP_HDR, s));
         const unsigned int over = (unsigned int)cap_tiles + 1u;
         HIP_TRY(hipMemcpyAsync(packet, &over, sizeof over, hipMemcpyHostToDevice, s));
         return RM_OK;
@@ -1264,16 +1264,11 @@ extern "C" int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets, int 
     HIP_TRY(hipSetDevice(ctx->device));
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, ntiles = tiles_x * tiles_y;
     const size_t pd = rm_heat_sparse_packet_doubles(cap_tiles);
-    int *map = nullptr, *flag = nullptr;
-    RM_TRY(ws(ctx, "sparse_map", (size_t)world * ntiles + 1, &map));
-    flag = map + (size_t)world * ntiles;
+    int *map = nullptr, *flag_dev = nullptr;
+    RM_TRY(ws(ctx, "sparse_map", (size_t)world * ntiles, &map));
     if (!ctx->h_flag) HIP_TRY(hipHostMalloc((void **)&ctx->h_flag, sizeof(int), hipHostMallocDefault));
-    HIP_TRY(hipMemsetAsync(map, 0xFF, sizeof(int) * (size_t)world * ntiles, s));
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_sparse_index, dim3(world), dim3(256), 0, s, packets, pd, world, cap_tiles, ntiles, map, flag);
-    LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
+    HIP_TRY(hipHostGetDevicePointer((void **)&flag_dev, ctx->h_flag, 0));
+    hipLaunchKernelGGL(k_sparse_index, dim3(1), dim3(256), 0, s, packets, pd, world, cap_tiles, ntiles, map, flag_dev, ctx->d_state);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sparse_merge, dim3(ntiles), dim3(256), 0, s, packets, pd, world, cap_tiles, H, W, tiles_x, ntiles, map, fused,
                        ctx->d_state, avg_T);

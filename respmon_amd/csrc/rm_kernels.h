@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(256) void k_sparse_background(const double *heat, i
         if (tile_nkept[i] == 0) atomicMin(&s_first, i);
     __syncthreads();
     if (threadIdx.x != 0) return;
+    packet[0] = 0.0; packet[1] = 0.0; packet[2] = 0.0; packet[3] = 0.0;   // header: count = 0 before k_sparse_pack counts
     if (s_first >= ntiles) { *reinterpret_cast<unsigned int *>(packet) = (unsigned int)cap + 1u; return; }
     const int ty = s_first / tiles_x, tx = s_first - ty * tiles_x;
     packet[1] = heat[(size_t)ty * CT_H * W + (size_t)tx * CT_W];
@@ -1194,18 +1195,27 @@ __global__ __launch_bounds__(256) void k_sparse_pack(const double *heat, int H, 
     for (int k = 0; k < CT_H * CT_W / 256; ++k) dst[threadIdx.x + 256 * k] = v[k];
 }
 
-// map[r][tile] = slot of `tile` in rank r's packet, or -1; flag[0] = 1 when some rank overflowed
+// ONE workgroup prepares the merge: map[r][tile] = slot of `tile` in rank r's packet or -1, flag_host[0] = 1 when some
+// rank overflowed (a pinned host word: the caller reads it after the ROI stage's synchronisation), and the stripes
+// the merge kernel reduces the fused heatmap's extrema into
 __global__ __launch_bounds__(256) void k_sparse_index(const double *packets, size_t packet_doubles, int world, int cap, int ntiles,
-                                                      int *map, int *flag)
+                                                      int *map, int *flag_host, CollapseState *st)
 {
-    const int r = blockIdx.x;
-    const double *pk = packets + (size_t)r * packet_doubles;
-    const unsigned int count = *reinterpret_cast<const unsigned int *>(pk);
-    if (count > (unsigned)cap) { if (threadIdx.x == 0) flag[0] = 1; return; }
-    for (unsigned int j = threadIdx.x; j < count; j += 256) {
-        const int tile = (int)pk[SP_HDR + j];
-        if (tile >= 0 && tile < ntiles) map[(size_t)r * ntiles + tile] = (int)j;
+    for (int i = threadIdx.x; i < world * ntiles; i += 256) map[i] = -1;
+    if (threadIdx.x < NSTRIPE) { st->heat_min_keys[threadIdx.x] = ~0ull; st->heat_max_keys[threadIdx.x] = 0ull; }
+    if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
+    __syncthreads();
+    int over = 0;
+    for (int r = 0; r < world; ++r) {
+        const double *pk = packets + (size_t)r * packet_doubles;
+        const unsigned int count = *reinterpret_cast<const unsigned int *>(pk);
+        if (count > (unsigned)cap) { over = 1; continue; }
+        for (unsigned int j = threadIdx.x; j < count; j += 256) {
+            const int tile = (int)pk[SP_HDR + j];
+            if (tile >= 0 && tile < ntiles) map[(size_t)r * ntiles + tile] = (int)j;
+        }
     }
+    if (threadIdx.x == 0) flag_host[0] = over;
 }
 
 // fused[p] = sum over ranks (in rank order) of heat_r[p]; also the fused heatmap's min / max (striped)
