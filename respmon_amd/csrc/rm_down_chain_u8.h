@@ -208,7 +208,10 @@ __global__ __launch_bounds__(64) void k_down_chain_u8(const Tin *frames, size_t 
 inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom &g, bool tiny = false)
 {
     if (S < 1 || S > 4 || (w[0] % 16) != 0) return false;
-    for (int k = 0; k < S; ++k) if (h[k] < 3) return false;
+    // every filtered level needs >= 3 rows (streaming vertical pass) and >= 3 columns: the in-lane border selects of
+    // hfilter() realise BORDER_REFLECT_101 as -2 -> 2, -1 -> 1, w -> w-2, which is only what OpenCV does for w >= 3
+    // (found by tools/fuzz_parity.py: 16-pixel-wide frames with 4 levels reach a 2-column level)
+    for (int k = 0; k < S; ++k) if (h[k] < 3 || w[k] < 3) return false;
     g.S = S; g.T = T; g.vec = 1; g.y_begin = 0; g.y_end = h[S];
     for (int k = 0; k <= S; ++k) { g.h[k] = h[k]; g.w[k] = w[k]; }
     g.strips = (w[0] + U8_STRIP_PX - 1) / U8_STRIP_PX;

@@ -383,6 +383,24 @@ def test_library_first_then_torch_in_a_fresh_process(hip):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
+def test_narrow_frames_found_by_the_fuzzer(hip, oracle):
+    """16-pixel-wide frames with skip 4 reach a 2-column pyramid level, where BORDER_REFLECT_101 is not the -2 -> 2
+    select of the register-resident chain (tools/fuzz_parity.py found it): those shapes must take the general kernel."""
+    from respmon_amd import synth, dist
+    for (T, H, W, L, S, dt) in [(40, 140, 16, 6, 4, np.float32), (96, 90, 16, 6, 4, np.uint8), (16, 175, 16, 7, 4, np.float32),
+                                (40, 20, 16, 8, 4, np.float16), (24, 64, 32, 6, 4, np.uint8), (24, 50, 16, 5, 3, np.uint8)]:
+        v8 = synth.synth_breathing(T, H, W, seed=H)
+        frames = v8 if dt == np.uint8 else oracle.uint8_to_float(v8).astype(dt)
+        ref_in = oracle.uint8_to_float(v8) if dt == np.uint8 else frames.astype(np.float64)
+        with np.errstate(all="ignore"):
+            ref, mid = oracle.locate(ref_in, 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
+        import torch
+        dev = torch.from_numpy(frames).cuda()
+        heat = dist.hip_calibrate(dev, 10, pyramid_levels=L, skip_levels_at_top=S).cpu().numpy()
+        assert _rel(heat, mid["avg_frame"]) <= 1e-12, (T, H, W, L, S, dt)
+        assert dist.hip_heatmap_to_roi(torch.from_numpy(heat).cuda(), 20) == ref
+
+
 def test_long_buffers(hip, oracle):
     """Long calibration buffers (T = 512 and 1024: 92 / 184 surviving rfft rows, several 256-frame rounds in the
     kept-frame compaction) against the oracle."""
