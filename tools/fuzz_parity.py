@@ -1,6 +1,9 @@
 """Randomised parity sweep on the GPU box (developer tool; the committed tests hold fixed cases):
-random (T, H, W, levels, skip, frame dtype) calibrations against the CPU oracle -- bit-exact ROI, heatmap within 1e-12
-relative -- plus the frame-sharded path against the unsharded one.      python tools/fuzz_parity.py [seconds] [seed]"""
+  calib  random (T, H, W, levels, skip, frame dtype) calibrations against the CPU oracle -- bit-exact ROI, heatmap within
+         1e-12 relative -- plus the staged (frame-sharded) path against the unsharded one;
+  flow   random ROI sizes / textures / sub-pixel shifts: Shi-Tomasi corners and pyramidal LK against the oracle, bit-exact;
+  roi    random heatmaps (many components, holes, frame-touching blobs) through the heatmap -> ROI stage.
+      python tools/fuzz_parity.py [seconds] [seed] [calib|flow|roi]"""
 import os
 import sys
 import time
@@ -11,7 +14,114 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def fuzz_flow(budget, seed):
+    import torch
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import synth
+    from respmon_amd.base import _Backend
+    oracle.build()
+    be = _Backend()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n = bad = 0
+    while time.time() < t_end:
+        H = int(rng.integers(24, 260)); W = int(rng.integers(24, 260))
+        render = synth.synth_texture(H, W, seed=int(rng.integers(1 << 30)), n_waves=int(rng.integers(3, 14)), n_spots=int(rng.integers(0, 50)))
+        a = render(0.0, 0.0)
+        b = render(float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+        mc = int(rng.choice([10, 100, 1000])); q = float(rng.choice([0.3, 0.05, 0.01])); md = float(rng.choice([3, 7, 12])); bs = int(rng.choice([3, 5, 7]))
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        try:
+            pts = be.good_features_to_track(dev(a), mc, q, md, bs)
+            ref = oracle.goodFeaturesToTrack(a, mc, q, md, blockSize=bs)
+            ok = (pts is None) == (ref is None) and (ref is None or np.array_equal(pts, ref))
+            if ok and ref is not None:
+                win = int(rng.choice([9, 15, 21])); ml = int(rng.integers(0, 4))
+                p1, st = be.calc_optical_flow_pyr_lk(dev(a), dev(b), pts, (win, win), ml, (3, int(rng.choice([5, 10, 30])), float(rng.choice([0.03, 0.01]))))
+                # same criteria for the oracle
+            n += 1
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            print("EXC", repr(e))
+        if not ok:
+            bad += 1
+            print("FLOW MISMATCH (corners)", dict(H=H, W=W, mc=mc, q=q, md=md, bs=bs), flush=True)
+    print("fuzz flow: %d cases, %d mismatches" % (n, bad))
+    return bad
+
+
+def fuzz_flow_lk(budget, seed):
+    import torch
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import synth
+    from respmon_amd.base import _Backend
+    oracle.build()
+    be = _Backend()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n = bad = 0
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    while time.time() < t_end:
+        H = int(rng.integers(24, 200)); W = int(rng.integers(24, 200))
+        render = synth.synth_texture(H, W, seed=int(rng.integers(1 << 30)))
+        a = render(0.0, 0.0); b = render(float(rng.uniform(-2.5, 2.5)), float(rng.uniform(-2.5, 2.5)))
+        npts = int(rng.integers(1, 60))
+        pts = np.stack([rng.uniform(-2, W + 2, npts), rng.uniform(-2, H + 2, npts)], axis=1).astype(np.float32).reshape(-1, 1, 2)
+        win = int(rng.choice([9, 15, 21])); ml = int(rng.integers(0, 4)); mcnt = int(rng.choice([5, 10, 30])); eps = float(rng.choice([0.03, 0.01]))
+        try:
+            p1, st = be.calc_optical_flow_pyr_lk(dev(a), dev(b), pts, (win, win), ml, (3, mcnt, eps))
+            r1, rs, _ = oracle.calcOpticalFlowPyrLK(a, b, pts, None, winSize=(win, win), maxLevel=ml, criteria=(3, mcnt, eps))
+            good = rs.ravel() == 1
+            ok = np.array_equal(st, rs) and np.array_equal(p1[good], r1[good])
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            print("EXC", repr(e))
+        n += 1
+        if not ok:
+            bad += 1
+            print("LK MISMATCH", dict(H=H, W=W, npts=npts, win=win, ml=ml, mcnt=mcnt, eps=eps), flush=True)
+    print("fuzz lk: %d cases, %d mismatches" % (n, bad))
+    return bad
+
+
+def fuzz_roi(budget, seed):
+    import scipy.ndimage as ndi
+    import torch
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import dist as rdist
+    oracle.build()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n = bad = 0
+    while time.time() < t_end:
+        H = int(rng.integers(1, 300)); W = int(rng.integers(1, 500))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            heat = (rng.random((H, W)) < rng.uniform(0.02, 0.7)).astype(np.float64)
+        elif kind == 1:
+            heat = ndi.gaussian_filter(rng.standard_normal((H, W)), float(rng.uniform(0.5, 4.0)))
+        else:
+            heat = (ndi.gaussian_filter(rng.standard_normal((H, W)), 2.0) > 0).astype(np.float64) * rng.random((H, W))
+        thr = int(rng.integers(0, 255))
+        with np.errstate(all="ignore"):
+            u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
+        ref = oracle.roi_from_heatmap_u8(u8, thr)
+        got = rdist.hip_heatmap_to_roi(torch.from_numpy(heat).cuda(), thr)
+        n += 1
+        if got != ref:
+            bad += 1
+            print("ROI MISMATCH", dict(H=H, W=W, kind=kind, thr=thr), got, ref, flush=True)
+    print("fuzz roi: %d cases, %d mismatches" % (n, bad))
+    return bad
+
+
 def main():
+    mode = sys.argv[3] if len(sys.argv) > 3 else "calib"
+    if mode != "calib":
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+        bad = {"flow": lambda: fuzz_flow(budget / 2, seed) + fuzz_flow_lk(budget / 2, seed), "roi": lambda: fuzz_roi(budget, seed)}[mode]()
+        return 1 if bad else 0
     import torch
     from oracle import respmon_oracle as oracle
     from respmon_amd import synth, dist as rdist
