@@ -3,7 +3,8 @@
          1e-12 relative -- plus the staged (frame-sharded) path against the unsharded one;
   flow   random ROI sizes / textures / sub-pixel shifts: Shi-Tomasi corners and pyramidal LK against the oracle, bit-exact;
   roi    random heatmaps (many components, holes, frame-touching blobs) through the heatmap -> ROI stage.
-      python tools/fuzz_parity.py [seconds] [seed] [calib|flow|roi]"""
+  big    calib at 200-620 x 300-1100 frames, T = 64-256, skip 2-4 (a few seconds of oracle per case).
+      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi]"""
 import os
 import sys
 import time
@@ -117,7 +118,8 @@ def fuzz_roi(budget, seed):
 
 def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else "calib"
-    if mode != "calib":
+    big = mode == "big"
+    if mode not in ("calib", "big"):
         budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
         bad = {"flow": lambda: fuzz_flow(budget / 2, seed) + fuzz_flow_lk(budget / 2, seed), "roi": lambda: fuzz_roi(budget, seed)}[mode]()
@@ -134,9 +136,13 @@ def main():
     while time.time() < t_end:
         T = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 128]))
         H = int(rng.integers(9, 200)); W = int(rng.integers(9, 330))
+        if big:     # sizes where the pruning, several strips / segments and the value store all come into play
+            T = int(rng.choice([64, 128, 256])); H = int(rng.integers(200, 620)); W = int(rng.integers(300, 1100))
         if rng.random() < 0.4:
             W = (W + 15) // 16 * 16            # the register-resident chains need W % 16 == 0
         L = int(rng.integers(2, 9)); S = int(rng.integers(0, L))
+        if big:
+            L = int(rng.integers(6, 10)); S = int(rng.integers(2, 5))
         dt = str(rng.choice(["f64", "u8", "f32", "f16"]))
         v8 = synth.synth_breathing(T, H, W, seed=int(rng.integers(1 << 30)), amplitude=float(rng.uniform(0.05, 0.3)),
                                    noise=float(rng.uniform(0.0, 0.04)), center=(float(rng.uniform(0.1, 0.9)), float(rng.uniform(0.1, 0.9))))
