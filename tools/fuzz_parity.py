@@ -3,8 +3,9 @@
          1e-12 relative -- plus the staged (frame-sharded) path against the unsharded one;
   flow   random ROI sizes / textures / sub-pixel shifts: Shi-Tomasi corners and pyramidal LK against the oracle, bit-exact;
   roi    random heatmaps (many components, holes, frame-touching blobs) through the heatmap -> ROI stage.
+  shard  the rm_shard_* stages with 2-8 emulated ranks (uneven shards) + the sparse exchange of the partial sums;
   big    calib at 200-620 x 300-1100 frames, T = 64-256, skip 2-4 (a few seconds of oracle per case).
-      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi]"""
+      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi|shard]"""
 import os
 import sys
 import time
@@ -85,6 +86,91 @@ def fuzz_flow_lk(budget, seed):
     return bad
 
 
+def fuzz_shard(budget, seed):
+    """Frame-sharded stages with emulated ranks (a library context each, collectives by hand) and the sparse heatmap
+    exchange, against the unsharded path."""
+    import ctypes
+    import torch
+    from respmon_amd import _capi, device, dist as rdist, synth
+    from respmon_amd.base import RespiratoryMonitor
+    lib = _capi.load()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n = bad = 0
+    sp = device.stream_ptr()
+    while time.time() < t_end:
+        T = int(rng.integers(6, 140)); H = int(rng.integers(12, 300)); W = int(rng.integers(12, 500))
+        L = int(rng.integers(3, 9)); S = int(rng.integers(1, L))
+        world = int(rng.integers(2, min(T, 9)))
+        dt = str(rng.choice(["f64", "u8"]))
+        v8 = synth.synth_breathing(T, H, W, seed=int(rng.integers(1 << 30)))
+        buf = torch.from_numpy(v8).cuda() if dt == "u8" else (torch.from_numpy(v8).cuda().to(torch.float64) * (1.0 / 255))
+        code = _capi.RM_U8 if dt == "u8" else _capi.RM_F64
+        ok = True
+        ctxs = []
+        try:
+            nn = ctypes.c_size_t()
+            _capi.check(lib, lib.rm_shard_layout(H, W, L, S, ctypes.byref(nn)), "layout")
+            NP = int(nn.value)
+            for _ in range(world):
+                c = ctypes.c_void_p()
+                _capi.check(lib, lib.rm_ctx_create(0, ctypes.byref(c)), "ctx")
+                ctxs.append(c)
+            spans = [rdist.shard_frames(T, r, world) for r in range(world)]
+            lap_all = torch.empty((T, max(NP, 1)), dtype=torch.float64, device="cuda")[:, :NP].contiguous()
+            for c, (t0, t1) in zip(ctxs, spans):
+                if NP:
+                    local = buf[t0:t1].contiguous()
+                    _capi.check(lib, lib.rm_shard_pyramid(c, device.ptr(local), code, t1 - t0, H, W, L, S, 0,
+                                                          ctypes.c_void_p(lap_all[t0:t1].data_ptr()), sp), "pyramid")
+            mms = []
+            for c, (t0, t1) in zip(ctxs, spans):
+                mm = torch.empty(2, dtype=torch.float64, device="cuda")
+                _capi.check(lib, lib.rm_shard_collapse(c, device.ptr(lap_all) if NP else None, T, t0, t1, H, W, 10.0, 0.1, 1.0, 500.0, L, S,
+                                                       0.7, 0, device.ptr(mm), sp), "collapse")
+                mms.append(mm)
+            mm = torch.stack(mms).max(dim=0).values
+            total = torch.zeros((H, W), dtype=torch.float64, device="cuda")
+            cap = 64
+            pd = int(lib.rm_heat_sparse_packet_doubles(cap))
+            packets = []
+            for c in ctxs:
+                hs = torch.empty((H, W), dtype=torch.float64, device="cuda")
+                _capi.check(lib, lib.rm_shard_heat(c, device.ptr(mm), 0.7, device.ptr(hs), sp), "heat")
+                total += hs
+                pk = torch.empty(pd, dtype=torch.float64, device="cuda")
+                _capi.check(lib, lib.rm_heat_sparse_pack(c, device.ptr(hs), H, W, cap, device.ptr(pk), sp), "pack")
+                packets.append(pk)
+            heat = torch.empty((H, W), dtype=torch.float64, device="cuda")
+            xywh = (ctypes.c_int32 * 4)()
+            rc = _capi.check(lib, lib.rm_shard_finish(ctxs[0], device.ptr(total), T, H, W, 20, device.ptr(heat), xywh, sp), "finish")
+            roi = None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
+            ref_heat = rdist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
+            ref_roi = rdist.hip_heatmap_to_roi(ref_heat, 20)
+            scale = float(ref_heat.abs().max())
+            err = float((heat - ref_heat).abs().max()) / scale if scale > 0 else float((heat - ref_heat).abs().max())
+            ok = err <= 1e-12
+            # the ROI may differ only on an exact uint8 truncation boundary of the re-associated sum: compare through the heat
+            ok = ok and (roi == ref_roi or roi == rdist.hip_heatmap_to_roi(heat, 20))
+            # sparse exchange of the partial sums == dense sum in rank order / T
+            fused = torch.empty((H, W), dtype=torch.float64, device="cuda")
+            rc2 = _capi.check(lib, lib.rm_heat_sparse_merge_roi(ctxs[0], device.ptr(torch.cat(packets)), world, H, W, cap, 20, T,
+                                                                device.ptr(fused), xywh, sp), "merge")
+            if rc2 != _capi.RM_SPARSE_FALLBACK:
+                ok = ok and torch.equal(fused, heat)
+        except Exception as e:      # noqa: BLE001
+            ok, err = False, repr(e)
+        finally:
+            for c in ctxs:
+                lib.rm_ctx_destroy(c)
+        n += 1
+        if not ok:
+            bad += 1
+            print("SHARD MISMATCH", dict(T=T, H=H, W=W, L=L, S=S, world=world, dtype=dt), "err", err, flush=True)
+    print("fuzz shard: %d cases, %d mismatches" % (n, bad))
+    return bad
+
+
 def fuzz_roi(budget, seed):
     import scipy.ndimage as ndi
     import torch
@@ -122,7 +208,8 @@ def main():
     if mode not in ("calib", "big"):
         budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-        bad = {"flow": lambda: fuzz_flow(budget / 2, seed) + fuzz_flow_lk(budget / 2, seed), "roi": lambda: fuzz_roi(budget, seed)}[mode]()
+        bad = {"flow": lambda: fuzz_flow(budget / 2, seed) + fuzz_flow_lk(budget / 2, seed), "roi": lambda: fuzz_roi(budget, seed),
+               "shard": lambda: fuzz_shard(budget, seed)}[mode]()
         return 1 if bad else 0
     import torch
     from oracle import respmon_oracle as oracle
