@@ -219,9 +219,9 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t_end = time.time() + budget
-    n = bad = 0
+    n = bad = ties = 0
     while time.time() < t_end:
-        T = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 128]))
+        T = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 128])) if rng.random() < 0.5 else int(rng.integers(2, 140))   # odd lengths too
         H = int(rng.integers(9, 200)); W = int(rng.integers(9, 330))
         if big:     # sizes where the pruning, several strips / segments and the value store all come into play
             T = int(rng.choice([64, 128, 256])); H = int(rng.integers(200, 620)); W = int(rng.integers(300, 1100))
@@ -259,10 +259,22 @@ def main():
         except Exception as e:     # noqa: BLE001 -- report and continue
             ok, err = False, repr(e)
         n += 1
+        if not ok and not isinstance(err, str):
+            # the hard threshold of transforms.py:188-192 makes the heatmap discontinuous in raw: a voxel sitting on
+            # `top` to within the rounding noise of the FFT (ours is the explicit operator, the oracle's is scipy's)
+            # may fall on either side.  Such a tie is a property of the reference algorithm, not a parity failure.
+            with np.errstate(all="ignore"):
+                _m, raw = oracle.eulerian_magnification_bandpass(ref_in, fps, 0.1, 1.0, 500, pyramid_levels=L, skip_levels_at_top=S)
+            mn_, mx_ = raw.min(), raw.max()
+            top_ = mx_ - (mx_ - mn_) * 0.7
+            if np.abs(raw - top_).min() <= 1e-11 * max(abs(mx_), abs(mn_), 1e-300):
+                ties += 1
+                ok = True
+                print("TIE at the mask threshold (inherent)", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, fps=fps), "err", err, flush=True)
         if not ok:
             bad += 1
             print("MISMATCH", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, fps=fps), "got", locals().get("got"), "ref", locals().get("ref"), "err", err, flush=True)
-    print("fuzz: %d cases, %d mismatches" % (n, bad))
+    print("fuzz: %d cases, %d mismatches, %d threshold ties" % (n, bad, ties))
     return 1 if bad else 0
 
 
