@@ -3,9 +3,10 @@
          1e-12 relative -- plus the staged (frame-sharded) path against the unsharded one;
   flow   random ROI sizes / textures / sub-pixel shifts: Shi-Tomasi corners and pyramidal LK against the oracle, bit-exact;
   roi    random heatmaps (many components, holes, frame-touching blobs) through the heatmap -> ROI stage.
+  api    pyramid / filter / dtype / average / ROI / colour functions of the drop-in surface on random shapes;
   shard  the rm_shard_* stages with 2-8 emulated ranks (uneven shards) + the sparse exchange of the partial sums;
   big    calib at 200-620 x 300-1100 frames, T = 64-256, skip 2-4 (a few seconds of oracle per case).
-      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi|shard]"""
+      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi|shard|api]"""
 import os
 import sys
 import time
@@ -171,6 +172,97 @@ def fuzz_shard(budget, seed):
     return bad
 
 
+def fuzz_api(budget, seed):
+    """The module-level functions of the drop-in surface on random shapes: pyramids (video and image forms), both
+    temporal filters, dtype helpers, time average, ROI mean / crop, BGR -> gray."""
+    import scipy.signal
+    import torch
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import montage, pyramid, transforms
+    from respmon_amd.base import _Backend
+    oracle.build()
+    be = _Backend()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n = bad = 0
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)) if a.size else 0.0
+    while time.time() < t_end:
+        kind = int(rng.integers(0, 7))
+        what, ok = "", True
+        try:
+            if kind == 0:      # Laplacian video pyramid + collapse, bit-exact
+                T, H, W, L = int(rng.integers(1, 6)), int(rng.integers(1, 150)), int(rng.integers(1, 260)), int(rng.integers(1, 9))
+                vid = rng.random((T, H, W))
+                what = "pyramid %s L=%d" % ((T, H, W), L)
+                got, ref = pyramid.create_laplacian_video_pyramid(vid, L), oracle.create_laplacian_video_pyramid(vid, L)
+                ok = all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(got, ref))
+                ok = ok and np.array_equal(pyramid.collapse_laplacian_video_pyramid([x.copy() for x in got]),
+                                           oracle.collapse_laplacian_video_pyramid([x.copy() for x in ref]))
+                img = vid[0]
+                ok = ok and all(np.array_equal(a, b) for a, b in zip(pyramid.create_gaussian_image_pyramid(img, L), oracle.create_gaussian_image_pyramid(img, L)))
+            elif kind == 1:    # FFT band-pass, any length
+                T = int(rng.integers(2, 300)); fps = float(rng.choice([10.0, 30.0, 5.01, 7.68, 2.5]))
+                x = rng.standard_normal((T, int(rng.integers(1, 9)), int(rng.integers(1, 40))))
+                fmin, fmax, amp = float(rng.uniform(0.05, 0.9)), float(rng.uniform(1.0, 3.0)), float(rng.choice([1.0, 50.0, 500.0]))
+                what = "fft T=%d fps=%g band=(%g,%g)" % (T, fps, fmin, fmax)
+                got = transforms.temporal_bandpass_filter_fft(x.copy(), fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+                ref = oracle.temporal_bandpass_filter_fft(x.copy(), fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+                ok = np.abs(got - ref).max() <= 1e-11 * max(np.abs(ref).max(), np.abs(x).max() * amp * 1e-3, 1e-300)
+            elif kind == 2:    # IIR filter
+                T = int(rng.integers(1, 200)); order = int(rng.integers(1, 7))
+                lo = float(rng.uniform(0.02, 0.3)); hi = float(rng.uniform(lo + 0.05, 0.9))
+                b, a = scipy.signal.butter(order, [lo, hi], btype="band")
+                x = rng.standard_normal((T, int(rng.integers(1, 60))))
+                what = "lfilter T=%d order=%d" % (T, order)
+                got = transforms.butter_bandpass_filter_fast(x.copy(), b, a, axis=0)
+                ref = scipy.signal.lfilter(b, a, x, axis=0)
+                ok = np.abs(got - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-300)
+            elif kind == 3:    # dtype helpers incl. out-of-range values (C cast semantics)
+                v = np.concatenate([rng.uniform(-3, 3, 200), rng.uniform(0, 1, 200), [0.0, 1.0, -0.0, 1.0 / 255, 254.999 / 255, 256.0 / 255, -1e-9, 1e9, -1e9]])
+                what = "float_to_uint8"
+                with np.errstate(all="ignore"):
+                    ok = np.array_equal(transforms.float_to_uint8(v), oracle.float_to_uint8(v))
+                k = rng.integers(0, 256, 300).astype(np.uint8)
+                ok = ok and np.array_equal(transforms.uint8_to_float(k), oracle.uint8_to_float(k))
+            elif kind == 4:    # time average of every frame dtype
+                T, H, W = int(rng.integers(1, 70)), int(rng.integers(1, 60)), int(rng.integers(1, 90))
+                dt = rng.choice([np.uint8, np.float16, np.float32, np.float64])
+                vid = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
+                what = "time_average %s %s" % ((T, H, W), dt.__name__)
+                ref_in = oracle.uint8_to_float(vid) if dt == np.uint8 else vid.astype(np.float64)
+                acc = np.zeros((H, W))
+                for fr in ref_in:
+                    acc = acc + fr
+                ok = np.array_equal(montage.time_average(vid).cpu().numpy(), acc / T)
+            elif kind == 5:    # ROI mean and crop -> uint8
+                H, W = int(rng.integers(2, 200)), int(rng.integers(2, 300))
+                g = (rng.random((H, W)) * 255).astype(np.uint8)
+                w, h = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
+                x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+                what = "roi %s (%d,%d,%d,%d)" % ((H, W), x, y, w, h)
+                dev = torch.from_numpy(g).cuda()
+                frame = oracle.uint8_to_float(g)
+                refm = np.average(frame[y:y + h, x:x + w])
+                ok = abs(be.roi_mean(dev, x, y, w, h) - refm) <= 1e-12 * max(abs(refm), 1e-300)
+                ok = ok and np.array_equal(be.roi_to_uint8(dev, x, y, w, h).cpu().numpy(), oracle.float_to_uint8(frame[y:y + h, x:x + w]))
+            else:              # BGR -> gray
+                H, W = int(rng.integers(1, 120)), int(rng.integers(1, 200))
+                bgr = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+                what = "bgr2gray %s" % ((H, W),)
+                ok = np.array_equal(be.bgr_to_gray(bgr).cpu().numpy(), oracle.cvtColor_bgr2gray(bgr))
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            what += " EXC " + repr(e)
+        n += 1
+        if not ok:
+            bad += 1
+            print("API MISMATCH", what, flush=True)
+    print("fuzz api: %d cases, %d mismatches" % (n, bad))
+    return bad
+
+
 def fuzz_roi(budget, seed):
     import scipy.ndimage as ndi
     import torch
@@ -209,7 +301,7 @@ def main():
         budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
         bad = {"flow": lambda: fuzz_flow(budget / 2, seed) + fuzz_flow_lk(budget / 2, seed), "roi": lambda: fuzz_roi(budget, seed),
-               "shard": lambda: fuzz_shard(budget, seed)}[mode]()
+               "shard": lambda: fuzz_shard(budget, seed), "api": lambda: fuzz_api(budget, seed)}[mode]()
         return 1 if bad else 0
     import torch
     from oracle import respmon_oracle as oracle
