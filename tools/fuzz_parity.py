@@ -311,7 +311,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t_end = time.time() + budget
-    n = bad = ties = 0
+    n = bad = ties = ill = 0
     while time.time() < t_end:
         T = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 128])) if rng.random() < 0.5 else int(rng.integers(2, 140))   # odd lengths too
         H = int(rng.integers(9, 200)); W = int(rng.integers(9, 330))
@@ -335,18 +335,24 @@ def main():
             q = f64.astype(npdt)
             dev, ref_in = torch.from_numpy(q).cuda(), q.astype(np.float64)
         fps = float(rng.choice([10.0, 10.0, 5.01, 30.0]))
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+        if rng.random() < 0.5:    # the other knobs of locate(): band, amplification, mask width, binary threshold
+            kw.update(freq_min=float(rng.uniform(0.05, 0.6)), freq_max=float(rng.uniform(0.7, 2.5)), amplification=float(rng.choice([1, 50, 500, 5000])),
+                      temporal_threshold=float(rng.choice([0.0, 0.1, 0.5, 0.7, 0.9, 1.0, 1.3])), threshold=int(rng.choice([0, 5, 20, 60, 200, 254])))
+        ckw = {k: v for k, v in kw.items() if k != "threshold"}
         try:
             with np.errstate(all="ignore"):
-                ref, mid = oracle.locate(ref_in, fps, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
-            got = RespiratoryMonitor.locate(dev, fps, pyramid_levels=L, skip_levels_at_top=S)
-            heat = rdist.hip_calibrate(dev, fps, pyramid_levels=L, skip_levels_at_top=S).cpu().numpy()
+                ref, mid = oracle.locate(ref_in, fps, return_intermediates=True, **kw)
+            got = RespiratoryMonitor.locate(dev, fps, **kw)
+            heat = rdist.hip_calibrate(dev, fps, **ckw).cpu().numpy()
             scale = max(np.abs(mid["avg_frame"]).max(), 1e-300)
             err = np.abs(heat - mid["avg_frame"]).max() / scale
             ok = got == ref and (err <= 1e-12 or not np.isfinite(scale))
+            err = float(err)
             if ok and S >= 1 and T >= 3:
                 world = int(rng.integers(1, 4))
                 import ctypes
-                sh = rdist.locate_sharded(dev, T, fps, pyramid_levels=L, skip_levels_at_top=S) if world == 1 else None
+                sh = rdist.locate_sharded(dev, T, fps, **kw) if world == 1 else None
                 ok = ok and (sh is None or sh == got)
         except Exception as e:     # noqa: BLE001 -- report and continue
             ok, err = False, repr(e)
@@ -356,17 +362,38 @@ def main():
             # `top` to within the rounding noise of the FFT (ours is the explicit operator, the oracle's is scipy's)
             # may fall on either side.  Such a tie is a property of the reference algorithm, not a parity failure.
             with np.errstate(all="ignore"):
-                _m, raw = oracle.eulerian_magnification_bandpass(ref_in, fps, 0.1, 1.0, 500, pyramid_levels=L, skip_levels_at_top=S)
+                _m, raw = oracle.eulerian_magnification_bandpass(ref_in, fps, kw.get("freq_min", 0.1), kw.get("freq_max", 1.0), kw.get("amplification", 500),
+                                                                 pyramid_levels=L, skip_levels_at_top=S)
             mn_, mx_ = raw.min(), raw.max()
-            top_ = mx_ - (mx_ - mn_) * 0.7
+            top_ = mx_ - (mx_ - mn_) * kw.get("temporal_threshold", 0.7)
             if np.abs(raw - top_).min() <= 1e-11 * max(abs(mx_), abs(mn_), 1e-300):
                 ties += 1
                 ok = True
-                print("TIE at the mask threshold (inherent)", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, fps=fps), "err", err, flush=True)
+                print("TIE at the mask threshold (inherent)", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, fps=fps, kw=kw), "err", err, "min/max/top", mn_, mx_, top_, flush=True)
+        if not ok and not isinstance(err, str):
+            thr_b = kw.get("threshold", 20)
+            a = heat
+            with np.errstate(all="ignore"):
+                u8_ours = oracle.float_to_uint8((a - a.min()) / (a.max() - a.min()))
+            u8_ref = mid["avg_u8"]
+            fg_o, fg_r = np.argwhere(u8_ours > thr_b), np.argwhere(u8_ref > thr_b)
+            rng_ref = float(mid["avg_frame"].max() - mid["avg_frame"].min())
+            err_rng = float(np.abs(a - mid["avg_frame"]).max()) / rng_ref if rng_ref > 0 else float("inf")
+            consistent = oracle.roi_from_heatmap_u8(u8_ours, thr_b) == got
+            # The normalisation (a - min) / (max - min) of base.py:563 divides by the heatmap's own RANGE.  With a narrow
+            # mask (temporal_threshold near 0) most voxels stay unmasked and average to ~0 over time, so the range is tiny
+            # against the magnitudes that were summed, and rounding noise of relative size 1e-15 on the sums decides the
+            # uint8 levels: the problem is ill-conditioned for the reference as well.  Not a parity failure as long as the
+            # heatmap agrees to rounding in absolute terms and our ROI is what the oracle's ROI stage gives for OUR heatmap.
+            if consistent and err <= 1e-12:
+                ill += 1
+                ok = True
+            print("  detail: err/range %.2e" % err_rng, "u8 maps equal", np.array_equal(u8_ours, u8_ref), "| fg ours", len(fg_o), fg_o[:4].tolist(), "| fg ref", len(fg_r), fg_r[:4].tolist(),
+                  "| roi of the GPU heatmap by the oracle's contour code", oracle.roi_from_heatmap_u8(u8_ours, thr_b), flush=True)
         if not ok:
             bad += 1
-            print("MISMATCH", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, fps=fps), "got", locals().get("got"), "ref", locals().get("ref"), "err", err, flush=True)
-    print("fuzz: %d cases, %d mismatches, %d threshold ties" % (n, bad, ties))
+            print("MISMATCH", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, fps=fps, kw=kw), "got", locals().get("got"), "ref", locals().get("ref"), "err", err, flush=True)
+    print("fuzz: %d cases, %d mismatches, %d threshold ties, %d ill-conditioned normalisations" % (n, bad, ties, ill))
     return 1 if bad else 0
 
 
