@@ -3,10 +3,11 @@
          1e-12 relative -- plus the staged (frame-sharded) path against the unsharded one;
   flow   random ROI sizes / textures / sub-pixel shifts: Shi-Tomasi corners and pyramidal LK against the oracle, bit-exact;
   roi    random heatmaps (many components, holes, frame-touching blobs) through the heatmap -> ROI stage.
+  run    the run() state machine with skip_calibration in 'flow' / 'average' mode on moving textures;
   api    pyramid / filter / dtype / average / ROI / colour functions of the drop-in surface on random shapes;
   shard  the rm_shard_* stages with 2-8 emulated ranks (uneven shards) + the sparse exchange of the partial sums;
   big    calib at 200-620 x 300-1100 frames, T = 64-256, skip 2-4 (a few seconds of oracle per case).
-      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi|shard|api]"""
+      python tools/fuzz_parity.py [seconds] [seed] [calib|big|flow|roi|shard|api|run]"""
 import os
 import sys
 import time
@@ -263,6 +264,56 @@ def fuzz_api(budget, seed):
     return bad
 
 
+def fuzz_run(budget, seed):
+    """RespiratoryMonitor.run() with skip_calibration in 'flow' and 'average' modes on random moving textures, against the
+    oracle's extract_motion restatement (corner init, LK, track loss -> nan, mean flow, row-unpack PCA)."""
+    from oracle import respmon_oracle as oracle
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    oracle.build()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    n = bad = 0
+    while time.time() < t_end:
+        H, W = int(rng.integers(60, 200)), int(rng.integers(60, 260))
+        T = int(rng.integers(5, 40))
+        render = synth.synth_texture(H, W, seed=int(rng.integers(1 << 30)))
+        ax, ay, ph = float(rng.uniform(0, 4)), float(rng.uniform(0, 2)), float(rng.uniform(0, 3))
+        frames = np.stack([render(ax * np.sin(2 * np.pi * 0.4 * t / 10), ay * np.sin(2 * np.pi * 0.4 * t / 10 + ph)) for t in range(T)])
+        w, h = int(rng.integers(20, W)), int(rng.integers(20, H))
+        x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        mode = str(rng.choice(["flow", "average"]))
+        try:
+            mon = RespiratoryMonitor(capture_target=synth.FakeCapture(frames, fps=10), visualize=None, save_all_data=False,
+                                     motion_extraction_method=mode, run_on_init=False)
+            mon.sync_to_fps = lambda: None
+            mon.skip_calibration(x, y, w, h)
+            mon.run()
+            got = np.array(mon.data, dtype=np.float64)
+            if mode == "average":
+                ref = np.array([oracle.roi_average(oracle.uint8_to_float(f), x, y, w, h) for f in frames])
+                ok = len(got) == T and np.allclose(got, ref, rtol=1e-12, atol=0)
+            else:
+                state = oracle.FlowState()
+                ref = []
+                for t in range(T):
+                    if state.prev is not None and (state.points is None or len(state.points) == 0):
+                        break       # no corners / every track lost: cv2 would raise in the reference, the monitor goes to 'error'
+                    ref.append(oracle.extract_motion_flow(state, oracle.uint8_to_float(frames[t])[y:y + h, x:x + w]))
+                ref = np.array(ref, dtype=np.float64)
+                k = min(len(got), len(ref))
+                ok = k >= 1 and np.allclose(got[:k], ref[:k], rtol=1e-9, atol=1e-12, equal_nan=True)
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            print("EXC", repr(e)[:300])
+        n += 1
+        if not ok:
+            bad += 1
+            print("RUN MISMATCH", dict(H=H, W=W, T=T, roi=(x, y, w, h), mode=mode), flush=True)
+    print("fuzz run: %d cases, %d mismatches" % (n, bad))
+    return bad
+
+
 def fuzz_roi(budget, seed):
     import scipy.ndimage as ndi
     import torch
@@ -301,7 +352,8 @@ def main():
         budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
         bad = {"flow": lambda: fuzz_flow(budget / 2, seed) + fuzz_flow_lk(budget / 2, seed), "roi": lambda: fuzz_roi(budget, seed),
-               "shard": lambda: fuzz_shard(budget, seed), "api": lambda: fuzz_api(budget, seed)}[mode]()
+               "shard": lambda: fuzz_shard(budget, seed), "api": lambda: fuzz_api(budget, seed),
+               "run": lambda: fuzz_run(budget, seed)}[mode]()
         return 1 if bad else 0
     import torch
     from oracle import respmon_oracle as oracle
