@@ -71,6 +71,7 @@ struct rm_ctx {
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
+    bool op_mfma = false;   // the cached operator also exists in the fragment-major form of k_temporal_mfma
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
@@ -491,7 +492,7 @@ static void two_stage_operator(int n, const std::vector<int> &kept, std::vector<
     }
 }
 
-struct TemporalOp { const double *R = nullptr, *C = nullptr; int nk = 0; };
+struct TemporalOp { const double *R = nullptr, *C = nullptr, *Rf = nullptr, *Cf = nullptr; int nk = 0; };  // Rf / Cf: fragment-major copies for k_temporal_mfma
 
 static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax, TemporalOp *op, hipStream_t s)
 {
@@ -504,10 +505,34 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
         double *dR = nullptr, *dC = nullptr;
         RM_TRY(ws(ctx, "temporal_R", R.size() + 1, &dR));
         RM_TRY(ws(ctx, "temporal_C", C.size() + 1, &dC));
+        // fragment-major copies for the matrix-core kernel (k_temporal_mfma), zero padded to TM_K rows of R / columns of C
+        const int nk = ctx->op_nk;
+        const bool mf = nk >= 1 && nk <= TM_K && T % 16 == 0;
+        std::vector<double> Rf(mf ? (size_t)(T / 4) * 3 * 64 : 1, 0.0), Cf(mf ? (size_t)(T / 16) * 12 * 64 : 1, 0.0);
+        if (mf) {
+            for (int t0 = 0; t0 < T; t0 += 4)
+                for (int ti = 0; ti < 3; ++ti)
+                    for (int l = 0; l < 64; ++l) {
+                        const int k = 16 * ti + (l & 15), t = t0 + (l >> 4);
+                        Rf[((size_t)(t0 / 4) * 3 + ti) * 64 + l] = k < nk ? R[(size_t)k * T + t] : 0.0;
+                    }
+            for (int m = 0; m < T / 16; ++m)
+                for (int q = 0; q < 12; ++q)
+                    for (int l = 0; l < 64; ++l) {
+                        const int sI = 16 * m + (l & 15), k = 16 * (q / 4) + 4 * (q % 4) + (l >> 4);
+                        Cf[((size_t)m * 12 + q) * 64 + l] = k < nk ? C[(size_t)sI * nk + k] : 0.0;
+                    }
+        }
+        double *dRf = nullptr, *dCf = nullptr;
+        RM_TRY(ws(ctx, "temporal_Rf", Rf.size(), &dRf));
+        RM_TRY(ws(ctx, "temporal_Cf", Cf.size(), &dCf));
+        ctx->op_mfma = mf;
         if (!R.empty()) {
             HIP_TRY(hipMemcpyAsync(dR, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(dC, C.data(), sizeof(double) * C.size(), hipMemcpyHostToDevice, s));
-            HIP_TRY(stream_wait(s));  // R, C are stack-lifetime vectors
+            HIP_TRY(hipMemcpyAsync(dRf, Rf.data(), sizeof(double) * Rf.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(dCf, Cf.data(), sizeof(double) * Cf.size(), hipMemcpyHostToDevice, s));
+            HIP_TRY(stream_wait(s));  // the sources are stack-lifetime vectors
         }
         ctx->op_T = T; ctx->op_fps = fps; ctx->op_fmin = fmin; ctx->op_fmax = fmax;
     }
@@ -515,6 +540,12 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
     RM_TRY(ws(ctx, "temporal_R", (size_t)ctx->op_nk * T + 1, &dR));
     RM_TRY(ws(ctx, "temporal_C", (size_t)ctx->op_nk * T + 1, &dC));
     op->R = dR; op->C = dC; op->nk = ctx->op_nk;
+    if (ctx->op_mfma) {
+        double *dRf = nullptr, *dCf = nullptr;
+        RM_TRY(ws(ctx, "temporal_Rf", (size_t)(T / 4) * 3 * 64, &dRf));
+        RM_TRY(ws(ctx, "temporal_Cf", (size_t)(T / 16) * 12 * 64, &dCf));
+        op->Rf = dRf; op->Cf = dCf;
+    }
     return RM_OK;
 }
 
@@ -525,6 +556,14 @@ static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const
         HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * (size_t)T * NP, s));
         return RM_OK;
     }
+#ifndef RM_HIPEMU
+    static const int env_valu = [] { const char *e = getenv("RM_TEMPORAL_VALU"); return e ? atoi(e) : 0; }();  // developer A/B knob
+    if (op.Rf && !env_valu) {
+        hipLaunchKernelGGL(k_temporal_mfma, dim3((unsigned)((NP + 15) / 16)), dim3(64 * TM_W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
+        LAUNCH_CHECK();
+        return RM_OK;
+    }
+#endif
     const size_t sh1 = sizeof(double) * (size_t)T * TF_KC, sh2 = sizeof(double) * (size_t)op.nk * TF_SC;
     if (sh1 > 64 * 1024 || sh2 > 64 * 1024) return fail(RM_E_UNSUPPORTED, "temporal filter: T=%d exceeds the LDS-staged operator (T <= 2048)", T);
     double *y = nullptr;
