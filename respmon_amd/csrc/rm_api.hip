@@ -71,7 +71,7 @@ struct rm_ctx {
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
-    bool op_mfma = false;   // the cached operator also exists in the fragment-major form of k_temporal_mfma
+    int op_mfma = 0;        // > 0: the cached operator also exists in the fragment-major form of k_temporal_mfma, with this many 16-row tiles
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
@@ -492,7 +492,7 @@ static void two_stage_operator(int n, const std::vector<int> &kept, std::vector<
     }
 }
 
-struct TemporalOp { const double *R = nullptr, *C = nullptr, *Rf = nullptr, *Cf = nullptr; int nk = 0; };  // Rf / Cf: fragment-major copies for k_temporal_mfma
+struct TemporalOp { const double *R = nullptr, *C = nullptr, *Rf = nullptr, *Cf = nullptr; int nk = 0, tiles = 0; };  // Rf / Cf: fragment-major copies for k_temporal_mfma
 
 static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax, TemporalOp *op, hipStream_t s)
 {
@@ -505,28 +505,30 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
         double *dR = nullptr, *dC = nullptr;
         RM_TRY(ws(ctx, "temporal_R", R.size() + 1, &dR));
         RM_TRY(ws(ctx, "temporal_C", C.size() + 1, &dC));
-        // fragment-major copies for the matrix-core kernel (k_temporal_mfma), zero padded to TM_K rows of R / columns of C
+        // fragment-major copies for the matrix-core kernel (k_temporal_mfma), zero padded to NT tiles of 16 rows of R /
+        // columns of C; NT = 3 covers the calibration defaults (46 rows at n = 256), 6 the long buffers (92 at n = 512)
         const int nk = ctx->op_nk;
-        const bool mf = nk >= 1 && nk <= TM_K && T % 16 == 0;
-        std::vector<double> Rf(mf ? (size_t)(T / 4) * 3 * 64 : 1, 0.0), Cf(mf ? (size_t)(T / 16) * 12 * 64 : 1, 0.0);
+        const int NT = nk <= 48 ? 3 : 6;
+        const bool mf = nk >= 1 && nk <= 16 * TM_MAX_TILES && T % 16 == 0;
+        std::vector<double> Rf(mf ? (size_t)(T / 4) * NT * 64 : 1, 0.0), Cf(mf ? (size_t)(T / 16) * 4 * NT * 64 : 1, 0.0);
         if (mf) {
             for (int t0 = 0; t0 < T; t0 += 4)
-                for (int ti = 0; ti < 3; ++ti)
+                for (int ti = 0; ti < NT; ++ti)
                     for (int l = 0; l < 64; ++l) {
                         const int k = 16 * ti + (l & 15), t = t0 + (l >> 4);
-                        Rf[((size_t)(t0 / 4) * 3 + ti) * 64 + l] = k < nk ? R[(size_t)k * T + t] : 0.0;
+                        Rf[((size_t)(t0 / 4) * NT + ti) * 64 + l] = k < nk ? R[(size_t)k * T + t] : 0.0;
                     }
             for (int m = 0; m < T / 16; ++m)
-                for (int q = 0; q < 12; ++q)
+                for (int q = 0; q < 4 * NT; ++q)
                     for (int l = 0; l < 64; ++l) {
                         const int sI = 16 * m + (l & 15), k = 16 * (q / 4) + 4 * (q % 4) + (l >> 4);
-                        Cf[((size_t)m * 12 + q) * 64 + l] = k < nk ? C[(size_t)sI * nk + k] : 0.0;
+                        Cf[((size_t)m * 4 * NT + q) * 64 + l] = k < nk ? C[(size_t)sI * nk + k] : 0.0;
                     }
         }
         double *dRf = nullptr, *dCf = nullptr;
         RM_TRY(ws(ctx, "temporal_Rf", Rf.size(), &dRf));
         RM_TRY(ws(ctx, "temporal_Cf", Cf.size(), &dCf));
-        ctx->op_mfma = mf;
+        ctx->op_mfma = mf ? NT : 0;
         if (!R.empty()) {
             HIP_TRY(hipMemcpyAsync(dR, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(dC, C.data(), sizeof(double) * C.size(), hipMemcpyHostToDevice, s));
@@ -542,9 +544,9 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
     op->R = dR; op->C = dC; op->nk = ctx->op_nk;
     if (ctx->op_mfma) {
         double *dRf = nullptr, *dCf = nullptr;
-        RM_TRY(ws(ctx, "temporal_Rf", (size_t)(T / 4) * 3 * 64, &dRf));
-        RM_TRY(ws(ctx, "temporal_Cf", (size_t)(T / 16) * 12 * 64, &dCf));
-        op->Rf = dRf; op->Cf = dCf;
+        RM_TRY(ws(ctx, "temporal_Rf", (size_t)(T / 4) * ctx->op_mfma * 64, &dRf));
+        RM_TRY(ws(ctx, "temporal_Cf", (size_t)(T / 16) * 4 * ctx->op_mfma * 64, &dCf));
+        op->Rf = dRf; op->Cf = dCf; op->tiles = ctx->op_mfma;
     }
     return RM_OK;
 }
@@ -559,7 +561,8 @@ static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const
 #ifndef RM_HIPEMU
     static const int env_valu = [] { const char *e = getenv("RM_TEMPORAL_VALU"); return e ? atoi(e) : 0; }();  // developer A/B knob
     if (op.Rf && !env_valu) {
-        hipLaunchKernelGGL(k_temporal_mfma, dim3((unsigned)((NP + 15) / 16)), dim3(64 * TM_W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
+        if (op.tiles == 3) hipLaunchKernelGGL((k_temporal_mfma<3>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TM_W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
+        else hipLaunchKernelGGL((k_temporal_mfma<6>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TM_W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
         LAUNCH_CHECK();
         return RM_OK;
     }

@@ -261,49 +261,52 @@ __global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, si
         if (s0 + j < T) out[(size_t)(s0 + j) * NP + p] = acc[j] * amp;
 }
 
-// Matrix-core form of the two stages for the hot shapes (T a multiple of 16, at most TM_K = 48 surviving rows).
+// Matrix-core form of the two stages for the hot shapes (T a multiple of 16, at most 16 * TM_MAX_TILES = 96 surviving rows).
 // The band-pass IS a dense contraction along T -- y = R x, out = amp * C y with R [nk x T], C [T x nk] -- and the only
 // place on this path where MFMA fits.  v_mfma_f64_16x16x4_f64 runs at the fp64 vector rate on gfx950, so the gain is
 // not flops but operand reuse: a workgroup owns 16 pixel columns and reads its x[T, 16] tile ONCE (the VALU form
-// re-reads x once per group of 4 rows of R: 12 x 22 MB through L2), keeps all of y in 3 accumulator tiles and feeds them
+// re-reads x once per group of 4 rows of R: 12 x 22 MB through L2), keeps all of y in NT accumulator tiles and feeds them
 // straight back as B operands of the second product -- the D layout of the first product (row = (lane >> 4) + 4 * reg,
 // col = lane & 15) is exactly the B layout the second one needs for K-step (tile, reg) -- so y never leaves registers.
 // The TM_W wavefronts of a workgroup share the 16 columns: wave w contracts its quarter of T in stage 1 (the partial y
 // tiles meet in LDS, summed in wave order) and produces every TM_W-th tile of 16 output frames in stage 2.
-// The operators arrive "fragment major" (built on the host, zero padded to TM_K rows), so that every A operand is one
-// coalesced 512-byte load:   Rf[(t0/4 * 3 + ti) * 64 + lane] = R[16 ti + (lane & 15)][t0 + (lane >> 4)]
-//                            Cf[((s0/16) * 12 + 4 ti + r) * 64 + lane] = C[s0 + (lane & 15)][16 ti + 4 r + (lane >> 4)]
+// The operators arrive "fragment major" (built on the host, zero padded to 16 NT rows), so that every A operand is one
+// coalesced 512-byte load (layouts beside the kernel).
 // fused == materialised == per-level stays bit for bit: every path through the library uses this same kernel.
-constexpr int TM_K = 48, TM_W = 4;
+constexpr int TM_W = 4;
+constexpr int TM_MAX_TILES = 6;   // up to 96 surviving rows (n = 512 at 10 fps has 92); NT = tiles of 16 rows actually used
 
 #ifndef RM_HIPEMU   // (the host emulation of tests/emu runs the two-stage VALU kernels above)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Rf[(t0/4 * NT + ti) * 64 + lane] = R[16 ti + (lane & 15)][t0 + (lane >> 4)]
+// Cf[((s0/16) * 4 NT + 4 ti + r) * 64 + lane] = C[s0 + (lane & 15)][16 ti + 4 r + (lane >> 4)]
+template <int NT>
 __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
                                                              const double *__restrict__ Cf, double amp, double *__restrict__ out)
 {
-    __shared__ double s_y[TM_W][12][64];
+    __shared__ double s_y[TM_W][4 * NT][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const size_t p = (size_t)blockIdx.x * 16 + lo;
     const size_t pc = p < NP ? p : NP - 1;     // columns past the end repeat the last one (never stored)
     const int per = T / TM_W;                  // T % 16 == 0: a multiple of 4 frames per wave
-    v4f64 acc[3];
+    v4f64 acc[NT];
 #pragma unroll
-    for (int ti = 0; ti < 3; ++ti) acc[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int ti = 0; ti < NT; ++ti) acc[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const double *xr = x + (size_t)hi * NP + pc;
     for (int t0 = wave * per; t0 < (wave + 1) * per; t0 += 4) {
         const double b = xr[(size_t)t0 * NP];
-        const double *rf = Rf + (size_t)(t0 >> 2) * 3 * 64 + lane;
+        const double *rf = Rf + (size_t)(t0 >> 2) * NT * 64 + lane;
 #pragma unroll
-        for (int ti = 0; ti < 3; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf[ti * 64], b, acc[ti], 0, 0, 0);
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf[ti * 64], b, acc[ti], 0, 0, 0);
     }
 #pragma unroll
-    for (int ti = 0; ti < 3; ++ti)
+    for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_y[wave][4 * ti + r][lane] = acc[ti][r];
     __syncthreads();
 #pragma unroll
-    for (int ti = 0; ti < 3; ++ti)
+    for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double v = s_y[0][4 * ti + r][lane];
@@ -314,10 +317,10 @@ __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__res
     const int mt = T / 16;                     // output tiles of 16 frames, dealt round-robin to the waves
     for (int m = wave; m < mt; m += TM_W) {
         const int s0 = 16 * m;
-        const double *cf = Cf + (size_t)m * 12 * 64 + lane;
+        const double *cf = Cf + (size_t)m * 4 * NT * 64 + lane;
         v4f64 o = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ti = 0; ti < 3; ++ti) {
+        for (int ti = 0; ti < NT; ++ti) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[(4 * ti + r) * 64], acc[ti][r], o, 0, 0, 0);
         }
