@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -992,12 +993,26 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
     RM_TRY(ws(ctx, "slot_min", slot_cap, &cp.slot_min));
     {
-        // per-frame separable form when its row-extrema table fits LDS, else the per-pair kernel
-        const size_t tbl = 2 * sizeof(double) * (size_t)g.h[g.S] * g.tiles_x;
-        if (tbl <= 150 * 1024 && ntiles < 65536) {
-            if (tbl > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void *)k_frame_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbl));
-            hipLaunchKernelGGL(k_frame_bounds, dim3(T), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st);
+        // per-frame separable form, in bands of tile rows whose row-extrema table fits 64 KB of LDS; the per-pair kernel
+        // remains for geometries where even one tile row does not fit
+        const size_t row_bytes = 2 * sizeof(double) * (size_t)g.tiles_x;
+        int band = g.tiles_y;
+        auto tbl_rows_of = [&](int b) {   // most level-S rows any band of b tile rows touches (exact: the device's own footprint rule)
+            int most = 0;
+            for (int ty0 = 0; ty0 < g.tiles_y; ty0 += b) {
+                const int ty1 = std::min(ty0 + b, g.tiles_y) - 1;
+                most = std::max(most, tile_region(g, ty1 * g.tiles_x, g.S).y1 - tile_region(g, ty0 * g.tiles_x, g.S).y0 + 1);
+            }
+            return most;
+        };
+        size_t tbl_max = 64 * 1024;
+        if (const char *e = getenv("RM_BOUNDS_TABLE_BYTES")) tbl_max = (size_t)atol(e);   // test hook: force small bands
+        while (band > 1 && (size_t)tbl_rows_of(band) * row_bytes > tbl_max) band = (band + 1) / 2;
+        const int tbl_rows = tbl_rows_of(band);
+        const size_t tbl = (size_t)tbl_rows * row_bytes;
+        if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
+            const unsigned nbands = (unsigned)((g.tiles_y + band - 1) / band);
+            hipLaunchKernelGGL(k_frame_bounds, dim3(T, nbands), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, band, tbl_rows);
         } else {
             hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi, st);
         }

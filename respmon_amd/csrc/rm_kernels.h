@@ -478,10 +478,10 @@ struct ChainGeom {
 
 struct Region { int y0, y1, x0, x1; };  // inclusive
 
-__device__ __forceinline__ int floordiv2(int a) { return a >> 1; }  // arithmetic shift == floor for negatives
+__host__ __device__ __forceinline__ int floordiv2(int a) { return a >> 1; }  // arithmetic shift == floor for negatives
 
 // footprint of `tile` at level k (0 = the tile itself): scalars only, so nothing lands in scratch
-__device__ __forceinline__ Region tile_region(const ChainGeom &g, int tile, int k)
+__host__ __device__ __forceinline__ Region tile_region(const ChainGeom &g, int tile, int k)
 {
     int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     Region R;
@@ -640,21 +640,26 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom
 // the min / max over the footprint rows of per-row extrema over the footprint columns (exact: min and max are
 // associative).  Row extrema for every (row, tile column) go to LDS first; ~3.6x fewer loads than k_tile_bounds
 // and no per-thread 2-D loop over global memory.  Used when the [h_S][tiles_x] x 2 table fits LDS.
+// blockIdx.y selects a band of `band` tile rows (large levels: the row-extrema table of a whole frame would not fit LDS);
+// the table then holds only the level-S rows [y_lo, y_hi] that band's footprints touch (at most `tbl_rows` of them).
 __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi,
-                                                      CollapseState *st)
+                                                      CollapseState *st, int band, int tbl_rows)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     const double inf = __builtin_huge_val();
     const int S = g.S, hS = g.h[S], wS = g.w[S], ntx = g.tiles_x;
     const int t = blockIdx.x;
-    double *rmin = lds, *rmax = lds + (size_t)hS * ntx;
+    const int ty0 = blockIdx.y * band, ty1 = min(ty0 + band, g.tiles_y) - 1;             // tile rows of this workgroup
+    const int y_lo = tile_region(g, ty0 * ntx, S).y0, y_hi = tile_region(g, ty1 * ntx, S).y1;   // level-S rows they touch
+    const int nrows = y_hi - y_lo + 1;
+    double *rmin = lds, *rmax = lds + (size_t)tbl_rows * ntx;
     const double *p = cS + (size_t)t * hS * wS;
     const float inv_ntx = 1.0f / (float)ntx;
-    for (int i = threadIdx.x; i < hS * ntx; i += 256) {
+    for (int i = threadIdx.x; i < nrows * ntx; i += 256) {
         int y, tx;
         split_rc(i, ntx, inv_ntx, y, tx);
         const Region R = tile_region(g, tx, S);   // tile tx of the first tile row: same column range as every tile below it
-        const double *row = p + (size_t)y * wS;
+        const double *row = p + (size_t)(y_lo + y) * wS;
         double mn = row[R.x0], mx = mn;
         for (int x = R.x0 + 1; x <= R.x1; ++x) {
             const double v = row[x];
@@ -665,13 +670,13 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
     }
     __syncthreads();
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
-    for (int tile = threadIdx.x; tile < ntiles; tile += 256) {
-        int ty, tx;
-        split_rc(tile, ntx, inv_ntx, ty, tx);
+    const int tile_begin = ty0 * ntx, tile_end = (ty1 + 1) * ntx;
+    for (int tile = tile_begin + threadIdx.x; tile < tile_end; tile += 256) {
+        const int tx = tile % ntx;
         const Region R = tile_region(g, tile, S);
-        double mn = rmin[R.y0 * ntx + tx], mx = rmax[R.y0 * ntx + tx];
+        double mn = rmin[(R.y0 - y_lo) * ntx + tx], mx = rmax[(R.y0 - y_lo) * ntx + tx];
         for (int y = R.y0 + 1; y <= R.y1; ++y) {
-            const double a = rmin[y * ntx + tx], b = rmax[y * ntx + tx];
+            const double a = rmin[(y - y_lo) * ntx + tx], b = rmax[(y - y_lo) * ntx + tx];
             mn = (a < mn) ? a : mn;
             mx = (b > mx) ? b : mx;
         }
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
     block_minmax(hi_mn, hi_mx);
     if (threadIdx.x == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
-        const int sp = blockIdx.x & (NSTRIPE - 1);
+        const int sp = (blockIdx.x + blockIdx.y * 7) & (NSTRIPE - 1);
         if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
         if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
         if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);

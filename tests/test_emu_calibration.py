@@ -281,3 +281,17 @@ def test_emu_contour_stage_many_components_and_nesting(emu, oracle):
         roi, u8, binary = emu.heatmap_to_roi(heat, threshold=20)
         assert np.array_equal(binary != 0, m)
         assert roi == oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20), m.shape
+
+
+def test_emu_banded_tile_bounds(emu, oracle, monkeypatch):
+    """k_frame_bounds in bands of tile rows (what 4K levels need: their row-extrema table exceeds LDS): forced here with a
+    tiny table budget; the heatmap must not change by a bit."""
+    v = oracle.uint8_to_float(synth.synth_breathing(12, 150, 200, seed=17))
+    for (L, S) in [(5, 2), (4, 1), (6, 3)]:
+        monkeypatch.delenv("RM_BOUNDS_TABLE_BYTES", raising=False)
+        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S)
+        for budget in ("600", "2000", "1"):      # a few tile rows per band ... one tile row per band (minimum)
+            monkeypatch.setenv("RM_BOUNDS_TABLE_BYTES", budget)
+            got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+            assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (L, S, budget)
+    monkeypatch.delenv("RM_BOUNDS_TABLE_BYTES", raising=False)
