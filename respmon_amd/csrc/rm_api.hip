@@ -745,6 +745,7 @@ struct SmallLevels {
     int S = 0;             // level the collapse stopped at (== skip when any level is filtered)
     const double *cS = nullptr;
     bool all_zero = false;  // no level is filtered: the band-passed pyramid is all zeros
+    bool state_ready = false;  // the collapse kernel that produced cS has already reset ctx->d_state (k_state_init's job)
 };
 
 struct PyrGeom {
@@ -870,7 +871,8 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         const size_t shmem = NP * sizeof(double);
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst);
+        hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
+        out.state_ready = true;
         LAUNCH_CHECK();
         c = dst;
     } else {
@@ -959,8 +961,10 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     cp.valid = false;
     cp.cS = sl.cS; cp.T = T; cp.t0 = t0; cp.t1 = t1; cp.H = sl.h[0]; cp.W = sl.w[0]; cp.S = sl.S;
     const size_t npix = (size_t)cp.H * cp.W;
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
-    LAUNCH_CHECK();
+    if (!sl.state_ready) {
+        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
+        LAUNCH_CHECK();
+    }
     const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
     if (sl.S == 0) {
         if (t0 != 0 || t1 != T) return fail(RM_E_UNSUPPORTED, "frame-sharded calibration needs skip_levels_at_top >= 1");

@@ -432,10 +432,16 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
     }
 }
 
-__global__ __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_all, SmallGeom g, double *cS)
+struct CollapseState;
+__device__ void state_init_lane(CollapseState *st, int i);   // defined with the state, below
+
+// st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
+// (k_state_init's job: one tiny launch less on the critical path)
+__global__ __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_all, SmallGeom g, double *cS, CollapseState *st_init)
 {
     HIP_DYNAMIC_SHARED(double, lds)   // the [NP] frame, levels laid out as in bp_all
     const int t = blockIdx.x, tid = threadIdx.x;
+    if (st_init && t == 0 && tid < 64) state_init_lane(st_init, tid);
     const int S = g.S, L = g.L;
     const double *src = bp_all + (size_t)t * g.NP;
     for (int i = tid; i < g.NP; i += SMALL_NT) lds[i] = src[i];
@@ -570,9 +576,9 @@ struct CollapseState {
     unsigned long long heat_min_key, heat_max_key;
 };
 
-__global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st)
+__device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIPE-1 of one wavefront
 {
-    const int i = threadIdx.x;
+    if (i >= NSTRIPE) return;
     st->lb_max_keys[i] = 0ull; st->ub_min_keys[i] = ~0ull; st->ub_max_keys[i] = 0ull; st->lb_min_keys[i] = ~0ull;
     st->min_keys[i] = ~0ull; st->max_keys[i] = 0ull;
     st->heat_min_keys[i] = ~0ull; st->heat_max_keys[i] = 0ull;
@@ -582,6 +588,8 @@ __global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st)
     st->margin = 0; st->top_ub = 0; st->min_val = 0; st->max_val = 0; st->top = 0;
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
 }
+
+__global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st) { state_init_lane(st, (int)threadIdx.x); }
 
 // fold the stripes of one target (plus its unstriped word); every lane of the wave gets the result
 __device__ __forceinline__ unsigned long long fold_min_keys(const unsigned long long *stripes, unsigned long long word)
