@@ -72,6 +72,7 @@ struct rm_ctx {
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
+    bool state_fresh = false;   // d_state was reset by the last kernel of front_pyramid and nothing has reduced into it since
     int op_mfma = 0;        // > 0: the cached operator also exists in the fragment-major form of k_temporal_mfma, with this many 16-row tiles
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
@@ -746,6 +747,7 @@ struct SmallLevels {
     const double *cS = nullptr;
     bool all_zero = false;  // no level is filtered: the band-passed pyramid is all zeros
     bool state_ready = false;  // the collapse kernel that produced cS has already reset ctx->d_state (k_state_init's job)
+    bool bounds_ready = false; // ... and left the tile bounds in the workspace buffers tile_lo / tile_hi and their extrema in the state
 };
 
 struct PyrGeom {
@@ -836,8 +838,9 @@ static int front_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int 
         const size_t shmem = pg.lds_levels * sizeof(double);
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_small_pyramid, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)g[S], pg.sg, lap);
+        hipLaunchKernelGGL(k_small_pyramid, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)g[S], pg.sg, lap, ctx->d_state);
         LAUNCH_CHECK();
+        ctx->state_fresh = true;
     } else {
         // Laplacian levels (pyramid.py:23-26): L_l = G_l - pyrUp(G_{l+1})
         for (int l = L - 2; l >= S; --l)
@@ -845,6 +848,8 @@ static int front_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     }
     return RM_OK;
 }
+
+static int make_geom(const SmallLevels &sl, ChainGeom &g);
 
 static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg, double fps, double fmin, double fmax, double amp,
                         SmallLevels &out, hipStream_t s)
@@ -871,8 +876,32 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         const size_t shmem = NP * sizeof(double);
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
-        out.state_ready = true;
+        // when the row-extrema table of a frame fits beside its small pyramid, the tile bounds of the collapse passes
+        // are taken here, from the LDS copy of C_S (k_small_collapse_bounds)
+        ChainGeom cg;
+        SmallLevels probe; probe.h = pg.h; probe.w = pg.w; probe.S = S;
+        const bool geom_ok = S >= 1 && S < MAX_CHAIN && make_geom(probe, cg) == RM_OK;
+        const size_t tbl = geom_ok ? 2 * sizeof(double) * (size_t)h[S] * cg.tiles_x : 0;
+        const long long npairs = geom_ok ? (long long)cg.tiles_x * cg.tiles_y * T : 0;
+        if (geom_ok && shmem + tbl <= 150 * 1024 && npairs < (1ll << 31) && !getenv("RM_NO_FUSED_BOUNDS")) {
+            double *lo = nullptr, *hi = nullptr;
+            RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
+            RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
+            if (!ctx->state_fresh) {   // the lap buffer did not come from front_pyramid on this context just now
+                hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
+                LAUNCH_CHECK();
+            }
+            const size_t sh2 = shmem + tbl;
+            if (sh2 > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
+            hipLaunchKernelGGL(k_small_collapse_bounds, dim3(T), dim3(SMALL_NT), sh2, s, (const double *)bp, pg.sg, dst, ctx->d_state, cg,
+                               cg.tiles_x * cg.tiles_y, lo, hi);
+            out.state_ready = true; out.bounds_ready = true;
+        } else {
+            hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
+            out.state_ready = true;
+        }
+        ctx->state_fresh = false;
         LAUNCH_CHECK();
         c = dst;
     } else {
@@ -996,7 +1025,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
     RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
     RM_TRY(ws(ctx, "slot_min", slot_cap, &cp.slot_min));
-    {
+    if (!sl.bounds_ready) {
         // per-frame separable form, in bands of tile rows whose row-extrema table fits 64 KB of LDS; the per-pair kernel
         // remains for geometries where even one tile row does not fit
         const size_t row_bytes = 2 * sizeof(double) * (size_t)g.tiles_x;

@@ -390,8 +390,13 @@ struct LdsPlain {
     __device__ __forceinline__ double operator()(int r, int c) const { return p[r * w + c]; }
 };
 
-__global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all)
+struct CollapseState;
+__device__ void state_init_lane(CollapseState *st, int i);   // defined with the state, below
+
+// st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
+__global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all, CollapseState *st_init)
 {
+    if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
     HIP_DYNAMIC_SHARED(double, lds)
     const int t = blockIdx.x, tid = threadIdx.x;
     const int S = g.S, L = g.L;
@@ -431,9 +436,6 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
         }
     }
 }
-
-struct CollapseState;
-__device__ void state_init_lane(CollapseState *st, int i);   // defined with the state, below
 
 // st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
 // (k_state_init's job: one tiny launch less on the critical path)
@@ -701,6 +703,85 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
         if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
         if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
         if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+    }
+}
+
+// k_small_collapse and k_frame_bounds in one: the collapsed level S of a frame is still in LDS when its tile bounds are
+// wanted, so they are taken from there (no second pass over C_S in memory, one kernel boundary less).  Used when the
+// row-extrema table of a whole frame fits beside the frame's small pyramid.
+__global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double *bp_all, SmallGeom sg, double *cS, CollapseState *st,
+                                                                     ChainGeom g, int ntiles, double *lo, double *hi)
+{
+    HIP_DYNAMIC_SHARED(double, lds)   // [NP] frame (levels laid out as in bp_all), then the row-extrema table
+    __shared__ double s_red[4][SMALL_NT / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int S = sg.S, L = sg.L;
+    // (st was reset by an EARLIER kernel on the stream -- k_small_pyramid or k_state_init: the atomics at the end of this
+    //  kernel must not race with a reset inside it)
+    const double *src = bp_all + (size_t)t * sg.NP;
+    for (int i = tid; i < sg.NP; i += SMALL_NT) lds[i] = src[i];
+    __syncthreads();
+    for (int l = L - 3; l >= S; --l) {
+        const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
+        LdsPlain c{lds + sg.np_off[l + 1], sw};
+        double *d = lds + sg.np_off[l];
+        for (int i = tid; i < dh * dw; i += SMALL_NT) {
+            const int y = i / dw, x = i - y * dw;
+            d[i] = up_at(c, y, x, sh, sw) + d[i];
+        }
+        __syncthreads();
+    }
+    const int hS = sg.h[S], wS = sg.w[S], n = hS * wS, ntx = g.tiles_x;
+    const double *c = lds + sg.np_off[S];
+    double *o = cS + (size_t)t * n;
+    for (int i = tid; i < n; i += SMALL_NT) o[i] = c[i];
+    // tile bounds from the LDS copy: per-row extrema over the footprint columns, then extrema over the footprint rows
+    double *rmin = lds + sg.NP, *rmax = rmin + (size_t)hS * ntx;
+    const float inv_ntx = 1.0f / (float)ntx;
+    for (int i = tid; i < hS * ntx; i += SMALL_NT) {
+        int y, tx;
+        split_rc(i, ntx, inv_ntx, y, tx);
+        const Region R = tile_region(g, tx, S);
+        const double *row = c + y * wS;
+        double mn = row[R.x0], mx = mn;
+        for (int x = R.x0 + 1; x <= R.x1; ++x) {
+            const double v = row[x];
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
+        }
+        rmin[i] = mn; rmax[i] = mx;
+    }
+    __syncthreads();
+    const double inf = __builtin_huge_val();
+    double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
+    for (int tile = tid; tile < ntiles; tile += SMALL_NT) {
+        const int tx = tile % ntx;
+        const Region R = tile_region(g, tile, S);
+        double mn = rmin[R.y0 * ntx + tx], mx = rmax[R.y0 * ntx + tx];
+        for (int y = R.y0 + 1; y <= R.y1; ++y) {
+            const double a = rmin[y * ntx + tx], b = rmax[y * ntx + tx];
+            mn = (a < mn) ? a : mn;
+            mx = (b > mx) ? b : mx;
+        }
+        lo[(size_t)t * ntiles + tile] = mn; hi[(size_t)t * ntiles + tile] = mx;
+        lo_mn = (mn < lo_mn) ? mn : lo_mn; lo_mx = (mn > lo_mx) ? mn : lo_mx;
+        hi_mn = (mx < hi_mn) ? mx : hi_mn; hi_mx = (mx > hi_mx) ? mx : hi_mx;
+    }
+    lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) { s_red[0][wave] = lo_mn; s_red[1][wave] = lo_mx; s_red[2][wave] = hi_mn; s_red[3][wave] = hi_mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < SMALL_NT / 64; ++w) {
+            lo_mn = (s_red[0][w] < lo_mn) ? s_red[0][w] : lo_mn; lo_mx = (s_red[1][w] > lo_mx) ? s_red[1][w] : lo_mx;
+            hi_mn = (s_red[2][w] < hi_mn) ? s_red[2][w] : hi_mn; hi_mx = (s_red[3][w] > hi_mx) ? s_red[3][w] : hi_mx;
+        }
+        const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
+        const int sp = blockIdx.x & (NSTRIPE - 1);
+        atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        atomicMin(&st->ub_min_keys[sp], k_hi_mn);
     }
 }
 

@@ -289,9 +289,14 @@ def test_emu_banded_tile_bounds(emu, oracle, monkeypatch):
     v = oracle.uint8_to_float(synth.synth_breathing(12, 150, 200, seed=17))
     for (L, S) in [(5, 2), (4, 1), (6, 3)]:
         monkeypatch.delenv("RM_BOUNDS_TABLE_BYTES", raising=False)
-        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S)
+        monkeypatch.delenv("RM_NO_FUSED_BOUNDS", raising=False)
+        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S)          # bounds taken inside the small-collapse kernel
+        monkeypatch.setenv("RM_NO_FUSED_BOUNDS", "1")               # the separate k_frame_bounds, whole frame at once
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+        assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (L, S)
         for budget in ("600", "2000", "1"):      # a few tile rows per band ... one tile row per band (minimum)
             monkeypatch.setenv("RM_BOUNDS_TABLE_BYTES", budget)
             got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
             assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (L, S, budget)
     monkeypatch.delenv("RM_BOUNDS_TABLE_BYTES", raising=False)
+    monkeypatch.delenv("RM_NO_FUSED_BOUNDS", raising=False)
