@@ -136,8 +136,9 @@ def _shard_methods():
         mms = []
         for c, (t0, t1) in zip(ctxs, spans):
             mm = np.empty(2)
-            self.ck(self.lib.rm_shard_collapse(c, ptr(lap_all) if NP else None, T, t0, t1, H, W, fps, fmin, fmax, amp, levels, skip,
-                                               thr, flags, ptr(mm), None), "shard_collapse")
+            for _ in range(2):   # twice: the second call finds the reduction state used (not freshly reset by rm_shard_pyramid)
+                self.ck(self.lib.rm_shard_collapse(c, ptr(lap_all) if NP else None, T, t0, t1, H, W, fps, fmin, fmax, amp, levels, skip,
+                                                   thr, flags, ptr(mm), None), "shard_collapse")
             mms.append(mm)
         mm = np.max(np.stack(mms), axis=0)
         total = np.zeros((H, W))
