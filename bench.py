@@ -144,6 +144,9 @@ def main():
     ncalls = ctypes.c_int()
     _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
     k_ms_total, k_calls = ms[0], ncalls.value     # frame-buffer kernel, HIP events inside the timed region
+    tn = ctypes.c_int(0)
+    _capi.check(lib, lib.rm_heat_sparse_tiles_needed(ctx, ctypes.byref(tn)), "rm_heat_sparse_tiles_needed")
+    tiles_needed = tn.value                       # largest per-rank tile count of the last sparse exchange (world > 1)
     # phase breakdown: separate untimed pass (bracketing every phase costs ~10 us of stream idle time each)
     _capi.check(lib, lib.rm_profile_enable(ctx, 2), "rm_profile_enable")
     for _ in range(3):
@@ -241,6 +244,7 @@ def main():
                                                           % (rdist.SPARSE_CAP_TILES, 8e-6 * (4 + rdist.SPARSE_CAP_TILES * 1025)),
                                                           "dense": "all-reduce(sum) of the [H,W] float64 heatmap"}[rdist.LAST_EXCHANGE])
                                 if world > 1 else None,
+            "heatmap_exchange_tiles_needed": tiles_needed if world > 1 else None,
             "alt_uint8_buffer": alt,
             "roi_flow": roi_flow,
             "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},

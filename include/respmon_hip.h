@@ -160,11 +160,15 @@ int rm_heatmap_to_roi(rm_ctx *ctx, const double *heatmap_dev, int H, int W, int 
  *                                 outputs: the sparse form of the heat-sum all-reduce + rm_shard_finish), then
  *                                 base.py:563-575 on it -> xywh_host.  Returns RM_OK / RM_NO_CONTOUR, or
  *                                 RM_SPARSE_FALLBACK when some rank needed more than cap_tiles tiles (every rank sees
- *                                 the same packets, so every rank falls back to the dense all-reduce together). */
+ *                                 the same packets, so every rank falls back to the dense all-reduce together).
+ *        rm_heat_sparse_tiles_needed  the largest tile count any rank needed in the LAST rm_heat_sparse_merge_roi on this
+ *                                 context (also when it overflowed): identical on every rank, so the ranks can size the
+ *                                 next exchange's packets from it without talking to each other. */
 size_t rm_heat_sparse_packet_doubles(int cap_tiles);
 int rm_heat_sparse_pack(rm_ctx *ctx, const double *heat_dev, int H, int W, int cap_tiles, double *packet_dev, void *stream);
 int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets_dev, int world, int H, int W, int cap_tiles, int threshold,
                              int avg_T, double *fused_dev, int32_t *xywh_host, void *stream);
+int rm_heat_sparse_tiles_needed(rm_ctx *ctx, int *tiles_host);
 
 /* ---- base.py:547-601 RespiratoryMonitor.locate = rm_calibrate + rm_heatmap_to_roi ------- */
 int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W, double fps,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rm_heat_sparse_packet_doubles": (_sz, [_i]),
     "rm_heat_sparse_pack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rm_heat_sparse_merge_roi": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rm_heat_sparse_tiles_needed": (_i, [_vp, _vp]),
     "rm_locate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
     "rm_shard_layout": (_i, [_i, _i, _i, _i, _c.POINTER(_sz)]),
     "rm_shard_pyramid": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _vp]),

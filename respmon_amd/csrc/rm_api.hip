@@ -77,7 +77,7 @@ struct rm_ctx {
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
-    int *h_flag = nullptr;          // pinned: overflow flag of the sparse heatmap merge
+    int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0;
     unsigned int *h_slots_seen = nullptr;  // pinned: n_slots of the previous rm_calibrate (async readback)
@@ -1329,13 +1329,12 @@ extern "C" int rm_heat_sparse_pack(rm_ctx *ctx, const double *heat, int H, int W
     if (ctx->nkept_H != H || ctx->nkept_W != W) {
         // no pruning bookkeeping for this heatmap (skip 0, zero result, foreign heatmap): report overflow -> dense exchange
         HIP_TRY(hipMemsetAsync(packet, 0, sizeof(double) * SP_HDR, s));
-        const unsigned int over = (unsigned int)cap_tiles + 1u;
-        HIP_TRY(hipMemcpyAsync(packet, &over, sizeof over, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(packet, 0xff, sizeof(unsigned int), s));   // SP_DENSE_ONLY
         return RM_OK;
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)ntiles, &tile_nkept));
-    hipLaunchKernelGGL(k_sparse_background, dim3(1), dim3(256), 0, s, heat, W, tiles_x, ntiles, tile_nkept, cap_tiles, packet);
+    hipLaunchKernelGGL(k_sparse_background, dim3(1), dim3(64), 0, s, heat, W, tiles_x, ntiles, tile_nkept, cap_tiles, packet);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sparse_pack, dim3(ntiles), dim3(256), 0, s, heat, H, W, tiles_x, tile_nkept, cap_tiles, packet);
     LAUNCH_CHECK();
@@ -1354,20 +1353,32 @@ extern "C" int rm_heat_sparse_merge_roi(rm_ctx *ctx, const double *packets, int 
     HIP_TRY(hipSetDevice(ctx->device));
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, ntiles = tiles_x * tiles_y;
     const size_t pd = rm_heat_sparse_packet_doubles(cap_tiles);
-    int *map = nullptr, *flag_dev = nullptr;
+    int *map = nullptr, *any = nullptr, *flag_dev = nullptr;
     RM_TRY(ws(ctx, "sparse_map", (size_t)world * ntiles, &map));
-    if (!ctx->h_flag) HIP_TRY(hipHostMalloc((void **)&ctx->h_flag, sizeof(int), hipHostMallocDefault));
+    RM_TRY(ws(ctx, "sparse_any", (size_t)ntiles, &any));
+    if (!ctx->h_flag) {
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_flag, 2 * sizeof(int), hipHostMallocDefault));
+        ctx->h_flag[0] = ctx->h_flag[1] = 0;
+    }
     HIP_TRY(hipHostGetDevicePointer((void **)&flag_dev, ctx->h_flag, 0));
-    hipLaunchKernelGGL(k_sparse_index, dim3(1), dim3(256), 0, s, packets, pd, world, cap_tiles, ntiles, map, flag_dev, ctx->d_state);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sparse_merge, dim3(ntiles), dim3(256), 0, s, packets, pd, world, cap_tiles, H, W, tiles_x, ntiles, map, fused,
+    hipLaunchKernelGGL(k_sparse_index, dim3(1), dim3(256), 0, s, packets, pd, world, cap_tiles, ntiles, map, any, flag_dev,
                        ctx->d_state, avg_T);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sparse_merge, dim3(ntiles), dim3(256), 0, s, packets, pd, world, cap_tiles, H, W, tiles_x, ntiles, map, any,
+                       fused, ctx->d_state, avg_T);
     LAUNCH_CHECK();
     // the ROI stage synchronises the stream; the overflow flag is in pinned memory by then
     const int rc = heatmap_to_roi_impl(ctx, fused, H, W, threshold, xywh, nullptr, nullptr, stream, true);
     if (rc < 0) return rc;
-    if (*ctx->h_flag) return RM_SPARSE_FALLBACK;
+    if (ctx->h_flag[0]) return RM_SPARSE_FALLBACK;
     return rc;
+}
+
+extern "C" int rm_heat_sparse_tiles_needed(rm_ctx *ctx, int *tiles)
+{
+    if (!ctx || !tiles) return fail(RM_E_BADARG, "rm_heat_sparse_tiles_needed: bad argument");
+    *tiles = ctx->h_flag ? ctx->h_flag[1] : 0;
+    return RM_OK;
 }
 
 extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,

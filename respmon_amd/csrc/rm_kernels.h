@@ -576,6 +576,7 @@ struct CollapseState {
     double top_ub;                  // upper bound of `top`, from the bounds alone
     double min_val, max_val, top;   // transforms.py:185-189, decoded by k_finish_minmax
     unsigned long long heat_min_key, heat_max_key;
+    double sp_bg;                   // sparse merge: rank-ordered sum of the packets' backgrounds (k_sparse_index)
 };
 
 __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIPE-1 of one wavefront
@@ -1306,20 +1307,24 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
 // ----------------------------------------------------------------------------------------
 constexpr int SP_HDR = 4;  // doubles
 
-// background constant = the heatmap value of the first tile without kept frames (header double 1); none -> overflow
-__global__ __launch_bounds__(256) void k_sparse_background(const double *heat, int W, int tiles_x, int ntiles, const int *tile_nkept,
-                                                           int cap, double *packet)
+// background constant = the heatmap value of the first tile without kept frames (header double 1); none -> overflow.
+// One wave, 64 tiles per ballot (the first tile is almost always one of them).
+struct alignas(16) F64Pair { double a, b; };
+constexpr unsigned int SP_DENSE_ONLY = 0xffffffffu;   // header count: this rank has no sparse form, use the dense exchange
+__global__ __launch_bounds__(64) void k_sparse_background(const double *heat, int W, int tiles_x, int ntiles, const int *tile_nkept,
+                                                          int cap, double *packet)
 {
-    __shared__ int s_first;
-    if (threadIdx.x == 0) s_first = ntiles;
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntiles; i += 256)
-        if (tile_nkept[i] == 0) atomicMin(&s_first, i);
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    int first = ntiles;
+    for (int base = 0; base < ntiles && first == ntiles; base += 64) {
+        const int i = base + lane;
+        const unsigned long long m = __ballot(i < ntiles && tile_nkept[i] == 0);
+        if (m) first = base + __builtin_ctzll(m);
+    }
+    if (lane != 0) return;
     packet[0] = 0.0; packet[1] = 0.0; packet[2] = 0.0; packet[3] = 0.0;   // header: count = 0 before k_sparse_pack counts
-    if (s_first >= ntiles) { *reinterpret_cast<unsigned int *>(packet) = (unsigned int)cap + 1u; return; }
-    const int ty = s_first / tiles_x, tx = s_first - ty * tiles_x;
+    if (first >= ntiles) { *reinterpret_cast<unsigned int *>(packet) = SP_DENSE_ONLY; return; }
+    const int ty = first / tiles_x, tx = first - ty * tiles_x;
     packet[1] = heat[(size_t)ty * CT_H * W + (size_t)tx * CT_W];
 }
 
@@ -1332,6 +1337,7 @@ __global__ __launch_bounds__(256) void k_sparse_pack(const double *heat, int H, 
     const int y0 = ty * CT_H, x0 = tx * CT_W;
     if (tile_nkept[tile] == 0) return;
     unsigned int *count = reinterpret_cast<unsigned int *>(packet);
+    if (*(volatile unsigned int *)count == SP_DENSE_ONLY) return;
     const double c = packet[1];
     double v[CT_H * CT_W / 256];
     bool differs = false;
@@ -1360,37 +1366,78 @@ __global__ __launch_bounds__(256) void k_sparse_pack(const double *heat, int H, 
     for (int k = 0; k < CT_H * CT_W / 256; ++k) dst[threadIdx.x + 256 * k] = v[k];
 }
 
-// ONE workgroup prepares the merge: map[r][tile] = slot of `tile` in rank r's packet or -1, flag_host[0] = 1 when some
-// rank overflowed (a pinned host word: the caller reads it after the ROI stage's synchronisation), and the stripes
-// the merge kernel reduces the fused heatmap's extrema into
+// ONE workgroup prepares the merge: map[r][tile] = slot of `tile` in rank r's packet or -1, any[tile] = 1 when some rank
+// sent the tile, flag_host[0] = 1 when some rank overflowed, flag_host[1] = the largest tile count a rank needed
+// (pinned host words: the caller reads them after the ROI stage's synchronisation), and the stripes the merge
+// kernel reduces the fused heatmap's extrema into
 __global__ __launch_bounds__(256) void k_sparse_index(const double *packets, size_t packet_doubles, int world, int cap, int ntiles,
-                                                      int *map, int *flag_host, CollapseState *st)
+                                                      int *map, int *any, int *flag_host, CollapseState *st, int avg_T)
 {
     for (int i = threadIdx.x; i < world * ntiles; i += 256) map[i] = -1;
+    for (int i = threadIdx.x; i < ntiles; i += 256) any[i] = 0;
     if (threadIdx.x < NSTRIPE) { st->heat_min_keys[threadIdx.x] = ~0ull; st->heat_max_keys[threadIdx.x] = 0ull; }
     if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
     __syncthreads();
     int over = 0;
+    unsigned int need = 0;
     for (int r = 0; r < world; ++r) {
         const double *pk = packets + (size_t)r * packet_doubles;
         const unsigned int count = *reinterpret_cast<const unsigned int *>(pk);
+        if (count != SP_DENSE_ONLY && count > need) need = count;
         if (count > (unsigned)cap) { over = 1; continue; }
         for (unsigned int j = threadIdx.x; j < count; j += 256) {
             const int tile = (int)pk[SP_HDR + j];
-            if (tile >= 0 && tile < ntiles) map[(size_t)r * ntiles + tile] = (int)j;
+            if (tile >= 0 && tile < ntiles) { map[(size_t)r * ntiles + tile] = (int)j; any[tile] = 1; }
         }
     }
-    if (threadIdx.x == 0) flag_host[0] = over;
+    if (threadIdx.x == 0) { flag_host[0] = over; flag_host[1] = (int)need; }
+    // the tiles nobody sent are one constant: the backgrounds summed in rank order (the per-pixel arithmetic, done once)
+    double bg = 0.0;
+    for (int r = 0; r < world; ++r) {
+        const double v = packets[(size_t)r * packet_doubles + 1];
+        bg = (r == 0) ? v : bg + v;
+    }
+    if (avg_T > 0) bg = bg / (double)avg_T;
+    __shared__ int s_const;
+    if (threadIdx.x == 0) s_const = 0;
+    __syncthreads();   // also orders the any[] writes above before the reads below
+    int mine = 0;
+    for (int i = threadIdx.x; i < ntiles; i += 256) mine |= (any[i] == 0);
+    if (mine) s_const = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->sp_bg = bg;
+        if (s_const) { st->heat_min_keys[0] = f64_key(bg); st->heat_max_keys[0] = f64_key(bg); }
+    }
 }
 
 // fused[p] = sum over ranks (in rank order) of heat_r[p]; also the fused heatmap's min / max (striped)
-// avg_T > 0: the packets hold partial time SUMS of a frame-sharded buffer; the fused value is their sum / avg_T
+// avg_T > 0: the packets hold partial time SUMS of a frame-sharded buffer; the fused value is their sum / avg_T.
+// A tile no rank sent is the constant k_sparse_index prepared (already in the extrema), stored 16 bytes per lane.
 __global__ __launch_bounds__(256) void k_sparse_merge(const double *packets, size_t packet_doubles, int world, int cap, int H, int W,
-                                                      int tiles_x, int ntiles, const int *map, double *fused, CollapseState *st,
-                                                      int avg_T)
+                                                      int tiles_x, int ntiles, const int *map, const int *any, double *fused,
+                                                      CollapseState *st, int avg_T)
 {
     const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * CT_H, x0 = tx * CT_W;
+    if (!any[tile]) {   // workgroup-uniform
+        const double acc = st->sp_bg;
+        const int x = x0 + 2 * (threadIdx.x & 31);
+        const bool pair = ((W & 1) == 0) && x + 1 < W;   // even W: every row starts 16-byte aligned (x is even)
+#pragma unroll
+        for (int k = 0; k < CT_H / 8; ++k) {
+            const int y = y0 + (threadIdx.x >> 5) + 8 * k;
+            if (y >= H) continue;
+            double *dst = fused + (size_t)y * W + x;
+            if (pair) {
+                *reinterpret_cast<F64Pair *>(dst) = F64Pair{acc, acc};
+            } else {
+                if (x < W) dst[0] = acc;
+                if (x + 1 < W) dst[1] = acc;
+            }
+        }
+        return;
+    }
     double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
     for (int i = threadIdx.x; i < CT_H * CT_W; i += 256) {
         const int y = y0 + i / CT_W, x = x0 + (i & (CT_W - 1));

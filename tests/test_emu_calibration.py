@@ -2,6 +2,7 @@
 against a host emulation of the HIP subset they use (tests/emu, test infrastructure only) and
 driven through the same C-ABI as the real library.  They catch index / border / ordering bugs
 before GPU time is spent; the parity tests proper are the `-m gpu` tests."""
+import ctypes
 import numpy as np
 import pytest
 
@@ -217,6 +218,53 @@ def test_emu_sparse_heatmap_exchange(emu, oracle):
     # no pruning bookkeeping (skip 0 takes the plain path) -> fallback
     rc3, _, _, _, counts3 = emu.sparse_exchange([v[:6, :20, :24] for v in vids], cap=8, levels=2, skip=0)
     assert rc3 == _capi.RM_SPARSE_FALLBACK
+
+
+def _handmade_packets(H, W, world, cap, seed, avg_T=0):
+    """Packets as rm_heat_sparse_pack lays them out (include/respmon_hip.h) + the dense per-rank heatmaps they stand for."""
+    rng = np.random.default_rng(seed)
+    tiles_x, tiles_y = (W + 63) // 64, (H + 15) // 16
+    pd = 4 + cap + cap * 1024
+    packets, dense = np.zeros((world, pd)), []
+    for r in range(world):
+        bg = float(rng.uniform(0.1, 0.9))
+        heat = np.full((H, W), bg)
+        tiles = rng.choice(tiles_x * tiles_y, size=min(cap, 1 + r), replace=False)
+        packets[r, :1].view(np.uint32)[0] = len(tiles)
+        packets[r, 1] = bg
+        for j, tl in enumerate(tiles):
+            ty, tx = divmod(int(tl), tiles_x)
+            vals = np.full((16, 64), bg)
+            hh, ww = min(16, H - 16 * ty), min(64, W - 64 * tx)
+            vals[:hh, :ww] = rng.uniform(0.0, 2.0, (hh, ww))
+            heat[16 * ty:16 * ty + hh, 64 * tx:64 * tx + ww] = vals[:hh, :ww]
+            packets[r, 4 + j] = tl
+            packets[r, 4 + cap + 1024 * j:4 + cap + 1024 * (j + 1)] = vals.ravel()
+        dense.append(heat)
+    acc = dense[0].copy()
+    for h in dense[1:]:
+        acc = acc + h
+    if avg_T:
+        acc = acc / avg_T
+    return packets.ravel(), acc
+
+
+@pytest.mark.parametrize("H,W,avg_T", [(70, 200, 0), (33, 201, 0), (48, 130, 7)])
+def test_emu_sparse_merge_handmade_packets(emu, oracle, H, W, avg_T):
+    """k_sparse_index / k_sparse_merge on hand-made packets: tiles nobody sent take the constant path (16-byte stores for
+    even W, scalar for odd W), sent tiles the per-pixel one; the result is the rank-ordered sum bit for bit."""
+    from tests.emu_harness import ptr
+    from respmon_amd import _capi
+    world, cap = 3, 6
+    allp, want = _handmade_packets(H, W, world, cap, seed=H * W, avg_T=avg_T)
+    fused = np.full((H, W), -1.0); xywh = np.zeros(4, np.int32)
+    rc = emu.lib.rm_heat_sparse_merge_roi(emu.ctx, ptr(allp), world, H, W, cap, 20, avg_T, ptr(fused), ptr(xywh), None)
+    assert rc in (_capi.RM_OK, _capi.RM_NO_CONTOUR)
+    assert np.array_equal(fused, want)
+    u8 = oracle.float_to_uint8((want - want.min()) / (want.max() - want.min()))
+    assert (tuple(int(v) for v in xywh) if rc == _capi.RM_OK else None) == oracle.roi_from_heatmap_u8(u8, 20)
+    n = ctypes.c_int(-1)
+    assert emu.lib.rm_heat_sparse_tiles_needed(emu.ctx, ctypes.byref(n)) == 0 and n.value == world
 
 
 def test_emu_error_conventions(emu):

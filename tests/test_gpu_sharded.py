@@ -205,6 +205,28 @@ def test_sparse_heatmap_exchange_emulated_ranks(hip, oracle):
     assert rc == _capi.RM_SPARSE_FALLBACK
 
 
+@pytest.mark.parametrize("H,W,avg_T", [(1080, 1920, 0), (271, 1001, 0), (540, 962, 5)])
+def test_sparse_merge_handmade_packets(hip, oracle, H, W, avg_T):
+    """The merge kernels on hand-made packets (tests/test_emu_calibration.py::_handmade_packets): constant path for the
+    tiles nobody sent (16-byte stores / odd-width scalar stores), per-pixel path for the others, partial edge tiles."""
+    import torch
+    from respmon_amd import _capi, device
+    from tests.test_emu_calibration import _handmade_packets
+    lib = hip
+    world, cap = 4, 9
+    allp_h, want = _handmade_packets(H, W, world, cap, seed=H + W, avg_T=avg_T)
+    allp = torch.from_numpy(allp_h).cuda()
+    fused = torch.full((H, W), -1.0, dtype=torch.float64, device="cuda")
+    xywh = (ctypes.c_int32 * 4)()
+    rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(allp), world, H, W, cap, 20, avg_T, device.ptr(fused), xywh,
+                                                       device.stream_ptr()), "merge")
+    assert np.array_equal(fused.cpu().numpy(), want)
+    u8 = oracle.float_to_uint8((want - want.min()) / (want.max() - want.min()))
+    assert (tuple(int(v) for v in xywh) if rc == _capi.RM_OK else None) == oracle.roi_from_heatmap_u8(u8, 20)
+    n = ctypes.c_int(-1)
+    assert lib.rm_heat_sparse_tiles_needed(device.ctx(), ctypes.byref(n)) == 0 and n.value == world
+
+
 def _worker_streams(rank, world, port, out_dir, T, H, W):
     import sys
     import torch
