@@ -393,6 +393,27 @@ struct LdsPlain {
 struct CollapseState;
 __device__ void state_init_lane(CollapseState *st, int i);   // defined with the state, below
 
+// global -> LDS copy by one SMALL_NT-thread workgroup with 8 loads in flight per lane: a plain
+// `for (i) lds[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per iteration, i.e. one HBM round trip
+// per 8 KB of a frame -- most of the run time of the one-workgroup-per-frame kernels below
+__device__ __forceinline__ void fill_lds(double *dst, const double *src, int n, int tid)
+{
+    constexpr int U = 8;
+    for (int base = 0; base < n; base += U * SMALL_NT) {
+        double v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = base + tid + k * SMALL_NT;
+            v[k] = (i < n) ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = base + tid + k * SMALL_NT;
+            if (i < n) dst[i] = v[k];
+        }
+    }
+}
+
 // st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
 __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all, CollapseState *st_init)
 {
@@ -400,11 +421,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
     HIP_DYNAMIC_SHARED(double, lds)
     const int t = blockIdx.x, tid = threadIdx.x;
     const int S = g.S, L = g.L;
-    {
-        const int n = g.h[S] * g.w[S];
-        const double *src = gS + (size_t)t * n;
-        for (int i = tid; i < n; i += SMALL_NT) lds[g.g_off[S] + i] = src[i];
-    }
+    fill_lds(lds + g.g_off[S], gS + (size_t)t * (g.h[S] * g.w[S]), g.h[S] * g.w[S], tid);
     __syncthreads();
     for (int l = S + 1; l < L; ++l) {
         const int sh = g.h[l - 1], sw = g.w[l - 1], dh = g.h[l], dw = g.w[l];
@@ -445,8 +462,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_al
     const int t = blockIdx.x, tid = threadIdx.x;
     if (st_init && t == 0 && tid < 64) state_init_lane(st_init, tid);
     const int S = g.S, L = g.L;
-    const double *src = bp_all + (size_t)t * g.NP;
-    for (int i = tid; i < g.NP; i += SMALL_NT) lds[i] = src[i];
+    fill_lds(lds, bp_all + (size_t)t * g.NP, g.NP, tid);
     __syncthreads();
     for (int l = L - 3; l >= S; --l) {
         const int dh = g.h[l], dw = g.w[l], sh = g.h[l + 1], sw = g.w[l + 1];
@@ -719,8 +735,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
     const int S = sg.S, L = sg.L;
     // (st was reset by an EARLIER kernel on the stream -- k_small_pyramid or k_state_init: the atomics at the end of this
     //  kernel must not race with a reset inside it)
-    const double *src = bp_all + (size_t)t * sg.NP;
-    for (int i = tid; i < sg.NP; i += SMALL_NT) lds[i] = src[i];
+    fill_lds(lds, bp_all + (size_t)t * sg.NP, sg.NP, tid);
     __syncthreads();
     for (int l = L - 3; l >= S; --l) {
         const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
