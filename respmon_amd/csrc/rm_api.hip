@@ -1052,7 +1052,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
         LAUNCH_CHECK();
     }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
-    hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 255) / 256), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
+    hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 256 * SEL_U - 1) / (256 * SEL_U)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
                        (unsigned)slot_cap, prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles);
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;

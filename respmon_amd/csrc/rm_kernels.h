@@ -385,13 +385,65 @@ struct SmallGeom {
     int NP;
 };
 
-struct LdsPlain {
-    const double *p; int w;
-    __device__ __forceinline__ double operator()(int r, int c) const { return p[r * w + c]; }
-};
-
 struct CollapseState;
 __device__ void state_init_lane(CollapseState *st, int i);   // defined with the state, below
+
+// ---- pyrUp inside LDS, separable and branch-free -------------------------------------------------------------
+// up_h() above chooses between five differently shaped expressions per column (interior / left / right border,
+// even / odd), which on a wavefront means divergent branches and every shape executed.  The same values, bit for
+// bit, come out of ONE shape with per-column operands and weights fixed once per level:
+//     h(x) = (A*wa + B*wb) + C*wc
+//   even interior  A=s[j-1] B=s[j] C=s[j+1]  w = 1,6,1    == s[j-1] + s[j]*6 + s[j+1]
+//   even left      B=s[0]   C=s[1]           w = 0,6,2    == s[0]*6 + s[1]*2          (0 + x is exact)
+//   even right     A=s[j-1] B=s[j]           w = 1,7,0    == s[j-1] + s[j]*7          (x + 0 is exact)
+//   odd  interior  B=s[j]   C=s[j+1]         w = 0,4,4    == (s[j] + s[j+1])*4        (scaling by 4 commutes with rounding)
+//   odd  right / single column  B=C=s[j]     w = 0,4,4    == s[j]*8
+// (only the sign of an exact zero can differ, which no later operation observes).  The vertical pass needs no such
+// trick: OpenCV's border rules are index clamps there, and row parity is uniform across a wavefront.
+struct HTap { int ia, ib, ic; double wa, wb, wc; };
+
+__device__ __forceinline__ HTap make_htap(int x, int sw)   // destination column x of a pyrUp from a source row of width sw
+{
+    HTap t;
+    const int j = x >> 1;
+    const bool odd = (x & 1) != 0, single = sw == 1, left = j == 0, right = j == sw - 1;
+    const bool four = odd || single;                      // the (B + C) * 4 shapes
+    t.ib = j;
+    t.ia = (four || left) ? j : j - 1;                   // unused (weight 0) in those shapes: any valid index
+    t.ic = (single || right) ? j : j + 1;
+    t.wa = (four || left) ? 0.0 : 1.0;
+    t.wb = four ? 4.0 : (right ? 7.0 : 6.0);
+    t.wc = four ? 4.0 : (left ? 2.0 : (right ? 0.0 : 1.0));
+    return t;
+}
+
+// whole-image pyrUp inside LDS for the one-workgroup-per-frame kernels: wave = destination row (parity and the
+// border rules of the row index are wave-uniform), lane = destination column (its taps and weights fixed once per
+// level, make_htap), so there is no index division and no divergent shape.  Same values as up_at(), bit for bit.
+// sink(i, v) receives destination element i = y * dw + x.
+template <typename Sink>
+__device__ __forceinline__ void small_up_level(const double *src, int sh, int sw, int dh, int dw, int tid, Sink &&sink)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int x = lane; x < dw; x += 64) {
+        const HTap t = make_htap(x, sw);
+        for (int y = wave; y < dh; y += SMALL_NT / 64) {
+            const int i = y >> 1;
+            const double *ri = src + i * sw, *r2 = src + ((i == sh - 1) ? i : i + 1) * sw;
+            const double hi_ = (ri[t.ia] * t.wa + ri[t.ib] * t.wb) + ri[t.ic] * t.wc;
+            const double h2 = (r2[t.ia] * t.wa + r2[t.ib] * t.wb) + r2[t.ic] * t.wc;
+            double v;
+            if (y & 1) {
+                v = ((hi_ + h2) * 4) * (1.0 / 64);
+            } else {
+                const double *r0 = src + ((i == 0) ? (sh > 1 ? 1 : 0) : i - 1) * sw;
+                const double h0 = (r0[t.ia] * t.wa + r0[t.ib] * t.wb) + r0[t.ic] * t.wc;
+                v = (h0 + hi_ * 6 + h2) * (1.0 / 64);
+            }
+            sink(y * dw + x, v);
+        }
+    }
+}
 
 // global -> LDS copy by one SMALL_NT-thread workgroup with 8 loads in flight per lane: a plain
 // `for (i) lds[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per iteration, i.e. one HBM round trip
@@ -427,30 +479,27 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
         const int sh = g.h[l - 1], sw = g.w[l - 1], dh = g.h[l], dw = g.w[l];
         const double *s = lds + g.g_off[l - 1];
         double *d = lds + g.g_off[l];
-        for (int i = tid; i < dh * dw; i += SMALL_NT) {
-            const int y = i / dw, x = i - y * dw;
+        for (int x = (tid & 63); x < dw; x += 64) {          // lane = column, wave = row: no index division
             const int c0 = reflect101(2 * x - 2, sw), c1 = reflect101(2 * x - 1, sw), c2 = reflect101(2 * x, sw);
             const int c3 = reflect101(2 * x + 1, sw), c4 = reflect101(2 * x + 2, sw);
-            double r[5];
+            for (int y = (tid >> 6); y < dh; y += SMALL_NT / 64) {
+                double r[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const double *row = s + reflect101(2 * y - 2 + k, sh) * sw;
-                r[k] = row[c2] * 6 + (row[c1] + row[c3]) * 4 + row[c0] + row[c4];
+                for (int k = 0; k < 5; ++k) {
+                    const double *row = s + reflect101(2 * y - 2 + k, sh) * sw;
+                    r[k] = row[c2] * 6 + (row[c1] + row[c3]) * 4 + row[c0] + row[c4];
+                }
+                d[y * dw + x] = (r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]) * (1.0 / 256);
             }
-            d[i] = (r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]) * (1.0 / 256);
         }
         __syncthreads();
     }
     double *out = lap_all + (size_t)t * g.NP;
     for (int l = L - 2; l >= S; --l) {
         const int dh = g.h[l], dw = g.w[l], sh = g.h[l + 1], sw = g.w[l + 1];
-        LdsPlain up{lds + g.g_off[l + 1], sw};
         const double *base = lds + g.g_off[l];
         double *o = out + g.np_off[l];
-        for (int i = tid; i < dh * dw; i += SMALL_NT) {
-            const int y = i / dw, x = i - y * dw;
-            o[i] = base[i] - up_at(up, y, x, sh, sw);
-        }
+        small_up_level(lds + g.g_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { o[i] = base[i] - v; });
     }
 }
 
@@ -466,12 +515,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_al
     __syncthreads();
     for (int l = L - 3; l >= S; --l) {
         const int dh = g.h[l], dw = g.w[l], sh = g.h[l + 1], sw = g.w[l + 1];
-        LdsPlain c{lds + g.np_off[l + 1], sw};
         double *d = lds + g.np_off[l];
-        for (int i = tid; i < dh * dw; i += SMALL_NT) {
-            const int y = i / dw, x = i - y * dw;
-            d[i] = up_at(c, y, x, sh, sw) + d[i];
-        }
+        small_up_level(lds + g.np_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = v + d[i]; });
         __syncthreads();
     }
     const int n = g.h[S] * g.w[S];
@@ -739,12 +784,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
     __syncthreads();
     for (int l = L - 3; l >= S; --l) {
         const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
-        LdsPlain c{lds + sg.np_off[l + 1], sw};
         double *d = lds + sg.np_off[l];
-        for (int i = tid; i < dh * dw; i += SMALL_NT) {
-            const int y = i / dw, x = i - y * dw;
-            d[i] = up_at(c, y, x, sh, sw) + d[i];
-        }
+        small_up_level(lds + sg.np_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = v + d[i]; });
         __syncthreads();
     }
     const int hS = sg.h[S], wS = sg.w[S], n = hS * wS, ntx = g.tiles_x;
@@ -809,12 +850,24 @@ constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is
 // which pairs need their full-resolution values:
 //   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max
 //   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum
+constexpr int SEL_U = 4;   // pairs per lane: their bound loads are issued together (the kernel is latency bound)
 __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
                                                       unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune,
                                                       double thr, int first_pair, int end_pair)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool in_range = i < n;
+    const int i0 = blockIdx.x * (256 * SEL_U) + threadIdx.x;
+    // the pairs' bounds first: nothing below depends on them until the comparisons
+    double l[SEL_U], h[SEL_U];
+    bool mine[SEL_U];
+#pragma unroll
+    for (int k = 0; k < SEL_U; ++k) {
+        const int i = i0 + 256 * k;
+        // frame shard (pairs are [t][tile]): the bounds below cover every frame, the evaluation only this
+        // rank's frames [first_pair, end_pair) / ntiles
+        mine[k] = i < n && i >= first_pair && i < end_pair;
+        l[k] = mine[k] ? lo[i] : 0.0;
+        h[k] = mine[k] ? hi[i] : 0.0;
+    }
     // margin and the bounds-only upper bound of top = max - (max - min) * thr (increasing in max and min
     // for 0 <= thr <= 1); every thread derives them from the reduced bounds
     const unsigned long long k_lb_max = fold_max_keys(st->lb_max_keys, st->lb_max_key), k_ub_min = fold_min_keys(st->ub_min_keys, st->ub_min_key);
@@ -825,64 +878,35 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
     const double m = PRUNE_REL_MARGIN * (aa > bb ? aa : bb);
     const double mx_ = ub_max + m, mn_ = ub_min + m;
     const double top_ub = (mx_ - (mx_ - mn_) * thr) + m;
-    if (i == 0) { st->margin = m; st->top_ub = top_ub; }
-    // frame shard (pairs are [t][tile]): the bounds above cover every frame, the evaluation only this
-    // rank's frames [first_pair, end_pair) / ntiles
-    const bool mine = in_range && i >= first_pair && i < end_pair;
-    bool isC = false, isD = false;
-    if (mine) {
-        const double l = lo[i], h = hi[i];
-        isC = no_prune || !(h + m < lb_max - m) || !(l - m > ub_min + m);
-        isD = no_prune || (l - m < top_ub);
-    }
-    // one atomic per wave and counter (ballot + prefix popcount), not one per selected pair
+    if (i0 == 0) { st->margin = m; st->top_ub = top_ub; }
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned long long mD = __ballot(isD);
-    unsigned base_slot = 0;
-    if (lane == 0 && mD) base_slot = atomicAdd(&st->n_slots, (unsigned)__popcll(mD));
-    base_slot = (unsigned)__shfl((int)base_slot, 0);
-    int slot = SLOT_PRUNED;
-    if (isD) {
-        const unsigned sidx = base_slot + (unsigned)__popcll(mD & below);
-        slot = (sidx < slot_cap) ? (int)sidx : SLOT_ON_THE_FLY;
+#pragma unroll
+    for (int k = 0; k < SEL_U; ++k) {
+        const int i = i0 + 256 * k;
+        bool isC = false, isD = false;
+        if (mine[k]) {
+            isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
+            isD = no_prune || (l[k] - m < top_ub);
+        }
+        // one atomic per wave and counter (ballot + prefix popcount), not one per selected pair
+        const unsigned long long mD = __ballot(isD);
+        unsigned base_slot = 0;
+        if (lane == 0 && mD) base_slot = atomicAdd(&st->n_slots, (unsigned)__popcll(mD));
+        base_slot = (unsigned)__shfl((int)base_slot, 0);
+        int slot = SLOT_PRUNED;
+        if (isD) {
+            const unsigned sidx = base_slot + (unsigned)__popcll(mD & below);
+            slot = (sidx < slot_cap) ? (int)sidx : SLOT_ON_THE_FLY;
+        }
+        if (i < n) slot_of[i] = slot;
+        const bool listed = isC || slot >= 0;
+        const unsigned long long mL = __ballot(listed);
+        unsigned base_list = 0;
+        if (lane == 0 && mL) base_list = atomicAdd(&st->n_list, (unsigned)__popcll(mL));
+        base_list = (unsigned)__shfl((int)base_list, 0);
+        if (listed) list[base_list + (unsigned)__popcll(mL & below)] = (unsigned)i;
     }
-    if (in_range) slot_of[i] = slot;
-    const bool listed = isC || slot >= 0;
-    const unsigned long long mL = __ballot(listed);
-    unsigned base_list = 0;
-    if (lane == 0 && mL) base_list = atomicAdd(&st->n_list, (unsigned)__popcll(mL));
-    base_list = (unsigned)__shfl((int)base_list, 0);
-    if (listed) list[base_list + (unsigned)__popcll(mL & below)] = (unsigned)i;
-}
-
-// ---- pyrUp inside LDS, separable and branch-free -------------------------------------------------------------
-// up_h() above chooses between five differently shaped expressions per column (interior / left / right border,
-// even / odd), which on a wavefront means divergent branches and every shape executed.  The same values, bit for
-// bit, come out of ONE shape with per-column operands and weights fixed once per level:
-//     h(x) = (A*wa + B*wb) + C*wc
-//   even interior  A=s[j-1] B=s[j] C=s[j+1]  w = 1,6,1    == s[j-1] + s[j]*6 + s[j+1]
-//   even left      B=s[0]   C=s[1]           w = 0,6,2    == s[0]*6 + s[1]*2          (0 + x is exact)
-//   even right     A=s[j-1] B=s[j]           w = 1,7,0    == s[j-1] + s[j]*7          (x + 0 is exact)
-//   odd  interior  B=s[j]   C=s[j+1]         w = 0,4,4    == (s[j] + s[j+1])*4        (scaling by 4 commutes with rounding)
-//   odd  right / single column  B=C=s[j]     w = 0,4,4    == s[j]*8
-// (only the sign of an exact zero can differ, which no later operation observes).  The vertical pass needs no such
-// trick: OpenCV's border rules are index clamps there, and row parity is uniform across a wavefront.
-struct HTap { int ia, ib, ic; double wa, wb, wc; };
-
-__device__ __forceinline__ HTap make_htap(int x, int sw)   // destination column x of a pyrUp from a source row of width sw
-{
-    HTap t;
-    const int j = x >> 1;
-    const bool odd = (x & 1) != 0, single = sw == 1, left = j == 0, right = j == sw - 1;
-    const bool four = odd || single;                      // the (B + C) * 4 shapes
-    t.ib = j;
-    t.ia = (four || left) ? j : j - 1;                   // unused (weight 0) in those shapes: any valid index
-    t.ic = (single || right) ? j : j + 1;
-    t.wa = (four || left) ? 0.0 : 1.0;
-    t.wb = four ? 4.0 : (right ? 7.0 : 6.0);
-    t.wc = four ? 4.0 : (left ? 2.0 : (right ? 0.0 : 1.0));
-    return t;
 }
 
 // stage the level-S footprint of `tile` for frame t
