@@ -1085,6 +1085,9 @@ __global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, co
 // exposed memory latencies.  (Measured alternatives: quarter tiles with one row per lane and 32-frame batches
 // shorten the chain of the few heavy tiles but quadruple the fixed cost of the ~2000 light ones: 105 us vs 75 us.)
 constexpr int MAX_T = 4096;
+// (measured: 8 waves x 2 rows with 16 frames per batch halves the dependent round trips of the heaviest tile but, at
+//  195 VGPRs, leaves one 512-thread workgroup per CU: 88 us instead of 49 -- the launch is bound by the rounds of
+//  light tiles, not by the heaviest one)
 constexpr int MS_B = 8;               // kept frames per batch
 constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 
