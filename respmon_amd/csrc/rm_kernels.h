@@ -1088,10 +1088,18 @@ constexpr int MAX_T = 4096;
 // (measured: 8 waves x 2 rows with 16 frames per batch halves the dependent round trips of the heaviest tile but, at
 //  195 VGPRs, leaves one 512-thread workgroup per CU: 88 us instead of 49 -- the launch is bound by the rounds of
 //  light tiles, not by the heaviest one)
-constexpr int MS_B = 8;               // kept frames per batch
+// batch depth x occupancy hint (tools/sweep_msum.sh, us per launch): 8/1 49, 8/3 47, 6/3 43, 5/3 43, 4/3 42, 4/4 43,
+// 3/4 44, 8/4 70 (spills), 12/2 51: three workgroups per CU with a 6-frame batch
+#ifndef RM_MS_B
+#define RM_MS_B 6
+#endif
+#ifndef RM_MS_MINBLK
+#define RM_MS_MINBLK 3
+#endif
+constexpr int MS_B = RM_MS_B;         // kept frames per batch
 constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
 
-__global__ __launch_bounds__(256) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
+__global__ __launch_bounds__(256, RM_MS_MINBLK) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
                                                           int *tile_nkept, unsigned int *slots_seen_host, const double *slot_min)
