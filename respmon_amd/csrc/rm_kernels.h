@@ -1089,7 +1089,9 @@ constexpr int MAX_T = 4096;
 //  195 VGPRs, leaves one 512-thread workgroup per CU: 88 us instead of 49 -- the launch is bound by the rounds of
 //  light tiles, not by the heaviest one)
 // batch depth x occupancy hint (tools/sweep_msum.sh, us per launch): 8/1 49, 8/3 47, 6/3 43, 5/3 43, 4/3 42, 4/4 43,
-// 3/4 44, 8/4 70 (spills), 12/2 51: three workgroups per CU with a 6-frame batch
+// 3/4 44, 8/4 70 (spills), 12/2 51: three workgroups per CU with a 6-frame batch.  Alone, the tiles with kept frames
+// take 36 us and the others 19 us: the tile with the most kept frames is the critical path.  A register ring of 3-8
+// batches in flight (loads issued several batches ahead) measured 51-69 us -- slower than this double buffer.
 #ifndef RM_MS_B
 #define RM_MS_B 6
 #endif
