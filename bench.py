@@ -1,17 +1,24 @@
 """bench.py -- Eulerian-calibration frames/sec on a 1080p x 256 buffer (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config P|Q|R] [--mode streams|sharded]
 
 One step = one locate() (calibration + ROI) over one [T,H,W] frame buffer already resident in HBM.
-N>1: one process per GPU, each with its own stream (weak scaling, Mode B of respmon_amd/dist.py) and one RCCL
-exchange of the [H,W] heatmaps per step (an all-gather of sparse packets; dense all-reduce(sum) as the fallback);
---mode sharded: ONE buffer split by frame index over the GPUs (Mode A, strong scaling).  Rank 0 prints ONE JSON line.
+N>1: one process per GPU.  When the script is started WITHOUT a launcher (`python bench.py --gpus 8`, WORLD_SIZE unset) it
+re-executes itself through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; started
+by the launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one rank of that job.  Default mode "streams"
+(Mode B of respmon_amd/dist.py, BASELINE config 4): an independent stream per GPU, weak scaling, one RCCL exchange of the
+[H,W] heatmaps per step (an all-gather of sparse packets; dense all-reduce(sum) as the fallback).  --mode sharded: ONE
+buffer split by frame index over the GPUs (Mode A, strong scaling).  Rank 0 prints ONE JSON line.
+
+--config picks the workload (SURVEY 8 sizes):  P = 256 x 1080p, L=9, S=4, float64 buffer (the metric's own configuration,
+default);  Q = 128 x 720p, L=4, S=2, float64 (BASELINE config 2);  R = 512 x 4K, L=6, S=2, float16 buffer (config 5).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,50 +29,111 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 DT_BYTES = {"f64": 8, "f32": 4, "f16": 2, "u8": 1}
+CONFIGS = {   # frames, height, width, levels, skip, frame-buffer dtype
+    "P": (256, 1080, 1920, 9, 4, "f64"),
+    "Q": (128, 720, 1280, 4, 2, "f64"),
+    "R": (512, 2160, 3840, 6, 2, "f16"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--in-dtype", default="f64", choices=list(DT_BYTES), help="device frame-buffer element type; "
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x ~1 ms: the timed region is >= 0.1 s)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="P", choices=sorted(CONFIGS), help="workload preset (see the module docstring); the "
+                    "explicit size flags below override its fields")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--in-dtype", default=None, choices=list(DT_BYTES), help="device frame-buffer element type; "
                     "f64 is the reference's calibration_buffer dtype (base.py:119)")
-    ap.add_argument("--levels", type=int, default=9)
-    ap.add_argument("--skip", type=int, default=4)
-    ap.add_argument("--prewarm-steps", type=int, default=600, help="untimed steps run BEFORE the W warmup steps (a fixed count so that "
+    ap.add_argument("--levels", type=int, default=None)
+    ap.add_argument("--skip", type=int, default=None)
+    ap.add_argument("--prewarm-steps", type=int, default=None, help="untimed steps run BEFORE the W warmup steps (a fixed count so that "
                     "all ranks issue the same collectives): a fresh box starts in a low power state and its clocks take a few hundred ms "
-                    "of load to settle -- measured 1.18 -> 1.14 ms/step (reported as pre_warm_steps; 0 disables)")
+                    "of load to settle -- measured 1.18 -> 1.14 ms/step (reported as pre_warm_steps; 0 disables; default ~0.7 s of work)")
     ap.add_argument("--mode", default="streams", choices=["streams", "sharded"], help="N>1 only.  streams (default, BASELINE config 4): one "
-                    "independent [T,H,W] stream per GPU + one heatmap all-reduce, weak scaling.  sharded: ONE [T,H,W] buffer split by frame "
+                    "independent [T,H,W] stream per GPU + one heatmap exchange, weak scaling.  sharded: ONE [T,H,W] buffer split by frame "
                     "index over the GPUs (respmon_amd.dist.locate_sharded), strong scaling")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip everything outside the contract line: uint8-buffer variant, ROI "
+                    "flow, no-prune / dense-stream data-dependence figures")
     ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
     ap.add_argument("--no-roi-flow", action="store_true", help="skip the per-frame ROI optical-flow measurement")
-    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T frames if host memory allows, else 64)")
-    return ap.parse_args()
+    ap.add_argument("--no-data-dependence", action="store_true", help="skip the no-prune and dense-stream measurements")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T "
+                    "frames if host memory allows, else 64)")
+    ap.add_argument("--cpu-workers", type=int, default=-1, help="threads of the all-cores CPU figure (0 = skip, -1 = min(64, host cores))")
+    ap.add_argument("--allow-env-knobs", action="store_true", help="run although RM_* developer variables are set (they silently change "
+                    "kernel geometry; the JSON line lists them as env_knobs either way)")
+    a = ap.parse_args()
+    T, H, W, L, S, dt = CONFIGS[a.config]
+    a.frames = a.frames or T
+    a.height = a.height or H
+    a.width = a.width or W
+    a.levels = a.levels if a.levels is not None else L
+    a.skip = a.skip if a.skip is not None else S
+    a.in_dtype = a.in_dtype or dt
+    return a
 
 
-def cpu_baseline(vid_u8, n_frames, levels, skip):
-    """The oracle (a port: the reference's materialising algorithm with the build's C restatement of the
-    cv2 calls) timed on this host, single thread like the reference, on the first n_frames frames."""
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def oracle_single(vid_u8, n_frames, levels, skip, in_dtype):
+    """The oracle (a port: the reference's materialising algorithm with the build's C restatement of the cv2 calls)
+    timed on this host, single thread like the reference, on the first n_frames frames."""
     from oracle import respmon_oracle as oracle
     oracle.build()
     frames = oracle.uint8_to_float(vid_u8[:n_frames])
+    if in_dtype in ("f32", "f16"):   # what the device buffer holds, widened exactly
+        frames = frames.astype({"f32": np.float32, "f16": np.float16}[in_dtype]).astype(np.float64)
     t0 = time.perf_counter()
     roi = oracle.locate(frames, 10, pyramid_levels=levels, skip_levels_at_top=skip)
     dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d frames of the same %dx%d video, oracle.locate (L=%d,S=%d), %.1f s, host has %d cores"
-                      % (n_frames, vid_u8.shape[0], vid_u8.shape[1], vid_u8.shape[2], levels, skip, dt, os.cpu_count()),
-            "roi": roi}
+    return frames, roi, dt
+
+
+def cpu_baseline(vid_u8, n_frames, levels, skip, in_dtype, workers):
+    from oracle import respmon_oracle as oracle
+    T = vid_u8.shape[0]
+    frames, roi, dt = oracle_single(vid_u8, n_frames, levels, skip, in_dtype)
+    out = {"value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%s %d of the %d frames of the same %dx%d video, oracle.locate (L=%d,S=%d), %.1f s, host has %d cores"
+                     % ("the first" if n_frames < T else "all", n_frames, T, vid_u8.shape[1], vid_u8.shape[2], levels, skip, dt, os.cpu_count()),
+           "reduced_T": n_frames < T, "roi": roi}
+    if workers:
+        # the same algorithm with its per-frame / per-pixel-column loops spread over host threads (the C calls release the GIL):
+        # bit-identical results, so the GPU is not only compared with a single-threaded strawman (SURVEY 8d)
+        nw = min(64, os.cpu_count() or 1) if workers < 0 else workers
+        t0 = time.perf_counter()
+        roi_mt = oracle.locate_parallel(frames, 10, pyramid_levels=levels, skip_levels_at_top=skip, workers=nw)
+        dtm = time.perf_counter() - t0
+        out["all_cores"] = {"value": n_frames / dtm, "unit": "frames/s", "cores": nw, "seconds": dtm, "roi_equals_single_thread": roi_mt == roi}
+    return out
 
 
 def main():
     a = parse()
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("RM_")}
+    if knobs and not a.allow_env_knobs:
+        sys.stderr.write("bench.py: developer variables %s are set; they change kernel geometry.  Unset them or pass "
+                         "--allow-env-knobs.\n" % sorted(knobs))
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
+
     import torch
     import torch.distributed as dist
     from respmon_amd import _capi, device, synth
@@ -74,6 +142,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend_name = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank per GPU; the modulo only matters for the single-GPU dry run of this path
@@ -87,24 +156,28 @@ def main():
             dist.init_process_group(backend_name)
     else:
         torch.cuda.set_device(0)
-    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
     T, H, W = a.frames, a.height, a.width
     sharded = world > 1 and a.mode == "sharded"
+    big = T * H * W > 1 << 30
+    gen = synth.synth_breathing_blocks if big else synth.synth_breathing
     # config 4: an independent stream per GPU; sharded mode: the same buffer everywhere, each rank keeps its frame shard
-    vid_u8 = synth.synth_breathing(T, H, W, seed=1234 + (0 if sharded else rank))
+    vid_u8 = gen(T, H, W, seed=1234 + (0 if sharded else rank))
     if sharded:
         t_lo, t_hi = rdist.shard_frames(T, rank, world)
         vid_u8 = vid_u8[t_lo:t_hi]
     tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[a.in_dtype]
-    dev_u8 = torch.from_numpy(vid_u8).cuda()
-    if a.in_dtype == "u8":
-        buf = dev_u8
-    else:
-        buf = torch.empty(tuple(dev_u8.shape), dtype=tdt, device="cuda")
-        for t0 in range(0, buf.shape[0], 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype
-            buf[t0:t0 + 16] = (dev_u8[t0:t0 + 16].to(torch.float64) * (1.0 / 255)).to(tdt)
-        del dev_u8
+
+    def to_device(v8):
+        if a.in_dtype == "u8":
+            return torch.from_numpy(v8).cuda()
+        b = torch.empty(tuple(v8.shape), dtype=tdt, device="cuda")
+        for t0 in range(0, b.shape[0], 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype
+            b[t0:t0 + 16] = (torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)).to(tdt)
+        return b
+
+    buf = to_device(vid_u8)
     torch.cuda.synchronize()
 
     lib = _capi.load()
@@ -115,9 +188,12 @@ def main():
     from respmon_amd.base import _Backend
     backend = _Backend()
 
+    def locate1(b, fl=flags):   # exactly RespiratoryMonitor.locate: one rm_locate call
+        return backend.locate(b, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, fl)
+
     def step():
-        if world == 1:   # exactly RespiratoryMonitor.locate: one rm_locate call
-            return backend.locate(buf, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
+        if world == 1:
+            return locate1(buf)
         if sharded:
             return rdist.locate_sharded(buf, T, 10, threshold=20, **kw)
         return rdist.locate_streams(buf, 10, threshold=20, **kw)
@@ -127,9 +203,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    roi = None
-    pre_steps = max(0, a.prewarm_steps)
-    for _ in range(pre_steps):   # clock ramp of a fresh box; not part of W or K
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = None
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) / max(n, 1) * 1e3
+
+    roi = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    roi = step()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-5)
+    pre_steps = a.prewarm_steps if a.prewarm_steps is not None else int(min(600, max(10, 0.7 / one)))   # clock ramp of a fresh box
+    if world > 1:   # every rank must issue the same number of collectives
+        n_t = torch.tensor([pre_steps], dtype=torch.int64, device="cuda")
+        dist.broadcast(n_t, 0)
+        pre_steps = int(n_t[0])
+    for _ in range(max(0, pre_steps)):
         roi = step()
     for _ in range(a.warmup):
         roi = step()
@@ -147,6 +241,9 @@ def main():
     tn = ctypes.c_int(0)
     _capi.check(lib, lib.rm_heat_sparse_tiles_needed(ctx, ctypes.byref(tn)), "rm_heat_sparse_tiles_needed")
     tiles_needed = tn.value                       # largest per-rank tile count of the last sparse exchange (world > 1)
+    dbg = (ctypes.c_longlong * 4)()
+    _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
+    pairs = {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]}
     # phase breakdown: separate untimed pass (bracketing every phase costs ~10 us of stream idle time each)
     _capi.check(lib, lib.rm_profile_enable(ctx, 2), "rm_profile_enable")
     for _ in range(3):
@@ -154,28 +251,31 @@ def main():
     torch.cuda.synchronize()
     _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
     _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+    phases = {"frame_buffer_kernel": ms[0] / max(ncalls.value, 1), "pyramid_rest_and_temporal": ms[1] / max(ncalls.value, 1),
+              "collapse_passes": ms[2] / max(ncalls.value, 1), "heatmap_to_roi": ms[3] / max(ncalls.value, 1)}
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+
+    extras = world == 1 and not a.no_extras
+    n_extra = max(3, min(a.steps, 20))
     # same video kept as uint8 in HBM (what a camera delivers; kernels apply uint8_to_float on the fly):
     # bit-identical ROI at 1/8 of the frame-buffer bytes.  Reported beside the headline, never as `value`.
     alt = None
-    if world == 1 and a.in_dtype != "u8" and not a.no_u8_alt:
+    if extras and a.in_dtype == "f64" and not a.no_u8_alt:
         buf8 = torch.from_numpy(vid_u8).cuda()
-        roi8 = None
         for _ in range(a.warmup):
-            roi8 = backend.locate(buf8, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
-        torch.cuda.synchronize()
-        t8 = time.perf_counter()
-        for _ in range(a.steps):
-            roi8 = backend.locate(buf8, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
-        torch.cuda.synchronize()
-        e8 = time.perf_counter() - t8
-        alt = {"frame_buffer_dtype": "u8", "value": T * a.steps / e8, "unit": "frames/s", "ms_per_step": e8 / a.steps * 1e3,
+            locate1(buf8)
+        roi8, ms8 = timed(lambda: locate1(buf8), n_extra)
+        alt = {"frame_buffer_dtype": "u8", "value": T / ms8 * 1e3, "unit": "frames/s", "ms_per_step": ms8,
                "roi": roi8, "roi_equals_headline": list(roi8 or []) == list(roi or [])}
         del buf8
     # BASELINE config 4 is "calibration + ROI flow": the per-frame motion extraction (base.py:354-407, 'flow' method) on the
     # ROI just found -- Shi-Tomasi corners once, then pyramidal LK + mean flow + PCA per frame.  Latency bound
     # (no roofline fraction is meaningful); reported beside the headline, never part of `value`.
     roi_flow = None
-    if world == 1 and roi is not None and not a.no_roi_flow:
+    if extras and roi is not None and not a.no_roi_flow and a.config == "P":
         x, y, w, h = roi
         n_fl = min(T - 1, 60)
         crops = [backend.roi_to_uint8(torch.from_numpy(vid_u8[i]).cuda(), x, y, w, h) for i in range(n_fl + 1)]
@@ -201,44 +301,78 @@ def main():
                         "frames_per_s": 1.0 / dtf if dtf > 0 else None, "budget_ms_at_30fps": 33.3}
         else:
             roi_flow = {"roi": [x, y, w, h], "corners": 0}
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
+    # Data dependence of the headline: the collapse passes skip every (frame, tile) pair that provably cannot
+    # hold the extrema or a value below `top`.  (1) the same buffer with pruning off (every pair evaluated, bit-identical
+    # heatmap); (2) a "dense" synthetic stream -- four breathing blobs and 3x the noise -- with its pair counts, its step
+    # time and the tiles a Mode-B sparse packet would need against the 128-tile cap.
+    no_prune = dense = None
+    if extras and not a.no_data_dependence and not a.no_prune:
+        for _ in range(2):
+            locate1(buf, _capi.RM_FLAG_NO_PRUNE)
+        roi_np, ms_np = timed(lambda: locate1(buf, _capi.RM_FLAG_NO_PRUNE), max(3, n_extra // 4))
+        no_prune = {"ms_per_step": ms_np, "frames_per_s": T / ms_np * 1e3, "roi_equals_headline": list(roi_np or []) == list(roi or [])}
+        del buf
+        torch.cuda.empty_cache()
+        dgen = synth.synth_breathing_dense
+        dbuf = to_device(dgen(T, H, W, seed=4321, workers=None if big else 8))
+        for _ in range(a.warmup + 20):
+            locate1(dbuf)
+        roi_d, ms_d = timed(lambda: locate1(dbuf), n_extra)
+        _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
+        heat_d = rdist.hip_calibrate(dbuf, 10, pyramid_levels=a.levels, skip_levels_at_top=a.skip)
+        need = rdist.hip_sparse_tiles(heat_d)
+        dense = {"video": "four blobs (A=0.2, 0.4 Hz, phases 0/90/180/270 deg) + noise sigma 0.06 (3x), seed 4321",
+                 "ms_per_step": ms_d, "frames_per_s": T / ms_d * 1e3, "roi": roi_d,
+                 "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
+                 "mode_b_sparse_tiles_needed": need, "mode_b_sparse_tile_cap": rdist.SPARSE_CAP_TILES,
+                 "mode_b_exchange": "sparse" if need is not None and need <= rdist.SPARSE_CAP_TILES else "dense fallback"}
+        del dbuf, heat_d
+        torch.cuda.empty_cache()
 
-    dbg = (ctypes.c_longlong * 4)()
-    _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
     if rank == 0:
         frames_total = (1 if sharded else world) * T * a.steps
+        t_local = int(vid_u8.shape[0])
         # one read of the (rank-local) frame buffer + the heatmap
-        b_alg = int(buf.shape[0]) * H * W * DT_BYTES[a.in_dtype] + H * W * 8
+        b_alg = t_local * H * W * DT_BYTES[a.in_dtype] + H * W * 8
         k_ms = k_ms_total / max(k_calls, 1)
+        step_ms = elapsed / a.steps * 1e3
         achieved = b_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        step_achieved = b_alg / (step_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "%s_%dx%dx%d" % (a.in_dtype, int(buf.shape[0]), H, W)
+                key = "%s_%dx%dx%d" % (a.in_dtype, t_local, H, W)
                 traffic = tj.get(key, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        metric = "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s" if (T, H, W) == (256, 1080, 1920) else \
+                 "Eulerian-calibration frames/sec on %dx%d x %d buffer; achieved HBM GB/s" % (W, H, T)
         out = {
-            "metric": "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s",
+            "metric": metric,
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "pre_warm_steps": pre_steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Eulerian calibration + ROI (locate) on a %dx%dx%d frame buffer, %d-level Laplacian pyramid, "
-                                   "skip %d, temporal FFT band-pass 0.1-1.0 Hz @10 fps; %s" % (T, H, W, a.levels, a.skip,
-                                   "ONE buffer sharded by frame index over the GPUs: all-gather of the small pyramid, min/max all-reduce, "
-                                   "one RCCL heatmap all-reduce" if sharded else "one independent stream per GPU + one RCCL exchange of the heatmaps"),
-                       "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "prune": not a.no_prune},
+            "ms_per_step": step_ms, "pre_warm_steps": pre_steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "vs_baseline": None,
+            "dtype": "f64", "frame_buffer_dtype": a.in_dtype, "data": "synthetic",
+            "config": {"workload": "%s: Eulerian calibration + ROI (locate) on a %dx%dx%d %s frame buffer, %d-level Laplacian pyramid, "
+                                   "skip %d, temporal FFT band-pass 0.1-1.0 Hz @10 fps; %s" % (
+                                       a.config, T, H, W, a.in_dtype, a.levels, a.skip,
+                                       "ONE buffer sharded by frame index over the GPUs: all-gather of the small pyramid, min/max all-reduce, "
+                                       "one RCCL heatmap exchange" if sharded else "one independent stream per GPU + one RCCL exchange of the heatmaps"),
+                       "preset": a.config, "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "levels": a.levels,
+                       "skip": a.skip, "prune": not a.no_prune, "mode": a.mode if world > 1 else "single"},
+            "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
+            "env_knobs": knobs,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+                                           if traffic else None,
                          "kernel": "frame-buffer pyrDown kernel (reads [T,H,W] once)", "kernel_ms": k_ms,
-                         "algorithmic_bytes": b_alg},
-            "phases_ms_per_step": {"frame_buffer_kernel": ms[0] / max(ncalls.value, 1), "pyramid_rest_and_temporal": ms[1] / max(ncalls.value, 1),
-                                   "collapse_passes": ms[2] / max(ncalls.value, 1), "heatmap_to_roi": ms[3] / max(ncalls.value, 1)},
+                         "algorithmic_bytes": b_alg,
+                         # the contract figure of SURVEY 8(d): the WHOLE step (all kernels + host contour stage) against the peak
+                         "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS},
+            "phases_ms_per_step": phases,
             "roi": roi,
             "heatmap_exchange": (rdist.LAST_EXCHANGE and {"sparse": "one all-gather of sparse packets (%d-tile cap, %.2f MB per rank)"
                                                           % (rdist.SPARSE_CAP_TILES, 8e-6 * (4 + rdist.SPARSE_CAP_TILES * 1025)),
@@ -247,7 +381,9 @@ def main():
             "heatmap_exchange_tiles_needed": tiles_needed if world > 1 else None,
             "alt_uint8_buffer": alt,
             "roi_flow": roi_flow,
-            "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
+            "collapse_pairs": pairs,
+            "no_prune": no_prune,
+            "dense_stream": dense,
         }
         if world == 1 and a.cpu_frames != 0:
             n_cpu = a.cpu_frames
@@ -255,12 +391,14 @@ def main():
                 import psutil
                 need = 6.0 * T * H * W * 8   # the materialising algorithm holds ~5-6 float64 [T,H,W] arrays
                 n_cpu = T if psutil.virtual_memory().available > 1.3 * need else 64
-            out["cpu_baseline"] = cpu_baseline(vid_u8, min(n_cpu, T), a.levels, a.skip)
-            if min(n_cpu, T) == T:
+            n_cpu = min(n_cpu, T)
+            out["cpu_baseline"] = cpu_baseline(vid_u8, n_cpu, a.levels, a.skip, a.in_dtype, a.cpu_workers)
+            if n_cpu == T:
                 out["cpu_baseline"]["roi_equals_gpu"] = list(out["cpu_baseline"]["roi"] or []) == list(roi or [])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

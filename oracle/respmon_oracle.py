@@ -378,6 +378,86 @@ def locate(calibration_video_data, fps, freq_min=0.1, freq_max=1.0, amplificatio
     return roi
 
 
+def locate_parallel(calibration_video_data, fps, freq_min=0.1, freq_max=1.0, amplification=500,
+                    pyramid_levels=9, skip_levels_at_top=4, temporal_threshold=0.7, threshold=20,
+                    workers=8, return_intermediates=False):
+    """locate() above with its independent loops spread over `workers` host threads -- frames for the pyramid build and
+    the collapse (pyramid.py:31-69), pixel rows for the temporal filter and the time average, frame chunks for the
+    whole-array passes of transforms.py:184-192.  Every element goes through the same operations in the same order, so
+    the results equal locate()'s bit for bit (tests/test_oracle_golden.py).  The reference itself is single-threaded:
+    this exists so that bench.py can quote an all-host-cores CPU figure beside the single-thread one."""
+    from concurrent.futures import ThreadPoolExecutor
+    vid = calibration_video_data
+    T = vid.shape[0]
+    L = pyramid_levels
+    workers = max(1, int(workers))
+
+    def chunks(n, parts):
+        parts = max(1, min(parts, n))
+        base, rem = divmod(n, parts)
+        out, a = [], 0
+        for k in range(parts):
+            b = a + base + (1 if k < rem else 0)
+            out.append((a, b))
+            a = b
+        return out
+
+    with ThreadPoolExecutor(workers) as ex:
+        # transforms.py:148 / pyramid.py:31-48
+        first = create_laplacian_image_pyramid(vid[0], L)
+        levels = [np.zeros((T,) + l.shape, dtype=np.float64) for l in first]
+
+        def build(span):
+            for t in range(*span):
+                for k, l in enumerate(create_laplacian_image_pyramid(vid[t], L)):
+                    levels[k][t] = l
+        list(ex.map(build, chunks(T, 4 * workers)))
+        # transforms.py:150-170
+        bandpassed = [np.zeros(l.shape) for l in levels]
+        for i, lv in enumerate(levels):
+            if i < skip_levels_at_top or i >= len(levels) - 1:
+                continue
+
+            def filt(span, lv=lv, dst=bandpassed[i]):
+                y0, y1 = span
+                dst[:, y0:y1] += temporal_bandpass_filter_fft(lv[:, y0:y1], fps, freq_min=freq_min, freq_max=freq_max,
+                                                              amplification_factor=amplification)
+            list(ex.map(filt, chunks(lv.shape[1], 2 * workers)))
+        del levels
+        # transforms.py:182 / pyramid.py:60-69
+        def collapse(span):
+            for t in range(*span):
+                bandpassed[0][t] = collapse_laplacian_pyramid([lvl[t] for lvl in bandpassed])
+        list(ex.map(collapse, chunks(T, 4 * workers)))
+        raw = bandpassed[0]
+        spans = chunks(T, 2 * workers)
+        mins = list(ex.map(lambda sp: raw[sp[0]:sp[1]].min(), spans))
+        maxs = list(ex.map(lambda sp: raw[sp[0]:sp[1]].max(), spans))
+        min_val, max_val = min(mins), max(maxs)                                           # :185,187
+        top = max_val - (max_val - min_val) * temporal_threshold                         # :188-189
+        masked = np.empty_like(raw)
+
+        def mask(sp):
+            m = raw[sp[0]:sp[1]].copy()                                                   # :191
+            m[raw[sp[0]:sp[1]] >= top] = min_val                                          # :190,192
+            masked[sp[0]:sp[1]] = m
+        list(ex.map(mask, spans))
+        # base.py:562: np.average over t, sequential per pixel
+        H = raw.shape[1]
+        avg_frame = np.empty(raw.shape[1:], dtype=np.float64)
+
+        def avg(sp):
+            avg_frame[sp[0]:sp[1]] = np.average(masked[:, sp[0]:sp[1]], axis=0)
+        list(ex.map(avg, chunks(H, 2 * workers)))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        avg_norm = (avg_frame - avg_frame.min()) / (avg_frame.max() - avg_frame.min())
+    avg_u8 = float_to_uint8(avg_norm)
+    roi = roi_from_heatmap_u8(avg_u8, threshold)
+    if return_intermediates:
+        return roi, dict(avg_frame=avg_frame, avg_u8=avg_u8, min=float(min_val), max=float(max_val))
+    return roi
+
+
 # --------------------------------------------------------------------------- #
 # tools.py:48-57
 # --------------------------------------------------------------------------- #

@@ -66,7 +66,7 @@ class _Backend:
             dst64 = buf[idx] if buf.dtype == t.float64 else t.empty(gray_u8.shape, dtype=t.float64, device=gray_u8.device)
             _capi.check(self.lib, self.lib.rm_uint8_to_float(device.ctx(), device.ptr(gray_u8), device.ptr(dst64),
                                                              gray_u8.numel(), device.stream_ptr()), "rm_uint8_to_float")
-            if dst64 is not buf[idx]:
+            if buf.dtype != t.float64:   # narrower float buffer: round the float64 value to the storage dtype
                 buf[idx].copy_(dst64)
 
     # -- measurement ------------------------------------------------------------------

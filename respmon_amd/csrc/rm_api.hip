@@ -638,6 +638,7 @@ extern "C" int rm_threshold_mask(rm_ctx *ctx, const double *raw, size_t n, doubl
     HIP_TRY(hipSetDevice(ctx->device));
     CollapseState *st = ctx->d_state;
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
+    ctx->state_fresh = false;   // this call reduces into the state
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, raw, n, st);
     LAUNCH_CHECK();
@@ -858,6 +859,10 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
     const int L = pg.L, S = pg.S;
     const size_t NP = pg.NP;
     out.h = pg.h; out.w = pg.w; out.S = S; out.all_zero = false;
+    // consumed here, on every path: whatever follows reduces into d_state, so the reset by front_pyramid's last kernel
+    // vouches for this call only (a later rm_shard_collapse with a foreign lap buffer must reset the state itself)
+    const bool state_fresh = ctx->state_fresh;
+    ctx->state_fresh = false;
     TemporalOp op;
     RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
     PhaseTimer pt_small(ctx, 1, s);
@@ -887,7 +892,7 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
             double *lo = nullptr, *hi = nullptr;
             RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
             RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
-            if (!ctx->state_fresh) {   // the lap buffer did not come from front_pyramid on this context just now
+            if (!state_fresh) {   // the lap buffer did not come from front_pyramid on this context just now
                 hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
                 LAUNCH_CHECK();
             }
@@ -901,7 +906,6 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
             hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
             out.state_ready = true;
         }
-        ctx->state_fresh = false;
         LAUNCH_CHECK();
         c = dst;
     } else {
@@ -969,6 +973,7 @@ __global__ __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st);
 // -> uint8 0 -> no contour, as the reference does (base.py:563-570).
 static int zero_result(rm_ctx *ctx, size_t npix, double *heat, double *minmax_host, hipStream_t s)
 {
+    ctx->state_fresh = false;
     HIP_TRY(hipMemsetAsync(heat, 0, sizeof(double) * npix, s));
     hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
     LAUNCH_CHECK();
@@ -1205,6 +1210,7 @@ extern "C" int rm_shard_finish(rm_ctx *ctx, const double *heat_sum, int T, int H
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
     hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
+    ctx->state_fresh = false;
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_heat_avg_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat_sum, npix, T, heatmap, ctx->d_state);
     LAUNCH_CHECK();
@@ -1276,6 +1282,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
     CollapseState *st = ctx->d_state;
+    ctx->state_fresh = false;   // the heatmap extrema are (or have been) reduced into the state
     // the thresholded image goes to the host bit-packed (npix / 8 bytes): the kernel stores its ballot words straight
     // into pinned, device-mapped host memory (one 8-byte store per 64 pixels rides the kernel; a separate
     // device-to-host copy costs ~15 us of copy-engine start-up on this path)

@@ -40,17 +40,22 @@ def all_reduce_minmax(mn, mx, like, group=None):
 
 
 def hip_calibrate(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4,
-                  temporal_threshold=0.7, flags=0):
-    """rm_calibrate on the current device -> float64 [H,W] heatmap tensor (asynchronous)."""
+                  temporal_threshold=0.7, flags=0, return_minmax=False):
+    """rm_calibrate on the current device -> float64 [H,W] heatmap tensor (asynchronous).
+    return_minmax=True also returns (raw.min(), raw.max()) of transforms.py:185-187 (synchronises the stream)."""
+    import ctypes
     from . import _capi, device
     t = device.require_gpu()
     lib = _capi.load()
     T, H, W = buf.shape
     heat = t.empty((H, W), dtype=t.float64, device=buf.device)
+    mm = (ctypes.c_double * 2)() if return_minmax else None
     _capi.check(lib, lib.rm_calibrate(device.ctx(), device.ptr(buf), device.dtype_code(buf), T, H, W, float(fps),
                                       float(freq_min), float(freq_max), float(amplification), int(pyramid_levels),
-                                      int(skip_levels_at_top), float(temporal_threshold), int(flags), device.ptr(heat), None,
+                                      int(skip_levels_at_top), float(temporal_threshold), int(flags), device.ptr(heat), mm,
                                       device.stream_ptr()), "rm_calibrate")
+    if return_minmax:
+        return heat, (mm[0], mm[1])
     return heat
 
 
@@ -105,6 +110,22 @@ def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TI
         return False, None, None
     roi = None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
     return True, roi, fused
+
+
+def hip_sparse_tiles(heat, cap_tiles=SPARSE_CAP_TILES):
+    """Tiles a sparse packet of the heatmap the LAST hip_calibrate on this context produced would have to carry (may
+    exceed `cap_tiles`: that is the overflow that sends every rank to the dense all-reduce); None when the heatmap has no
+    pruning bookkeeping (dense exchange only).  Diagnostic for bench.py; synchronises the stream."""
+    from . import _capi, device
+    t = device.require_gpu()
+    lib = _capi.load()
+    H, W = heat.shape
+    pd = int(lib.rm_heat_sparse_packet_doubles(cap_tiles))
+    packet = t.empty(pd, dtype=t.float64, device=heat.device)
+    _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(heat), H, W, cap_tiles, device.ptr(packet), device.stream_ptr()),
+                "rm_heat_sparse_pack")
+    count = int(packet[:1].view(t.int32)[0].item()) & 0xffffffff
+    return None if count == 0xffffffff else count
 
 
 def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrate, roi_fn=hip_heatmap_to_roi, sparse=None,

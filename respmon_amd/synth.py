@@ -50,6 +50,88 @@ def synth_breathing(T, H, W, seed=1234, fps=10.0, breath_hz=0.4, amplitude=0.2, 
     return out
 
 
+def synth_breathing_blocks(T, H, W, seed=1234, fps=10.0, breath_hz=0.4, amplitude=0.2, noise=0.02,
+                           center=(0.6, 0.4), sigma=(0.10, 0.08), block=8, workers=None):
+    """The same video model as synth_breathing for the large configurations (4K x 512 is 4.2 G samples): every `block`
+    frames draw their noise from their own child generator (SeedSequence(seed).spawn), so blocks are filled by a thread
+    pool (numpy releases the GIL) and the result depends only on (T, H, W, seed, block), not on the worker count.
+    NOT sample-identical to synth_breathing (one sequential generator there; the goldens use that one)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    rng0 = np.random.Generator(np.random.PCG64(seed))
+    tex = _lowpass_noise(rng0, H, W)
+    yy = (np.arange(H)[:, None] - center[0] * H) / (sigma[0] * H)
+    xx = (np.arange(W)[None, :] - center[1] * W) / (sigma[1] * W)
+    blob = (amplitude * 255.0 * np.exp(-0.5 * (yy * yy + xx * xx))).astype(np.float32)
+    base = (255.0 * (0.5 + 0.25 * tex)).astype(np.float32)
+    sig = np.float32(255.0 * noise)
+    out = np.empty((T, H, W), dtype=np.uint8)
+    starts = list(range(0, T, block))
+    children = np.random.SeedSequence(seed).spawn(len(starts))
+
+    def fill(k):
+        t0 = starts[k]
+        t1 = min(T, t0 + block)
+        rng = np.random.Generator(np.random.PCG64(children[k]))
+        s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps).astype(np.float32)[:, None, None]
+        g = rng.standard_normal((t1 - t0, H, W), dtype=np.float32)
+        g *= sig
+        g += base[None]
+        g += blob[None] * s
+        np.rint(g, out=g)
+        np.clip(g, 0, 255, out=g)
+        out[t0:t1] = g.astype(np.uint8)
+
+    if workers is None:
+        workers = max(1, min(32, (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(fill, range(len(starts))))
+    return out
+
+
+def synth_breathing_dense(T, H, W, seed=4321, fps=10.0, breath_hz=0.4, amplitude=0.2, noise=0.06, block=8, workers=None):
+    """A stream that is hard on the pruning of the collapse passes (bench.py `dense_stream`): FOUR breathing blobs spread
+    over the frame, a quarter period apart, and three times the sensor noise of synth_breathing -- low-tail voxels
+    of the band-passed video are no longer confined to one corner of the image.  Block-parallel like
+    synth_breathing_blocks."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    rng0 = np.random.Generator(np.random.PCG64(seed))
+    tex = _lowpass_noise(rng0, H, W)
+    centers = [(0.25, 0.2), (0.3, 0.75), (0.7, 0.35), (0.75, 0.8)]
+    sig_y, sig_x = 0.10, 0.08
+    blobs = []
+    for (cy, cx) in centers:
+        yy = (np.arange(H)[:, None] - cy * H) / (sig_y * H)
+        xx = (np.arange(W)[None, :] - cx * W) / (sig_x * W)
+        blobs.append((amplitude * 255.0 * np.exp(-0.5 * (yy * yy + xx * xx))).astype(np.float32))
+    base = (255.0 * (0.5 + 0.25 * tex)).astype(np.float32)
+    sig = np.float32(255.0 * noise)
+    out = np.empty((T, H, W), dtype=np.uint8)
+    starts = list(range(0, T, block))
+    children = np.random.SeedSequence(seed).spawn(len(starts))
+
+    def fill(k):
+        t0 = starts[k]
+        t1 = min(T, t0 + block)
+        rng = np.random.Generator(np.random.PCG64(children[k]))
+        g = rng.standard_normal((t1 - t0, H, W), dtype=np.float32)
+        g *= sig
+        g += base[None]
+        for q, blob in enumerate(blobs):
+            s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps + q * np.pi / 2).astype(np.float32)[:, None, None]
+            g += blob[None] * s
+        np.rint(g, out=g)
+        np.clip(g, 0, 255, out=g)
+        out[t0:t1] = g.astype(np.uint8)
+
+    if workers is None:
+        workers = max(1, min(32, (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(fill, range(len(starts))))
+    return out
+
+
 def synth_brightness_video(T, H, W, fps=10.0, hz=0.4):
     """Config 1: whole-frame brightness 0.5 + 0.2 sin(2 pi hz t / fps), BGR uint8 [T,H,W,3]."""
     t = np.arange(T)

@@ -127,8 +127,9 @@ def eulerian_magnification_bandpass(vid_data, fps, freq_min, freq_max, amplifica
     This is the MATERIALISING form kept for API parity; calibration itself uses the fused path
     (RespiratoryMonitor.locate -> rm_calibrate) that never writes a [T,H,W] array.
     `temporal_filter_function` defaults to temporal_bandpass_filter_fft (one fused C-ABI call); any other
-    callable with the reference's filter signature (e.g. temporal_bandpass_filter) runs the reference's own
-    sequence -- pyramid, filter per level, collapse, mask -- on device tensors."""
+    callable with the reference's filter signature (e.g. temporal_bandpass_filter, or a plain scipy filter) runs the
+    reference's own sequence -- pyramid, filter per level, collapse, mask; the callable is handed numpy levels when
+    `vid_data` is numpy and device tensors when it is a device tensor."""
     t = device.require_gpu()
     lib = _capi.load()
     vid = device.to_device(vid_data)
@@ -149,8 +150,10 @@ def eulerian_magnification_bandpass(vid_data, fps, freq_min, freq_max, amplifica
         for i, lv in enumerate(vid_pyramid):                                                         # :156-170
             if i < skip_levels_at_top or i >= len(vid_pyramid) - 1:
                 continue
-            bandpassed[i] = device.to_device(temporal_filter_function(lv, fps, freq_min=freq_min, freq_max=freq_max,
-                                                                      amplification_factor=amplification,
+            # the callable sees what the caller works in: numpy levels for numpy input (a scipy / numpy filter with the
+            # reference's signature must run unchanged), device tensors for device input
+            bandpassed[i] = device.to_device(temporal_filter_function(device.like_input(lv, vid_data), fps, freq_min=freq_min,
+                                                                      freq_max=freq_max, amplification_factor=amplification,
                                                                       debug='{0},{1}:'.format('n/a', i), verbose=verbose), t.float64)
         raw = pyramid.collapse_laplacian_video_pyramid(bandpassed)                                   # :182
         _capi.check(lib, lib.rm_threshold_mask(device.ctx(), device.ptr(raw), raw.numel(), float(threshold), device.ptr(masked), mm,

@@ -167,6 +167,39 @@ def test_emu_frame_sharded_stages(emu, oracle):
     assert roi is None and not heat.any() and emu.locate(frames, 10.0, levels=3, skip=2) is None
 
 
+def test_emu_shard_collapse_after_single_level_calibrate(emu, oracle):
+    """a calibration that filters ONE level (levels - 2 == skip) used to leave the context believing its
+    reduction state was freshly reset; an rm_shard_collapse of a foreign small pyramid on the same context then reduced
+    min / max into stale state.  Every public sequence must give the extrema of the buffer it was handed."""
+    import ctypes
+    from tests.emu_harness import DT, ptr
+    lib, ctx = emu.lib, emu.ctx
+    a = oracle.uint8_to_float(synth.synth_breathing(20, 40, 56, seed=31))
+    b = oracle.uint8_to_float(synth.synth_breathing(20, 40, 56, seed=32)) * 0.5
+    L, S = 5, 2
+    T, H, W = b.shape
+    n = ctypes.c_size_t()
+    emu.ck(lib.rm_shard_layout(H, W, L, S, ctypes.byref(n)), "layout")
+    NP = int(n.value)
+    other = emu.new_ctx()
+    lap = np.empty((T, NP))
+    emu.ck(lib.rm_shard_pyramid(other, ptr(b), DT[b.dtype], T, H, W, L, S, 0, ptr(lap), None), "shard_pyramid")
+    _, mm_ref = emu.calibrate(b, 10.0, levels=L, skip=S)
+    for prelude in ("single_level_calibrate", "threshold_mask", "shard_pyramid_then_mask"):
+        if prelude == "single_level_calibrate":
+            emu.calibrate(a, 10.0, levels=3, skip=1)           # levels - 2 == skip: one filtered level
+        elif prelude == "threshold_mask":
+            emu.threshold_mask(np.linspace(-900.0, 900.0, 64))
+        else:
+            scratch = np.empty((T, NP))
+            emu.ck(lib.rm_shard_pyramid(ctx, ptr(a), DT[a.dtype], T, H, W, L, S, 0, ptr(scratch), None), "shard_pyramid")
+            emu.threshold_mask(np.linspace(-900.0, 900.0, 64))   # dirties the state after front_pyramid reset it
+        mm = np.empty(2)
+        emu.ck(lib.rm_shard_collapse(ctx, ptr(lap), T, 0, T, H, W, 10.0, 0.1, 1.0, 500.0, L, S, 0.7, 0, ptr(mm), None), "shard_collapse")
+        assert (-mm[0], mm[1]) == tuple(mm_ref), prelude
+    lib.rm_ctx_destroy(other)
+
+
 def test_emu_iir_filter_and_threshold_mask(emu, oracle, golden):
     """rm_lfilter == scipy.signal.lfilter in the reference's temporal_bandpass_filter (G8, authentic
     scipy), and rm_threshold_mask == transforms.py:184-192."""

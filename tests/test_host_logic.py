@@ -169,3 +169,25 @@ def test_tools_and_peaks(golden):
     assert np.allclose(p, [2.0, 3.0, 0.5], atol=1e-6)
     b = tools.Benchmarker(); b.add_tag("x"); b.tick_start("x"); b.tick_end("x")
     assert b.has_tag("x") and "x, " in b.get_report()
+
+
+def test_bench_presets_and_knob_refusal(monkeypatch):
+    """bench.py host logic that needs no GPU: the --config presets (SURVEY 8 sizes P / Q / R), explicit flags overriding
+    them, and the refusal to measure with RM_* developer variables set."""
+    import subprocess
+    import sys
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.config, a.frames, a.height, a.width, a.levels, a.skip, a.in_dtype) == (1, "P", 256, 1080, 1920, 9, 4, "f64")
+    assert a.steps * 1.0e-3 >= 0.1          # ~1 ms per step: the default timed region is at least 0.1 s
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "Q"])
+    a = bench.parse()
+    assert (a.frames, a.height, a.width, a.levels, a.skip, a.in_dtype) == (128, 720, 1280, 4, 2, "f64")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "R", "--frames", "64", "--skip", "3"])
+    a = bench.parse()
+    assert (a.frames, a.height, a.width, a.levels, a.skip, a.in_dtype) == (64, 2160, 3840, 6, 3, "f16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RM_DC_LDS_FRONT_END="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 2 and "RM_DC_LDS_FRONT_END" in out.stderr

@@ -119,3 +119,16 @@ def test_g8_iir_filter_and_eulerian(oracle, golden):
                                                          temporal_filter_function=oracle.temporal_bandpass_filter)
     assert np.array_equal(raw, g["e_raw"])
     assert np.array_equal(np.average(masked, axis=0), g["e_avg"])
+
+
+def test_thread_parallel_oracle_equals_locate(oracle):
+    """oracle.locate_parallel (the all-host-cores CPU figure of bench.py) is locate() with its independent loops on threads:
+    ROI, heatmap, uint8 heatmap and raw extrema must be identical to the last bit."""
+    from respmon_amd import synth
+    for (T, H, W, L, S) in [(48, 77, 131, 6, 2), (32, 135, 240, 9, 4), (40, 64, 64, 5, 1), (16, 40, 48, 4, 0)]:
+        fr = oracle.uint8_to_float(synth.synth_breathing(T, H, W, seed=T))
+        r1, m1 = oracle.locate(fr, 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
+        for workers in (1, 3, 8):
+            r2, m2 = oracle.locate_parallel(fr, 10, pyramid_levels=L, skip_levels_at_top=S, workers=workers, return_intermediates=True)
+            assert r1 == r2 and m1["min"] == m2["min"] and m1["max"] == m2["max"]
+            assert np.array_equal(m1["avg_frame"], m2["avg_frame"]) and np.array_equal(m1["avg_u8"], m2["avg_u8"])
