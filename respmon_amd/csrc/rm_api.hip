@@ -54,9 +54,9 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 struct CollapsePlan {
     ChainGeom g;
     int ntiles = 0, npairs = 0;
-    double *lo = nullptr, *hi = nullptr, *store = nullptr, *slot_min = nullptr;
-    unsigned int *list = nullptr;
-    int *slot_of = nullptr;
+    double *lo = nullptr, *hi = nullptr, *store = nullptr;
+    unsigned int *list = nullptr, *heavy = nullptr;
+    int *slot_of = nullptr, *sel_cnt = nullptr;
     size_t shmem = 0;
     const double *cS = nullptr;
     int T = 0, t0 = 0, t1 = 0, H = 0, W = 0, S = 0;
@@ -890,8 +890,10 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         const long long npairs = geom_ok ? (long long)cg.tiles_x * cg.tiles_y * T : 0;
         if (geom_ok && shmem + tbl <= 150 * 1024 && npairs < (1ll << 31) && !getenv("RM_NO_FUSED_BOUNDS")) {
             double *lo = nullptr, *hi = nullptr;
+            int *sel_cnt = nullptr;
             RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
             RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
+            RM_TRY(ws(ctx, "sel_cnt", (size_t)cg.tiles_x * cg.tiles_y, &sel_cnt));
             if (!state_fresh) {   // the lap buffer did not come from front_pyramid on this context just now
                 hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
                 LAUNCH_CHECK();
@@ -900,7 +902,7 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
             if (sh2 > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
             hipLaunchKernelGGL(k_small_collapse_bounds, dim3(T), dim3(SMALL_NT), sh2, s, (const double *)bp, pg.sg, dst, ctx->d_state, cg,
-                               cg.tiles_x * cg.tiles_y, lo, hi);
+                               cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt);
             out.state_ready = true; out.bounds_ready = true;
         } else {
             hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
@@ -961,6 +963,28 @@ static int make_geom(const SmallLevels &sl, ChainGeom &g)
     g.lds_total = off;
     g.tiles_x = (sl.w[0] + CT_W - 1) / CT_W;
     g.tiles_y = (sl.h[0] + CT_H - 1) / CT_H;
+    // weights of the lattice samples (rm_kernels.h lattice_sample): a unit impulse pushed through S interior 1-D pyrUp
+    // steps (even: (s[j-1] + 6 s[j] + s[j+1]) / 8, odd: (s[j] + s[j+1]) / 2), read at position 1 << S of a 3-pixel line
+    {
+        double w[3];
+        for (int k = 0; k < 3; ++k) {
+            std::vector<double> v(5, 0.0);
+            v[1 + k] = 1.0;                      // pixels y-1, y, y+1 sit at 1, 2, 3; 0 and 4 are never reached from the lattice point
+            int centre = 2;
+            for (int i = 0; i < S; ++i) {
+                std::vector<double> u(2 * v.size(), 0.0);
+                for (size_t j = 0; j < v.size(); ++j) {
+                    const double a = j > 0 ? v[j - 1] : 0.0, c = j + 1 < v.size() ? v[j + 1] : 0.0;
+                    u[2 * j] = (a + 6 * v[j] + c) / 8;
+                    u[2 * j + 1] = (v[j] + c) / 2;
+                }
+                v.swap(u);
+                centre *= 2;
+            }
+            w[k] = v[centre];
+        }
+        g.lat_a = w[0]; g.lat_b = w[1];   // w[2] == w[0]
+    }
     return RM_OK;
 }
 
@@ -1029,7 +1053,8 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
     RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
-    RM_TRY(ws(ctx, "slot_min", slot_cap, &cp.slot_min));
+    RM_TRY(ws(ctx, "sel_cnt", (size_t)ntiles, &cp.sel_cnt));
+    RM_TRY(ws(ctx, "heavy_tiles", (size_t)ntiles, &cp.heavy));
     if (!sl.bounds_ready) {
         // per-frame separable form, in bands of tile rows whose row-extrema table fits 64 KB of LDS; the per-pair kernel
         // remains for geometries where even one tile row does not fit
@@ -1050,19 +1075,21 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
         const size_t tbl = (size_t)tbl_rows * row_bytes;
         if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
             const unsigned nbands = (unsigned)((g.tiles_y + band - 1) / band);
-            hipLaunchKernelGGL(k_frame_bounds, dim3(T, nbands), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, band, tbl_rows);
+            hipLaunchKernelGGL(k_frame_bounds, dim3(T, nbands), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, band, tbl_rows, cp.sel_cnt);
         } else {
-            hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi, st);
+            hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi, st, cp.sel_cnt);
         }
         LAUNCH_CHECK();
     }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 256 * SEL_U - 1) / (256 * SEL_U)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
-                       (unsigned)slot_cap, prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles);
+                       (unsigned)slot_cap, prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy);
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
-    unsigned egrid = (unsigned)(npairs < 16384 ? npairs : 16384);
-    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list, cp.slot_of, st, cp.store, cp.slot_min);
+    // one resident round of single-wave workgroups (18 per CU, measured) that loop over the list: the list length
+    // lives on the device, and dispatching thousands of workgroups that find nothing to do costs more than the loop
+    unsigned egrid = (unsigned)(npairs < 256 * 18 ? npairs : 256 * 18);
+    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list, cp.slot_of, st, cp.store);
     LAUNCH_CHECK();
     cp.valid = true;
     return RM_OK;
@@ -1091,8 +1118,13 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
     unsigned int *slots_seen_dev = nullptr;   // the slot demand of this call goes straight to pinned host memory
     HIP_TRY(hipHostGetDevicePointer((void **)&slots_seen_dev, ctx->h_slots_seen, 0));
-    hipLaunchKernelGGL(k_masked_sum_tiles, dim3(cp.ntiles), dim3(256), cp.shmem, s, cp.cS, cp.g, cp.t0, cp.t1, cp.ntiles, cp.slot_of,
-                       cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev, cp.slot_min);
+    // worker workgroups for the tiles with kept pairs (MS_Q items each) + fill workgroups for all the others
+    const int nworkers = std::min(cp.ntiles * MS_Q, 1024), nfill = std::min(cp.ntiles, 512);
+    const size_t ms_lds = masked_sum_lds_bytes(cp.g, cp.T);
+    if (ms_lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k_masked_sum_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds));
+    hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers + nfill), dim3(64 * MS_RQ), ms_lds, s, cp.cS, cp.g, cp.t0, cp.t1, cp.T, cp.ntiles,
+                       cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev, cp.sel_cnt, cp.heavy, nworkers);
     LAUNCH_CHECK();
     ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;   // the constant tiles of this heatmap (or partial heat sum of a frame shard) are known
     ctx->slots_seen_pairs = cp.npairs;
@@ -1490,3 +1522,28 @@ extern "C" int rm_pca_reduce(rm_ctx *ctx, const float *motion, int n, double *ou
     if (rc < 0) return fail(rc, "%s", err.c_str());
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------
+// developer build only (-DRM_TRACE, librespmon_hip_trace.so; tools/trace_tail.py): workgroup timelines
+// ------------------------------------------------------------------------------------------
+#ifdef RM_TRACE
+static TraceRec *g_trace_dev = nullptr;
+extern "C" int rm_trace_start(void)
+{
+
+    const size_t bytes = sizeof(TraceRec) * (size_t)TRACE_KERNELS * TRACE_BLOCKS;
+    if (!g_trace_dev) HIP_TRY(hipMalloc((void **)&g_trace_dev, bytes));
+    HIP_TRY(hipMemset(g_trace_dev, 0, bytes));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &g_trace_dev, sizeof(g_trace_dev)));
+    HIP_TRY(hipDeviceSynchronize());
+    return RM_OK;
+}
+extern "C" int rm_trace_read(void *host, size_t bytes)
+{
+    const size_t all = sizeof(TraceRec) * (size_t)TRACE_KERNELS * TRACE_BLOCKS;
+    if (!g_trace_dev || !host || bytes < all) return fail(RM_E_BADARG, "rm_trace_read: need %zu bytes", all);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, g_trace_dev, all, hipMemcpyDeviceToHost));
+    return RM_OK;
+}
+#endif

@@ -34,6 +34,7 @@ struct DownGeom {
     int S;
     int h[MAX_CHAIN], w[MAX_CHAIN];  // level sizes, 0 = input
     int seg_h;                       // segment size in level-S rows
+    int seg_split;                   // > 0: TWO uneven segments, [y_begin, seg_split) and [seg_split, y_end) (see k_down_chain)
     int y_begin, y_end;              // level-S rows [y_begin, y_end) covered by this launch
     int strips, segs;                // per frame
     int wpg;                         // waves (= adjacent strips of one segment) per workgroup, marching in lockstep
@@ -526,7 +527,8 @@ struct DownChain {
     {
         // ranges, from level S back to 0
         cx0[S] = strip * SW; cx1[S] = min(cx0[S] + SW, g.w[S]) - 1;
-        next[S] = g.y_begin + seg * g.seg_h; last[S] = min(next[S] + g.seg_h, g.y_end) - 1;
+        if (g.seg_split > 0) { next[S] = seg ? g.seg_split : g.y_begin; last[S] = (seg ? g.y_end : g.seg_split) - 1; }
+        else { next[S] = g.y_begin + seg * g.seg_h; last[S] = min(next[S] + g.seg_h, g.y_end) - 1; }
 #pragma unroll
         for (int k = S - 1; k >= 0; --k) {
             cx0[k] = max(0, 2 * cx0[k + 1] - 2); cx1[k] = min(g.w[k] - 1, 2 * cx1[k + 1] + 2);
@@ -556,17 +558,29 @@ constexpr int DC_MAX_WPG = 2;  // waves per workgroup (launch bound).  Measured 
 template <typename Tin, int S, bool VB>
 __global__ __launch_bounds__(64 * DC_MAX_WPG) void k_down_chain(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
 {
+    RM_TRACE_SCOPE(0);
     HIP_DYNAMIC_SHARED(double, lds_all)
     // XCD-aware mapping: block b runs on XCD b % 8; give each XCD whole frames so the strips and
     // segments of a frame share halo lines in one L2.  A workgroup = g.wpg adjacent strips of one segment,
     // one wave each (private LDS slice, no data exchanged between the waves).
     const int groups = (g.strips + g.wpg - 1) / g.wpg;
-    const int per_frame = groups * g.segs;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int t = (j / per_frame) * 8 + xcd;
+    int t, seg, grp;
+    if (g.seg_split > 0) {
+        // Two uneven segments per frame, the upper (larger) one on an even XCD and the lower one on its odd neighbour: the
+        // odd XCDs of an MI355X stream ~4-5 % slower than the even ones (workgroup timelines, tools/trace_tail.py, on every
+        // box measured), and with equal shares the launch waits for them while the even XCDs sit idle.
+        const int pair = xcd >> 1;
+        seg = xcd & 1;
+        t = (j / groups) * 4 + pair;
+        grp = j - (j / groups) * groups;
+    } else {
+        const int per_frame = groups * g.segs;
+        t = (j / per_frame) * 8 + xcd;
+        const int inner = j % per_frame;
+        seg = inner / groups; grp = inner - seg * groups;
+    }
     if (t >= g.T) return;
-    const int inner = j % per_frame;
-    const int seg = inner / groups, grp = inner - seg * groups;
 #ifdef RM_HIPEMU
     const int wave = threadIdx.x >> 6;
 #else
@@ -581,7 +595,12 @@ __global__ __launch_bounds__(64 * DC_MAX_WPG) void k_down_chain(const Tin *frame
 
 // host-side geometry
 
-inline unsigned down_chain_grid(const DownGeom &g) { return (unsigned)(((g.T + 7) / 8) * 8 * ((g.strips + g.wpg - 1) / g.wpg) * g.segs); }
+inline unsigned down_chain_grid(const DownGeom &g)
+{
+    const int groups = (g.strips + g.wpg - 1) / g.wpg;
+    if (g.seg_split > 0) return (unsigned)(((g.T + 3) / 4) * 8 * groups);   // 4 XCD pairs, one frame segment per XCD
+    return (unsigned)(((g.T + 7) / 8) * 8 * groups * g.segs);
+}
 inline unsigned down_chain_block(const DownGeom &g) { return 64u * (unsigned)g.wpg; }
 
 // level-S row range [y0, y1) whose dependency cone needs no vertical border handling at any level
@@ -633,6 +652,13 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
     g.seg_h = (rows + segs - 1) / segs;
     if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
     g.segs = (rows + g.seg_h - 1) / g.seg_h;
+    // exactly two segments: split them 51.3 : 48.7 between an even XCD and its (slower) odd neighbour, see k_down_chain
+    g.seg_split = 0;
+    if (g.segs == 2 && !tiny && rows >= 8) {
+        int upper = (int)(rows * 0.513 + 0.5);
+        if (upper >= rows) upper = rows - 1;
+        if (upper > g.seg_h) g.seg_split = y_begin + upper;
+    }
     // workgroup = up to DC_MAX_WPG adjacent strips in lockstep, split evenly when a row has more strips
     const int ngroups = (g.strips + DC_MAX_WPG - 1) / DC_MAX_WPG;
     g.wpg = (g.strips + ngroups - 1) / ngroups;

@@ -34,6 +34,45 @@ inline hipError_t stream_wait(hipStream_t s)
 
 
 // ----------------------------------------------------------------------------------------
+// Workgroup timeline tracing -- DEVELOPER BUILD ONLY (make librespmon_hip_trace.so, tools/trace_tail.py).  In the product
+// library RM_TRACE is undefined and both macros expand to nothing.  A traced workgroup records the 100 MHz wall clock at
+// entry and exit plus the CU it ran on, so launch ramps, imbalance and per-workgroup latency can be read off per kernel.
+// ----------------------------------------------------------------------------------------
+#ifdef RM_TRACE
+struct TraceRec { unsigned long long t0, t1, c0, c1; unsigned int hwid, xcc; };   // t: 100 MHz wall clock, c: shader clock (s_memtime)
+constexpr int TRACE_KERNELS = 16, TRACE_BLOCKS = 20480;
+__device__ TraceRec *g_trace_buf = nullptr;
+__device__ __forceinline__ void trace_end(int kid, unsigned long long t0, unsigned long long c0)
+{
+    if (threadIdx.x != 0 || !g_trace_buf) return;
+    const unsigned b = blockIdx.x + blockIdx.y * gridDim.x;
+    if (b >= (unsigned)TRACE_BLOCKS) return;
+    TraceRec &r = g_trace_buf[(size_t)kid * TRACE_BLOCKS + b];
+    r.t0 = t0; r.t1 = wall_clock64(); r.c0 = c0; r.c1 = clock64();
+    r.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    r.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+}
+struct TraceScope {
+    int kid; unsigned long long t0, c0;
+    __device__ __forceinline__ TraceScope(int k) : kid(k), t0(wall_clock64()), c0(clock64()) {}
+    __device__ __forceinline__ ~TraceScope() { trace_end(kid, t0, c0); }
+};
+#define RM_TRACE_SCOPE(KID) TraceScope rm_trace_scope_(KID)
+// phase marks inside ONE workgroup (block 5) of a kernel: mark i = wall clock when thread 0 passes the call; they live in
+// the records of the last pseudo-kernel (TRACE_KERNELS - 1), field t0 of record kid * TRACE_MARKS + i
+constexpr int TRACE_MARKS = 16;
+__device__ __forceinline__ void trace_mark(int kid, int i)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 5 && blockIdx.y == 0 && g_trace_buf)
+        g_trace_buf[(size_t)(TRACE_KERNELS - 1) * TRACE_BLOCKS + kid * TRACE_MARKS + i].t0 = wall_clock64();
+}
+#define RM_TRACE_MARK(KID, I) trace_mark(KID, I)
+#else
+#define RM_TRACE_SCOPE(KID)
+#define RM_TRACE_MARK(KID, I)
+#endif
+
+// ----------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -285,6 +324,7 @@ template <int NT>
 __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
                                                              const double *__restrict__ Cf, double amp, double *__restrict__ out)
 {
+    RM_TRACE_SCOPE(2);
     __shared__ double s_y[TM_W][4 * NT][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const size_t p = (size_t)blockIdx.x * 16 + lo;
@@ -293,17 +333,46 @@ __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__res
     v4f64 acc[NT];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) acc[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    RM_TRACE_MARK(2, 0);
     const double *xr = x + (size_t)hi * NP + pc;
-    for (int t0 = wave * per; t0 < (wave + 1) * per; t0 += 4) {
-        const double b = xr[(size_t)t0 * NP];
-        const double *rf = Rf + (size_t)(t0 >> 2) * NT * 64 + lane;
+    // The operands of TM_U K-steps are requested together, then consumed in order: a loop that loads one step's operands,
+    // waits and multiplies is a chain of T / 16 L2 round trips per wave (16 at T = 256: most of the kernel's 18 us).
+    // The order of the products into each accumulator is unchanged.
+    constexpr int TM_U = NT <= 3 ? 8 : 4;
+    const int t_end = (wave + 1) * per;
+    for (int t0 = wave * per; t0 < t_end; t0 += 4 * TM_U) {
+        double bb[TM_U], rr[TM_U][NT];
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf[ti * 64], b, acc[ti], 0, 0, 0);
+        for (int u = 0; u < TM_U; ++u) {
+            const int tu = t0 + 4 * u;
+            if (tu < t_end) {
+                bb[u] = xr[(size_t)tu * NP];
+                const double *rf = Rf + (size_t)(tu >> 2) * NT * 64 + lane;
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) rr[u][ti] = rf[ti * 64];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TM_U; ++u) {
+            if (t0 + 4 * u < t_end) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][ti], bb[u], acc[ti], 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_y[wave][4 * ti + r][lane] = acc[ti][r];
+    RM_TRACE_MARK(2, 1);
+    const int mt = T / 16;                     // output tiles of 16 frames, dealt round-robin to the waves
+    // the A operands of this wave's first output tile travel while the partial y tiles meet in LDS
+    double cfv[4 * NT];
+    if (wave < mt) {
+        const double *cf = Cf + (size_t)wave * 4 * NT * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
+    }
     __syncthreads();
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
@@ -314,20 +383,28 @@ __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__res
             for (int w = 1; w < TM_W; ++w) v = v + s_y[w][4 * ti + r][lane];
             acc[ti][r] = v;
         }
-    const int mt = T / 16;                     // output tiles of 16 frames, dealt round-robin to the waves
+    RM_TRACE_MARK(2, 2);
     for (int m = wave; m < mt; m += TM_W) {
         const int s0 = 16 * m;
-        const double *cf = Cf + (size_t)m * 4 * NT * 64 + lane;
+        double cur[4 * NT];
+#pragma unroll
+        for (int q = 0; q < 4 * NT; ++q) cur[q] = cfv[q];
+        if (m + TM_W < mt) {   // next tile's operands, one tile ahead
+            const double *cf = Cf + (size_t)(m + TM_W) * 4 * NT * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
+        }
         v4f64 o = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[(4 * ti + r) * 64], acc[ti][r], o, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[4 * ti + r], acc[ti][r], o, 0, 0, 0);
         }
         if (p < NP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(size_t)(s0 + hi + 4 * r) * NP + p] = o[r] * amp;
         }
+        RM_TRACE_MARK(2, 3 + m / TM_W);
     }
 }
 #endif
@@ -469,12 +546,15 @@ __device__ __forceinline__ void fill_lds(double *dst, const double *src, int n, 
 // st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
 __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all, CollapseState *st_init)
 {
+    RM_TRACE_SCOPE(1);
     if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
     HIP_DYNAMIC_SHARED(double, lds)
     const int t = blockIdx.x, tid = threadIdx.x;
     const int S = g.S, L = g.L;
+    RM_TRACE_MARK(1, 0);
     fill_lds(lds + g.g_off[S], gS + (size_t)t * (g.h[S] * g.w[S]), g.h[S] * g.w[S], tid);
     __syncthreads();
+    RM_TRACE_MARK(1, 1);
     for (int l = S + 1; l < L; ++l) {
         const int sh = g.h[l - 1], sw = g.w[l - 1], dh = g.h[l], dw = g.w[l];
         const double *s = lds + g.g_off[l - 1];
@@ -493,6 +573,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
             }
         }
         __syncthreads();
+        RM_TRACE_MARK(1, 2 + (l - S - 1));
     }
     double *out = lap_all + (size_t)t * g.NP;
     for (int l = L - 2; l >= S; --l) {
@@ -500,6 +581,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
         const double *base = lds + g.g_off[l];
         double *o = out + g.np_off[l];
         small_up_level(lds + g.g_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { o[i] = base[i] - v; });
+        RM_TRACE_MARK(1, 8 + (L - 2 - l));
     }
 }
 
@@ -543,6 +625,7 @@ struct ChainGeom {
     int lds_hbuf;                // offset of the scratch buffer of the horizontal pass (chain_step)
     int lds_total;               // doubles
     int tiles_x, tiles_y;
+    double lat_a, lat_b;         // raw[t, y << S, x << S] == lat_a * (c[y-1] + c[y+1]) + lat_b * c[y] per axis (lattice_sample)
 };
 
 struct Region { int y0, y1, x0, x1; };  // inclusive
@@ -631,8 +714,10 @@ struct CollapseState {
     unsigned long long lb_max_keys[NSTRIPE], ub_min_keys[NSTRIPE], ub_max_keys[NSTRIPE], lb_min_keys[NSTRIPE];
     unsigned long long min_keys[NSTRIPE], max_keys[NSTRIPE];  // stripes of the six words above
     unsigned long long heat_min_keys[NSTRIPE], heat_max_keys[NSTRIPE];  // stripes of heat_min_key / heat_max_key
+    unsigned long long smp_min_keys[NSTRIPE], smp_max_keys[NSTRIPE];    // extrema of the lattice samples (true raw values)
     unsigned int n_list;            // (frame, tile) pairs that must be evaluated
     unsigned int n_slots;           // pairs whose values are kept for the masked time sum
+    unsigned int n_heavy;           // tiles with at least one such pair among this rank's frames (k_select_pairs -> heavy[])
     double margin;                  // absolute safety margin of the bounds
     double top_ub;                  // upper bound of `top`, from the bounds alone
     double min_val, max_val, top;   // transforms.py:185-189, decoded by k_finish_minmax
@@ -646,9 +731,10 @@ __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIP
     st->lb_max_keys[i] = 0ull; st->ub_min_keys[i] = ~0ull; st->ub_max_keys[i] = 0ull; st->lb_min_keys[i] = ~0ull;
     st->min_keys[i] = ~0ull; st->max_keys[i] = 0ull;
     st->heat_min_keys[i] = ~0ull; st->heat_max_keys[i] = 0ull;
+    st->smp_min_keys[i] = ~0ull; st->smp_max_keys[i] = 0ull;
     if (i != 0) return;
     st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->ub_max_key = 0ull; st->lb_min_key = ~0ull;
-    st->min_key = ~0ull; st->max_key = 0ull; st->n_list = 0; st->n_slots = 0;
+    st->min_key = ~0ull; st->max_key = 0ull; st->n_list = 0; st->n_slots = 0; st->n_heavy = 0;
     st->margin = 0; st->top_ub = 0; st->min_val = 0; st->max_val = 0; st->top = 0;
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
 }
@@ -669,12 +755,32 @@ __device__ __forceinline__ unsigned long long fold_max_keys(const unsigned long 
     return (word > v) ? word : v;
 }
 
+// Lattice samples.  The tile bounds say where raw.min() / raw.max() CAN be; how low `top` can be -- and with it how many
+// pairs must be evaluated -- hangs on an UPPER bound of raw.min() and a LOWER bound of raw.max(), and the bounds alone
+// give poor ones (min over pairs of hi, max over pairs of lo: -39 / +40 against the true -50 / +51 on the synthetic
+// 1080p stream, so top_ub = -12 instead of -19.7 and 9 066 pairs kept instead of ~5 000).  Any true value of raw
+// bounds them far better, and some come almost for free: the full-resolution pixel (y << S, x << S) of an interior
+// level-S pixel is, through every pyrUp step, the even-even sample of its 3 x 3 level-S neighbourhood -- per axis
+// lat_a * (c[y-1] + c[y+1]) + lat_b * c[y] with dyadic weights (S = 4: 85/512, 342/512) -- because position p << k at level
+// S-k only ever draws on positions (p << (k-1)) - 1 .. + 1 one level up, none of which touches a border rule for 1 <= p <=
+// size - 2.  The weights are applied directly (a few roundings, ~3e-15 relative to max|c|, against the chain's own few), so
+// the samples enter the selection with twice the pruning margin (1e-12 relative).  Pruning stays exact: the evaluated
+// pairs still yield the exact extrema, only fewer pairs need evaluating.
+__device__ __forceinline__ double lattice_sample(const double *r0, const double *r1, const double *r2, int x, double a, double b)
+{
+    const double h0 = (r0[x - 1] + r0[x + 1]) * a + r0[x] * b;
+    const double h1 = (r1[x - 1] + r1[x + 1]) * a + r1[x] * b;
+    const double h2 = (r2[x - 1] + r2[x + 1]) * a + r2[x] * b;
+    return (h0 + h2) * a + h1 * b;
+}
+
 // The four extrema of the bounds (over ALL pairs) are reduced here as well: block-level min/max, then striped
 // atomics that are skipped when they cannot change the result.
 __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
-                                                     double *lo, double *hi, CollapseState *st)
+                                                     double *lo, double *hi, CollapseState *st, int *sel_cnt)
 {
     const double inf = __builtin_huge_val();
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < ntiles; i += 256) sel_cnt[i] = 0;   // k_select_pairs counts into it
     int idx = blockIdx.x * 256 + threadIdx.x;
     double mn = inf, mx = -inf;
     if (idx < ntiles * T) {
@@ -715,9 +821,10 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom
 // blockIdx.y selects a band of `band` tile rows (large levels: the row-extrema table of a whole frame would not fit LDS);
 // the table then holds only the level-S rows [y_lo, y_hi] that band's footprints touch (at most `tbl_rows` of them).
 __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi,
-                                                      CollapseState *st, int band, int tbl_rows)
+                                                      CollapseState *st, int band, int tbl_rows, int *sel_cnt)
 {
     HIP_DYNAMIC_SHARED(double, lds)
+    if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < ntiles; i += 256) sel_cnt[i] = 0;   // k_select_pairs counts into it
     const double inf = __builtin_huge_val();
     const int S = g.S, hS = g.h[S], wS = g.w[S], ntx = g.tiles_x;
     const int t = blockIdx.x;
@@ -756,8 +863,25 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
         lo_mn = (mn < lo_mn) ? mn : lo_mn; lo_mx = (mn > lo_mx) ? mn : lo_mx;
         hi_mn = (mx < hi_mn) ? mx : hi_mn; hi_mx = (mx > hi_mx) ? mx : hi_mx;
     }
+    // lattice samples (true raw values: see lattice_sample) of the level-S rows this band owns: rows [ry0, ry1) split the
+    // frame between the bands without overlap
+    double sm_mn = inf, sm_mx = -inf;
+    if (hS >= 3 && wS >= 3) {
+        const int nb = (int)gridDim.y;
+        const int ry0 = 1 + (int)(((long long)(hS - 2) * blockIdx.y) / nb), ry1 = 1 + (int)(((long long)(hS - 2) * (blockIdx.y + 1)) / nb);
+        const int iw = wS - 2;
+        const float inv_iw = 1.0f / (float)iw;
+        for (int i = threadIdx.x; i < (ry1 - ry0) * iw; i += 256) {
+            int y, x;
+            split_rc(i, iw, inv_iw, y, x);
+            const double *r1 = p + (size_t)(ry0 + y) * wS;
+            const double v = lattice_sample(r1 - wS, r1, r1 + wS, x + 1, g.lat_a, g.lat_b);
+            sm_mn = (v < sm_mn) ? v : sm_mn; sm_mx = (v > sm_mx) ? v : sm_mx;
+        }
+    }
     block_minmax(lo_mn, lo_mx);
     block_minmax(hi_mn, hi_mx);
+    block_minmax(sm_mn, sm_mx);
     if (threadIdx.x == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (blockIdx.x + blockIdx.y * 7) & (NSTRIPE - 1);
@@ -765,6 +889,11 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
         if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
         if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
         if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        if (sm_mn <= sm_mx) {
+            const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
+            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
+            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+        }
     }
 }
 
@@ -772,26 +901,42 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
 // wanted, so they are taken from there (no second pass over C_S in memory, one kernel boundary less).  Used when the
 // row-extrema table of a whole frame fits beside the frame's small pyramid.
 __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double *bp_all, SmallGeom sg, double *cS, CollapseState *st,
-                                                                     ChainGeom g, int ntiles, double *lo, double *hi)
+                                                                     ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
 {
+    RM_TRACE_SCOPE(3);
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < ntiles; i += SMALL_NT) sel_cnt[i] = 0;   // k_select_pairs counts into it
     HIP_DYNAMIC_SHARED(double, lds)   // [NP] frame (levels laid out as in bp_all), then the row-extrema table
-    __shared__ double s_red[4][SMALL_NT / 64];
+    __shared__ double s_red[6][SMALL_NT / 64];
+    __shared__ int s_arg[2][SMALL_NT / 64];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int S = sg.S, L = sg.L;
     // (st was reset by an EARLIER kernel on the stream -- k_small_pyramid or k_state_init: the atomics at the end of this
     //  kernel must not race with a reset inside it)
+    RM_TRACE_MARK(3, 0);
     fill_lds(lds, bp_all + (size_t)t * sg.NP, sg.NP, tid);
     __syncthreads();
+    RM_TRACE_MARK(3, 1);
     for (int l = L - 3; l >= S; --l) {
         const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
         double *d = lds + sg.np_off[l];
         small_up_level(lds + sg.np_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = v + d[i]; });
         __syncthreads();
+        RM_TRACE_MARK(3, 2 + (L - 3 - l));
     }
     const int hS = sg.h[S], wS = sg.w[S], n = hS * wS, ntx = g.tiles_x;
     const double *c = lds + sg.np_off[S];
     double *o = cS + (size_t)t * n;
-    for (int i = tid; i < n; i += SMALL_NT) o[i] = c[i];
+    // (the copy-out loop also finds where this frame's C_S is lowest / highest: the lattice samples are taken there)
+    const double inf = __builtin_huge_val();
+    double c_mn = inf, c_mx = -inf;
+    int i_mn = 0, i_mx = 0;
+    for (int i = tid; i < n; i += SMALL_NT) {
+        const double v = c[i];
+        o[i] = v;
+        if (v < c_mn) { c_mn = v; i_mn = i; }
+        if (v > c_mx) { c_mx = v; i_mx = i; }
+    }
+    RM_TRACE_MARK(3, 8);
     // tile bounds from the LDS copy: per-row extrema over the footprint columns, then extrema over the footprint rows
     double *rmin = lds + sg.NP, *rmax = rmin + (size_t)hS * ntx;
     const float inv_ntx = 1.0f / (float)ntx;
@@ -809,7 +954,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
         rmin[i] = mn; rmax[i] = mx;
     }
     __syncthreads();
-    const double inf = __builtin_huge_val();
+    RM_TRACE_MARK(3, 9);
+    
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
     for (int tile = tid; tile < ntiles; tile += SMALL_NT) {
         const int tx = tile % ntx;
@@ -825,21 +971,56 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
         hi_mn = (mx < hi_mn) ? mx : hi_mn; hi_mx = (mx > hi_mx) ? mx : hi_mx;
     }
     lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
+    // wave-level arg-min / arg-max of C_S (value and position travel together)
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(c_mn, m); const int oi = __shfl_xor(i_mn, m);
+        if (ov < c_mn) { c_mn = ov; i_mn = oi; }
+        const double pv = __shfl_xor(c_mx, m); const int pi = __shfl_xor(i_mx, m);
+        if (pv > c_mx) { c_mx = pv; i_mx = pi; }
+    }
     const int wave = tid >> 6;
-    if ((tid & 63) == 0) { s_red[0][wave] = lo_mn; s_red[1][wave] = lo_mx; s_red[2][wave] = hi_mn; s_red[3][wave] = hi_mx; }
+    if ((tid & 63) == 0) {
+        s_red[0][wave] = lo_mn; s_red[1][wave] = lo_mx; s_red[2][wave] = hi_mn; s_red[3][wave] = hi_mx;
+        s_red[4][wave] = c_mn; s_red[5][wave] = c_mx; s_arg[0][wave] = i_mn; s_arg[1][wave] = i_mx;
+    }
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < SMALL_NT / 64; ++w) {
-            lo_mn = (s_red[0][w] < lo_mn) ? s_red[0][w] : lo_mn; lo_mx = (s_red[1][w] > lo_mx) ? s_red[1][w] : lo_mx;
-            hi_mn = (s_red[2][w] < hi_mn) ? s_red[2][w] : hi_mn; hi_mx = (s_red[3][w] > hi_mx) ? s_red[3][w] : hi_mx;
+    RM_TRACE_MARK(3, 11);
+    if (wave != 0) return;
+    {   // wave 0 folds the per-wave partials: lane w takes wave w's
+        const bool have = tid < SMALL_NT / 64;
+        lo_mn = have ? s_red[0][tid] : inf; lo_mx = have ? s_red[1][tid] : -inf;
+        hi_mn = have ? s_red[2][tid] : inf; hi_mx = have ? s_red[3][tid] : -inf;
+        c_mn = have ? s_red[4][tid] : inf; c_mx = have ? s_red[5][tid] : -inf;
+        i_mn = have ? s_arg[0][tid] : 0; i_mx = have ? s_arg[1][tid] : 0;
+        lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double ov = __shfl_xor(c_mn, m); const int oi = __shfl_xor(i_mn, m);
+            if (ov < c_mn) { c_mn = ov; i_mn = oi; }
+            const double pv = __shfl_xor(c_mx, m); const int pi = __shfl_xor(i_mx, m);
+            if (pv > c_mx) { c_mx = pv; i_mx = pi; }
         }
+    }
+    if (tid == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = blockIdx.x & (NSTRIPE - 1);
         atomicMax(&st->lb_max_keys[sp], k_lo_mx);
         atomicMin(&st->lb_min_keys[sp], k_lo_mn);
         atomicMax(&st->ub_max_keys[sp], k_hi_mx);
         atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        // lattice samples (true raw values: see lattice_sample) at the interior pixels nearest to this frame's lowest and
+        // highest C_S: on the synthetic 1080p stream they bound the extrema as tightly as sampling every pixel would
+        if (hS >= 3 && wS >= 3) {
+            int ya = i_mn / wS, xa = i_mn - ya * wS, yb = i_mx / wS, xb = i_mx - yb * wS;
+            ya = min(max(ya, 1), hS - 2); xa = min(max(xa, 1), wS - 2);
+            yb = min(max(yb, 1), hS - 2); xb = min(max(xb, 1), wS - 2);
+            const double *ra = c + ya * wS, *rb = c + yb * wS;
+            const double va = lattice_sample(ra - wS, ra, ra + wS, xa, g.lat_a, g.lat_b);
+            const double vb = lattice_sample(rb - wS, rb, rb + wS, xb, g.lat_a, g.lat_b);
+            atomicMin(&st->smp_min_keys[sp], f64_key(va < vb ? va : vb));
+            atomicMax(&st->smp_max_keys[sp], f64_key(va > vb ? va : vb));
+        }
     }
+    RM_TRACE_MARK(3, 12);
 }
 
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
@@ -851,10 +1032,20 @@ constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is
 //   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max
 //   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum
 constexpr int SEL_U = 4;   // pairs per lane: their bound loads are issued together (the kernel is latency bound)
+// Slot / list positions: ballots + prefix popcounts inside the workgroup, then ONE returning atomic per counter and
+// workgroup, both issued together (a wave-level atomic per counter and per k was a chain of up to eight dependent
+// ~2.5 us round trips in the workgroups that select anything: 20 us of a 21 us kernel).
+// sel_cnt[tile] counts the kept pairs of a tile among this rank's frames (zeroed by the bounds kernel that ran before);
+// the first pair of a tile appends it to heavy[]: k_masked_sum_tiles gives those tiles to its worker workgroups and
+// finishes every other tile with a constant fill.
 __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
                                                       unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune,
-                                                      double thr, int first_pair, int end_pair)
+                                                      double thr, int first_pair, int end_pair, int ntiles, int *sel_cnt,
+                                                      unsigned int *heavy)
 {
+    RM_TRACE_SCOPE(4);
+    __shared__ unsigned int s_cnt[2][SEL_U][4];   // [kept | listed][k][wave]
+    __shared__ unsigned int s_base[2];
     const int i0 = blockIdx.x * (256 * SEL_U) + threadIdx.x;
     // the pairs' bounds first: nothing below depends on them until the comparisons
     double l[SEL_U], h[SEL_U];
@@ -872,40 +1063,73 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
     // for 0 <= thr <= 1); every thread derives them from the reduced bounds
     const unsigned long long k_lb_max = fold_max_keys(st->lb_max_keys, st->lb_max_key), k_ub_min = fold_min_keys(st->ub_min_keys, st->ub_min_key);
     const unsigned long long k_ub_max = fold_max_keys(st->ub_max_keys, st->ub_max_key), k_lb_min = fold_min_keys(st->lb_min_keys, st->lb_min_key);
-    const double lb_max = f64_unkey(k_lb_max), ub_min = f64_unkey(k_ub_min);
+    double lb_max = f64_unkey(k_lb_max), ub_min = f64_unkey(k_ub_min);
     const double ub_max = f64_unkey(k_ub_max), lb_min = f64_unkey(k_lb_min);
     const double aa = ub_max < 0 ? -ub_max : ub_max, bb = lb_min < 0 ? -lb_min : lb_min;
     const double m = PRUNE_REL_MARGIN * (aa > bb ? aa : bb);
+    {   // true raw values (lattice samples) bound raw.min() from above and raw.max() from below far better than the tile bounds
+        const unsigned long long k_smn = fold_min_keys(st->smp_min_keys, ~0ull), k_smx = fold_max_keys(st->smp_max_keys, 0ull);
+        if (k_smn != ~0ull) {
+            const double s_mn = f64_unkey(k_smn) + 2 * m, s_mx = f64_unkey(k_smx) - 2 * m;
+            ub_min = (s_mn < ub_min) ? s_mn : ub_min;
+            lb_max = (s_mx > lb_max) ? s_mx : lb_max;
+        }
+    }
     const double mx_ = ub_max + m, mn_ = ub_min + m;
     const double top_ub = (mx_ - (mx_ - mn_) * thr) + m;
     if (i0 == 0) { st->margin = m; st->top_ub = top_ub; }
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
+    bool isD[SEL_U], isL[SEL_U];
+    unsigned long long mD[SEL_U], mL[SEL_U];
+#pragma unroll
+    for (int k = 0; k < SEL_U; ++k) {
+        bool isC = false;
+        isD[k] = false;
+        if (mine[k]) {
+            isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
+            isD[k] = no_prune || (l[k] - m < top_ub);
+        }
+        // listed = evaluated by k_eval_pairs: C pairs (exact extrema) and every kept pair (a kept pair beyond the value
+        // store's capacity is evaluated there for the extrema only and once more inside the sum kernel)
+        isL[k] = isC || isD[k];
+        mD[k] = __ballot(isD[k]);
+        mL[k] = __ballot(isL[k]);
+        if (lane == 0) { s_cnt[0][k][wave] = (unsigned)__popcll(mD[k]); s_cnt[1][k][wave] = (unsigned)__popcll(mL[k]); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned totD = 0, totL = 0;
+#pragma unroll
+        for (int k = 0; k < SEL_U; ++k)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { totD += s_cnt[0][k][w]; totL += s_cnt[1][k][w]; }
+        unsigned bD = 0, bL = 0;
+        if (totD) bD = atomicAdd(&st->n_slots, totD);
+        if (totL) bL = atomicAdd(&st->n_list, totL);
+        s_base[0] = bD; s_base[1] = bL;
+    }
+    __syncthreads();
+    unsigned offD = s_base[0], offL = s_base[1];
 #pragma unroll
     for (int k = 0; k < SEL_U; ++k) {
         const int i = i0 + 256 * k;
-        bool isC = false, isD = false;
-        if (mine[k]) {
-            isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
-            isD = no_prune || (l[k] - m < top_ub);
+        unsigned myD = offD, myL = offL;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned cD = s_cnt[0][k][w], cL = s_cnt[1][k][w];
+            myD += (w < wave) ? cD : 0; myL += (w < wave) ? cL : 0;
+            offD += cD; offL += cL;
         }
-        // one atomic per wave and counter (ballot + prefix popcount), not one per selected pair
-        const unsigned long long mD = __ballot(isD);
-        unsigned base_slot = 0;
-        if (lane == 0 && mD) base_slot = atomicAdd(&st->n_slots, (unsigned)__popcll(mD));
-        base_slot = (unsigned)__shfl((int)base_slot, 0);
         int slot = SLOT_PRUNED;
-        if (isD) {
-            const unsigned sidx = base_slot + (unsigned)__popcll(mD & below);
+        if (isD[k]) {
+            const unsigned sidx = myD + (unsigned)__popcll(mD[k] & below);
             slot = (sidx < slot_cap) ? (int)sidx : SLOT_ON_THE_FLY;
+            const int t = i / ntiles, tile = i - t * ntiles;
+            if (atomicAdd(&sel_cnt[tile], 1) == 0) heavy[atomicAdd(&st->n_heavy, 1u)] = (unsigned)tile;
         }
         if (i < n) slot_of[i] = slot;
-        const bool listed = isC || slot >= 0;
-        const unsigned long long mL = __ballot(listed);
-        unsigned base_list = 0;
-        if (lane == 0 && mL) base_list = atomicAdd(&st->n_list, (unsigned)__popcll(mL));
-        base_list = (unsigned)__shfl((int)base_list, 0);
-        if (listed) list[base_list + (unsigned)__popcll(mL & below)] = (unsigned)i;
+        if (isL[k]) list[myL + (unsigned)__popcll(mL[k] & below)] = (unsigned)i;
     }
 }
 
@@ -967,7 +1191,8 @@ __device__ __forceinline__ Region chain_step(const ChainGeom &g, int tile, doubl
 __device__ __forceinline__ void chain_to_level1(const ChainGeom &g, int tile, const double *cS_t, double *lds)
 {
     Region Rk = chain_stage(g, tile, cS_t, lds);
-    for (int k = g.S; k >= 2; --k) Rk = chain_step(g, tile, lds, k, Rk);
+    RM_TRACE_MARK(5, 2);
+    for (int k = g.S; k >= 2; --k) { Rk = chain_step(g, tile, lds, k, Rk); RM_TRACE_MARK(5, 3 + (g.S - k)); }
 }
 
 // level 1 (LDS) -> level 0 for this lane's column: out[j] = raw[t, y0 + j0 + j, x], j < NR (j0, NR even)
@@ -1002,8 +1227,9 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
 // Exact raw.min()/raw.max() (transforms.py:185,187) come from here; values of pairs that can fall
 // below `top` are parked in `store` ([slot][row][lane], coalesced) for the masked time sum.
 __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list,
-                                                   const int *slot_of, CollapseState *st, double *store, double *slot_min)
+                                                   int *slot_of, CollapseState *st, double *store)
 {
+    RM_TRACE_SCOPE(5);
     HIP_DYNAMIC_SHARED(double, lds)
     const unsigned n = st->n_list;
     const int lane = threadIdx.x;
@@ -1011,13 +1237,16 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     const double top_ub = st->top_ub;   // upper bound of `top` from the tile bounds (k_select_pairs)
     double mn = inf, mx = -inf;
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
+        RM_TRACE_MARK(5, 0);
         const unsigned idx = (unsigned)uniform((int)list[c]);   // wave-uniform: the tile geometry stays in scalar registers
         const int t = idx / ntiles, tile = idx - t * ntiles;
         const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
+        RM_TRACE_MARK(5, 1);
         chain_to_level1(g, tile, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
+        RM_TRACE_MARK(5, 6);
         int x = R0.x0 + lane;
         const int slot = uniform(slot_of[idx]);
-        double pmn = inf;   // minimum of this pair's tile: the sum pass skips kept frames that turn out fully masked
+        double pmn = inf;   // minimum of this pair's tile
         double v[CT_H];
         const int rows = R0.y1 - R0.y0 + 1;
         if (x <= R0.x1) {
@@ -1027,20 +1256,24 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
                 if (j < rows) { pmn = (v[j] < pmn) ? v[j] : pmn; mx = (v[j] > mx) ? v[j] : mx; }
         }
         mn = (pmn < mn) ? pmn : mn;
-        if (slot >= 0) {   // wave-uniform
+        RM_TRACE_MARK(5, 7);
+        if (slot != SLOT_PRUNED) {   // wave-uniform
             pmn = wave_min(pmn);
-            // nothing of this tile can fall below top (top <= top_ub): no values to park, the sum pass treats it as pruned
-            const bool masked_for_sure = pmn >= top_ub;
-            if (lane == 0) slot_min[slot] = masked_for_sure ? inf : pmn;
-            if (!masked_for_sure && x <= R0.x1) {
+            // nothing of this tile can fall below top (top <= top_ub): every pixel adds `min`, exactly like a pruned pair --
+            // no values to park, and the sum pass never sees the frame
+            if (pmn >= top_ub) {
+                if (lane == 0) slot_of[idx] = SLOT_PRUNED;
+            } else if (slot >= 0 && x <= R0.x1) {
                 double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
 #pragma unroll
                 for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
             }
         }
+        RM_TRACE_MARK(5, 8);
         __syncthreads();
     }
     mn = wave_min(mn); mx = wave_max(mx);
+    RM_TRACE_MARK(5, 9);
     if (lane == 0 && blockIdx.x < n) {
         // striped, and skipped when they cannot change the result
         const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
@@ -1079,156 +1312,179 @@ __global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, co
 }
 
 // pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order, base.py:562).
-// Pruned pairs add `min`; kept pairs read their values back from `store`.  A 256-thread workgroup owns a
-// tile (wave w: rows 4w..4w+3 of every column) and walks the ordered list of kept frames in batches of
-// MS_B whose loads are issued one batch ahead, so a tile with hundreds of kept frames is not a chain of
-// exposed memory latencies.  (Measured alternatives: quarter tiles with one row per lane and 32-frame batches
-// shorten the chain of the few heavy tiles but quadruple the fixed cost of the ~2000 light ones: 105 us vs 75 us.)
+// Pruned pairs add `min`; kept pairs read their values back from `store`.
+//
+// Two kinds of workgroups in one launch (256 threads each), workers first so that the long chains start at once:
+//   * blockIdx.x <  nworkers: WORKERS.  Worker item i is (heavy[i / MS_Q], row group i % MS_Q): the tile's ordered list of
+//     kept frames is compacted by ballot / popcount (every worker of the tile repeats that cheap, parallel step), then
+//     thread (wave, lane) owns pixel (row MS_RQ * q + wave, column lane) and walks the kept frames in batches of MS_B
+//     loads issued one batch ahead.  The longest dependent chain of the launch is therefore ceil(kept / MS_B) round
+//     trips of ONE tile row group, not 256 / 6 of a whole tile (the earlier form: one 256-thread workgroup per tile, 4 rows
+//     per lane, 6-frame batches -- its heaviest tile alone took 29 us and every empty tile 8-10 us in three rounds).
+//   * blockIdx.x >= nworkers: FILL.  A tile without a kept pair (sel_cnt[tile] == 0: 94 % of the tiles of the synthetic
+//     1080p stream) is one constant -- T sequential additions of `min` -- which a fill workgroup computes once and stores
+//     into every such tile of its share (tiles f, f + nfill, ...).
+// Dynamic LDS: the chain buffers of the on-the-fly evaluation (g.lds_total doubles), then the compacted kept-frame list
+// s_kt[T] (frame) and s_ks[T] (slot).
 constexpr int MAX_T = 4096;
-// (measured: 8 waves x 2 rows with 16 frames per batch halves the dependent round trips of the heaviest tile but, at
-//  195 VGPRs, leaves one 512-thread workgroup per CU: 88 us instead of 49 -- the launch is bound by the rounds of
-//  light tiles, not by the heaviest one)
-// batch depth x occupancy hint (tools/sweep_msum.sh, us per launch): 8/1 49, 8/3 47, 6/3 43, 5/3 43, 4/3 42, 4/4 43,
-// 3/4 44, 8/4 70 (spills), 12/2 51: three workgroups per CU with a 6-frame batch.  Alone, the tiles with kept frames
-// take 36 us and the others 19 us: the tile with the most kept frames is the critical path.  A register ring of 3-8
-// batches in flight (loads issued several batches ahead) measured 51-69 us -- slower than this double buffer.
-#ifndef RM_MS_B
-#define RM_MS_B 6
-#endif
-#ifndef RM_MS_MINBLK
-#define RM_MS_MINBLK 3
-#endif
-constexpr int MS_B = RM_MS_B;         // kept frames per batch
-constexpr int MS_R = CT_H / 4;        // rows per lane (4 waves per tile)
+constexpr int MS_Q = 4;              // row groups (worker items) per heavy tile
+constexpr int MS_RQ = CT_H / MS_Q;   // rows per worker == waves per workgroup
+constexpr int MS_B = 12;             // kept frames per batch
 
-__global__ __launch_bounds__(256, RM_MS_MINBLK) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int ntiles,
+__host__ __device__ inline size_t masked_sum_lds_bytes(const ChainGeom &g, int T)
+{
+    return sizeof(double) * (size_t)g.lds_total + 2 * sizeof(int) * (size_t)T + 16;
+}
+
+__global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
-                                                          int *tile_nkept, unsigned int *slots_seen_host, const double *slot_min)
+                                                          int *tile_nkept, unsigned int *slots_seen_host,
+                                                          const int *sel_cnt, const unsigned int *heavy, int nworkers)
 {
+    RM_TRACE_SCOPE(6);
     HIP_DYNAMIC_SHARED(double, lds)
-    __shared__ int s_slot[MAX_T];
-    __shared__ short s_kept_t[MAX_T + MS_B];
-    __shared__ int s_wcnt[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j0 = wave * MS_R;
-    const int tile = blockIdx.x;
+    __shared__ int s_wcnt[MS_RQ];
+    int *s_kt = reinterpret_cast<int *>(lds + g.lds_total);            // kept frames of the tile, in order
+    int *s_ks = s_kt + T;                                              // ... and their value-store slots
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;
-    if (tile == 0 && tid == 0) {
+    RM_TRACE_MARK(6, 0);
+    if (blockIdx.x == 0 && tid == 0) {
         st->min_val = min_val; st->max_val = max_val; st->top = top;
         if (slots_seen_host) *slots_seen_host = st->n_slots;   // pinned host word: the next call sizes the value store from it
-    }
-    const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
-    // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks).
-    // Ordered compaction of the frames that are not pruned: ballot + prefix popcount, 256 frames per round.
-    int nkept = 0;
-    for (int c0 = t_first; c0 < t_end; c0 += 256) {
-        const int t = c0 + tid;
-        int slot = (t < t_end) ? slot_of[(size_t)t * ntiles + tile] : SLOT_PRUNED;
-        // a kept frame whose whole tile is >= top adds `min` to every pixel, exactly like a pruned one: drop it here
-        // (its exact minimum was recorded by the evaluation pass) instead of loading its 8 KB of values
-        if (slot >= 0 && slot_min[slot] >= top) slot = SLOT_PRUNED;
-        if (t < t_end) s_slot[t] = slot;
-        const bool kept = slot != SLOT_PRUNED;
-        const unsigned long long m = __ballot(kept);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = nkept, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
-        if (kept) s_kept_t[off + __popcll(m & ((1ull << lane) - 1ull))] = (short)t;
-        nkept += tot;
-        __syncthreads();
-    }
-    if (tid == 0 && tile_nkept) tile_nkept[tile] = nkept;   // 0: every pixel of the tile ends up as the same constant
-    const int x = R0.x0 + lane;
-    const int rows = R0.y1 - R0.y0 + 1;
-    const bool active = x <= R0.x1;
-    double acc[MS_R];
-#pragma unroll
-    for (int j = 0; j < MS_R; ++j) acc[j] = 0.0;
-    double nxt[MS_B][MS_R];
-#pragma unroll
-    for (int b = 0; b < MS_B; ++b)
-#pragma unroll
-        for (int j = 0; j < MS_R; ++j) nxt[b][j] = 0.0;
-    auto fetch = [&](int ib, double (&v)[MS_B][MS_R]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int b = 0; b < MS_B; ++b) {
-            const int i = ib + b;
-            const int slot = (i < nkept) ? s_slot[s_kept_t[i]] : -1;
-            if (slot >= 0 && active) {
-                const double *d = store + (size_t)slot * (CT_H * CT_W) + (size_t)j0 * CT_W + lane;
-#pragma unroll
-                for (int j = 0; j < MS_R; ++j) v[b][j] = d[j * CT_W];
-            }
-        }
-    };
-    fetch(0, nxt);
-    int t_done = t_first;
-    {   // every row starts with the same run of pruned frames: one chain of `+ min` instead of one per row
-        const int t_lead = (nkept > 0) ? (int)s_kept_t[0] : t_end;
-        double lead = 0.0;
-        for (int t = t_first; t < t_lead; ++t) lead = lead + min_val;
-#pragma unroll
-        for (int j = 0; j < MS_R; ++j) acc[j] = lead;
-        t_done = t_lead;
-    }
-    for (int ib = 0; ib < nkept; ib += MS_B) {
-        double cur[MS_B][MS_R];
-#pragma unroll
-        for (int b = 0; b < MS_B; ++b)
-#pragma unroll
-            for (int j = 0; j < MS_R; ++j) cur[b][j] = nxt[b][j];
-        fetch(ib + MS_B, nxt);
-#pragma unroll
-        for (int b = 0; b < MS_B; ++b) {
-            if (ib + b < nkept) {
-                const int t_stop = s_kept_t[ib + b];  // frames [t_done, t_stop) are pruned
-                for (int t = t_done; t < t_stop; ++t) {
-#pragma unroll
-                    for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + min_val;
-                }
-                if (s_slot[t_stop] < 0) {  // SLOT_ON_THE_FLY: the value store was full, evaluate here
-                    __syncthreads();
-                    chain_to_level1(g, tile, cS + (size_t)t_stop * g.h[g.S] * g.w[g.S], lds);
-                    if (active) level0_rows<MS_R>(g, R0, R1, lds, x, j0, cur[b]);
-                }
-                if (active) {
-#pragma unroll
-                    for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + ((cur[b][j] >= top) ? min_val : cur[b][j]);
-                }
-                t_done = t_stop + 1;
-            }
-        }
-    }
-    for (int t = t_done; t < t_end; ++t) {
-#pragma unroll
-        for (int j = 0; j < MS_R; ++j) acc[j] = acc[j] + min_val;
     }
     // avg_T > 0 (the whole buffer is summed here): write np.average = sum / T (base.py:562) and reduce the
     // heatmap's min / max for the normalisation (base.py:563) on the way out
     const double cnt = (double)avg_T;
-    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
-    if (active) {
+    if ((int)blockIdx.x >= nworkers) {
+        const int nfill = (int)gridDim.x - nworkers;
+        double lead = 0.0;
+        for (int t = t_first; t < t_end; ++t) lead = lead + min_val;
+        const double v = avg_T > 0 ? lead / cnt : lead;
+        bool any = false;
+        constexpr int FU = 4;    // tiles whose kept-pair counts are requested together
+        for (int base = (int)blockIdx.x - nworkers; base < ntiles; base += FU * nfill) {
+            int cntk[FU];
 #pragma unroll
-        for (int j = 0; j < MS_R; ++j)
-            if (j0 + j < rows) {
-                const double v = avg_T > 0 ? acc[j] / cnt : acc[j];
-                heat_sum[(size_t)(R0.y0 + j0 + j) * g.w[0] + x] = v;
-                hmn = (v < hmn) ? v : hmn;
-                hmx = (v > hmx) ? v : hmx;
+            for (int k = 0; k < FU; ++k) { const int tile = base + k * nfill; cntk[k] = tile < ntiles ? sel_cnt[tile] : 1; }
+#pragma unroll
+            for (int k = 0; k < FU; ++k) {
+                const int tile = base + k * nfill;
+                if (cntk[k] != 0) continue;               // past the end, or a worker sums this tile
+                any = true;
+                const Region R0 = tile_region(g, tile, 0);
+                const int x = R0.x0 + lane, rows = R0.y1 - R0.y0 + 1;
+                if (x <= R0.x1) {
+#pragma unroll
+                    for (int j = 0; j < CT_H / MS_RQ; ++j) {
+                        const int r = wave * (CT_H / MS_RQ) + j;
+                        if (r < rows) heat_sum[(size_t)(R0.y0 + r) * g.w[0] + x] = v;
+                    }
+                }
+                if (tid == 0 && tile_nkept) tile_nkept[tile] = 0;     // 0: every pixel of the tile is the same constant
             }
-    }
-    if (avg_T > 0) {
-        block_minmax(hmn, hmx);
-        if (tid == 0) {
-            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
-            const int sp = blockIdx.x & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
         }
+        if (any && tid == 0 && avg_T > 0) {
+            const unsigned long long kv = f64_key(v);
+            const int sp = blockIdx.x & (NSTRIPE - 1);
+            if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kv);
+            if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kv);
+        }
+        return;
+    }
+    const int nitems = (int)st->n_heavy * MS_Q;
+    for (int item = (int)blockIdx.x; item < nitems; item += nworkers) {
+        const int tile = (int)heavy[item / MS_Q], q = item % MS_Q;
+        const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
+        // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks).
+        // Ordered compaction of the frames that are not pruned (by the selection, or by the evaluation pass when the whole
+        // tile turned out >= top_ub): ballot + prefix popcount, 256 frames per round.
+        int nkept = 0;
+        for (int c0 = t_first; c0 < t_end; c0 += 64 * MS_RQ) {
+            const int t = c0 + tid;
+            const int slot = (t < t_end) ? slot_of[(size_t)t * ntiles + tile] : SLOT_PRUNED;
+            const bool kept = slot != SLOT_PRUNED;
+            const unsigned long long m = __ballot(kept);
+            if (lane == 0) s_wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = nkept, tot = 0;
+#pragma unroll
+            for (int w = 0; w < MS_RQ; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
+            if (kept) { const int i = off + __popcll(m & ((1ull << lane) - 1ull)); s_kt[i] = t; s_ks[i] = slot; }
+            nkept += tot;
+            __syncthreads();
+        }
+        if (tid == 0 && q == 0 && tile_nkept) tile_nkept[tile] = nkept;   // 0: every pixel of the tile ends up as the same constant
+        RM_TRACE_MARK(6, 1);
+        const int x = R0.x0 + lane;
+        const int row = q * MS_RQ + wave;
+        const bool active = x <= R0.x1 && R0.y0 + row <= R0.y1;
+        double acc = 0.0;
+        // a batch = MS_B kept frames: their frame numbers, slots and (one batch ahead) values sit in registers, so the
+        // serial part below touches neither LDS nor memory (per-frame LDS look-ups were 2/3 of the heaviest worker's time)
+        double nxt[MS_B];
+        int ktn[MS_B];      // frame number; bit 30 set: the frame's values are not in the store (SLOT_ON_THE_FLY)
+#pragma unroll
+        for (int b = 0; b < MS_B; ++b) nxt[b] = 0.0;
+        auto fetch = [&](int ib) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < MS_B; ++b) {
+                const int i = ib + b;
+                const bool ok = i < nkept;
+                const int ks = ok ? s_ks[i] : SLOT_PRUNED;
+                ktn[b] = (ok ? s_kt[i] : t_end) | (ks == SLOT_ON_THE_FLY ? (1 << 30) : 0);
+                if (ks >= 0 && active) nxt[b] = store[(size_t)ks * (CT_H * CT_W) + (size_t)row * CT_W + lane];
+            }
+        };
+        fetch(0);
+        RM_TRACE_MARK(6, 2);
+        int t_done = t_first;
+        for (int ib = 0; ib < nkept; ib += MS_B) {
+            double cur[MS_B];
+            int kt[MS_B];
+#pragma unroll
+            for (int b = 0; b < MS_B; ++b) { cur[b] = nxt[b]; kt[b] = ktn[b]; }
+            fetch(ib + MS_B);
+#pragma unroll
+            for (int b = 0; b < MS_B; ++b) {
+                if (ib + b < nkept) {
+                    const int code = uniform(kt[b]);
+                    const int t_stop = code & ~(1 << 30);     // frames [t_done, t_stop) are pruned
+                    for (int t = t_done; t < t_stop; ++t) acc = acc + min_val;
+                    if (code & (1 << 30)) {  // SLOT_ON_THE_FLY: the value store was full, evaluate here
+                        __syncthreads();
+                        chain_to_level1(g, tile, cS + (size_t)t_stop * g.h[g.S] * g.w[g.S], lds);
+                        double two[2];
+                        if (x <= R0.x1) { level0_rows<2>(g, R0, R1, lds, x, row & ~1, two); cur[b] = two[row & 1]; }
+                    }
+                    if (active) acc = acc + ((cur[b] >= top) ? min_val : cur[b]);
+                    t_done = t_stop + 1;
+                }
+            }
+            RM_TRACE_MARK(6, 3 + ib / MS_B);
+        }
+        for (int t = t_done; t < t_end; ++t) acc = acc + min_val;
+        RM_TRACE_MARK(6, 12);
+        double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+        if (active) {
+            const double v = avg_T > 0 ? acc / cnt : acc;
+            heat_sum[(size_t)(R0.y0 + row) * g.w[0] + x] = v;
+            hmn = v; hmx = v;
+        }
+        if (avg_T > 0) {
+            block_minmax(hmn, hmx);
+            if (tid == 0) {
+                const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+                const int sp = blockIdx.x & (NSTRIPE - 1);
+                if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
+                if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+            }
+        }
+        RM_TRACE_MARK(6, 13);
+        __syncthreads();   // s_kt / s_ks are rewritten by the next item
     }
 }
 
@@ -1329,6 +1585,7 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
                                                     unsigned long long *bits)
 {
+    RM_TRACE_SCOPE(7);
     const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
     const double mx = f64_unkey(fold_max_keys(st->heat_max_keys, st->heat_max_key));
     const double range = mx - mn;
