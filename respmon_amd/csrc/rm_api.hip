@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -69,7 +70,8 @@ struct rm_ctx {
     std::map<std::string, DevBuf> bufs;
     CollapseState *d_state = nullptr;
     CollapseState *h_state = nullptr;  // pinned
-    uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned
+    uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned: bit-packed thresholded image + H row flags (k_heat_to_u8)
+    uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     bool state_fresh = false;   // d_state was reset by the last kernel of front_pyramid and nothing has reduced into it since
@@ -80,8 +82,6 @@ struct rm_ctx {
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0;
-    unsigned int *h_slots_seen = nullptr;  // pinned: n_slots of the previous rm_calibrate (async readback)
-    int slots_seen_pairs = 0;              // npairs that readback belongs to
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
     bool prof_on = false;
     int prof_calls = 0;
@@ -148,8 +148,6 @@ extern "C" int rm_ctx_create(int device, rm_ctx **out)
     c->device = device;
     HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(CollapseState)));
     HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(CollapseState), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&c->h_slots_seen, sizeof(unsigned int), hipHostMallocDefault));
-    *c->h_slots_seen = 0;
     *out = c;
     return RM_OK;
 }
@@ -162,7 +160,6 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
-    if (ctx->h_slots_seen) (void)hipHostFree(ctx->h_slots_seen);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
@@ -511,7 +508,7 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
         // columns of C; NT = 3 covers the calibration defaults (46 rows at n = 256), 6 the long buffers (92 at n = 512)
         const int nk = ctx->op_nk;
         const int NT = nk <= 48 ? 3 : 6;
-        const bool mf = nk >= 1 && nk <= 16 * TM_MAX_TILES && T % 16 == 0;
+        const bool mf = nk >= 1 && nk <= 16 * TM_MAX_TILES && T % (4 * (NT == 3 ? TemporalWaves<3>::W : TemporalWaves<6>::W)) == 0;
         std::vector<double> Rf(mf ? (size_t)(T / 4) * NT * 64 : 1, 0.0), Cf(mf ? (size_t)(T / 16) * 4 * NT * 64 : 1, 0.0);
         if (mf) {
             for (int t0 = 0; t0 < T; t0 += 4)
@@ -563,8 +560,8 @@ static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const
 #ifndef RM_HIPEMU
     static const int env_valu = [] { const char *e = getenv("RM_TEMPORAL_VALU"); return e ? atoi(e) : 0; }();  // developer A/B knob
     if (op.Rf && !env_valu) {
-        if (op.tiles == 3) hipLaunchKernelGGL((k_temporal_mfma<3>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TM_W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
-        else hipLaunchKernelGGL((k_temporal_mfma<6>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TM_W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
+        if (op.tiles == 3) hipLaunchKernelGGL((k_temporal_mfma<3>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<3>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
+        else hipLaunchKernelGGL((k_temporal_mfma<6>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<6>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
         LAUNCH_CHECK();
         return RM_OK;
     }
@@ -1037,22 +1034,14 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     const int ntiles = g.tiles_x * g.tiles_y;
     const int npairs = ntiles * T;
     cp.ntiles = ntiles; cp.npairs = npairs;
-    // value store for the pairs the masked sum needs: 1/8 of all pairs (>= 4096 slots); pairs beyond
-    // the capacity are re-evaluated inside the sum kernel, so the size is a speed knob, not a limit
-    // The store adapts without a host sync: every call leaves its slot demand in pinned memory
-    // (asynchronous copy); the next call with the same geometry sizes the store from it (+25 %).
-    size_t slot_cap = (size_t)npairs / 8;
-    if (ctx->slots_seen_pairs == npairs && (size_t)*ctx->h_slots_seen > slot_cap)
-        slot_cap = (size_t)*ctx->h_slots_seen + (size_t)*ctx->h_slots_seen / 4;
-    if (slot_cap < 4096) slot_cap = 4096;
-    if (slot_cap > (size_t)npairs) slot_cap = (size_t)npairs;
-    if (flags & RM_FLAG_TINY_STORE) slot_cap = 3;
-    ctx->dbg_pairs = npairs; ctx->dbg_cap = (long long)slot_cap;
+    // value store: one slot per (tile, frame) pair, tile-major (rm_kernels.h SLOT_KEPT) -- the size of ONE float64 [T,H,W]
+    // array (rounded up to whole tiles), of which only the kept pairs are ever written or read
+    ctx->dbg_pairs = npairs; ctx->dbg_cap = (long long)npairs;
     RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &cp.lo));
     RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &cp.hi));
     RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
-    RM_TRY(ws(ctx, "value_store", slot_cap * CT_H * CT_W, &cp.store));
+    RM_TRY(ws(ctx, "value_store", (size_t)npairs * CT_H * CT_W, &cp.store));
     RM_TRY(ws(ctx, "sel_cnt", (size_t)ntiles, &cp.sel_cnt));
     RM_TRY(ws(ctx, "heavy_tiles", (size_t)ntiles, &cp.heavy));
     if (!sl.bounds_ready) {
@@ -1083,13 +1072,13 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 256 * SEL_U - 1) / (256 * SEL_U)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
-                       (unsigned)slot_cap, prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy);
+                       prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy);
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
     // one resident round of single-wave workgroups (18 per CU, measured) that loop over the list: the list length
     // lives on the device, and dispatching thousands of workgroups that find nothing to do costs more than the loop
     unsigned egrid = (unsigned)(npairs < 256 * 18 ? npairs : 256 * 18);
-    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list, cp.slot_of, st, cp.store);
+    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, T, ntiles, cp.list, cp.slot_of, st, cp.store);
     LAUNCH_CHECK();
     cp.valid = true;
     return RM_OK;
@@ -1116,18 +1105,12 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
-    unsigned int *slots_seen_dev = nullptr;   // the slot demand of this call goes straight to pinned host memory
-    HIP_TRY(hipHostGetDevicePointer((void **)&slots_seen_dev, ctx->h_slots_seen, 0));
-    // worker workgroups for the tiles with kept pairs (MS_Q items each) + fill workgroups for all the others
-    const int nworkers = std::min(cp.ntiles * MS_Q, 1024), nfill = std::min(cp.ntiles, 512);
-    const size_t ms_lds = masked_sum_lds_bytes(cp.g, cp.T);
-    if (ms_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)k_masked_sum_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds));
-    hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers + nfill), dim3(64 * MS_RQ), ms_lds, s, cp.cS, cp.g, cp.t0, cp.t1, cp.T, cp.ntiles,
-                       cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, slots_seen_dev, cp.sel_cnt, cp.heavy, nworkers);
+    // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
+    const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
+    hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
+                       cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers);
     LAUNCH_CHECK();
     ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;   // the constant tiles of this heatmap (or partial heat sum of a frame shard) are known
-    ctx->slots_seen_pairs = cp.npairs;
     return RM_OK;
 }
 
@@ -1315,18 +1298,20 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     const size_t npix = (size_t)H * W;
     CollapseState *st = ctx->d_state;
     ctx->state_fresh = false;   // the heatmap extrema are (or have been) reduced into the state
-    // the thresholded image goes to the host bit-packed (npix / 8 bytes): the kernel stores its ballot words straight
-    // into pinned, device-mapped host memory (one 8-byte store per 64 pixels rides the kernel; a separate
-    // device-to-host copy costs ~15 us of copy-engine start-up on this path)
+    // the thresholded image goes to the host bit-packed (npix / 8 bytes) plus one "row holds foreground" byte per row: the
+    // kernel stores both straight into pinned, device-mapped host memory (no copy-engine hop)
     const size_t nwords = (npix + 63) / 64;
-    if (ctx->h_bin_cap < nwords * 8) {
-        if (ctx->h_bin) HIP_TRY(hipHostFree(ctx->h_bin));
+    const size_t need = nwords * 8 + (size_t)H;
+    if (ctx->h_bin_cap < need) {
+        if (ctx->h_bin) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(ctx->h_bin)); }
         ctx->h_bin = nullptr; ctx->h_bin_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, nwords * 8, hipHostMallocDefault));
-        ctx->h_bin_cap = nwords * 8;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, need, hipHostMallocDefault));
+        ctx->h_bin_cap = need;
     }
-    unsigned long long *bits = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void **)&bits, ctx->h_bin, 0));
+    uint8_t *h_rows = ctx->h_bin + nwords * 8;
+    if (ctx->h_rows_dirty != h_rows) { std::memset(h_rows, 0, (size_t)H); ctx->h_rows_dirty = h_rows; }   // (zero again after every use)
+    uint8_t *dev_bin = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dev_bin, ctx->h_bin, 0));
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
     if (!have_minmax) {  // rm_calibrate has just left the heatmap's min / max in the state
@@ -1335,14 +1320,18 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, st, threshold, avg_u8, binary, bits);
+    hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
+                       (unsigned long long *)dev_bin, dev_bin + nwords * 8);
     LAUNCH_CHECK();
     delete pt_roi; pt_roi = nullptr;
     HIP_TRY(stream_wait(s));
     RoiResult r;
     {
         auto t0 = std::chrono::steady_clock::now();
-        largest_external_contour_bits((const uint64_t *)ctx->h_bin, H, W, &r);
+        int y0 = H, y1 = -1;   // rows that hold foreground
+        for (int y = 0; y < H; ++y)
+            if (h_rows[y]) { if (y < y0) y0 = y; y1 = y; h_rows[y] = 0; }
+        largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
         if (ctx->prof_on)
             ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

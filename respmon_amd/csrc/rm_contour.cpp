@@ -60,6 +60,7 @@ struct Tracer {
             }
             for (; x < W; ++x) d[x] = s[x] ? FG : BG;
         }
+        win_y0 = 0; win_y1 = H - 1;   // (this entry keeps no row window: a later prepare_bits() must visit every row)
         const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
         const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
         for (int i = 0; i < 8; ++i) nbr[i] = nbr[i + 8] = dy[i] * step + dx[i];
@@ -81,8 +82,12 @@ struct Tracer {
         return v;
     }
 
-    void prepare_bits(const uint64_t *bits, int H, int W)
+    int win_y0 = 0, win_y1 = -1;     // rows the previous prepare_bits() found foreground in (they hold marks to clear)
+
+    // rows outside [ya, yb] are known to hold no foreground in `bits`; rows the previous image dirtied are visited as well
+    void prepare_bits(const uint64_t *bits, int H, int W, int ya = 0, int yb = -2)
     {
+        if (yb == -2) yb = H - 1;
         static uint64_t lut[256];
         static bool lut_ok = false;
         if (!lut_ok) {  // byte of 8 pixel bits -> 8 bytes FG / BG
@@ -98,12 +103,20 @@ struct Tracer {
             step = new_step; rows_dirty_h = H;
             buf.assign((size_t)step * (H + 2), BG);
             dirty.assign(H, 0);
+            win_y0 = 0; win_y1 = -1;
         }
         if ((int)clr_x0.size() != H) { clr_x0.assign(H, 0); clr_x1.assign(H, W - 1); }
         own_row_any.assign(H, 0);
         row_x0.assign(H, 0); row_x1.assign(H, -1);
         grp_a.assign(H, 0); grp_b.assign(H, -1);
-        for (int y = 0; y < H; ++y) {
+        if (ya < 0) ya = 0;
+        if (yb > H - 1) yb = H - 1;
+        if (win_y1 >= win_y0) {   // marks of the previous image
+            if (yb < ya) { ya = win_y0; yb = win_y1; }
+            else { ya = ya < win_y0 ? ya : win_y0; yb = yb > win_y1 ? yb : win_y1; }
+        }
+        win_y0 = H; win_y1 = -1;
+        for (int y = ya; y <= yb; ++y) {
             signed char *d = buf.data() + (size_t)(y + 1) * step + 1;
             const size_t r0 = (size_t)y * W;
             // the part of the working row the previous image (and its border marks) touched is cleared; only the
@@ -140,6 +153,8 @@ struct Tracer {
             }
             if (x0 < 0) continue;
             dirty[y] = 1; own_row_any[y] = 1; row_x0[y] = x0; row_x1[y] = x1; grp_a[y] = xa; grp_b[y] = xb;
+            if (y < win_y0) win_y0 = y;
+            win_y1 = y;
             clr_x0[y] = x0 & ~63; clr_x1[y] = ((x1 | 63) < W - 1) ? (x1 | 63) : W - 1;   // whole groups were written
         }
         const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
@@ -208,11 +223,13 @@ int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *r
 //   a run starts a new outer border iff its first pixel is still unmarked and the last marked pixel to its left in
 //   this row is not a SEEN (entering) border, i.e. we are not inside an already traced component (RETR_EXTERNAL);
 //   the "last marked pixel" then moves to the last marked pixel of this run, if it has one.
-static int scan_runs(Tracer &tr, const uint64_t *bits, int H, int W, RoiResult *out)
+static int scan_runs(Tracer &tr, const uint64_t *bits, int H, int W, RoiResult *out, int ya = 0, int yb = -2)
 {
     const int step = tr.step;
     double best = -1.0;
-    for (int y = 0; y < H; ++y) {
+    if (yb == -2 || yb > H - 1) yb = H - 1;
+    if (ya < 0) ya = 0;
+    for (int y = ya; y <= yb; ++y) {
         if (!tr.own_row_any[y]) continue;
         signed char *row = tr.buf.data() + (size_t)(y + 1) * step + 1;   // row[c] = pixel c
         const size_t r0 = (size_t)y * W;
@@ -262,6 +279,16 @@ int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult 
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare_bits(bits, H, W);
     return scan_runs(g_tracer, bits, H, W, out);
+}
+
+int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out)
+{
+    out->found = 0; out->n_contours = 0; out->area = 0.0;
+    out->x = out->y = out->w = out->h = 0;
+    if (H <= 0 || W <= 0) return 0;
+    g_tracer.prepare_bits(bits, H, W, y0, y1 < y0 ? y0 - 1 : y1);
+    if (y1 < y0) return 0;
+    return scan_runs(g_tracer, bits, H, W, out, y0, y1);
 }
 
 // `have_ranges`: pixels left of row_x0 / right of row_x1 are background without marks (borders only visit

@@ -13,4 +13,7 @@ struct RoiResult {
 int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out);
 // the same on a bit-packed image: bit (p & 63) of word (p >> 6) = pixel p = y*W + x; words beyond H*W bits are not read
 int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult *out);
+// ... when the caller knows that only rows [y0, y1] can hold foreground now or held any in the previous image given to
+// this thread's tracer (y1 < y0: no such row): the other rows are neither read nor cleaned
+int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out);
 }  // namespace rm

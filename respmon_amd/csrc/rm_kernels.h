@@ -312,7 +312,10 @@ __global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, si
 // The operators arrive "fragment major" (built on the host, zero padded to 16 NT rows), so that every A operand is one
 // coalesced 512-byte load (layouts beside the kernel).
 // fused == materialised == per-level stays bit for bit: every path through the library uses this same kernel.
-constexpr int TM_W = 4;
+// waves per workgroup: 8 when the accumulators are 3 tiles (each wave then has T / 32 K-steps -- 8 at T = 256 -- and requests
+// ALL its operands before the first product: one memory round trip instead of a chain), 4 for the 6-tile form (LDS: the
+// partial y tiles of 8 waves would be 98 KB)
+template <int NT> struct TemporalWaves { static constexpr int W = 4; static constexpr int MINW = NT <= 3 ? 3 : 2; };   // MINW: waves per SIMD the register budget must allow (3 workgroups per CU for NT = 3)
 constexpr int TM_MAX_TILES = 6;   // up to 96 surviving rows (n = 512 at 10 fps has 92); NT = tiles of 16 rows actually used
 
 #ifndef RM_HIPEMU   // (the host emulation of tests/emu runs the two-stage VALU kernels above)
@@ -321,15 +324,16 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Rf[(t0/4 * NT + ti) * 64 + lane] = R[16 ti + (lane & 15)][t0 + (lane >> 4)]
 // Cf[((s0/16) * 4 NT + 4 ti + r) * 64 + lane] = C[s0 + (lane & 15)][16 ti + 4 r + (lane >> 4)]
 template <int NT>
-__global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
+__global__ __launch_bounds__(64 * TemporalWaves<NT>::W, TemporalWaves<NT>::MINW) void k_temporal_mfma(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
                                                              const double *__restrict__ Cf, double amp, double *__restrict__ out)
 {
     RM_TRACE_SCOPE(2);
+    constexpr int TM_W = TemporalWaves<NT>::W;
     __shared__ double s_y[TM_W][4 * NT][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const size_t p = (size_t)blockIdx.x * 16 + lo;
     const size_t pc = p < NP ? p : NP - 1;     // columns past the end repeat the last one (never stored)
-    const int per = T / TM_W;                  // T % 16 == 0: a multiple of 4 frames per wave
+    const int per = T / TM_W;                  // T % (4 TM_W) == 0: a multiple of 4 frames per wave
     v4f64 acc[NT];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) acc[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__res
                 for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][ti], bb[u], acc[ti], 0, 0, 0);
             }
         }
+        RM_TRACE_MARK(2, 8 + (t0 - wave * per) / (4 * TM_U));
     }
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
@@ -386,26 +391,23 @@ __global__ __launch_bounds__(64 * TM_W) void k_temporal_mfma(const double *__res
     RM_TRACE_MARK(2, 2);
     for (int m = wave; m < mt; m += TM_W) {
         const int s0 = 16 * m;
-        double cur[4 * NT];
-#pragma unroll
-        for (int q = 0; q < 4 * NT; ++q) cur[q] = cfv[q];
-        if (m + TM_W < mt) {   // next tile's operands, one tile ahead
-            const double *cf = Cf + (size_t)(m + TM_W) * 4 * NT * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
-        }
         v4f64 o = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[4 * ti + r], acc[ti][r], o, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cfv[4 * ti + r], acc[ti][r], o, 0, 0, 0);
+        }
+        if (m + TM_W < mt) {   // the next tile's operands travel while this one is stored
+            const double *cf = Cf + (size_t)(m + TM_W) * 4 * NT * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
         }
         if (p < NP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(size_t)(s0 + hi + 4 * r) * NP + p] = o[r] * amp;
         }
-        RM_TRACE_MARK(2, 3 + m / TM_W);
     }
+    RM_TRACE_MARK(2, 3);
 }
 #endif
 
@@ -1026,7 +1028,11 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
 
 constexpr int SLOT_PRUNED = -1;    // every value of the pair is provably >= top: contributes `min`
-constexpr int SLOT_ON_THE_FLY = -2;  // must be evaluated but the value store is full
+constexpr int SLOT_KEPT = 0;       // the pair's values are parked in the value store for the masked time sum
+// The value store is indexed by the pair itself -- store[(tile * T + t)][CT_H][CT_W], i.e. one (sparsely touched) float64
+// [T,H,W] array in tile-major order: a tile's kept frames sit in ONE contiguous T x 8 KB region, which is what the sum
+// pass walks (slots handed out by an atomic counter scattered a tile's frames over the whole store: every batch of the
+// sum pass paid a TLB / DRAM-page miss per frame, ~3.5 us per batch of 12), and there is no capacity to overflow.
 
 // which pairs need their full-resolution values:
 //   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max
@@ -1039,7 +1045,7 @@ constexpr int SEL_U = 4;   // pairs per lane: their bound loads are issued toget
 // the first pair of a tile appends it to heavy[]: k_masked_sum_tiles gives those tiles to its worker workgroups and
 // finishes every other tile with a constant fill.
 __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
-                                                      unsigned int *list, int *slot_of, unsigned int slot_cap, int no_prune,
+                                                      unsigned int *list, int *slot_of, int no_prune,
                                                       double thr, int first_pair, int end_pair, int ntiles, int *sel_cnt,
                                                       unsigned int *heavy)
 {
@@ -1090,8 +1096,7 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
             isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
             isD[k] = no_prune || (l[k] - m < top_ub);
         }
-        // listed = evaluated by k_eval_pairs: C pairs (exact extrema) and every kept pair (a kept pair beyond the value
-        // store's capacity is evaluated there for the extrema only and once more inside the sum kernel)
+        // listed = evaluated by k_eval_pairs: C pairs (exact extrema) and every kept pair
         isL[k] = isC || isD[k];
         mD[k] = __ballot(isD[k]);
         mL[k] = __ballot(isL[k]);
@@ -1104,31 +1109,28 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
         for (int k = 0; k < SEL_U; ++k)
 #pragma unroll
             for (int w = 0; w < 4; ++w) { totD += s_cnt[0][k][w]; totL += s_cnt[1][k][w]; }
-        unsigned bD = 0, bL = 0;
-        if (totD) bD = atomicAdd(&st->n_slots, totD);
+        unsigned bL = 0;
+        if (totD) atomicAdd(&st->n_slots, totD);      // reported only (rm_debug_counters)
         if (totL) bL = atomicAdd(&st->n_list, totL);
-        s_base[0] = bD; s_base[1] = bL;
+        s_base[1] = bL;
     }
     __syncthreads();
-    unsigned offD = s_base[0], offL = s_base[1];
+    unsigned offL = s_base[1];
 #pragma unroll
     for (int k = 0; k < SEL_U; ++k) {
         const int i = i0 + 256 * k;
-        unsigned myD = offD, myL = offL;
+        unsigned myL = offL;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const unsigned cD = s_cnt[0][k][w], cL = s_cnt[1][k][w];
-            myD += (w < wave) ? cD : 0; myL += (w < wave) ? cL : 0;
-            offD += cD; offL += cL;
+            const unsigned cL = s_cnt[1][k][w];
+            myL += (w < wave) ? cL : 0;
+            offL += cL;
         }
-        int slot = SLOT_PRUNED;
         if (isD[k]) {
-            const unsigned sidx = myD + (unsigned)__popcll(mD[k] & below);
-            slot = (sidx < slot_cap) ? (int)sidx : SLOT_ON_THE_FLY;
             const int t = i / ntiles, tile = i - t * ntiles;
             if (atomicAdd(&sel_cnt[tile], 1) == 0) heavy[atomicAdd(&st->n_heavy, 1u)] = (unsigned)tile;
         }
-        if (i < n) slot_of[i] = slot;
+        if (i < n) slot_of[i] = isD[k] ? SLOT_KEPT : SLOT_PRUNED;
         if (isL[k]) list[myL + (unsigned)__popcll(mL[k] & below)] = (unsigned)i;
     }
 }
@@ -1225,8 +1227,8 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
 
 // the one evaluation pass: full-resolution values of every listed (frame, tile) pair, once.
 // Exact raw.min()/raw.max() (transforms.py:185,187) come from here; values of pairs that can fall
-// below `top` are parked in `store` ([slot][row][lane], coalesced) for the masked time sum.
-__global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list,
+// below `top` are parked in `store` ([tile][t][row][lane], coalesced) for the masked time sum.
+__global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int T, int ntiles, const unsigned int *list,
                                                    int *slot_of, CollapseState *st, double *store)
 {
     RM_TRACE_SCOPE(5);
@@ -1263,8 +1265,8 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
             // no values to park, and the sum pass never sees the frame
             if (pmn >= top_ub) {
                 if (lane == 0) slot_of[idx] = SLOT_PRUNED;
-            } else if (slot >= 0 && x <= R0.x1) {
-                double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
+            } else if (x <= R0.x1) {
+                double *d = store + ((size_t)tile * T + t) * (CT_H * CT_W) + lane;
 #pragma unroll
                 for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
             }
@@ -1314,98 +1316,61 @@ __global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, co
 // pass D: heat_sum[y,x] = sum_t (raw >= top ? min : raw), sequential in t (np.average order, base.py:562).
 // Pruned pairs add `min`; kept pairs read their values back from `store`.
 //
-// Two kinds of workgroups in one launch (256 threads each), workers first so that the long chains start at once:
-//   * blockIdx.x <  nworkers: WORKERS.  Worker item i is (heavy[i / MS_Q], row group i % MS_Q): the tile's ordered list of
-//     kept frames is compacted by ballot / popcount (every worker of the tile repeats that cheap, parallel step), then
-//     thread (wave, lane) owns pixel (row MS_RQ * q + wave, column lane) and walks the kept frames in batches of MS_B
-//     loads issued one batch ahead.  The longest dependent chain of the launch is therefore ceil(kept / MS_B) round
-//     trips of ONE tile row group, not 256 / 6 of a whole tile (the earlier form: one 256-thread workgroup per tile, 4 rows
-//     per lane, 6-frame batches -- its heaviest tile alone took 29 us and every empty tile 8-10 us in three rounds).
-//   * blockIdx.x >= nworkers: FILL.  A tile without a kept pair (sel_cnt[tile] == 0: 94 % of the tiles of the synthetic
-//     1080p stream) is one constant -- T sequential additions of `min` -- which a fill workgroup computes once and stores
-//     into every such tile of its share (tiles f, f + nfill, ...).
-// Dynamic LDS: the chain buffers of the on-the-fly evaluation (g.lds_total doubles), then the compacted kept-frame list
-// s_kt[T] (frame) and s_ks[T] (slot).
+// One launch of `nworkers` 256-thread workgroups:
+//   * WORKER items.  Item i is (heavy[i / MS_Q], row group i % MS_Q): the tile's ordered list of kept frames is compacted by
+//     ballot / popcount (every worker of the tile repeats that cheap, parallel step), then thread (wave, lane) owns pixel
+//     (row MS_RQ * q + wave, column lane) and walks the kept frames in batches of MS_B loads issued one batch ahead.  The
+//     longest dependent chain of the launch is therefore ceil(kept / MS_B) round trips of ONE tile row group, not
+//     256 / 6 of a whole tile (the earlier form: one 256-thread workgroup per tile, 4 rows per lane, 6-frame batches --
+//     its heaviest tile alone took 29 us and every empty tile 8-10 us in three rounds).
+//   * FILL.  A tile without a kept pair (sel_cnt[tile] == 0: 94 % of the tiles of the synthetic 1080p stream) is one
+//     constant -- T sequential additions of `min` -- computed once per workgroup and stored into every such tile of its
+//     share.  The workgroups that found no worker item do the filling (they are free at once; separate fill workgroups
+//     queued behind the workers' registers and started 5-14 us late); when every workgroup has items, all of them fill
+//     after their items.
+// Dynamic LDS: s_kt[T], the tile's kept frames in order.
 constexpr int MAX_T = 4096;
 constexpr int MS_Q = 4;              // row groups (worker items) per heavy tile
 constexpr int MS_RQ = CT_H / MS_Q;   // rows per worker == waves per workgroup
-constexpr int MS_B = 12;             // kept frames per batch
+constexpr int MS_B = 16;             // kept frames per batch
 
-__host__ __device__ inline size_t masked_sum_lds_bytes(const ChainGeom &g, int T)
-{
-    return sizeof(double) * (size_t)g.lds_total + 2 * sizeof(int) * (size_t)T + 16;
-}
-
-__global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles,
+__global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int t_end, int T, int ntiles, int W0, int H0,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
-                                                          int *tile_nkept, unsigned int *slots_seen_host,
-                                                          const int *sel_cnt, const unsigned int *heavy, int nworkers)
+                                                          int *tile_nkept, const int *sel_cnt, const unsigned int *heavy, int nworkers)
 {
     RM_TRACE_SCOPE(6);
-    HIP_DYNAMIC_SHARED(double, lds)
+    HIP_DYNAMIC_SHARED(int, s_kt)     // kept frames of the tile, in order
     __shared__ int s_wcnt[MS_RQ];
-    int *s_kt = reinterpret_cast<int *>(lds + g.lds_total);            // kept frames of the tile, in order
-    int *s_ks = s_kt + T;                                              // ... and their value-store slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (W0 + CT_W - 1) / CT_W;
+    // everything that does not depend on the state is requested before it: the tile of this workgroup's first item and its
+    // first slot_of column (speculatively: heavy[] and slot_of[] are valid memory whatever n_heavy turns out to be)
+    const int tile0 = (int)(heavy[blockIdx.x / MS_Q] % (unsigned)ntiles);
+    int slot0 = SLOT_PRUNED;
+    if (t_first + tid < t_end) slot0 = slot_of[(size_t)(t_first + tid) * ntiles + tile0];
+    const int nitems = (int)st->n_heavy * MS_Q;
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;
     RM_TRACE_MARK(6, 0);
-    if (blockIdx.x == 0 && tid == 0) {
-        st->min_val = min_val; st->max_val = max_val; st->top = top;
-        if (slots_seen_host) *slots_seen_host = st->n_slots;   // pinned host word: the next call sizes the value store from it
-    }
+    if (blockIdx.x == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     // avg_T > 0 (the whole buffer is summed here): write np.average = sum / T (base.py:562) and reduce the
     // heatmap's min / max for the normalisation (base.py:563) on the way out
     const double cnt = (double)avg_T;
-    if ((int)blockIdx.x >= nworkers) {
-        const int nfill = (int)gridDim.x - nworkers;
-        double lead = 0.0;
-        for (int t = t_first; t < t_end; ++t) lead = lead + min_val;
-        const double v = avg_T > 0 ? lead / cnt : lead;
-        bool any = false;
-        constexpr int FU = 4;    // tiles whose kept-pair counts are requested together
-        for (int base = (int)blockIdx.x - nworkers; base < ntiles; base += FU * nfill) {
-            int cntk[FU];
-#pragma unroll
-            for (int k = 0; k < FU; ++k) { const int tile = base + k * nfill; cntk[k] = tile < ntiles ? sel_cnt[tile] : 1; }
-#pragma unroll
-            for (int k = 0; k < FU; ++k) {
-                const int tile = base + k * nfill;
-                if (cntk[k] != 0) continue;               // past the end, or a worker sums this tile
-                any = true;
-                const Region R0 = tile_region(g, tile, 0);
-                const int x = R0.x0 + lane, rows = R0.y1 - R0.y0 + 1;
-                if (x <= R0.x1) {
-#pragma unroll
-                    for (int j = 0; j < CT_H / MS_RQ; ++j) {
-                        const int r = wave * (CT_H / MS_RQ) + j;
-                        if (r < rows) heat_sum[(size_t)(R0.y0 + r) * g.w[0] + x] = v;
-                    }
-                }
-                if (tid == 0 && tile_nkept) tile_nkept[tile] = 0;     // 0: every pixel of the tile is the same constant
-            }
-        }
-        if (any && tid == 0 && avg_T > 0) {
-            const unsigned long long kv = f64_key(v);
-            const int sp = blockIdx.x & (NSTRIPE - 1);
-            if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kv);
-            if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kv);
-        }
-        return;
-    }
-    const int nitems = (int)st->n_heavy * MS_Q;
     for (int item = (int)blockIdx.x; item < nitems; item += nworkers) {
-        const int tile = (int)heavy[item / MS_Q], q = item % MS_Q;
-        const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
+        const bool first = item == (int)blockIdx.x;
+        const int tile = first ? tile0 : (int)heavy[item / MS_Q], q = item % MS_Q;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         // frames [t_first, t_end): the whole buffer, or this rank's frame shard (partial time sums add up across ranks).
         // Ordered compaction of the frames that are not pruned (by the selection, or by the evaluation pass when the whole
         // tile turned out >= top_ub): ballot + prefix popcount, 256 frames per round.
         int nkept = 0;
         for (int c0 = t_first; c0 < t_end; c0 += 64 * MS_RQ) {
             const int t = c0 + tid;
-            const int slot = (t < t_end) ? slot_of[(size_t)t * ntiles + tile] : SLOT_PRUNED;
+            int slot = SLOT_PRUNED;
+            if (first && c0 == t_first) slot = slot0;
+            else if (t < t_end) slot = slot_of[(size_t)t * ntiles + tile];
             const bool kept = slot != SLOT_PRUNED;
             const unsigned long long m = __ballot(kept);
             if (lane == 0) s_wcnt[wave] = __popcll(m);
@@ -1413,20 +1378,21 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *c
             int off = nkept, tot = 0;
 #pragma unroll
             for (int w = 0; w < MS_RQ; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
-            if (kept) { const int i = off + __popcll(m & ((1ull << lane) - 1ull)); s_kt[i] = t; s_ks[i] = slot; }
+            if (kept) s_kt[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
             nkept += tot;
             __syncthreads();
         }
         if (tid == 0 && q == 0 && tile_nkept) tile_nkept[tile] = nkept;   // 0: every pixel of the tile ends up as the same constant
         RM_TRACE_MARK(6, 1);
-        const int x = R0.x0 + lane;
-        const int row = q * MS_RQ + wave;
-        const bool active = x <= R0.x1 && R0.y0 + row <= R0.y1;
+        const int x = tx * CT_W + lane;
+        const int row = q * MS_RQ + wave, y = ty * CT_H + row;
+        const bool active = x < W0 && y < H0;
+        const double *mine = store + (size_t)tile * T * (CT_H * CT_W) + (size_t)row * CT_W + lane;   // + t * 1024: this pixel in frame t
         double acc = 0.0;
-        // a batch = MS_B kept frames: their frame numbers, slots and (one batch ahead) values sit in registers, so the
-        // serial part below touches neither LDS nor memory (per-frame LDS look-ups were 2/3 of the heaviest worker's time)
+        // a batch = MS_B kept frames: their frame numbers and (one batch ahead) values sit in registers, so the serial
+        // part below touches neither LDS nor memory (per-frame LDS look-ups were 2/3 of the heaviest worker's time)
         double nxt[MS_B];
-        int ktn[MS_B];      // frame number; bit 30 set: the frame's values are not in the store (SLOT_ON_THE_FLY)
+        int ktn[MS_B];
 #pragma unroll
         for (int b = 0; b < MS_B; ++b) nxt[b] = 0.0;
         auto fetch = [&](int ib) __attribute__((always_inline)) {
@@ -1434,9 +1400,8 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *c
             for (int b = 0; b < MS_B; ++b) {
                 const int i = ib + b;
                 const bool ok = i < nkept;
-                const int ks = ok ? s_ks[i] : SLOT_PRUNED;
-                ktn[b] = (ok ? s_kt[i] : t_end) | (ks == SLOT_ON_THE_FLY ? (1 << 30) : 0);
-                if (ks >= 0 && active) nxt[b] = store[(size_t)ks * (CT_H * CT_W) + (size_t)row * CT_W + lane];
+                ktn[b] = ok ? s_kt[i] : t_end;
+                if (ok && active) nxt[b] = mine[(size_t)ktn[b] * (CT_H * CT_W)];
             }
         };
         fetch(0);
@@ -1451,15 +1416,8 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *c
 #pragma unroll
             for (int b = 0; b < MS_B; ++b) {
                 if (ib + b < nkept) {
-                    const int code = uniform(kt[b]);
-                    const int t_stop = code & ~(1 << 30);     // frames [t_done, t_stop) are pruned
+                    const int t_stop = uniform(kt[b]);     // frames [t_done, t_stop) are pruned
                     for (int t = t_done; t < t_stop; ++t) acc = acc + min_val;
-                    if (code & (1 << 30)) {  // SLOT_ON_THE_FLY: the value store was full, evaluate here
-                        __syncthreads();
-                        chain_to_level1(g, tile, cS + (size_t)t_stop * g.h[g.S] * g.w[g.S], lds);
-                        double two[2];
-                        if (x <= R0.x1) { level0_rows<2>(g, R0, R1, lds, x, row & ~1, two); cur[b] = two[row & 1]; }
-                    }
                     if (active) acc = acc + ((cur[b] >= top) ? min_val : cur[b]);
                     t_done = t_stop + 1;
                 }
@@ -1471,7 +1429,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *c
         double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
         if (active) {
             const double v = avg_T > 0 ? acc / cnt : acc;
-            heat_sum[(size_t)(R0.y0 + row) * g.w[0] + x] = v;
+            heat_sum[(size_t)y * W0 + x] = v;
             hmn = v; hmx = v;
         }
         if (avg_T > 0) {
@@ -1484,7 +1442,44 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(const double *c
             }
         }
         RM_TRACE_MARK(6, 13);
-        __syncthreads();   // s_kt / s_ks are rewritten by the next item
+        __syncthreads();   // s_kt is rewritten by the next item
+    }
+    // FILL: by the workgroups without items when there are any, by every workgroup otherwise
+    const int idle = nworkers - min(nitems, nworkers);
+    const int nfill = idle > 0 ? idle : nworkers;
+    const int fid = idle > 0 ? (int)blockIdx.x - nitems : (int)blockIdx.x;
+    if (fid < 0) return;
+    double lead = 0.0;
+    for (int t = t_first; t < t_end; ++t) lead = lead + min_val;
+    const double v = avg_T > 0 ? lead / cnt : lead;
+    bool any = false;
+    constexpr int FU = 4;    // tiles whose kept-pair counts are requested together
+    for (int base = fid; base < ntiles; base += FU * nfill) {
+        int cntk[FU];
+#pragma unroll
+        for (int k = 0; k < FU; ++k) { const int tile = base + k * nfill; cntk[k] = tile < ntiles ? sel_cnt[tile] : 1; }
+#pragma unroll
+        for (int k = 0; k < FU; ++k) {
+            const int tile = base + k * nfill;
+            if (cntk[k] != 0) continue;               // past the end, or a worker sums this tile
+            any = true;
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int x = tx * CT_W + lane, y0 = ty * CT_H;
+            if (x < W0) {
+#pragma unroll
+                for (int j = 0; j < CT_H / MS_RQ; ++j) {
+                    const int y = y0 + wave * (CT_H / MS_RQ) + j;
+                    if (y < H0) heat_sum[(size_t)y * W0 + x] = v;
+                }
+            }
+            if (tid == 0 && tile_nkept) tile_nkept[tile] = 0;     // 0: every pixel of the tile is the same constant
+        }
+    }
+    if (any && tid == 0 && avg_T > 0) {
+        const unsigned long long kv = f64_key(v);
+        const int sp = blockIdx.x & (NSTRIPE - 1);
+        if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kv);
+        if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kv);
     }
 }
 
@@ -1579,11 +1574,16 @@ __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t 
     }
 }
 
-// `bits` receives the thresholded image bit-packed (bit p & 63 of word p >> 6 = pixel p, row-major): 1/8 of a
-// byte per pixel, so the host contour stage gets the whole image in ONE small device-to-host copy.
-__global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, const CollapseState *st,
+// `bits` receives the thresholded image bit-packed (bit p & 63 of word p >> 6 = pixel p, row-major): 1/8 of a byte per
+// pixel, stored straight into pinned, device-mapped host memory.  `row_any[y]` (pinned bytes the host zeroes after use) is set
+// for every row that holds foreground: the host contour stage then reads only those rows of `bits` -- the breathing region
+// covers ~1/5 of a 1080p frame, and reading memory the device has just written (lines no host cache holds) was most of that
+// stage.  (Tried and dropped: a sparse list of the non-zero words with a `done` word the host spins on instead of the
+// runtime's completion query -- the kernel's own hand-off cost 14 us more, and a stream the runtime never sees complete
+// makes the NEXT launch ~100 us slower.)
+__global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
-                                                    unsigned long long *bits)
+                                                    unsigned long long *bits, uint8_t *row_any)
 {
     RM_TRACE_SCOPE(7);
     const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
@@ -1602,7 +1602,13 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
             if (binary) binary[i] = b;
         }
         const unsigned long long m = __ballot(b != 0);
-        if (lane == 0 && bits) bits[base >> 6] = m;
+        if (lane == 0 && bits) {
+            bits[base >> 6] = m;
+            if (m && row_any) {   // the group may straddle row ends: flag every row it touches (a superset is fine)
+                const size_t last = (base + 63 < npix ? base + 63 : npix - 1);
+                for (size_t y = base / (size_t)W; y <= last / (size_t)W; ++y) row_any[y] = 1;
+            }
+        }
     }
 }
 

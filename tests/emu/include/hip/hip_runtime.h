@@ -165,6 +165,7 @@ inline int atomicMin(int *p, int v) {
 }
 inline int atomicAdd(int *p, int v) { return reinterpret_cast<std::atomic<int> *>(p)->fetch_add(v); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->fetch_add(v); }
+inline unsigned atomicExch(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->exchange(v); }
 inline unsigned atomicMax(unsigned *p, unsigned v) {
     auto *a = reinterpret_cast<std::atomic<unsigned> *>(p);
     unsigned o = a->load();
@@ -183,6 +184,7 @@ inline double __longlong_as_double(long long l) { double r; std::memcpy(&r, &l, 
 inline int __float_as_int(float f) { int r; std::memcpy(&r, &f, 4); return r; }
 inline float __int_as_float(int i) { float r; std::memcpy(&r, &i, 4); return r; }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+inline void __threadfence_system() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 /* half: only widening loads are needed */
 struct __half { uint16_t bits; };
@@ -215,6 +217,7 @@ inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h;
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 #define hipErrorNotReady 600
 inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
