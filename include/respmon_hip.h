@@ -47,6 +47,7 @@ extern "C" {
 #define RM_FLAG_UNFUSED_DOWN 2u  /* build the Gaussian levels one pyrDown launch per level */
 #define RM_FLAG_UNFUSED_SMALL 16u /* build / collapse the small pyramid with one launch per level (A/B + fallback path) */
 #define RM_FLAG_TINY_STRIPS 8u   /* test hook: 3-column strips / 2-row segments in the fused pyrDown chain */
+#define RM_FLAG_CONTOUR_CLIP_FRAME 32u /* rm_locate: cv2.findContours as OpenCV <= 3.1 did it (see rm_set_contour_clip_frame) */
 #define RM_FLAG_TINY_STORE 4u    /* accepted and ignored: the value store has one slot per (tile, frame) pair, nothing to overflow */
 
 typedef struct rm_ctx rm_ctx;
@@ -232,6 +233,15 @@ int rm_pca_reduce(rm_ctx *ctx, const float *motion_host, int n, double *out_host
 
 /* ---- base.py:230-231: cv2.cvtColor(BGR2GRAY) then uint8_to_float, on device ("next" row f3) */
 int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gray_dev, void *stream);
+
+/* ---- base.py:567-568: which cv2.findContours the ROI stage reproduces.  The reference pins no OpenCV version (README.md:12
+ *      installs "opencv3" from conda channel menpo; base.py:567 keeps a `thresh_copy` because the version its author ran MUTATED
+ *      the input).  OpenCV <= 3.1 zeroes the 1-pixel image frame in place before tracing, so components are clipped to
+ *      [1, W-2] x [1, H-2]; OpenCV >= 3.2 traces on a zero-padded copy and frame pixels count.
+ *      on = 0 (default): the >= 3.2 rule.  on = 1: the <= 3.1 rule, for every later ROI extraction of this context
+ *      (rm_heatmap_to_roi, rm_locate, rm_shard_finish, rm_heat_sparse_merge_roi); rm_locate also takes it per call as
+ *      RM_FLAG_CONTOUR_CLIP_FRAME. */
+int rm_set_contour_clip_frame(rm_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -267,11 +267,44 @@ def g8(R):
     np.savez_compressed(os.path.join(OUT, "g8_iir.npz"), **out)
 
 
+def g9(R):
+    """the reference's own measure() / find_peaks() (base.py:312-352), run unbound on a plain namespace.
+    scipy's filtfilt is authentic; peakutils (un-pinned pip dependency, not installable here) is served by the build's
+    restatement respmon_amd/peaks.py, so the fixture pins the reference's GLUE (windowing of the fits, the gaussian_cutoff
+    test, peak_times -> BPM), not peakutils itself."""
+    import types
+    from respmon_amd import peaks
+    R.peakutils.indexes = peaks.indexes
+    R.peakutils.gaussian = peaks.gaussian
+    R.peakutils.gaussian_fit = lambda x, y, center_only=True: (peaks.gaussian_fit(x, y)[1] if center_only else peaks.gaussian_fit(x, y))
+    g6v = np.load(os.path.join(OUT, "g6_run_trace.npz"))
+    rng = np.random.Generator(np.random.PCG64(99))
+    n = 128
+    cases = [
+        (np.array(g6v["c1_data"], dtype=np.float64), np.array(g6v["c1_t"], dtype=np.float64), 10.0),        # config 1: 0.4 Hz brightness, 64 frames
+        (np.sin(2 * np.pi * 0.3 * np.arange(n) / 10.0) + 0.15 * rng.standard_normal(n), np.arange(n) / 10.0, 10.0),
+        (0.5 + 0.2 * np.sin(2 * np.pi * 0.25 * np.arange(n) / 7.5 + 0.7) + 0.02 * rng.standard_normal(n), np.arange(n) / 7.5, 7.5),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for i, (data, t, fps) in enumerate(cases):
+        self = types.SimpleNamespace(data=list(data), t=list(t), fps=fps, freq_max=1.0, filter_order=3, gaussian_cutoff=10.0,
+                                     peak_minimum_sample_distance=int(np.floor(fps / 1.0)), freq=[])       # base.py:83,100,101,171
+        self.find_peaks = lambda self=self: R.base.RespiratoryMonitor.find_peaks(self)
+        R.base.RespiratoryMonitor.measure(self)
+        out["data%d" % i] = np.array(data)
+        out["t%d" % i] = np.array(t)
+        out["fps%d" % i] = np.array(fps)
+        out["filtered%d" % i] = np.array(self.filtered_data)
+        out["peaks%d" % i] = np.array(self.peak_indices, dtype=np.int64)
+        out["freq%d" % i] = np.array(self.freq, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g9_measure.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load()
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         if only and fn.__name__ not in only:
             continue
         fn(R)

@@ -103,14 +103,20 @@ def threshold(img_u8, thresh, maxval, threshold_type=THRESH_BINARY):
     return float(thresh), dst
 
 
-def findContours(img_u8, mode=RETR_EXTERNAL, method=CHAIN_APPROX_SIMPLE):
+def findContours(img_u8, mode=RETR_EXTERNAL, method=CHAIN_APPROX_SIMPLE, clip_frame=False):
     """cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_*) -- base.py:568.
 
     Returns the contour list in cv2's order (reverse raster discovery), each an
     int32 array of shape [n, 1, 2] holding (x, y).
+    clip_frame: the reference pins no OpenCV version.  False = OpenCV >= 3.2 (tracing on a zero-padded copy: pixels on the
+    image frame count); True = OpenCV <= 3.1, which zeroes the 1-pixel image frame (in place -- hence base.py:567's
+    thresh_copy) before tracing, so components are clipped to [1, W-2] x [1, H-2].
     """
     assert mode == RETR_EXTERNAL
     src = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    if clip_frame:
+        src = src.copy()
+        src[0, :] = 0; src[-1, :] = 0; src[:, 0] = 0; src[:, -1] = 0
     h, w = src.shape
     cap_pts = 2 * src.size + 16
     cap_off = src.size + 2
@@ -355,10 +361,10 @@ def heatmap_u8(masked):
     return avg_frame, float_to_uint8(avg_norm)
 
 
-def roi_from_heatmap_u8(avg_u8, thresh_value):
+def roi_from_heatmap_u8(avg_u8, thresh_value, clip_frame=False):
     """base.py:566-575 -- threshold, external contours, largest contourArea, boundingRect."""
     _, binary = threshold(avg_u8, thresh_value, 255, THRESH_BINARY)
-    contours = findContours(binary, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
+    contours = findContours(binary, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE, clip_frame=clip_frame)
     if len(contours) <= 0:
         return None
     c = max(contours, key=contourArea)
@@ -367,12 +373,12 @@ def roi_from_heatmap_u8(avg_u8, thresh_value):
 
 def locate(calibration_video_data, fps, freq_min=0.1, freq_max=1.0, amplification=500,
            pyramid_levels=9, skip_levels_at_top=4, temporal_threshold=0.7, threshold=20,
-           return_intermediates=False):
+           return_intermediates=False, contour_clip_frame=False):
     masked, raw = eulerian_magnification_bandpass(calibration_video_data, fps, freq_min, freq_max, amplification,
                                                   skip_levels_at_top=skip_levels_at_top,
                                                   pyramid_levels=pyramid_levels, threshold=temporal_threshold)
     avg_frame, avg = heatmap_u8(masked)
-    roi = roi_from_heatmap_u8(avg, threshold)
+    roi = roi_from_heatmap_u8(avg, threshold, clip_frame=contour_clip_frame)
     if return_intermediates:
         return roi, dict(avg_frame=avg_frame, avg_u8=avg, min=float(raw.min()), max=float(raw.max()))
     return roi

@@ -16,6 +16,7 @@ RM_FLAG_UNFUSED_DOWN = 2
 RM_FLAG_TINY_STORE = 4
 RM_FLAG_TINY_STRIPS = 8
 RM_FLAG_UNFUSED_SMALL = 16
+RM_FLAG_CONTOUR_CLIP_FRAME = 32
 
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint
@@ -28,6 +29,7 @@ SIGNATURES = {
     "rm_abi_version": (_i, []),
     "rm_ctx_workspace_bytes": (_sz, [_vp]),
     "rm_profile_enable": (_i, [_vp, _i]),
+    "rm_set_contour_clip_frame": (_i, [_vp, _i]),
     "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_debug_counters": (_i, [_vp, _vp, _vp]),
     "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -382,6 +382,11 @@ class RespiratoryMonitor:
             return be.pca_reduce(np.array(self.motion_data, dtype=np.float32))  # base.py:396-405
         return 0.0
 
+    # Which cv2.findContours the ROI stage reproduces (the reference pins no OpenCV version, README.md:12): False = OpenCV >= 3.2
+    # (pixels on the image frame count), True = OpenCV <= 3.1 (the 1-pixel frame is zeroed before tracing; base.py:567's
+    # `thresh_copy` exists because that version mutated its input).  include/respmon_hip.h rm_set_contour_clip_frame.
+    opencv_contours_clip_frame = False
+
     # ------------------------------------------------------------------ hot path A
     @staticmethod
     def locate(calibration_video_data, fps,
@@ -396,7 +401,8 @@ class RespiratoryMonitor:
         logging.info("Beginning processing calibration frames...")
         buf = device.to_device(calibration_video_data)
         roi = _Backend().locate(buf, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
-                                temporal_threshold, threshold)
+                                temporal_threshold, threshold,
+                                flags=_capi.RM_FLAG_CONTOUR_CLIP_FRAME if RespiratoryMonitor.opencv_contours_clip_frame else 0)
         if save_calibration_image and roi is not None:     # base.py:577-596 (the reference returns before it when no contour)
             from . import montage
             logging.info('Creating calibration image.')

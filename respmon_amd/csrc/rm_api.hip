@@ -71,6 +71,7 @@ struct rm_ctx {
     CollapseState *d_state = nullptr;
     CollapseState *h_state = nullptr;  // pinned
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned: bit-packed thresholded image + H row flags (k_heat_to_u8)
+    bool clip_frame = false, clip_frame_once = false;      // cv2.findContours of OpenCV <= 3.1 (rm_set_contour_clip_frame / RM_FLAG_CONTOUR_CLIP_FRAME)
     uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
@@ -1331,6 +1332,17 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         int y0 = H, y1 = -1;   // rows that hold foreground
         for (int y = 0; y < H; ++y)
             if (h_rows[y]) { if (y < y0) y0 = y; y1 = y; h_rows[y] = 0; }
+        if ((ctx->clip_frame || ctx->clip_frame_once) && y1 >= y0) {
+            // OpenCV <= 3.1: the 1-pixel image frame is zeroed before tracing (the host copy is ours to change)
+            uint64_t *hb = (uint64_t *)ctx->h_bin;
+            auto clear_bit = [&](size_t p) { hb[p >> 6] &= ~(1ull << (p & 63)); };
+            for (int y = y0; y <= y1; ++y) {
+                const size_t r0 = (size_t)y * W;
+                if (y == 0 || y == H - 1) { for (int x = 0; x < W; ++x) clear_bit(r0 + x); }
+                else { clear_bit(r0); clear_bit(r0 + W - 1); }
+            }
+        }
+        ctx->clip_frame_once = false;
         largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
         if (ctx->prof_on)
             ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1409,6 +1421,13 @@ extern "C" int rm_heat_sparse_tiles_needed(rm_ctx *ctx, int *tiles)
     return RM_OK;
 }
 
+extern "C" int rm_set_contour_clip_frame(rm_ctx *ctx, int on)
+{
+    if (!ctx) return fail(RM_E_BADARG, "rm_set_contour_clip_frame: ctx is NULL");
+    ctx->clip_frame = on != 0;
+    return RM_OK;
+}
+
 extern "C" int rm_heatmap_to_roi(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
                                  uint8_t *binary, void *stream)
 {
@@ -1423,6 +1442,7 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     double *heat = nullptr;
     RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
     RM_TRY(rm_calibrate(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream));
+    ctx->clip_frame_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
     return heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
 }
 

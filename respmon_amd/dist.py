@@ -59,14 +59,19 @@ def hip_calibrate(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyram
     return heat
 
 
-def hip_heatmap_to_roi(heat, threshold=20):
+def hip_heatmap_to_roi(heat, threshold=20, clip_frame=False):
+    """base.py:563-575 on a device heatmap.  clip_frame=True: cv2.findContours as OpenCV <= 3.1 did it (rm_set_contour_clip_frame)."""
     import ctypes
     from . import _capi, device
     lib = _capi.load()
     H, W = heat.shape
     xywh = (ctypes.c_int32 * 4)()
-    rc = _capi.check(lib, lib.rm_heatmap_to_roi(device.ctx(), device.ptr(heat), H, W, int(threshold), xywh, None, None,
-                                                device.stream_ptr()), "rm_heatmap_to_roi")
+    _capi.check(lib, lib.rm_set_contour_clip_frame(device.ctx(), 1 if clip_frame else 0), "rm_set_contour_clip_frame")
+    try:
+        rc = _capi.check(lib, lib.rm_heatmap_to_roi(device.ctx(), device.ptr(heat), H, W, int(threshold), xywh, None, None,
+                                                    device.stream_ptr()), "rm_heatmap_to_roi")
+    finally:
+        lib.rm_set_contour_clip_frame(device.ctx(), 0)
     return None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
 
 

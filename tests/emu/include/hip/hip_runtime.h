@@ -232,6 +232,7 @@ inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 template <typename F> inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }

@@ -110,6 +110,10 @@ def test_emu_contour_stage_matches_oracle(emu, oracle):
         ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
         assert np.array_equal(u8, ref_u8)
         assert roi == oracle.roi_from_heatmap_u8(ref_u8, 150)
+        # cv2.findContours as OpenCV <= 3.1 did it (1-pixel frame zeroed first): rm_set_contour_clip_frame vs the oracle's twin
+        roi_old, _, _ = emu.heatmap_to_roi(heat, threshold=150, clip_frame=True)
+        assert roi_old == oracle.roi_from_heatmap_u8(ref_u8, 150, clip_frame=True)
+        assert emu.heatmap_to_roi(heat, threshold=150)[0] == roi       # the option does not stick
 
 
 def test_emu_contour_stage_reuses_its_working_copy(emu, oracle):

@@ -521,3 +521,55 @@ def test_long_buffers(hip, oracle):
         frames = oracle.uint8_to_float(synth.synth_breathing(T, H, W, seed=T))
         ref = oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S)
         assert RespiratoryMonitor.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S) == ref, (T, H, W)
+
+
+def test_contour_version_switch(hip, oracle):
+    """SURVEY App. B3 / VERDICT r1: the reference pins no OpenCV version.  Default = OpenCV >= 3.2 (frame pixels count);
+    RM_FLAG_CONTOUR_CLIP_FRAME / rm_set_contour_clip_frame = OpenCV <= 3.1 (1-pixel frame zeroed before tracing).  A breathing
+    blob pushed against the image border gives the two documented ROIs, each equal to the oracle's twin."""
+    import torch
+    import scipy.ndimage as ndi
+    from respmon_amd import synth, dist
+    from respmon_amd.base import RespiratoryMonitor
+    rng = np.random.default_rng(4)
+    for k, shape in enumerate([(37, 61), (64, 130), (90, 200), (33, 64)]):
+        heat = ndi.gaussian_filter(rng.standard_normal(shape), 2.5)
+        if k % 2 == 0:
+            heat[:, 0] = heat.max(); heat[0, :] = heat.max()
+        else:
+            heat[-1, :] = heat.max(); heat[:, -1] = heat.max()
+        u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
+        dev = torch.from_numpy(heat).cuda()
+        new, old = dist.hip_heatmap_to_roi(dev, 150), dist.hip_heatmap_to_roi(dev, 150, clip_frame=True)
+        assert new == oracle.roi_from_heatmap_u8(u8, 150) and old == oracle.roi_from_heatmap_u8(u8, 150, clip_frame=True)
+        assert new != old and dist.hip_heatmap_to_roi(dev, 150) == new
+    # through locate(): blob centred on the left image edge
+    v8 = synth.synth_breathing(64, 96, 128, seed=3, center=(0.5, 0.0), sigma=(0.2, 0.15))
+    frames = oracle.uint8_to_float(v8)
+    kw = dict(pyramid_levels=6, skip_levels_at_top=2)
+    ref_new = oracle.locate(frames, 10, **kw)
+    ref_old = oracle.locate(frames, 10, contour_clip_frame=True, **kw)
+    assert RespiratoryMonitor.locate(frames, 10, **kw) == ref_new
+    RespiratoryMonitor.opencv_contours_clip_frame = True
+    try:
+        assert RespiratoryMonitor.locate(frames, 10, **kw) == ref_old
+    finally:
+        RespiratoryMonitor.opencv_contours_clip_frame = False
+    assert ref_new is not None and ref_new[0] == 0 and (ref_old is None or ref_old[0] >= 1)
+
+
+def test_bpm_estimate_config1_on_the_gpu(hip, golden):
+    """Row f2 end to end: the 0.4 Hz brightness video through run() on the GPU ('average' mode, ROI means from rm_roi_mean)
+    => mon.freq[-1] within 1 BPM of 24 and equal to the reference's estimate for the same samples (G9 case 0)."""
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    g = golden("g9_measure.npz")
+    frames = synth.synth_brightness_video(64, 240, 320)
+    mon = RespiratoryMonitor(capture_target=synth.FakeCapture(frames, fps=10), visualize=None, save_all_data=False,
+                             motion_extraction_method="average", run_on_init=False)
+    mon.sync_to_fps = lambda: None
+    mon.skip_calibration(100, 80, 70, 51)
+    mon.run()
+    assert len(mon.freq) > 0 and abs(mon.freq[-1] - 24.0) < 1.0
+    assert abs(mon.freq[-1] - float(g["freq0"][-1])) <= 1e-9 * float(g["freq0"][-1])
+    assert list(mon.peak_indices) == list(g["peaks0"])

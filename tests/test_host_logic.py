@@ -191,3 +191,37 @@ def test_bench_presets_and_knob_refusal(monkeypatch):
     env = dict(os.environ, RM_DC_LDS_FRONT_END="1")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 2 and "RM_DC_LDS_FRONT_END" in out.stderr
+
+
+def test_measure_and_find_peaks_match_reference_fixture(golden):
+    """SURVEY 8f row f2 / VERDICT r1 Next 7: G9 holds what the reference's own measure() / find_peaks() (base.py:312-352,
+    run unbound on a namespace in the build container; filtfilt authentic, peakutils served by respmon_amd/peaks.py) make of
+    three signals.  The drop-in's measure() must give the same filtered signal, peak indices and BPM."""
+    from respmon_amd import synth
+    g = golden("g9_measure.npz")
+    for i in range(int(g["ncases"])):
+        fps = float(g["fps%d" % i])
+        mon = _monitor(synth.synth_brightness_video(2, 8, 8), 10, RecordingBackend())
+        mon.fps = fps
+        mon.data = list(g["data%d" % i]); mon.t = list(g["t%d" % i])
+        mon.peak_minimum_sample_distance = int(np.floor(fps / mon.freq_max))       # base.py:171
+        mon.freq = []
+        mon.measure()
+        assert np.allclose(mon.filtered_data, g["filtered%d" % i], rtol=1e-12, atol=1e-14)
+        assert list(mon.peak_indices) == list(g["peaks%d" % i])
+        assert np.allclose(mon.freq, g["freq%d" % i], rtol=1e-12)
+    assert abs(float(g["freq0"][-1]) - 24.0) < 1.0          # config 1: 0.4 Hz brightness = 24 breaths per minute
+
+
+def test_run_reports_bpm_for_config1(golden):
+    """run() in 'average' mode on the config-1 brightness video (0.4 Hz): measure() fires once more than 12 samples exist
+    (base.py:479-480) and the last estimate equals the reference's for the same data (G9 case 0)."""
+    from respmon_amd import synth
+    g = golden("g9_measure.npz")
+    frames = synth.synth_brightness_video(64, 240, 320)
+    mon = _monitor(frames, 10, RecordingBackend(), motion_extraction_method="average")
+    mon.skip_calibration(100, 80, 70, 51)
+    mon.run()
+    assert len(mon.data) == 64 and len(mon.freq) > 0
+    assert abs(mon.freq[-1] - float(g["freq0"][-1])) <= 1e-9 * float(g["freq0"][-1])
+    assert abs(mon.freq[-1] - 24.0) < 1.0

@@ -137,3 +137,22 @@ def test_bgr2gray(oracle):
     g = oracle.cvtColor_bgr2gray(px)
     exp = [(b * 1868 + gg * 9617 + r * 4899 + 8192) >> 14 for b, gg, r in px[0].astype(int)]
     assert g[0].tolist() == exp and g[0, 0] == 255 and g[0, 2] == 29 and g[0, 3] == 150 and g[0, 4] == 76
+
+
+def test_find_contours_version_switch(oracle):
+    """OpenCV <= 3.1 zeroes the 1-pixel image frame before tracing, >= 3.2 traces on a padded copy.  A
+    rectangle touching the top-left corner gives the two documented results; a blob away from the frame gives the same."""
+    img = np.zeros((12, 16), np.uint8)
+    img[0:5, 0:7] = 255                       # rows 0..4, cols 0..6, touching the frame
+    c_new = oracle.findContours(img)
+    c_old = oracle.findContours(img, clip_frame=True)
+    assert len(c_new) == 1 and len(c_old) == 1
+    assert oracle.boundingRect(c_new[0]) == (0, 0, 7, 5) and oracle.contourArea(c_new[0]) == 6 * 4      # (w-1)(h-1)
+    assert oracle.boundingRect(c_old[0]) == (1, 1, 6, 4) and oracle.contourArea(c_old[0]) == 5 * 3      # clipped to [1, W-2] x [1, H-2]
+    assert oracle.roi_from_heatmap_u8(img, 20) == (0, 0, 7, 5) and oracle.roi_from_heatmap_u8(img, 20, clip_frame=True) == (1, 1, 6, 4)
+    # a one-pixel line ON the frame disappears entirely under the <= 3.1 rule
+    line = np.zeros((8, 9), np.uint8); line[:, 8] = 255
+    assert oracle.roi_from_heatmap_u8(line, 20) == (8, 0, 1, 8) and oracle.roi_from_heatmap_u8(line, 20, clip_frame=True) is None
+    inner = np.zeros((12, 16), np.uint8); inner[3:8, 4:11] = 255
+    assert oracle.roi_from_heatmap_u8(inner, 20) == oracle.roi_from_heatmap_u8(inner, 20, clip_frame=True) == (4, 3, 7, 5)
+    assert img[0, 0] == 255                   # the caller's image is not modified (the reference passes a copy, base.py:567)

@@ -70,3 +70,19 @@ def test_min_eigen_val_matches_independent_float64(oracle):
     a, b, c = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
     ref = (a + c) - np.sqrt((a - c) ** 2 + b * b)
     assert np.abs(e - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_lk_against_float64_brute_force(oracle):
+    """Independent cross-check without cv2 (VERDICT r1 Next 6b): the restated fixed-point calcOpticalFlowPyrLK against a plain
+    float64 Lucas-Kanade (tests/lk_bruteforce.py) on the config-3 texture -- within 1e-2 px point by point -- and both near the
+    known sub-pixel shift."""
+    from tests import lk_bruteforce as bf
+    a, b, pts, (dx, dy) = bf.config3_case(oracle)
+    r1, st, _ = oracle.calcOpticalFlowPyrLK(a, b, pts.reshape(-1, 1, 2), None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+    ok = st.ravel() == 1
+    assert ok.sum() >= 100
+    ref = bf.lk_float(a, b, pts[ok])
+    err = np.linalg.norm(r1.reshape(-1, 2)[ok] - ref, axis=1)
+    assert err.max() <= 1e-2 and np.median(err) <= 3e-3
+    flow = r1.reshape(-1, 2)[ok] - pts[ok]
+    assert np.median(np.linalg.norm(flow - np.array([dx, dy]), axis=1)) <= 0.05
