@@ -1308,9 +1308,11 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         ctx->h_bin = nullptr; ctx->h_bin_cap = 0;
         HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, need, hipHostMallocDefault));
         ctx->h_bin_cap = need;
+        ctx->h_rows_dirty = nullptr;
     }
     uint8_t *h_rows = ctx->h_bin + nwords * 8;
-    if (ctx->h_rows_dirty != h_rows) { std::memset(h_rows, 0, (size_t)H); ctx->h_rows_dirty = h_rows; }   // (zero again after every use)
+    // invariant between calls: image words and row flags are all zero (the rows a call read are zeroed again below)
+    if (ctx->h_rows_dirty != h_rows) { std::memset(ctx->h_bin, 0, need); ctx->h_rows_dirty = h_rows; }
     uint8_t *dev_bin = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dev_bin, ctx->h_bin, 0));
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
@@ -1344,6 +1346,10 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         }
         ctx->clip_frame_once = false;
         largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
+        if (y1 >= y0) {   // restore the all-zero image: the words that cover rows y0 .. y1
+            const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
+            std::memset(ctx->h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
+        }
         if (ctx->prof_on)
             ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

@@ -108,17 +108,78 @@ __device__ __forceinline__ uint8_t f64_to_u8_trunc(double v255)
     return (uint8_t)((int)v255 & 255);
 }
 
-// wave (64-lane) min / max reduction by shuffles; result valid in every lane
-__device__ __forceinline__ double wave_min(double v)
+// Wave (64-lane) reductions; the result is valid in every lane.
+// On the GPU they run on DPP row shifts / broadcasts (VALU speed): a __shfl_xor butterfly compiles to ds_bpermute, i.e. six
+// dependent LDS round trips per 32-bit word -- the latency-bound tail kernels spent 1-3 us each in their folds and extrema.
+//   row_shr:1,2,4,8 leave the reduction of each 16-lane row in its last lane (a lane without a source keeps its own value:
+//   harmless for min / max), row_bcast:15 folds rows 0->1 and 2->3, row_bcast:31 folds the lower half into lane 63.
+#ifdef RM_HIPEMU
+template <typename T, typename Op> __device__ __forceinline__ T wave_reduce(T v, Op op)
 {
-    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m); v = (o < v) ? o : v; }
+    for (int m = 32; m >= 1; m >>= 1) { const T o = __shfl_xor(v, m); v = op(o, v); }
     return v;
 }
-__device__ __forceinline__ double wave_max(double v)
+template <typename Less> __device__ __forceinline__ void wave_arg_reduce(double &v, int &idx, Less less)
 {
-    for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(v, m); v = (o > v) ? o : v; }
-    return v;
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m); const int oi = __shfl_xor(idx, m);
+        if (less(ov, v)) { v = ov; idx = oi; }
+    }
 }
+#else
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    const int lo = dpp_i32<CTRL, ROW_MASK>((int)(unsigned)v), hi = dpp_i32<CTRL, ROW_MASK>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long bits_of(double d) { return (unsigned long long)__double_as_longlong(d); }
+__device__ __forceinline__ unsigned long long bits_of(unsigned long long d) { return d; }
+__device__ __forceinline__ void from_bits(unsigned long long b, double &d) { d = __longlong_as_double((long long)b); }
+__device__ __forceinline__ void from_bits(unsigned long long b, unsigned long long &d) { d = b; }
+template <int CTRL, int ROW_MASK, typename T> __device__ __forceinline__ T dpp_get(T v)
+{
+    T o;
+    from_bits(dpp_u64<CTRL, ROW_MASK>(bits_of(v)), o);
+    return o;
+}
+template <typename T, typename Op> __device__ __forceinline__ T wave_reduce(T v, Op op)   // T: double or unsigned long long
+{
+    v = op(dpp_get<0x111, 0xF>(v), v);   // row_shr:1
+    v = op(dpp_get<0x112, 0xF>(v), v);   // row_shr:2
+    v = op(dpp_get<0x114, 0xF>(v), v);   // row_shr:4
+    v = op(dpp_get<0x118, 0xF>(v), v);   // row_shr:8
+    v = op(dpp_get<0x142, 0xA>(v), v);   // row_bcast:15 into rows 1 and 3
+    v = op(dpp_get<0x143, 0xC>(v), v);   // row_bcast:31 into rows 2 and 3
+    const unsigned long long b = bits_of(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    T r;
+    from_bits(((unsigned long long)hi << 32) | lo, r);
+    return r;
+}
+// arg-reduction: the value and the position that holds it travel together
+template <typename Less> __device__ __forceinline__ void wave_arg_reduce(double &v, int &idx, Less less)
+{
+#define RM_ARG_STEP(CTRL, MASK)                                                  \
+    {                                                                            \
+        const double ov = dpp_get<CTRL, MASK>(v);                                \
+        const int oi = dpp_i32<CTRL, MASK>(idx);                                 \
+        if (less(ov, v)) { v = ov; idx = oi; }                                   \
+    }
+    RM_ARG_STEP(0x111, 0xF) RM_ARG_STEP(0x112, 0xF) RM_ARG_STEP(0x114, 0xF) RM_ARG_STEP(0x118, 0xF)
+    RM_ARG_STEP(0x142, 0xA) RM_ARG_STEP(0x143, 0xC)
+#undef RM_ARG_STEP
+    const unsigned long long b = bits_of(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    from_bits(((unsigned long long)hi << 32) | lo, v);
+    idx = __builtin_amdgcn_readlane(idx, 63);
+}
+#endif
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, [](double o, double w) { return (o < w) ? o : w; }); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, [](double o, double w) { return (o > w) ? o : w; }); }
 
 // ----------------------------------------------------------------------------------------
 // K1  cv2.pyrDown (pyramid.py:14) on every frame: [T,h,w] Tin -> [T,dh,dw] f64
@@ -747,13 +808,13 @@ __global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st) { sta
 __device__ __forceinline__ unsigned long long fold_min_keys(const unsigned long long *stripes, unsigned long long word)
 {
     unsigned long long v = stripes[threadIdx.x & (NSTRIPE - 1)];
-    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = (o < v) ? o : v; }
+    v = wave_reduce(v, [](unsigned long long o, unsigned long long w) { return (o < w) ? o : w; });
     return (word < v) ? word : v;
 }
 __device__ __forceinline__ unsigned long long fold_max_keys(const unsigned long long *stripes, unsigned long long word)
 {
     unsigned long long v = stripes[threadIdx.x & (NSTRIPE - 1)];
-    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(v, m); v = (o > v) ? o : v; }
+    v = wave_reduce(v, [](unsigned long long o, unsigned long long w) { return (o > w) ? o : w; });
     return (word > v) ? word : v;
 }
 
@@ -974,12 +1035,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
     }
     lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
     // wave-level arg-min / arg-max of C_S (value and position travel together)
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = __shfl_xor(c_mn, m); const int oi = __shfl_xor(i_mn, m);
-        if (ov < c_mn) { c_mn = ov; i_mn = oi; }
-        const double pv = __shfl_xor(c_mx, m); const int pi = __shfl_xor(i_mx, m);
-        if (pv > c_mx) { c_mx = pv; i_mx = pi; }
-    }
+    wave_arg_reduce(c_mn, i_mn, [](double o, double w) { return o < w; });
+    wave_arg_reduce(c_mx, i_mx, [](double o, double w) { return o > w; });
     const int wave = tid >> 6;
     if ((tid & 63) == 0) {
         s_red[0][wave] = lo_mn; s_red[1][wave] = lo_mx; s_red[2][wave] = hi_mn; s_red[3][wave] = hi_mx;
@@ -995,12 +1052,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
         c_mn = have ? s_red[4][tid] : inf; c_mx = have ? s_red[5][tid] : -inf;
         i_mn = have ? s_arg[0][tid] : 0; i_mx = have ? s_arg[1][tid] : 0;
         lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double ov = __shfl_xor(c_mn, m); const int oi = __shfl_xor(i_mn, m);
-            if (ov < c_mn) { c_mn = ov; i_mn = oi; }
-            const double pv = __shfl_xor(c_mx, m); const int pi = __shfl_xor(i_mx, m);
-            if (pv > c_mx) { c_mx = pv; i_mx = pi; }
-        }
+        wave_arg_reduce(c_mn, i_mn, [](double o, double w) { return o < w; });
+        wave_arg_reduce(c_mx, i_mx, [](double o, double w) { return o > w; });
     }
     if (tid == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
@@ -1233,6 +1286,9 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
 {
     RM_TRACE_SCOPE(5);
     HIP_DYNAMIC_SHARED(double, lds)
+    // the first list entry is requested together with the list length (the list buffer is valid memory whatever n turns out
+    // to be): one memory round trip less at the head of every workgroup's dependent chain
+    unsigned first_idx = list[blockIdx.x];
     const unsigned n = st->n_list;
     const int lane = threadIdx.x;
     const double inf = __builtin_huge_val();
@@ -1240,14 +1296,14 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     double mn = inf, mx = -inf;
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
         RM_TRACE_MARK(5, 0);
-        const unsigned idx = (unsigned)uniform((int)list[c]);   // wave-uniform: the tile geometry stays in scalar registers
+        const unsigned idx = (unsigned)uniform((int)(c == blockIdx.x ? first_idx : list[c]));   // wave-uniform: the tile geometry stays in scalar registers
+        const int slot = uniform(slot_of[idx]);                // (needed after the chain: requested now)
         const int t = idx / ntiles, tile = idx - t * ntiles;
         const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
         RM_TRACE_MARK(5, 1);
         chain_to_level1(g, tile, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
         RM_TRACE_MARK(5, 6);
         int x = R0.x0 + lane;
-        const int slot = uniform(slot_of[idx]);
         double pmn = inf;   // minimum of this pair's tile
         double v[CT_H];
         const int rows = R0.y1 - R0.y0 + 1;
@@ -1575,10 +1631,11 @@ __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t 
 }
 
 // `bits` receives the thresholded image bit-packed (bit p & 63 of word p >> 6 = pixel p, row-major): 1/8 of a byte per
-// pixel, stored straight into pinned, device-mapped host memory.  `row_any[y]` (pinned bytes the host zeroes after use) is set
-// for every row that holds foreground: the host contour stage then reads only those rows of `bits` -- the breathing region
-// covers ~1/5 of a 1080p frame, and reading memory the device has just written (lines no host cache holds) was most of that
-// stage.  (Tried and dropped: a sparse list of the non-zero words with a `done` word the host spins on instead of the
+// pixel, stored straight into pinned, device-mapped host memory.  `row_any[y]` (pinned bytes) is set for every row that holds
+// foreground: the host contour stage then reads only those rows of `bits` -- the breathing region covers ~1/5 of a 1080p frame,
+// and reading memory the device has just written (lines no host cache holds) was most of that stage.  The host zeroes the
+// flags AND the rows it read after use, so the image is all-zero between calls and the kernel stores only the words that
+// have a bit set (~12 KB instead of 259 KB over PCIe: the launch's end-of-kernel flush of host-memory writes shrinks with it).  (Tried and dropped: a sparse list of the non-zero words with a `done` word the host spins on instead of the
 // runtime's completion query -- the kernel's own hand-off cost 14 us more, and a stream the runtime never sees complete
 // makes the NEXT launch ~100 us slower.)
 __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
@@ -1586,27 +1643,42 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                                                     unsigned long long *bits, uint8_t *row_any)
 {
     RM_TRACE_SCOPE(7);
+    const int lane = threadIdx.x & 63;
+    // `base` is the first pixel of this wave's 64-pixel group: the same for all lanes, so the ballot is complete.
+    // HU groups per trip: their heat values are requested together and BEFORE the extrema are folded from the state
+    constexpr int HU = 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t first = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u);
+    double hv[HU];
+#pragma unroll
+    for (int k = 0; k < HU; ++k) { const size_t i = first + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
     const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
     const double mx = f64_unkey(fold_max_keys(st->heat_max_keys, st->heat_max_key));
     const double range = mx - mn;
-    const int lane = threadIdx.x & 63;
-    // `base` is the first pixel of this wave's 64-pixel group: the same for all lanes, so the ballot is complete
-    for (size_t base = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u); base < npix; base += (size_t)gridDim.x * 256) {
-        const size_t i = base + lane;
-        uint8_t b = 0;
-        if (i < npix) {
-            double nrm = (heat[i] - mn) / range;          // base.py:563 (NaN when the heatmap is flat)
-            uint8_t u = f64_to_u8_trunc(nrm * 255);       // transforms.py:26-29
-            b = (u > threshold) ? 255 : 0;                // cv2.threshold THRESH_BINARY, base.py:566
-            if (avg_u8) avg_u8[i] = u;
-            if (binary) binary[i] = b;
+    for (size_t base0 = first; base0 < npix; base0 += HU * stride) {
+        if (base0 != first) {
+#pragma unroll
+            for (int k = 0; k < HU; ++k) { const size_t i = base0 + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
         }
-        const unsigned long long m = __ballot(b != 0);
-        if (lane == 0 && bits) {
-            bits[base >> 6] = m;
-            if (m && row_any) {   // the group may straddle row ends: flag every row it touches (a superset is fine)
-                const size_t last = (base + 63 < npix ? base + 63 : npix - 1);
-                for (size_t y = base / (size_t)W; y <= last / (size_t)W; ++y) row_any[y] = 1;
+#pragma unroll
+        for (int k = 0; k < HU; ++k) {
+            const size_t base = base0 + k * stride, i = base + lane;
+            if (base >= npix) break;                          // wave-uniform
+            uint8_t b = 0;
+            if (i < npix) {
+                double nrm = (hv[k] - mn) / range;            // base.py:563 (NaN when the heatmap is flat)
+                uint8_t u = f64_to_u8_trunc(nrm * 255);       // transforms.py:26-29
+                b = (u > threshold) ? 255 : 0;                // cv2.threshold THRESH_BINARY, base.py:566
+                if (avg_u8) avg_u8[i] = u;
+                if (binary) binary[i] = b;
+            }
+            const unsigned long long m = __ballot(b != 0);
+            if (lane == 0 && bits && m) {   // the host keeps the image all-zero between calls: only set words travel
+                bits[base >> 6] = m;
+                if (row_any) {   // the group may straddle row ends: flag every row it touches (a superset is fine)
+                    const size_t last = (base + 63 < npix ? base + 63 : npix - 1);
+                    for (size_t y = base / (size_t)W; y <= last / (size_t)W; ++y) row_any[y] = 1;
+                }
             }
         }
     }
