@@ -1079,6 +1079,9 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     // one resident round of single-wave workgroups (18 per CU, measured) that loop over the list: the list length
     // lives on the device, and dispatching thousands of workgroups that find nothing to do costs more than the loop
     unsigned egrid = (unsigned)(npairs < 256 * 18 ? npairs : 256 * 18);
+#ifdef RM_HIPEMU
+    if (egrid > 64) egrid = 64;   // (host emulation: a fiber per lane -- fewer, looping workgroups compute the same thing)
+#endif
     hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, T, ntiles, cp.list, cp.slot_of, st, cp.store);
     LAUNCH_CHECK();
     cp.valid = true;
@@ -1107,7 +1110,11 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
     // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
+#ifdef RM_HIPEMU
+    const int nworkers = std::min(cp.ntiles * MS_Q, 24);    // (host emulation: fewer, looping workgroups compute the same thing)
+#else
     const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
+#endif
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
                        cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers);
     LAUNCH_CHECK();
