@@ -335,9 +335,10 @@ def test_config_r_fp16_buffer(hip, oracle):
 def test_config_r_4k_512_fp16_full_size(hip, oracle):
     """BASELINE config 5 at its stated size: 4K x 512 frames, 6-level pyramid, skip 2, float16 frame buffer (8.5 GB; the
     filtered levels are 2.8 GB per array, n = 512 keeps 92 rfft rows = 6 MFMA tiles, tile bounds in bands).  The oracle
-    needs ~6 float64 [T,H,W] arrays on the host (T = 512: 204 GB), so the full buffer is checked through size-independent
-    identities and the oracle's ROI stage on the GPU heatmap, and the first 64 frames (the largest T a 32 GB host budget
-    holds at 4K) against a complete oracle run fed the SAME float16-rounded values."""
+    needs ~6 float64 [T,H,W] arrays on the host (T = 512: 204 GB): where the host has that much, the full buffer is compared with
+    a complete oracle run; everywhere, it is checked through size-independent identities and the oracle's ROI stage on the GPU
+    heatmap, and its first 64 frames (the largest T a 32 GB host budget holds at 4K) against a complete oracle run fed the SAME
+    float16-rounded values."""
     import torch
     from respmon_amd import synth, dist
     from respmon_amd.base import RespiratoryMonitor
@@ -362,6 +363,16 @@ def test_config_r_4k_512_fp16_full_size(hip, oracle):
     assert roi == oracle.roi_from_heatmap_u8(oracle.float_to_uint8((a - a.min()) / (a.max() - a.min())), 20)
     x, y, w, h = roi
     assert abs(x + w / 2 - 0.4 * W) < 0.1 * W and abs(y + h / 2 - 0.6 * H) < 0.12 * H   # on the breathing blob
+    # a host with > 270 GB of free memory (the MI355X boxes of this pool have 3 TB) takes the oracle on the FULL buffer, all host
+    # threads (oracle.locate_parallel: bit-identical to oracle.locate, tests/test_oracle_golden.py): ROI bit-exact, heatmap 1e-12
+    if _host_can_hold(6.5 * T * H * W * 8):
+        full_in = b16.cpu().numpy().astype(np.float64)
+        ref_full, mid_full = oracle.locate_parallel(full_in, 10, pyramid_levels=L, skip_levels_at_top=S, workers=min(64, os.cpu_count() or 1),
+                                                    return_intermediates=True)
+        del full_in
+        assert roi == ref_full
+        assert _rel(a, mid_full["avg_frame"]) <= 1e-12
+        print("config R: oracle run on all 512 4K frames, ROI", ref_full)
     # complete oracle run on the first 64 frames of the same float16 buffer
     Ts = 64
     assert _host_can_hold(6.0 * Ts * H * W * 8), "host memory too small for the 4K x 64 oracle run"
