@@ -1061,6 +1061,8 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
         size_t tbl_max = 64 * 1024;
         if (const char *e = getenv("RM_BOUNDS_TABLE_BYTES")) tbl_max = (size_t)atol(e);   // test hook: force small bands
         while (band > 1 && (size_t)tbl_rows_of(band) * row_bytes > tbl_max) band = (band + 1) / 2;
+        // ... and enough workgroups to fill the chip: one workgroup per frame leaves half of it idle at T = 128
+        while (band > 4 && (long long)T * ((g.tiles_y + band - 1) / band) < 1024) band = (band + 1) / 2;
         const int tbl_rows = tbl_rows_of(band);
         const size_t tbl = (size_t)tbl_rows * row_bytes;
         if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
