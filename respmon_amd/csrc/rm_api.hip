@@ -85,7 +85,7 @@ struct rm_ctx {
     long long dbg_pairs = 0, dbg_cap = 0;
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
     bool prof_on = false;
-    int prof_calls = 0;
+    int prof_calls = 0, prof_sampled = 0;
     std::vector<hipEvent_t> prof_ev[RM_PROFILE_PHASES];  // start/stop pairs per phase
     std::vector<hipEvent_t> prof_pool;
     double prof_host_ms[RM_PROFILE_PHASES] = {0, 0, 0, 0};
@@ -101,7 +101,9 @@ struct PhaseTimer {
         else (void)hipEventCreate(&e);
         return e;
     }
-    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_mode == 2 || (c_->prof_mode == 1 && phase_ == 0))
+    // mode 1 brackets the frame-buffer kernel of every 4th call only: the two event records in front of that launch sit on the
+    // host's critical path between two steps (~4 us each time, rocprofv3 --hip-runtime-trace)
+    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_mode == 2 || (c_->prof_mode == 1 && phase_ == 0 && (c_->prof_calls & 3) == 0))
     {
         if (!on) return;
         hipEvent_t e = get(c);
@@ -185,6 +187,7 @@ extern "C" int rm_profile_read(rm_ctx *ctx, double *ms, int *n)
         double total = ctx->prof_host_ms[p];
         ctx->prof_host_ms[p] = 0;
         std::vector<hipEvent_t> &v = ctx->prof_ev[p];
+        if (p == 0) ctx->prof_sampled = (int)(v.size() / 2);
         for (size_t i = 0; i + 1 < v.size(); i += 2) {
             HIP_TRY(hipEventSynchronize(v[i + 1]));
             float t = 0.f;
@@ -195,8 +198,8 @@ extern "C" int rm_profile_read(rm_ctx *ctx, double *ms, int *n)
         v.clear();
         ms[p] = total;
     }
-    if (n) *n = ctx->prof_calls;
-    ctx->prof_calls = 0;
+    if (n) *n = ctx->prof_sampled;      // calls whose phase 0 was bracketed (every call in mode 2, every 4th in mode 1)
+    ctx->prof_calls = 0; ctx->prof_sampled = 0;
     return RM_OK;
 }
 
