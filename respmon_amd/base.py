@@ -30,22 +30,31 @@ class _Backend:
     Tests of the host logic replace it with a recording double; there is no CPU implementation."""
 
     def __init__(self):
+        import ctypes
         self.lib = _capi.load()
         self.t = device.require_gpu()
+        self._xywh = (ctypes.c_int32 * 4)()
 
     # -- calibration ------------------------------------------------------------------
     def locate(self, buf, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
                temporal_threshold, threshold, flags=0):
         import ctypes
         T, H, W = buf.shape
-        xywh = (ctypes.c_int32 * 4)()
-        rc = _capi.check(self.lib, self.lib.rm_locate(device.ctx(), device.ptr(buf), device.dtype_code(buf), T, H, W,
-                                                      float(fps), float(freq_min), float(freq_max), float(amplification),
-                                                      int(pyramid_levels), int(skip_levels_at_top), float(temporal_threshold),
-                                                      int(threshold), int(flags), xywh, device.stream_ptr()), "rm_locate")
+        xywh = self._xywh
+        # (this call sits on the host path between two calibrations: the context of the buffer's device is looked up without asking
+        #  the runtime, the stream is the current one of that device)
+        idx = buf.device.index
+        ctx = device._CTX.get(idx) or device.ctx(idx)
+        stream = ctypes.c_void_p(self.t.cuda.current_stream(idx).cuda_stream)
+        rc = self.lib.rm_locate(ctx, ctypes.c_void_p(buf.data_ptr()), device.dtype_code(buf), T, H, W,
+                                float(fps), float(freq_min), float(freq_max), float(amplification),
+                                int(pyramid_levels), int(skip_levels_at_top), float(temporal_threshold),
+                                int(threshold), int(flags), xywh, stream)
+        if rc < 0:
+            _capi.check(self.lib, rc, "rm_locate")
         if rc == _capi.RM_NO_CONTOUR:
             return None
-        return int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3])
+        return xywh[0], xywh[1], xywh[2], xywh[3]
 
     # -- ingest -----------------------------------------------------------------------
     def bgr_to_gray(self, bgr_u8_host):
