@@ -39,8 +39,23 @@ def all_reduce_minmax(mn, mx, like, group=None):
     return -float(t[0]), float(t[1])
 
 
+_SCRATCH = {}
+
+
+def _scratch(name, shape, dtype, device):
+    """Per-step temporaries of the multi-GPU step that nobody outside it sees (packets, the gathered packets, a heatmap the caller
+    did not ask for): allocated once per (name, shape, dtype, device) instead of once per step."""
+    from . import device as _device
+    t = _device.require_gpu()
+    key = (name, tuple(shape), dtype, str(device))
+    b = _SCRATCH.get(key)
+    if b is None:
+        b = _SCRATCH[key] = t.empty(tuple(shape), dtype=dtype, device=device)
+    return b
+
+
 def hip_calibrate(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4,
-                  temporal_threshold=0.7, flags=0, return_minmax=False):
+                  temporal_threshold=0.7, flags=0, return_minmax=False, out=None):
     """rm_calibrate on the current device -> float64 [H,W] heatmap tensor (asynchronous).
     return_minmax=True also returns (raw.min(), raw.max()) of transforms.py:185-187 (synchronises the stream)."""
     import ctypes
@@ -48,7 +63,7 @@ def hip_calibrate(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyram
     t = device.require_gpu()
     lib = _capi.load()
     T, H, W = buf.shape
-    heat = t.empty((H, W), dtype=t.float64, device=buf.device)
+    heat = out if out is not None else t.empty((H, W), dtype=t.float64, device=buf.device)
     mm = (ctypes.c_double * 2)() if return_minmax else None
     _capi.check(lib, lib.rm_calibrate(device.ctx(), device.ptr(buf), device.dtype_code(buf), T, H, W, float(fps),
                                       float(freq_min), float(freq_max), float(amplification), int(pyramid_levels),
@@ -79,11 +94,12 @@ LAST_EXCHANGE = None      # "sparse" / "dense": how the last locate_streams summ
 SPARSE_CAP_TILES = 128   # tiles (64x16 px) a packet can carry: 1 MB per rank; the synthetic 1080p x 256 stream needs ~80
 
 
-def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TILES, avg_T=0):
+def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TILES, avg_T=0, keep_fused=True):
     """All ranks' heatmaps summed in rank order through ONE all-gather of sparse packets (include/respmon_hip.h
     rm_heat_sparse_*), then the ROI stage.  Returns (status, roi, fused): status False = a packet overflowed on some
     rank (every rank sees that) and the caller must use the dense all-reduce.
-    avg_T > 0: `heat` is this rank's partial time SUM of a frame-sharded buffer (rm_shard_heat); fused = sum / avg_T."""
+    avg_T > 0: `heat` is this rank's partial time SUM of a frame-sharded buffer (rm_shard_heat); fused = sum / avg_T.
+    keep_fused=False: the caller only wants the ROI; `fused` then lives in a scratch buffer the next call overwrites."""
     import ctypes
     from . import _capi, device
     t = device.require_gpu()
@@ -92,7 +108,7 @@ def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TI
     rank, world = _world(group)
     H, W = heat.shape
     pd = int(lib.rm_heat_sparse_packet_doubles(cap_tiles))
-    packet = t.empty(pd, dtype=t.float64, device=heat.device)
+    packet = _scratch("packet", (pd,), t.float64, heat.device)
     _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(heat), H, W, cap_tiles, device.ptr(packet), device.stream_ptr()),
                 "rm_heat_sparse_pack")
     if world > 1:
@@ -102,11 +118,11 @@ def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TI
             dist.all_gather_into_tensor(allp, host, group=group)
             allp = allp.to(heat.device)
         else:
-            allp = t.empty(world * pd, dtype=t.float64, device=heat.device)
+            allp = _scratch("packets", (world * pd,), t.float64, heat.device)
             dist.all_gather_into_tensor(allp, packet, group=group)
     else:
         allp = packet
-    fused = t.empty((H, W), dtype=t.float64, device=heat.device)
+    fused = t.empty((H, W), dtype=t.float64, device=heat.device) if keep_fused else _scratch("fused", (H, W), t.float64, heat.device)
     xywh = (ctypes.c_int32 * 4)()
     rc = _capi.check(lib, lib.rm_heat_sparse_merge_roi(device.ctx(), device.ptr(allp), world, H, W, cap_tiles, int(threshold),
                                                        int(avg_T), device.ptr(fused), xywh, device.stream_ptr()),
@@ -141,11 +157,15 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
     tiles that survive the pruning: 1 MB per rank instead of a 16.6 MB all-reduce at 1080p, summed in rank order);
     `sparse=False`, a test double for the calibration, or a packet overflow uses the dense all-reduce(sum)."""
     global LAST_EXCHANGE
-    heat = calibrate_fn(buf, fps, **kw)
+    if calibrate_fn is hip_calibrate and not return_heatmap:   # nobody sees this rank's own heatmap: no allocation per step
+        from . import device as _device
+        heat = hip_calibrate(buf, fps, out=_scratch("heat", buf.shape[1:], _device.torch().float64, buf.device), **kw)
+    else:
+        heat = calibrate_fn(buf, fps, **kw)
     if sparse is None:
         sparse = calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and _world(group)[1] > 1
     if sparse:
-        ok, roi, fused = hip_sparse_exchange_roi(heat, threshold, group)
+        ok, roi, fused = hip_sparse_exchange_roi(heat, threshold, group, keep_fused=return_heatmap)
         if ok:
             LAST_EXCHANGE = "sparse"
             return (roi, fused) if return_heatmap else roi
@@ -294,7 +314,7 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
         sparse = stages is None and world > 1
     global LAST_EXCHANGE
     if sparse:   # the partial heat sums are one constant outside a few tiles too: sparse all-gather instead of a 16.6 MB all-reduce
-        ok, roi, heat = hip_sparse_exchange_roi(heat_sum, threshold, group, avg_T=T)
+        ok, roi, heat = hip_sparse_exchange_roi(heat_sum, threshold, group, avg_T=T, keep_fused=return_heatmap)
         if ok:
             LAST_EXCHANGE = "sparse"
             return (roi, heat) if return_heatmap else roi
