@@ -115,6 +115,25 @@ template <> struct VecTraits<uint8_t> { static constexpr int V = 16; };
 
 struct alignas(16) Raw16 { unsigned int x, y, z, w; };
 
+// One 16-byte lane-load of the frame buffer, NON-TEMPORAL (global_load_dwordx4 ... nt): every byte of the buffer is used once,
+// and without the hint the 4.25 GB stream allocates in L2 / Infinity Cache like data that will be re-read.  Measured on one box,
+// same process layout, alternating libraries (tools/ab_lib.py): 0.780-0.823 ms -> 0.756-0.759 ms per launch, and the run-to-run
+// spread of the plain loads disappears; the columns two lockstep strips share still arrive once (PMC traffic in DESIGN 4.1).
+#ifndef RM_DC_PLAIN_LOADS
+#define RM_DC_NT_LOADS 1
+#endif
+__device__ __forceinline__ Raw16 load_raw16(const void *p)
+{
+#if defined(RM_DC_NT_LOADS) && !defined(RM_HIPEMU)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    Raw16 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+#else
+    return *reinterpret_cast<const Raw16 *>(p);
+#endif
+}
+
 template <typename Tin> __device__ __forceinline__ double unpack_px(const Raw16 &r, int e);
 template <> __device__ __forceinline__ double unpack_px<double>(const Raw16 &r, int e)
 {
@@ -409,7 +428,7 @@ struct DownChain {
 #endif
             const size_t ro = (size_t)row * W;
 #pragma unroll
-            for (int q = 0; q < NQ1; ++q) r[q] = *reinterpret_cast<const Raw16 *>(lane_src[q] + ro);
+            for (int q = 0; q < NQ1; ++q) r[q] = load_raw16(lane_src[q] + ro);
         };
         // BORDER_REFLECT_101 on the column index: only chunks that contain slots outside the image need it
         // (chunk 0 at the left image edge, the chunk(s) holding columns W, W+1 at the right edge).  Per lane
@@ -483,7 +502,7 @@ struct DownChain {
             auto issue = [&](int row, Raw16 (&r)[NL]) __attribute__((always_inline)) {
                 const size_t ro = (size_t)row * W;
 #pragma unroll
-                for (int q = 0; q < NL; ++q) r[q] = *reinterpret_cast<const Raw16 *>(lane_src[q] + ro);
+                for (int q = 0; q < NL; ++q) r[q] = load_raw16(lane_src[q] + ro);
             };
             // column c0 + j*V + e sits at buffer index j*V + e + 2: even half (j*V)/2 + e/2 + 1
             double *ev0 = lds + L::rowbuf_off(0) + (lane * V) / 2 + 1;
