@@ -115,14 +115,17 @@ template <> struct VecTraits<uint8_t> { static constexpr int V = 16; };
 
 struct alignas(16) Raw16 { unsigned int x, y, z, w; };
 
-// One 16-byte lane-load of the frame buffer, NON-TEMPORAL (global_load_dwordx4 ... nt): every byte of the buffer is used once,
-// and without the hint the 4.25 GB stream allocates in L2 / Infinity Cache like data that will be re-read.  Measured on one box,
-// same process layout, alternating libraries (tools/ab_lib.py): 0.780-0.823 ms -> 0.756-0.759 ms per launch, and the run-to-run
-// spread of the plain loads disappears; the columns two lockstep strips share still arrive once (PMC traffic in DESIGN 4.1).
+// 16-byte lane-loads of the frame buffer.  NON-TEMPORAL (global_load_dwordx4 ... nt) for everything only this strip reads: every
+// such byte is used once, and without the hint the 4.25 GB stream allocates in L2 / Infinity Cache like data that will be re-read.
+// PLAIN for the first / last 128-pixel chunk of a row when a neighbouring strip (the other strip of the lockstep pair, or the next
+// workgroup of the frame on the same XCD) reads ~60 of its columns as well: those lines are wanted twice.  (A per-LANE choice --
+// two exec-masked loads per chunk -- destroyed the counted-prefetch pipeline: 1.30 ms.)  Measured (tools/ab_lib.py, alternating processes on one box; PMC traffic):
+//   all plain 0.777 ms, 1.091x algorithmic | all nt 0.759 ms, 1.154x (the shared columns travel twice) | split: DESIGN 4.1.
 #ifndef RM_DC_PLAIN_LOADS
 #define RM_DC_NT_LOADS 1
 #endif
-__device__ __forceinline__ Raw16 load_raw16(const void *p)
+__device__ __forceinline__ Raw16 load_raw16(const void *p) { return *reinterpret_cast<const Raw16 *>(p); }
+__device__ __forceinline__ Raw16 load_raw16_stream(const void *p)
 {
 #if defined(RM_DC_NT_LOADS) && !defined(RM_HIPEMU)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -413,6 +416,8 @@ struct DownChain {
     // with a_prev, b_prev, a_next taken from the neighbouring lanes by DPP wave shifts: no LDS, no waits.
     // Chunk q covers columns P + 124*q + [0,128): consecutive chunks overlap by two lanes so that lanes
     // 1..62 of every chunk own 62 consecutive level-1 columns and lanes 0 / 63 only provide halo.
+    // PL / PR: the first / last chunk of a row holds columns a neighbouring strip reads too -> plain (cache-allocating) loads there
+    template <bool PL, bool PR>
     __device__ __forceinline__ void run_dpp(const Tin *frame, int p_first, int p_last)
     {
         constexpr int NQ1 = L::nq(1);
@@ -428,7 +433,10 @@ struct DownChain {
 #endif
             const size_t ro = (size_t)row * W;
 #pragma unroll
-            for (int q = 0; q < NQ1; ++q) r[q] = load_raw16(lane_src[q] + ro);
+            for (int q = 0; q < NQ1; ++q) {
+                if ((q == 0 && PL) || (q == NQ1 - 1 && PR)) r[q] = load_raw16(lane_src[q] + ro);
+                else r[q] = load_raw16_stream(lane_src[q] + ro);
+            }
         };
         // BORDER_REFLECT_101 on the column index: only chunks that contain slots outside the image need it
         // (chunk 0 at the left image edge, the chunk(s) holding columns W, W+1 at the right edge).  Per lane
@@ -564,7 +572,19 @@ struct DownChain {
         out_frame = out_t;
         setup_level<0>();
         if constexpr (kF64) {
-            if (dpp) { run_dpp(frame, next[0], last[0]); return; }
+            if (dpp) {
+#ifdef RM_DC_ALL_STREAM
+                run_dpp<false, false>(frame, next[0], last[0]);
+#else
+                // wave-uniform choice, made once: inside the march the loads are straight-line code
+                const bool pl = cx0[S] > 0, pr = cx1[S] < g.w[S] - 1;
+                if (pl && pr) run_dpp<true, true>(frame, next[0], last[0]);
+                else if (pl) run_dpp<true, false>(frame, next[0], last[0]);
+                else if (pr) run_dpp<false, true>(frame, next[0], last[0]);
+                else run_dpp<false, false>(frame, next[0], last[0]);
+#endif
+                return;
+            }
         }
         run_lds(frame, next[0], last[0], vec);
     }
