@@ -577,7 +577,13 @@ struct DownChain {
                 run_dpp<false, false>(frame, next[0], last[0]);
 #else
                 // wave-uniform choice, made once: inside the march the loads are straight-line code
+#if defined(RM_DC_POLICY_LEFT)
+                const bool pl = cx0[S] > 0, pr = false;
+#elif defined(RM_DC_POLICY_RIGHT)
+                const bool pl = false, pr = cx1[S] < g.w[S] - 1;
+#else
                 const bool pl = cx0[S] > 0, pr = cx1[S] < g.w[S] - 1;
+#endif
                 if (pl && pr) run_dpp<true, true>(frame, next[0], last[0]);
                 else if (pl) run_dpp<true, false>(frame, next[0], last[0]);
                 else if (pr) run_dpp<false, true>(frame, next[0], last[0]);
