@@ -48,6 +48,8 @@ extern "C" {
 #define RM_FLAG_UNFUSED_SMALL 16u /* build / collapse the small pyramid with one launch per level (A/B + fallback path) */
 #define RM_FLAG_TINY_STRIPS 8u   /* test hook: 3-column strips / 2-row segments in the fused pyrDown chain */
 #define RM_FLAG_CONTOUR_CLIP_FRAME 32u /* rm_locate: cv2.findContours as OpenCV <= 3.1 did it (see rm_set_contour_clip_frame) */
+#define RM_FLAG_FILTER_LAPLACIANS 64u /* build the small pyramid in the reference's order -- Laplacians first, filter them, collapse (bit for bit equal to the per-level
+                                         path) -- instead of the filter-first form (filter G_S, then Laplacians + collapse in one kernel; equal to ~1e-15) */
 #define RM_FLAG_TINY_STORE 4u    /* accepted and ignored: the value store has one slot per (tile, frame) pair, nothing to overflow */
 
 typedef struct rm_ctx rm_ctx;
@@ -182,7 +184,8 @@ int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int 
  *      "Mode A", BASELINE north_star).  Same arithmetic as rm_calibrate (transforms.py:144-198, base.py:562),
  *      cut at the three points where frames meet; the caller runs a collective at each cut
  *      (respmon_amd/dist.py::locate_sharded uses torch.distributed / RCCL):
- *        rm_shard_pyramid   frames[t0:t1] -> lap_local[(t1-t0), NP]   Laplacian levels skip..L-2 (pyramid.py:20-48)
+ *        rm_shard_pyramid   frames[t0:t1] -> lap_local[(t1-t0), NP]   the Gaussian level `skip` of every frame (filter-first form, the
+ *                           default where it fits LDS) or the Laplacian levels skip..L-2 (pyramid.py:20-48): see rm_shard_layout_flags
  *          -- all-gather lap_local -> lap_all[T, NP] --
  *        rm_shard_collapse  temporal band-pass + collapse of every frame (cheap, identical on every rank),
  *                           full-resolution evaluation of this rank's frames [t0,t1) only;
@@ -195,6 +198,9 @@ int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int 
  *      ranks the time sum is associated per shard (<= 1e-15 relative on the heatmap).
  *      rm_shard_layout returns NP (0 when no level is filtered).  Requires skip_levels_at_top >= 1. */
 int rm_shard_layout(int H, int W, int pyramid_levels, int skip_levels_at_top, size_t *np_out);
+/* ... for the `flags` the other stages will be given (RM_FLAG_FILTER_LAPLACIANS / RM_FLAG_UNFUSED_SMALL change what travels between the
+ * stages: the Laplacian levels S .. L-2, NP = their pixel count, instead of the Gaussian level S, NP = h_S * w_S); rm_shard_layout = flags 0 */
+int rm_shard_layout_flags(int H, int W, int pyramid_levels, int skip_levels_at_top, unsigned flags, size_t *np_out);
 int rm_shard_pyramid(rm_ctx *ctx, const void *frames_local_dev, int dtype, int T_local, int H, int W, int pyramid_levels,
                      int skip_levels_at_top, unsigned flags, double *lap_local_dev, void *stream);
 int rm_shard_collapse(rm_ctx *ctx, const double *lap_all_dev, int T, int t0, int t1, int H, int W, double fps,

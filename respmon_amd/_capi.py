@@ -17,6 +17,7 @@ RM_FLAG_TINY_STORE = 4
 RM_FLAG_TINY_STRIPS = 8
 RM_FLAG_UNFUSED_SMALL = 16
 RM_FLAG_CONTOUR_CLIP_FRAME = 32
+RM_FLAG_FILTER_LAPLACIANS = 64
 
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint
@@ -52,6 +53,7 @@ SIGNATURES = {
     "rm_heat_sparse_tiles_needed": (_i, [_vp, _vp]),
     "rm_locate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
     "rm_shard_layout": (_i, [_i, _i, _i, _i, _c.POINTER(_sz)]),
+    "rm_shard_layout_flags": (_i, [_i, _i, _i, _i, _c.c_uint, _c.POINTER(_sz)]),
     "rm_shard_pyramid": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _vp]),
     "rm_shard_collapse": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _u, _vp, _vp]),
     "rm_shard_heat": (_i, [_vp, _vp, _d, _vp, _vp]),

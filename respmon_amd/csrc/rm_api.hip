@@ -79,6 +79,7 @@ struct rm_ctx {
     int op_mfma = 0;        // > 0: the cached operator also exists in the fragment-major form of k_temporal_mfma, with this many 16-row tiles
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
+    size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     // measurement hook (rm_profile_*)
@@ -555,17 +556,19 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
 }
 
 // out[T, NP] = amp * C (R x), x[T, NP]   (transforms.py:86-99)
-static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const TemporalOp &op, double amp, double *out, hipStream_t s)
+static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const TemporalOp &op, double amp, double *out, hipStream_t s,
+                           CollapseState *st_init = nullptr)
 {
     if (op.nk == 0) {  // nothing survives the mask
         HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * (size_t)T * NP, s));
+        if (st_init) { hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st_init); LAUNCH_CHECK(); }
         return RM_OK;
     }
 #ifndef RM_HIPEMU
     static const int env_valu = [] { const char *e = getenv("RM_TEMPORAL_VALU"); return e ? atoi(e) : 0; }();  // developer A/B knob
     if (op.Rf && !env_valu) {
-        if (op.tiles == 3) hipLaunchKernelGGL((k_temporal_mfma<3>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<3>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
-        else hipLaunchKernelGGL((k_temporal_mfma<6>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<6>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out);
+        if (op.tiles == 3) hipLaunchKernelGGL((k_temporal_mfma<3>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<3>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out, st_init);
+        else hipLaunchKernelGGL((k_temporal_mfma<6>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<6>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out, st_init);
         LAUNCH_CHECK();
         return RM_OK;
     }
@@ -575,7 +578,7 @@ static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const
     double *y = nullptr;
     RM_TRY(ws(ctx, "temporal_y", (size_t)op.nk * NP, &y));
     dim3 g1((unsigned)((NP + 63) / 64), (op.nk + TF_KC - 1) / TF_KC), g2((unsigned)((NP + 63) / 64), (T + TF_SC - 1) / TF_SC);
-    hipLaunchKernelGGL(k_temporal_fwd, g1, dim3(64), sh1, s, x, T, NP, op.R, op.nk, y);
+    hipLaunchKernelGGL(k_temporal_fwd, g1, dim3(64), sh1, s, x, T, NP, op.R, op.nk, y, st_init);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_temporal_inv, g2, dim3(64), sh2, s, y, op.nk, NP, op.C, T, amp, out);
     LAUNCH_CHECK();
@@ -761,6 +764,8 @@ struct PyrGeom {
     bool all_zero = false;
     bool chain = false;        // the fused pyrDown chain builds G_S
     bool fuse_small = false;   // per-frame LDS kernels build / collapse the small pyramid
+    bool filter_first = false; // ... in the filter-first form (k_small_filter_first): the [T, NP] array between the stages is G_S itself
+    size_t NP_lap = 0;         // filtered pixels per frame in the Laplacian layout (levels S .. L-2 side by side)
     SmallGeom sg;
 };
 
@@ -780,6 +785,7 @@ static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom
     const size_t LDS_LIMIT = 150 * 1024;
     pg.fuse_small = pg.chain && !(flags & RM_FLAG_UNFUSED_SMALL) && L <= SMALL_MAX_LEVELS &&
                     pg.lds_levels * sizeof(double) <= LDS_LIMIT && pg.NP * sizeof(double) <= LDS_LIMIT;
+    pg.NP_lap = pg.NP;
     if (pg.fuse_small) {
         SmallGeom &sg = pg.sg;
         sg.S = S; sg.L = L; sg.NP = (int)pg.NP;
@@ -788,6 +794,14 @@ static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom
             sg.h[l] = pg.h[l]; sg.w[l] = pg.w[l];
             sg.g_off[l] = 0; sg.np_off[l] = (int)pg.off[l];
             if (l >= S) { sg.g_off[l] = o; o += pg.h[l] * pg.w[l]; }
+        }
+        // filter-first form (rm_kernels.h k_small_filter_first): the Gaussian levels, the collapsed levels S+1 .. L-2 and the
+        // row-extrema table of the tile bounds must fit LDS together
+        if (!(flags & RM_FLAG_FILTER_LAPLACIANS) && S >= 1 && S < MAX_CHAIN) {
+            const size_t nS = (size_t)pg.h[S] * pg.w[S];
+            const size_t tiles_x = (size_t)(W + CT_W - 1) / CT_W;
+            const size_t need = sizeof(double) * (pg.lds_levels + (pg.NP - nS) + 2 * (size_t)pg.h[S] * tiles_x);
+            if (need <= LDS_LIMIT) { pg.filter_first = true; pg.NP = nS; }
         }
     }
 }
@@ -803,6 +817,13 @@ static int front_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     std::vector<double *> g(L, nullptr);
     const void *cur = frames; int cur_dtype = dtype;
     int first = 1;
+    if (pg.filter_first) {
+        // filter-first form: the array the stages exchange is G_S itself; the small pyramid is built after the temporal filter
+        PhaseTimer pt(ctx, 0, s);
+        RM_TRY(launch_down_chain(ctx, frames, dtype, T, h, w, S, lap, s, (flags & RM_FLAG_TINY_STRIPS) != 0));
+        ctx->state_fresh = false;
+        return RM_OK;
+    }
     if (pg.chain) {
         // one launch reads the frame buffer once and writes only G_S
         double *dst = nullptr;
@@ -869,6 +890,31 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
     PhaseTimer pt_small(ctx, 1, s);
     double *bp = nullptr;
     RM_TRY(ws(ctx, "bp_all", (size_t)T * NP, &bp));
+    if (pg.filter_first) {
+        // X = B(G_S) for all frames (its workgroup 0 resets the reduction state), then ONE per-frame kernel: Gaussian levels of X,
+        // Laplacians, collapse to C_S, tile bounds and lattice samples
+        RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s, ctx->d_state));
+        ChainGeom cg;
+        SmallLevels probe; probe.h = pg.h; probe.w = pg.w; probe.S = S;
+        RM_TRY(make_geom(probe, cg));
+        const long long npairs = (long long)cg.tiles_x * cg.tiles_y * T;
+        if (npairs >= (1ll << 31)) return fail(RM_E_UNSUPPORTED, "calibration: %lld (tile, frame) pairs exceed 2^31", npairs);
+        double *dst = nullptr, *lo = nullptr, *hi = nullptr;
+        int *sel_cnt = nullptr;
+        RM_TRY(ws(ctx, "cS", (size_t)T * NP, &dst));
+        RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
+        RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
+        RM_TRY(ws(ctx, "sel_cnt", (size_t)cg.tiles_x * cg.tiles_y, &sel_cnt));
+        const size_t sh = sizeof(double) * (pg.lds_levels + (pg.NP_lap - NP) + 2 * (size_t)h[S] * cg.tiles_x);
+        if (sh > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_small_filter_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_small_filter_first, dim3(T), dim3(SMALL_NT), sh, s, (const double *)bp, pg.sg, (int)pg.lds_levels, dst, ctx->d_state, cg,
+                           cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt);
+        LAUNCH_CHECK();
+        out.state_ready = true; out.bounds_ready = true;
+        out.cS = dst;
+        return RM_OK;
+    }
     // temporal band-pass of every level at once (transforms.py:162,169)
     RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
     // collapse of the band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x);
@@ -947,21 +993,22 @@ static int make_geom(const SmallLevels &sl, ChainGeom &g)
     if (S < 1 || S >= MAX_CHAIN) return fail(RM_E_UNSUPPORTED, "fused collapse supports 1 <= skip_levels_at_top <= %d", MAX_CHAIN - 1);
     g.S = S;
     for (int k = 0; k <= S; ++k) { g.h[k] = sl.h[k]; g.w[k] = sl.w[k]; }
-    int off = 0;
-    g.lds_off[0] = 0;
-    for (int k = 1; k <= S; ++k) {
-        g.lds_off[k] = off;
-        off += (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k) + 1);
-    }
-    // scratch of the separable pyrUp steps: every source row of level k at the destination columns of level k-1
-    int hb = 0;
-    for (int k = 2; k <= S; ++k) {
-        const int n = (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k - 1) + 1);
-        if (n > hb) hb = n;
-    }
-    g.lds_hbuf = off;
-    off += hb;
-    g.lds_total = off;
+    // LDS layout of one evaluation workgroup (doubles).  Step k -> k-1 of the chain needs level k, level k-1 and the scratch of
+    // its horizontal pass (every source row of level k at the destination columns of level k-1); level k is dead afterwards:
+    //   [ level 1 ][ level 2 ][ B ]   B = levels 3 .. S and the scratch of steps S .. 3 behind them, reused as the (largest)
+    //                                     scratch of step 2 -> 1 once those levels are dead
+    // 889 doubles at S = 4 instead of 1034 side by side: 22 single-wave workgroups per CU instead of 18.
+    auto lvl = [](int k) { return (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k) + 1); };
+    auto scratch = [](int k) { return (chain_extent(CT_H, k) + 1) * (chain_extent(CT_W, k - 1) + 1); };
+    for (int k = 0; k < MAX_CHAIN; ++k) { g.lds_off[k] = 0; g.lds_hb[k] = 0; }
+    int off = lvl(1);
+    if (S >= 2) { g.lds_off[2] = off; off += lvl(2); }
+    const int B = off;
+    int small = 0, hb_small = 0;
+    for (int k = 3; k <= S; ++k) { g.lds_off[k] = B + small; small += lvl(k); hb_small = std::max(hb_small, scratch(k)); }
+    for (int k = 3; k <= S; ++k) g.lds_hb[k] = B + small;
+    if (S >= 2) g.lds_hb[2] = B;
+    g.lds_total = B + (S >= 2 ? std::max(scratch(2), S >= 3 ? small + hb_small : 0) : 0);
     g.tiles_x = (sl.w[0] + CT_W - 1) / CT_W;
     g.tiles_y = (sl.h[0] + CT_H - 1) / CT_H;
     // weights of the lattice samples (rm_kernels.h lattice_sample): a unit impulse pushed through S interior 1-D pyrUp
@@ -1081,11 +1128,29 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
                        prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy);
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
-    // one resident round of single-wave workgroups (18 per CU, measured) that loop over the list: the list length
-    // lives on the device, and dispatching thousands of workgroups that find nothing to do costs more than the loop
-    unsigned egrid = (unsigned)(npairs < 256 * 18 ? npairs : 256 * 18);
-#ifdef RM_HIPEMU
-    if (egrid > 64) egrid = 64;   // (host emulation: a fiber per lane -- fewer, looping workgroups compute the same thing)
+    // one resident round of single-wave workgroups that loop over the list: the list length lives on the device, and
+    // dispatching thousands of workgroups that find nothing to do costs more than the loop.  "Resident" is what the
+    // kernel's registers and this geometry's LDS footprint allow per CU (asked of the runtime once per footprint).
+    unsigned egrid = 64;   // (host emulation: a fiber per lane -- few, looping workgroups compute the same thing)
+#ifndef RM_HIPEMU
+    {
+        size_t &cached_shmem = ctx->eval_shmem;
+        int &cached_per_cu = ctx->eval_per_cu, &cached_cus = ctx->eval_cus;
+        if (cached_shmem != cp.shmem) {
+            int per_cu = 0, cus = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_eval_pairs, 64, cp.shmem));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+            per_cu -= 1;   // (measured: the runtime's figure ignores the LDS allocation granule -- its last workgroup queues)
+#ifdef RM_EVAL_PER_CU
+            per_cu = RM_EVAL_PER_CU;
+#endif
+            cached_per_cu = per_cu < 1 ? 1 : per_cu; cached_cus = cus < 1 ? 1 : cus; cached_shmem = cp.shmem;
+        }
+        const long long cap = (long long)cached_per_cu * cached_cus;
+        egrid = (unsigned)(npairs < cap ? npairs : cap);
+    }
+#else
+    if ((long long)egrid > npairs) egrid = (unsigned)npairs;
 #endif
     hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, T, ntiles, cp.list, cp.slot_of, st, cp.store);
     LAUNCH_CHECK();
@@ -1164,14 +1229,16 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
 // them with torch.distributed (RCCL): all-gather of the small pyramid, all-reduce(MAX) of {-min, max},
 // all-reduce(SUM) of the [H,W] heat sum.
 // ------------------------------------------------------------------------------------------
-extern "C" int rm_shard_layout(int H, int W, int levels, int skip, size_t *np_out)
+extern "C" int rm_shard_layout_flags(int H, int W, int levels, int skip, unsigned flags, size_t *np_out)
 {
     if (!np_out || H < 1 || W < 1 || levels < 1 || skip < 0) return fail(RM_E_BADARG, "rm_shard_layout: bad argument");
     PyrGeom pg;
-    pyr_geom(H, W, levels, skip, 0, pg);
+    pyr_geom(H, W, levels, skip, flags, pg);
     *np_out = pg.all_zero ? 0 : pg.NP;
     return RM_OK;
 }
+
+extern "C" int rm_shard_layout(int H, int W, int levels, int skip, size_t *np_out) { return rm_shard_layout_flags(H, W, levels, skip, 0, np_out); }
 
 extern "C" int rm_shard_pyramid(rm_ctx *ctx, const void *frames, int dtype, int Tl, int H, int W, int levels, int skip,
                                 unsigned flags, double *lap_local, void *stream)

@@ -296,9 +296,13 @@ constexpr int TF_KC = 4, TF_SC = 8, TF_U = 16;
 // one fused kernel per 64 pixel columns that reads x once, keeps all y[k] in registers and takes the
 // coefficients through the scalar cache (128 us vs 64 us for both stages: one workgroup per CU exposes every
 // scalar-load and global-load latency, the two-stage form has 8-20 waves per CU to hide them).
-__global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y)
+__device__ void state_init_lane(struct CollapseState *st, int i);   // defined with the state, below
+
+// st_init (nullable): workgroup (0, 0) also resets the reduction state of the collapse passes that follow on the stream
+__global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y, struct CollapseState *st_init)
 {
     HIP_DYNAMIC_SHARED(double, s_r)  // [T][TF_KC]
+    if (st_init && blockIdx.x == 0 && blockIdx.y == 0) state_init_lane(st_init, (int)threadIdx.x);
     const int k0 = blockIdx.y * TF_KC;
     for (int i = threadIdx.x; i < T * TF_KC; i += 64) {
         int t = i / TF_KC, k = i - t * TF_KC;
@@ -386,9 +390,10 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Cf[((s0/16) * 4 NT + 4 ti + r) * 64 + lane] = C[s0 + (lane & 15)][16 ti + 4 r + (lane >> 4)]
 template <int NT>
 __global__ __launch_bounds__(64 * TemporalWaves<NT>::W, TemporalWaves<NT>::MINW) void k_temporal_mfma(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
-                                                             const double *__restrict__ Cf, double amp, double *__restrict__ out)
+                                                             const double *__restrict__ Cf, double amp, double *__restrict__ out, struct CollapseState *st_init)
 {
     RM_TRACE_SCOPE(2);
+    if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
     constexpr int TM_W = TemporalWaves<NT>::W;
     __shared__ double s_y[TM_W][4 * NT][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
@@ -585,6 +590,36 @@ __device__ __forceinline__ void small_up_level(const double *src, int sh, int sw
     }
 }
 
+// the same for TWO sources of one geometry at once (taps and weights are shared): sink(i, vA, vB)
+template <typename Sink>
+__device__ __forceinline__ void small_up_level2(const double *srcA, const double *srcB, int sh, int sw, int dh, int dw, int tid, Sink &&sink)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int x = lane; x < dw; x += 64) {
+        const HTap t = make_htap(x, sw);
+        for (int y = wave; y < dh; y += SMALL_NT / 64) {
+            const int i = y >> 1;
+            const int o1 = i * sw, o2 = ((i == sh - 1) ? i : i + 1) * sw;
+            const double a1 = (srcA[o1 + t.ia] * t.wa + srcA[o1 + t.ib] * t.wb) + srcA[o1 + t.ic] * t.wc;
+            const double a2 = (srcA[o2 + t.ia] * t.wa + srcA[o2 + t.ib] * t.wb) + srcA[o2 + t.ic] * t.wc;
+            const double b1 = (srcB[o1 + t.ia] * t.wa + srcB[o1 + t.ib] * t.wb) + srcB[o1 + t.ic] * t.wc;
+            const double b2 = (srcB[o2 + t.ia] * t.wa + srcB[o2 + t.ib] * t.wb) + srcB[o2 + t.ic] * t.wc;
+            double vA, vB;
+            if (y & 1) {
+                vA = ((a1 + a2) * 4) * (1.0 / 64);
+                vB = ((b1 + b2) * 4) * (1.0 / 64);
+            } else {
+                const int o0 = ((i == 0) ? (sh > 1 ? 1 : 0) : i - 1) * sw;
+                const double a0 = (srcA[o0 + t.ia] * t.wa + srcA[o0 + t.ib] * t.wb) + srcA[o0 + t.ic] * t.wc;
+                const double b0 = (srcB[o0 + t.ia] * t.wa + srcB[o0 + t.ib] * t.wb) + srcB[o0 + t.ic] * t.wc;
+                vA = (a0 + a1 * 6 + a2) * (1.0 / 64);
+                vB = (b0 + b1 * 6 + b2) * (1.0 / 64);
+            }
+            sink(y * dw + x, vA, vB);
+        }
+    }
+}
+
 // global -> LDS copy by one SMALL_NT-thread workgroup with 8 loads in flight per lane: a plain
 // `for (i) lds[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per iteration, i.e. one HBM round trip
 // per 8 KB of a frame -- most of the run time of the one-workgroup-per-frame kernels below
@@ -685,7 +720,7 @@ struct ChainGeom {
     int S;                       // number of pyrUp steps (== skip_levels_at_top), 1..MAX_CHAIN-1
     int h[MAX_CHAIN], w[MAX_CHAIN];  // level sizes, index 0 = full resolution
     int lds_off[MAX_CHAIN];      // offset (doubles) of level k's tile buffer in LDS, k = 1..S
-    int lds_hbuf;                // offset of the scratch buffer of the horizontal pass (chain_step)
+    int lds_hb[MAX_CHAIN];       // offset of the scratch buffer of the horizontal pass of step k -> k-1 (chain_step), k = 2..S
     int lds_total;               // doubles
     int tiles_x, tiles_y;
     double lat_a, lat_b;         // raw[t, y << S, x << S] == lat_a * (c[y-1] + c[y+1]) + lat_b * c[y] per axis (lattice_sample)
@@ -969,31 +1004,16 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
 // k_small_collapse and k_frame_bounds in one: the collapsed level S of a frame is still in LDS when its tile bounds are
 // wanted, so they are taken from there (no second pass over C_S in memory, one kernel boundary less).  Used when the
 // row-extrema table of a whole frame fits beside the frame's small pyramid.
-__global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double *bp_all, SmallGeom sg, double *cS, CollapseState *st,
-                                                                     ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
+// What follows the collapse of a frame, with C_S of the frame in LDS at `c`: copy-out to cS[t], tile bounds (per-row extrema
+// over the footprint columns, then extrema over the footprint rows) from the LDS copy, their extrema and the lattice samples
+// into the striped state.  rmin / rmax: the row-extrema table, 2 x hS x tiles_x doubles of LDS.  One SMALL_NT-thread workgroup.
+__device__ __forceinline__ void frame_bounds_from_lds(const double *c, double *rmin_base, const SmallGeom &sg, const ChainGeom &g, int ntiles, int t,
+                                                      double *cS, double *lo, double *hi, CollapseState *st, double (*s_red)[SMALL_NT / 64],
+                                                      int (*s_arg)[SMALL_NT / 64], int mark_kid)
 {
-    RM_TRACE_SCOPE(3);
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < ntiles; i += SMALL_NT) sel_cnt[i] = 0;   // k_select_pairs counts into it
-    HIP_DYNAMIC_SHARED(double, lds)   // [NP] frame (levels laid out as in bp_all), then the row-extrema table
-    __shared__ double s_red[6][SMALL_NT / 64];
-    __shared__ int s_arg[2][SMALL_NT / 64];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int S = sg.S, L = sg.L;
-    // (st was reset by an EARLIER kernel on the stream -- k_small_pyramid or k_state_init: the atomics at the end of this
-    //  kernel must not race with a reset inside it)
-    RM_TRACE_MARK(3, 0);
-    fill_lds(lds, bp_all + (size_t)t * sg.NP, sg.NP, tid);
-    __syncthreads();
-    RM_TRACE_MARK(3, 1);
-    for (int l = L - 3; l >= S; --l) {
-        const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
-        double *d = lds + sg.np_off[l];
-        small_up_level(lds + sg.np_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = v + d[i]; });
-        __syncthreads();
-        RM_TRACE_MARK(3, 2 + (L - 3 - l));
-    }
+    const int tid = threadIdx.x;
+    const int S = sg.S;
     const int hS = sg.h[S], wS = sg.w[S], n = hS * wS, ntx = g.tiles_x;
-    const double *c = lds + sg.np_off[S];
     double *o = cS + (size_t)t * n;
     // (the copy-out loop also finds where this frame's C_S is lowest / highest: the lattice samples are taken there)
     const double inf = __builtin_huge_val();
@@ -1005,9 +1025,9 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
         if (v < c_mn) { c_mn = v; i_mn = i; }
         if (v > c_mx) { c_mx = v; i_mx = i; }
     }
-    RM_TRACE_MARK(3, 8);
+    RM_TRACE_MARK(mark_kid, 8);
     // tile bounds from the LDS copy: per-row extrema over the footprint columns, then extrema over the footprint rows
-    double *rmin = lds + sg.NP, *rmax = rmin + (size_t)hS * ntx;
+    double *rmin = rmin_base, *rmax = rmin + (size_t)hS * ntx;
     const float inv_ntx = 1.0f / (float)ntx;
     for (int i = tid; i < hS * ntx; i += SMALL_NT) {
         int y, tx;
@@ -1023,7 +1043,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
         rmin[i] = mn; rmax[i] = mx;
     }
     __syncthreads();
-    RM_TRACE_MARK(3, 9);
+    RM_TRACE_MARK(mark_kid, 9);
     
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
     for (int tile = tid; tile < ntiles; tile += SMALL_NT) {
@@ -1049,7 +1069,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
         s_red[4][wave] = c_mn; s_red[5][wave] = c_mx; s_arg[0][wave] = i_mn; s_arg[1][wave] = i_mx;
     }
     __syncthreads();
-    RM_TRACE_MARK(3, 11);
+    RM_TRACE_MARK(mark_kid, 11);
     if (wave != 0) return;
     {   // wave 0 folds the per-wave partials: lane w takes wave w's
         const bool have = tid < SMALL_NT / 64;
@@ -1081,7 +1101,95 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
             atomicMax(&st->smp_max_keys[sp], f64_key(va > vb ? va : vb));
         }
     }
-    RM_TRACE_MARK(3, 12);
+    RM_TRACE_MARK(mark_kid, 12);
+}
+
+__global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double *bp_all, SmallGeom sg, double *cS, CollapseState *st,
+                                                                     ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
+{
+    RM_TRACE_SCOPE(3);
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < ntiles; i += SMALL_NT) sel_cnt[i] = 0;   // k_select_pairs counts into it
+    HIP_DYNAMIC_SHARED(double, lds)   // [NP] frame (levels laid out as in bp_all), then the row-extrema table
+    __shared__ double s_red[6][SMALL_NT / 64];
+    __shared__ int s_arg[2][SMALL_NT / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int S = sg.S, L = sg.L;
+    // (st was reset by an EARLIER kernel on the stream -- k_small_pyramid or k_state_init: the atomics at the end of this
+    //  kernel must not race with a reset inside it)
+    RM_TRACE_MARK(3, 0);
+    fill_lds(lds, bp_all + (size_t)t * sg.NP, sg.NP, tid);
+    __syncthreads();
+    RM_TRACE_MARK(3, 1);
+    for (int l = L - 3; l >= S; --l) {
+        const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
+        double *d = lds + sg.np_off[l];
+        small_up_level(lds + sg.np_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = v + d[i]; });
+        __syncthreads();
+        RM_TRACE_MARK(3, 2 + (L - 3 - l));
+    }
+    frame_bounds_from_lds(lds + sg.np_off[S], lds + sg.NP, sg, g, ntiles, t, cS, lo, hi, st, s_red, s_arg, 3);
+}
+
+// ---- filter-first form of the small pyramid (round 2) ---------------------------------------------------------------------
+// The temporal band-pass is linear and acts per pixel, the pyramid steps are linear and act per frame: they commute.  Filtering
+// the Gaussian level S itself (X = B(G_S), [T, h_S w_S]) and THEN building the Laplacians L_l = X_l - pyrUp(X_{l+1}) and collapsing them
+// (pyramid.py:23-26, 51-57, same operations in the same order as the reference applies them to its own levels) needs ONE per-frame
+// kernel and no [T, NP] Laplacian / band-passed arrays: k_small_pyramid, its 22 MB array and a quarter of the filter's pixels go.
+// The price is the rounding ORDER: the reference filters the Laplacians, this filters their common source, so C_S agrees with the
+// per-level path to ~1e-15 relative instead of bit for bit (the ROI and the uint8 heatmap are unaffected except on exact ties of the
+// mask threshold -- the same class of event the explicit filter operator already belongs to).
+// LDS: X levels S .. L-1 (sg.g_off), the collapsed levels S+1 .. L-2 (at lds_levels + np_off[l] - np_off[S+1]), the bounds table.
+__global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *xg, SmallGeom sg, int lds_levels, double *cS, CollapseState *st,
+                                                                  ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
+{
+    RM_TRACE_SCOPE(3);
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < ntiles; i += SMALL_NT) sel_cnt[i] = 0;   // k_select_pairs counts into it
+    HIP_DYNAMIC_SHARED(double, lds)
+    __shared__ double s_red[6][SMALL_NT / 64];
+    __shared__ int s_arg[2][SMALL_NT / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int S = sg.S, L = sg.L;
+    const int nS = sg.h[S] * sg.w[S];
+    RM_TRACE_MARK(3, 0);
+    fill_lds(lds + sg.g_off[S], xg + (size_t)t * nS, nS, tid);
+    __syncthreads();
+    RM_TRACE_MARK(3, 1);
+    for (int l = S + 1; l < L; ++l) {   // cv2.pyrDown chain of the filtered level (pyramid.py:14)
+        const int sh = sg.h[l - 1], sw = sg.w[l - 1], dh = sg.h[l], dw = sg.w[l];
+        const double *sp = lds + sg.g_off[l - 1];
+        double *d = lds + sg.g_off[l];
+        for (int x = (tid & 63); x < dw; x += 64) {
+            const int c0 = reflect101(2 * x - 2, sw), c1 = reflect101(2 * x - 1, sw), c2 = reflect101(2 * x, sw);
+            const int c3 = reflect101(2 * x + 1, sw), c4 = reflect101(2 * x + 2, sw);
+            for (int y = (tid >> 6); y < dh; y += SMALL_NT / 64) {
+                double r[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const double *row = sp + reflect101(2 * y - 2 + k, sh) * sw;
+                    r[k] = row[c2] * 6 + (row[c1] + row[c3]) * 4 + row[c0] + row[c4];
+                }
+                d[y * dw + x] = (r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]) * (1.0 / 256);
+            }
+        }
+        __syncthreads();
+    }
+    RM_TRACE_MARK(3, 2);
+    double *cbase = lds + lds_levels - sg.np_off[S + 1 < L - 1 ? S + 1 : S];   // c_l at cbase + np_off[l], l = S+1 .. L-2
+    for (int l = L - 2; l >= S; --l) {
+        const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
+        double *xl = lds + sg.g_off[l];
+        const double *xu = lds + sg.g_off[l + 1];
+        const bool top = l == L - 2;                      // the coarsest band-passed level is zeros: c_{L-2} = L_{L-2}
+        const double *cu = top ? xu : cbase + sg.np_off[l + 1];
+        double *dst = (l == S) ? xl : cbase + sg.np_off[l];   // level S in place: element i is read by its own thread only
+        small_up_level2(xu, cu, sh, sw, dh, dw, tid, [&](int i, double vA, double vB) {
+            const double lap = xl[i] - vA;               // L_l = X_l - pyrUp(X_{l+1})            pyramid.py:25
+            dst[i] = top ? lap : vB + lap;               // img = pyrUp(img) + L_l               pyramid.py:55
+        });
+        __syncthreads();
+    }
+    RM_TRACE_MARK(3, 4);
+    frame_bounds_from_lds(lds + sg.g_off[S], lds + lds_levels + (sg.NP - nS), sg, g, ntiles, t, cS, lo, hi, st, s_red, s_arg, 3);
 }
 
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
@@ -1219,7 +1327,7 @@ __device__ __forceinline__ Region chain_step(const ChainGeom &g, int tile, doubl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
     const Region Rd = tile_region(g, tile, k - 1);
     const double *src = lds + g.lds_off[k];
-    double *hb = lds + g.lds_hbuf, *dst = lds + g.lds_off[k - 1];
+    double *hb = lds + g.lds_hb[k], *dst = lds + g.lds_off[k - 1];
     const int sp = Rk.x1 - Rk.x0 + 1, srows = Rk.y1 - Rk.y0 + 1;      // source pitch / rows
     const int dw = Rd.x1 - Rd.x0 + 1, drows = Rd.y1 - Rd.y0 + 1;
     const int sh = g.h[k], sw = g.w[k];

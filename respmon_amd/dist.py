@@ -248,10 +248,10 @@ class HipShardStages:
         self.t = device.require_gpu()
         self.lib = _capi.load()
 
-    def layout(self, H, W, levels, skip):
+    def layout(self, H, W, levels, skip, flags=0):
         import ctypes
         n = ctypes.c_size_t()
-        self._capi.check(self.lib, self.lib.rm_shard_layout(H, W, levels, skip, ctypes.byref(n)), "rm_shard_layout")
+        self._capi.check(self.lib, self.lib.rm_shard_layout_flags(H, W, levels, skip, int(flags), ctypes.byref(n)), "rm_shard_layout_flags")
         return int(n.value)
 
     def pyramid(self, buf_local, levels, skip, flags, NP):
@@ -304,7 +304,7 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
     st = stages if stages is not None else HipShardStages()
     _, H, W = buf_local.shape
     L, S = int(pyramid_levels), int(skip_levels_at_top)
-    NP = st.layout(H, W, L, S)
+    NP = st.layout(H, W, L, S, flags)   # doubles per frame the ranks exchange: G_S (default) or the Laplacian levels S .. L-2
     lap_local = st.pyramid(buf_local, L, S, flags, NP)
     lap_all = all_gather_frames(lap_local, T, group) if NP else lap_local
     mm = st.collapse(lap_all, T, t0, t1, H, W, fps, freq_min, freq_max, amplification, L, S, temporal_threshold, flags)

@@ -119,7 +119,7 @@ def _shard_methods():
         frames = np.ascontiguousarray(frames)
         T, H, W = frames.shape
         n = ctypes.c_size_t()
-        self.ck(self.lib.rm_shard_layout(H, W, levels, skip, ctypes.byref(n)), "shard_layout")
+        self.ck(self.lib.rm_shard_layout_flags(H, W, levels, skip, flags, ctypes.byref(n)), "shard_layout")
         NP = int(n.value)
         spans = []
         base, rem = divmod(T, world)

@@ -99,7 +99,7 @@ class _OracleShardStages:
             ws.append((ws[-1] + 1) // 2)
         return hs, ws
 
-    def layout(self, H, W, L, S):
+    def layout(self, H, W, L, S, flags=0):
         hs, ws = self._sizes(H, W, L)
         return 0 if S >= L - 1 else sum(hs[l] * ws[l] for l in range(S, L - 1))
 

@@ -24,6 +24,11 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
+def _close(a, b, tol=1e-12):
+    """device tensors equal to rounding (two float64 operation orders of the same linear pipeline)"""
+    return float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-300)
+
+
 def test_native_library_is_loaded(hip):
     import os
     from respmon_amd import _capi
@@ -117,10 +122,18 @@ def test_fused_down_chain_equals_per_level(hip):
             v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
             buf = torch.from_numpy(v).cuda()
             kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+            # flags=2: one kernel per pyramid level, the reference's operation order (Laplacians first, then the temporal filter).
+            # In that order (64) the fused pyrDown chain + LDS-resident small pyramid reproduce it bit for bit -- tiny strips (8)
+            # and per-level small pyramid (16) included
             per_level = dist.hip_calibrate(buf, 10, flags=2, **kw)
-            assert torch.equal(dist.hip_calibrate(buf, 10, **kw), per_level), (dt, T, H, W, L, S)
-            assert torch.equal(dist.hip_calibrate(buf, 10, flags=8, **kw), per_level), (dt, T, H, W, L, S)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=64, **kw), per_level), (dt, T, H, W, L, S)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=64 | 8, **kw), per_level), (dt, T, H, W, L, S)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=16, **kw), per_level), (dt, T, H, W, L, S)
+            # the default filters G_S first and builds the Laplacians of the filtered images (the same linear map): equal to
+            # rounding, and independent of the strip geometry bit for bit
+            ff = dist.hip_calibrate(buf, 10, **kw)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=8, **kw), ff), (dt, T, H, W, L, S)
+            assert _close(ff, per_level), (dt, T, H, W, L, S)
 
 
 def test_locate_golden_roi_bit_exact(hip, golden):
@@ -192,8 +205,11 @@ def test_full_size_1080p_vs_oracle(hip, oracle):
     assert torch.equal(heat, heat_u8in)                       # uint8 ingest == float64 buffer, bit for bit
     heat_np = dist.hip_calibrate(buf, 10, flags=1)
     assert torch.equal(heat, heat_np)                         # pruned == exhaustive, bit for bit
-    assert torch.equal(heat, dist.hip_calibrate(buf, 10, flags=2))   # fused pyrDown chain == per-level kernels
-    assert torch.equal(heat, dist.hip_calibrate(buf, 10, flags=16))  # LDS-resident small pyramid == per-level launches
+    assert torch.equal(dist.hip_calibrate(buf, 10, flags=64), dist.hip_calibrate(buf, 10, flags=2))   # fused chain == per-level kernels
+    ref_order = dist.hip_calibrate(buf, 10, flags=16)          # Laplacians first, per-level launches (the reference's order)
+    assert torch.equal(dist.hip_calibrate(buf, 10, flags=64), ref_order)   # LDS-resident small pyramid, same order: bit for bit
+    assert _close(heat, ref_order)                            # default: temporal filter on G_S first (linearity), equal to rounding
+    assert dist.hip_heatmap_to_roi(ref_order, 20) == dist.hip_heatmap_to_roi(heat, 20)
     assert torch.equal(heat, dist.hip_calibrate(buf, 10))     # deterministic
     roi = dist.hip_heatmap_to_roi(heat, 20)
     assert RespiratoryMonitor.locate(buf, 10) == roi          # the one-call form (rm_locate)
@@ -351,7 +367,11 @@ def test_config_r_4k_512_fp16_full_size(hip, oracle):
     kw = dict(pyramid_levels=L, skip_levels_at_top=S)
     h0 = dist.hip_calibrate(b16, 10, **kw)
     assert torch.equal(h0, dist.hip_calibrate(b16, 10, flags=1, **kw))   # pruned == exhaustive
-    assert torch.equal(h0, dist.hip_calibrate(b16, 10, flags=2, **kw))   # fused chain == per-level kernels
+    per_level = dist.hip_calibrate(b16, 10, flags=2, **kw)               # one kernel per level, the reference's operation order
+    assert torch.equal(dist.hip_calibrate(b16, 10, flags=64, **kw), per_level)   # fused chain, same order: bit for bit
+    assert _close(h0, per_level)                                         # default (temporal filter on G_S first): to rounding
+    assert dist.hip_heatmap_to_roi(per_level, 20) == dist.hip_heatmap_to_roi(h0, 20)
+    del per_level
     assert torch.equal(h0, dist.hip_calibrate(b16, 10, **kw))            # deterministic
     b64 = b16.to(torch.float64)
     assert torch.equal(h0, dist.hip_calibrate(b64, 10, **kw))            # exact widening of the stored halves
@@ -420,13 +440,14 @@ def test_iir_temporal_filter_golden(hip, oracle, golden):
     assert _rel(raw, g["e_raw"]) <= 1e-9
     assert _rel(np.average(masked, axis=0), g["e_avg"]) <= 1e-9
     # any callable with the reference's filter signature works (transforms.py:146): here the FFT filter passed explicitly
-    # through the general path must equal the fused default
+    # through the general path (Laplacian levels filtered one by one, the reference's order) equals the fused default (temporal
+    # filter applied to G_S once, then the Laplacians of the filtered images -- the same linear map) to rounding
     def fft_again(vid, fps, freq_min, freq_max, amplification_factor, **_):
         return transforms.temporal_bandpass_filter_fft(vid, fps, freq_min=freq_min, freq_max=freq_max, amplification_factor=amplification_factor)
     m1, r1 = transforms.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L), skip_levels_at_top=int(S),
                                                         temporal_filter_function=fft_again)
     m0, r0 = transforms.eulerian_magnification_bandpass(vid, fps, 0.1, 1.0, 500, pyramid_levels=int(L), skip_levels_at_top=int(S))
-    assert np.array_equal(r1, r0) and np.array_equal(m1, m0)
+    assert _rel(r1, r0) <= 1e-12 and _rel(m1, m0) <= 1e-12
     # ... including a plain numpy / scipy filter (numpy video in -> the callable gets numpy levels): here scipy's lfilter with
     # the reference's Butterworth coefficients, which must reproduce the reference's own IIR outputs (G8)
     import scipy.signal
