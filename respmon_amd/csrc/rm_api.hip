@@ -765,7 +765,6 @@ struct PyrGeom {
     bool chain = false;        // the fused pyrDown chain builds G_S
     bool fuse_small = false;   // per-frame LDS kernels build / collapse the small pyramid
     bool filter_first = false; // ... in the filter-first form (k_small_filter_first): the [T, NP] array between the stages is G_S itself
-    size_t NP_lap = 0;         // filtered pixels per frame in the Laplacian layout (levels S .. L-2 side by side)
     SmallGeom sg;
 };
 
@@ -785,7 +784,6 @@ static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom
     const size_t LDS_LIMIT = 150 * 1024;
     pg.fuse_small = pg.chain && !(flags & RM_FLAG_UNFUSED_SMALL) && L <= SMALL_MAX_LEVELS &&
                     pg.lds_levels * sizeof(double) <= LDS_LIMIT && pg.NP * sizeof(double) <= LDS_LIMIT;
-    pg.NP_lap = pg.NP;
     if (pg.fuse_small) {
         SmallGeom &sg = pg.sg;
         sg.S = S; sg.L = L; sg.NP = (int)pg.NP;
@@ -795,12 +793,12 @@ static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom
             sg.g_off[l] = 0; sg.np_off[l] = (int)pg.off[l];
             if (l >= S) { sg.g_off[l] = o; o += pg.h[l] * pg.w[l]; }
         }
-        // filter-first form (rm_kernels.h k_small_filter_first): the Gaussian levels, the collapsed levels S+1 .. L-2 and the
-        // row-extrema table of the tile bounds must fit LDS together
+        // filter-first form (rm_kernels.h k_small_filter_first): the Gaussian levels and the row-extrema table of the tile
+        // bounds must fit LDS together
         if (!(flags & RM_FLAG_FILTER_LAPLACIANS) && S >= 1 && S < MAX_CHAIN) {
             const size_t nS = (size_t)pg.h[S] * pg.w[S];
             const size_t tiles_x = (size_t)(W + CT_W - 1) / CT_W;
-            const size_t need = sizeof(double) * (pg.lds_levels + (pg.NP - nS) + 2 * (size_t)pg.h[S] * tiles_x);
+            const size_t need = sizeof(double) * (pg.lds_levels + 2 * (size_t)pg.h[S] * tiles_x);
             if (need <= LDS_LIMIT) { pg.filter_first = true; pg.NP = nS; }
         }
     }
@@ -905,7 +903,7 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
         RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
         RM_TRY(ws(ctx, "sel_cnt", (size_t)cg.tiles_x * cg.tiles_y, &sel_cnt));
-        const size_t sh = sizeof(double) * (pg.lds_levels + (pg.NP_lap - NP) + 2 * (size_t)h[S] * cg.tiles_x);
+        const size_t sh = sizeof(double) * (pg.lds_levels + 2 * (size_t)h[S] * cg.tiles_x);
         if (sh > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_filter_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(k_small_filter_first, dim3(T), dim3(SMALL_NT), sh, s, (const double *)bp, pg.sg, (int)pg.lds_levels, dst, ctx->d_state, cg,

@@ -590,36 +590,6 @@ __device__ __forceinline__ void small_up_level(const double *src, int sh, int sw
     }
 }
 
-// the same for TWO sources of one geometry at once (taps and weights are shared): sink(i, vA, vB)
-template <typename Sink>
-__device__ __forceinline__ void small_up_level2(const double *srcA, const double *srcB, int sh, int sw, int dh, int dw, int tid, Sink &&sink)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int x = lane; x < dw; x += 64) {
-        const HTap t = make_htap(x, sw);
-        for (int y = wave; y < dh; y += SMALL_NT / 64) {
-            const int i = y >> 1;
-            const int o1 = i * sw, o2 = ((i == sh - 1) ? i : i + 1) * sw;
-            const double a1 = (srcA[o1 + t.ia] * t.wa + srcA[o1 + t.ib] * t.wb) + srcA[o1 + t.ic] * t.wc;
-            const double a2 = (srcA[o2 + t.ia] * t.wa + srcA[o2 + t.ib] * t.wb) + srcA[o2 + t.ic] * t.wc;
-            const double b1 = (srcB[o1 + t.ia] * t.wa + srcB[o1 + t.ib] * t.wb) + srcB[o1 + t.ic] * t.wc;
-            const double b2 = (srcB[o2 + t.ia] * t.wa + srcB[o2 + t.ib] * t.wb) + srcB[o2 + t.ic] * t.wc;
-            double vA, vB;
-            if (y & 1) {
-                vA = ((a1 + a2) * 4) * (1.0 / 64);
-                vB = ((b1 + b2) * 4) * (1.0 / 64);
-            } else {
-                const int o0 = ((i == 0) ? (sh > 1 ? 1 : 0) : i - 1) * sw;
-                const double a0 = (srcA[o0 + t.ia] * t.wa + srcA[o0 + t.ib] * t.wb) + srcA[o0 + t.ic] * t.wc;
-                const double b0 = (srcB[o0 + t.ia] * t.wa + srcB[o0 + t.ib] * t.wb) + srcB[o0 + t.ic] * t.wc;
-                vA = (a0 + a1 * 6 + a2) * (1.0 / 64);
-                vB = (b0 + b1 * 6 + b2) * (1.0 / 64);
-            }
-            sink(y * dw + x, vA, vB);
-        }
-    }
-}
-
 // global -> LDS copy by one SMALL_NT-thread workgroup with 8 loads in flight per lane: a plain
 // `for (i) lds[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per iteration, i.e. one HBM round trip
 // per 8 KB of a frame -- most of the run time of the one-workgroup-per-frame kernels below
@@ -1131,14 +1101,18 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
 }
 
 // ---- filter-first form of the small pyramid (round 2) ---------------------------------------------------------------------
-// The temporal band-pass is linear and acts per pixel, the pyramid steps are linear and act per frame: they commute.  Filtering
-// the Gaussian level S itself (X = B(G_S), [T, h_S w_S]) and THEN building the Laplacians L_l = X_l - pyrUp(X_{l+1}) and collapsing them
-// (pyramid.py:23-26, 51-57, same operations in the same order as the reference applies them to its own levels) needs ONE per-frame
-// kernel and no [T, NP] Laplacian / band-passed arrays: k_small_pyramid, its 22 MB array and a quarter of the filter's pixels go.
-// The price is the rounding ORDER: the reference filters the Laplacians, this filters their common source, so C_S agrees with the
-// per-level path to ~1e-15 relative instead of bit for bit (the ROI and the uint8 heatmap are unaffected except on exact ties of the
-// mask threshold -- the same class of event the explicit filter operator already belongs to).
-// LDS: X levels S .. L-1 (sg.g_off), the collapsed levels S+1 .. L-2 (at lds_levels + np_off[l] - np_off[S+1]), the bounds table.
+// The temporal band-pass is linear and acts per pixel, the pyramid steps are linear and act per frame: they commute.  With
+// X_l = B(G_l) = pyrDown^(l-S)(X_S) the band-passed Laplacians are L_l = X_l - pyrUp(X_{l+1}) (pyramid.py:23-26), and the collapse
+// (pyramid.py:51-57: img = pyrUp(img) + L_l from a zero coarsest level) telescopes:
+//     C_{L-2} = X_{L-2} - pyrUp(X_{L-1}),   C_l = pyrUp(C_{l+1}) + X_l - pyrUp(X_{l+1}) = X_l - pyrUp^(L-1-l)(X_{L-1})
+// so  C_S = X_S - pyrUp^(L-1-S)(pyrDown^(L-1-S)(X_S)):  filter G_S once ([T, h_S w_S]), then ONE per-frame kernel walks down to
+// the coarsest level, back up, and subtracts.  k_small_pyramid, its [T, NP] Laplacian / band-passed arrays, a quarter of the
+// filter's pixels and half of the collapse's pyrUp work go.
+// The price is the rounding ORDER: the reference filters the Laplacians and adds them up, this filters their common source, so
+// C_S agrees with the per-level path to ~1e-15 relative instead of bit for bit (the ROI and the uint8 heatmap are unaffected
+// except on exact ties of the mask threshold -- the same class of event the explicit filter operator already belongs to).
+// RM_FLAG_FILTER_LAPLACIANS selects the reference's order (k_small_pyramid / k_small_collapse_bounds above).
+// LDS: the levels S .. L-1 (sg.g_off; levels S+1 .. L-2 are overwritten on the way up), then the bounds table.
 __global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *xg, SmallGeom sg, int lds_levels, double *cS, CollapseState *st,
                                                                   ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
 {
@@ -1174,22 +1148,15 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *x
         __syncthreads();
     }
     RM_TRACE_MARK(3, 2);
-    double *cbase = lds + lds_levels - sg.np_off[S + 1 < L - 1 ? S + 1 : S];   // c_l at cbase + np_off[l], l = S+1 .. L-2
-    for (int l = L - 2; l >= S; --l) {
+    for (int l = L - 2; l >= S; --l) {   // back up: U_l = pyrUp(U_{l+1}) over the dead X_l, and C_S = X_S - U_S in place
         const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
-        double *xl = lds + sg.g_off[l];
-        const double *xu = lds + sg.g_off[l + 1];
-        const bool top = l == L - 2;                      // the coarsest band-passed level is zeros: c_{L-2} = L_{L-2}
-        const double *cu = top ? xu : cbase + sg.np_off[l + 1];
-        double *dst = (l == S) ? xl : cbase + sg.np_off[l];   // level S in place: element i is read by its own thread only
-        small_up_level2(xu, cu, sh, sw, dh, dw, tid, [&](int i, double vA, double vB) {
-            const double lap = xl[i] - vA;               // L_l = X_l - pyrUp(X_{l+1})            pyramid.py:25
-            dst[i] = top ? lap : vB + lap;               // img = pyrUp(img) + L_l               pyramid.py:55
-        });
+        double *d = lds + sg.g_off[l];
+        const bool last = l == S;
+        small_up_level(lds + sg.g_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = last ? d[i] - v : v; });
         __syncthreads();
     }
     RM_TRACE_MARK(3, 4);
-    frame_bounds_from_lds(lds + sg.g_off[S], lds + lds_levels + (sg.NP - nS), sg, g, ntiles, t, cS, lo, hi, st, s_red, s_arg, 3);
+    frame_bounds_from_lds(lds + sg.g_off[S], lds + lds_levels, sg, g, ntiles, t, cS, lo, hi, st, s_red, s_arg, 3);
 }
 
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
