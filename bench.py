@@ -243,7 +243,8 @@ def main():
     tiles_needed = tn.value                       # largest per-rank tile count of the last sparse exchange (world > 1)
     dbg = (ctypes.c_longlong * 4)()
     _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
-    pairs = {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]}
+    pairs = {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3],
+             "sum_path": "dense (every pair recomputed by the sum kernel, no value store)" if dbg[3] == 0 and dbg[0] else "sparse"}
     # phase breakdown: separate untimed pass (bracketing every phase costs ~10 us of stream idle time each)
     _capi.check(lib, lib.rm_profile_enable(ctx, 2), "rm_profile_enable")
     for _ in range(3):
@@ -323,7 +324,8 @@ def main():
         need = rdist.hip_sparse_tiles(heat_d)
         dense = {"video": "four blobs (A=0.2, 0.4 Hz, phases 0/90/180/270 deg) + noise sigma 0.06 (3x), seed 4321",
                  "ms_per_step": ms_d, "frames_per_s": T / ms_d * 1e3, "roi": roi_d,
-                 "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3]},
+                 "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3],
+                                    "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
                  "mode_b_sparse_tiles_needed": need, "mode_b_sparse_tile_cap": rdist.SPARSE_CAP_TILES,
                  "mode_b_exchange": "sparse" if need is not None and need <= rdist.SPARSE_CAP_TILES else "dense fallback"}
         del dbuf, heat_d

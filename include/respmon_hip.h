@@ -50,6 +50,9 @@ extern "C" {
 #define RM_FLAG_CONTOUR_CLIP_FRAME 32u /* rm_locate: cv2.findContours as OpenCV <= 3.1 did it (see rm_set_contour_clip_frame) */
 #define RM_FLAG_FILTER_LAPLACIANS 64u /* build the small pyramid in the reference's order -- Laplacians first, filter them, collapse (bit for bit equal to the per-level
                                          path) -- instead of the filter-first form (filter G_S, then Laplacians + collapse in one kernel; equal to ~1e-15) */
+#define RM_FLAG_DENSE_SUM 128u    /* take the masked time sum with the dense kernel (recomputes every value, no value store) ... */
+#define RM_FLAG_SPARSE_SUM 256u   /* ... or with the sparse path (evaluate + store the pairs that can fall below `top`).  Neither: chosen by
+                                     what the previous call of the same geometry on this context kept.  Bit-identical results. */
 #define RM_FLAG_TINY_STORE 4u    /* accepted and ignored: the value store has one slot per (tile, frame) pair, nothing to overflow */
 
 typedef struct rm_ctx rm_ctx;
@@ -74,8 +77,9 @@ int rm_profile_enable(rm_ctx *ctx, int mode);
 int rm_profile_read(rm_ctx *ctx, double *ms_host, int *n_host);
 
 /* counters of the last rm_calibrate on this context (diagnostics): out_host[0] = (frame, tile) pairs,
- * [1] = pairs evaluated at full resolution, [2] = pairs whose values were kept for the masked sum,
- * [3] = capacity of the value store (pairs) */
+ * [1] = pairs evaluated at full resolution by the selection's evaluation pass, [2] = pairs the selection kept for the masked sum,
+ * [3] = capacity of the value store (pairs); 0 = the dense sum kernel took the sum (it recomputes every pair itself, [1] then
+ * counts only the pairs evaluated for the exact raw.min() / raw.max()) */
 int rm_debug_counters(rm_ctx *ctx, long long *out_host, void *stream);
 
 /* ---- dtype helpers: transforms.py:20-23 uint8_to_float, transforms.py:26-29 float_to_uint8 */

@@ -18,6 +18,8 @@ RM_FLAG_TINY_STRIPS = 8
 RM_FLAG_UNFUSED_SMALL = 16
 RM_FLAG_CONTOUR_CLIP_FRAME = 32
 RM_FLAG_FILTER_LAPLACIANS = 64
+RM_FLAG_DENSE_SUM = 128
+RM_FLAG_SPARSE_SUM = 256
 
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint

@@ -20,6 +20,7 @@
 #include "rm_kernels.h"
 #include "rm_down_chain.h"
 #include "rm_down_chain_u8.h"
+#include "rm_dense_sum.h"
 #include "rm_flow.h"
 
 using namespace rm;
@@ -62,6 +63,7 @@ struct CollapsePlan {
     const double *cS = nullptr;
     int T = 0, t0 = 0, t1 = 0, H = 0, W = 0, S = 0;
     bool valid = false;
+    bool dense = false;    // the sum is taken by k_dense_sum (rm_dense_sum.h): no value store, C pairs only in `list`
 };
 
 
@@ -80,6 +82,10 @@ struct rm_ctx {
     FlowWorkspace flow;
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
+    // pinned {pairs the selection kept, pairs} written by the last sum kernel, and the geometry they belong to: the next call
+    // of the same geometry takes the dense sum kernel when more than 1 / DENSE_ONE_IN of its pairs were kept
+    unsigned int *h_stats = nullptr;
+    int stats_T = 0, stats_H = 0, stats_W = 0, stats_S = 0;
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     // measurement hook (rm_profile_*)
@@ -166,6 +172,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -765,6 +772,7 @@ struct PyrGeom {
     bool chain = false;        // the fused pyrDown chain builds G_S
     bool fuse_small = false;   // per-frame LDS kernels build / collapse the small pyramid
     bool filter_first = false; // ... in the filter-first form (k_small_filter_first): the [T, NP] array between the stages is G_S itself
+    bool ff_levels = false;    // filter-first with one launch per level (the small pyramid does not fit LDS): same arithmetic
     SmallGeom sg;
 };
 
@@ -799,8 +807,14 @@ static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom
             const size_t nS = (size_t)pg.h[S] * pg.w[S];
             const size_t tiles_x = (size_t)(W + CT_W - 1) / CT_W;
             const size_t need = sizeof(double) * (pg.lds_levels + 2 * (size_t)pg.h[S] * tiles_x);
-            if (need <= LDS_LIMIT) { pg.filter_first = true; pg.NP = nS; }
+            if (need <= LDS_LIMIT && !getenv("RM_FF_PER_LEVEL")) { pg.filter_first = true; pg.NP = nS; }   // (env: test hook)
         }
+    }
+    // the same form with one launch per pyramid level when the levels are too large for LDS (4K, skip 2): the temporal filter
+    // runs over G_S only and the Laplacian levels are never materialised
+    if (pg.chain && !pg.filter_first && (!pg.fuse_small || getenv("RM_FF_PER_LEVEL")) &&
+        !(flags & (RM_FLAG_FILTER_LAPLACIANS | RM_FLAG_UNFUSED_SMALL)) && S >= 1 && S < MAX_CHAIN) {
+        pg.ff_levels = true; pg.fuse_small = false; pg.NP = (size_t)pg.h[S] * pg.w[S];
     }
 }
 
@@ -815,7 +829,7 @@ static int front_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     std::vector<double *> g(L, nullptr);
     const void *cur = frames; int cur_dtype = dtype;
     int first = 1;
-    if (pg.filter_first) {
+    if (pg.filter_first || pg.ff_levels) {
         // filter-first form: the array the stages exchange is G_S itself; the small pyramid is built after the temporal filter
         PhaseTimer pt(ctx, 0, s);
         RM_TRY(launch_down_chain(ctx, frames, dtype, T, h, w, S, lap, s, (flags & RM_FLAG_TINY_STRIPS) != 0));
@@ -910,6 +924,24 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
                            cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt);
         LAUNCH_CHECK();
         out.state_ready = true; out.bounds_ready = true;
+        out.cS = dst;
+        return RM_OK;
+    }
+    if (pg.ff_levels) {
+        // X_S = B(G_S); X_l = pyrDown(X_{l-1}); U_{L-1} = X_{L-1}, U_l = pyrUp(U_{l+1}); C_S = X_S - pyrUp(U_{S+1})
+        // (rm_kernels.h k_small_filter_first: the telescoped collapse, here with the per-level kernels)
+        RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
+        std::vector<double *> x(L, nullptr);
+        x[S] = bp;
+        for (int l = S + 1; l < L; ++l) {
+            RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &x[l]));
+            RM_TRY(launch_pyr_down(x[l - 1], RM_F64, T, h[l - 1], w[l - 1], x[l], s));
+        }
+        for (int l = L - 2; l > S; --l)   // over the dead X_l
+            RM_TRY(launch_pyr_up(x[l + 1], T, h[l + 1], w[l + 1], x[l], h[l], w[l], 0, nullptr, s));
+        double *dst = nullptr;
+        RM_TRY(ws(ctx, "cS", (size_t)T * NP, &dst));
+        RM_TRY(launch_pyr_up(x[S + 1], T, h[S + 1], w[S + 1], dst, h[S], w[S], 1, bp, s));
         out.cS = dst;
         return RM_OK;
     }
@@ -1090,7 +1122,22 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &cp.hi));
     RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
-    RM_TRY(ws(ctx, "value_store", (size_t)npairs * CT_H * CT_W, &cp.store));
+    // sparse or dense sum (bit-identical results): forced by a flag, else by what the selection of the previous call of this
+    // geometry on this context kept -- the first call of a geometry is sparse
+    if (!ctx->h_stats) {
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_stats, 2 * sizeof(unsigned int), hipHostMallocDefault));
+        ctx->h_stats[0] = ctx->h_stats[1] = 0;
+    }
+    cp.dense = false;
+    if (flags & RM_FLAG_DENSE_SUM) cp.dense = true;
+    else if (!(flags & RM_FLAG_SPARSE_SUM)) {
+        const bool same = ctx->stats_T == T && ctx->stats_H == cp.H && ctx->stats_W == cp.W && ctx->stats_S == sl.S;
+        const unsigned int kept = *(volatile unsigned int *)&ctx->h_stats[0], of = *(volatile unsigned int *)&ctx->h_stats[1];
+        cp.dense = (same && of == (unsigned)npairs && (unsigned long long)kept * DENSE_ONE_IN > (unsigned long long)of);
+    }
+    ctx->stats_T = T; ctx->stats_H = cp.H; ctx->stats_W = cp.W; ctx->stats_S = sl.S;
+    if (!cp.dense) RM_TRY(ws(ctx, "value_store", (size_t)npairs * CT_H * CT_W, &cp.store));
+    ctx->dbg_cap = cp.dense ? 0 : (long long)npairs;
     RM_TRY(ws(ctx, "sel_cnt", (size_t)ntiles, &cp.sel_cnt));
     RM_TRY(ws(ctx, "heavy_tiles", (size_t)ntiles, &cp.heavy));
     if (!sl.bounds_ready) {
@@ -1123,7 +1170,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 256 * SEL_U - 1) / (256 * SEL_U)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
-                       prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy);
+                       prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy, cp.dense ? 1 : 0);
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
     // one resident round of single-wave workgroups that loop over the list: the list length lives on the device, and
@@ -1177,6 +1224,48 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
+    unsigned int *stats_dev = nullptr;
+    if (ctx->h_stats) HIP_TRY(hipHostGetDevicePointer((void **)&stats_dev, ctx->h_stats, 0));
+    if (cp.dense) {
+        // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
+        // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts
+        int cus = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+#endif
+        const ChainGeom &g = cp.g;
+        int rows = 64;
+        while (rows > 16 && (long long)g.tiles_x * ((cp.H + rows - 1) / rows) < 2ll * cus) rows >>= 1;
+        if (const char *e = getenv("RM_DENSE_ROWS")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) rows = v; }   // test hook
+        DenseGeom dg;
+        dg.rows = rows; dg.nsx = g.tiles_x; dg.nsy = (cp.H + rows - 1) / rows;
+        const int S = cp.S;
+        auto lvl = [&](int k) { return (chain_extent(rows, k) + 1) * (chain_extent(CT_W, k) + 1); };
+        auto scratch = [&](int k) { return (chain_extent(rows, k) + 1) * (chain_extent(CT_W, k - 1) + 1); };
+        for (int k = 0; k < MAX_CHAIN; ++k) { dg.lds_off[k] = 0; dg.lds_hb[k] = 0; }
+        int off = lvl(1);                                   // [ level 1 ][ level 2 ][ B ], as make_geom lays out k_eval_pairs
+        if (S >= 2) { dg.lds_off[2] = off; off += lvl(2); }
+        const int B = off;
+        int small = 0, hb_small = 0;
+        for (int k = 3; k <= S; ++k) { dg.lds_off[k] = B + small; small += lvl(k); hb_small = std::max(hb_small, scratch(k)); }
+        for (int k = 3; k <= S; ++k) dg.lds_hb[k] = B + small;
+        if (S >= 2) dg.lds_hb[2] = B;
+        dg.lds_total = B + (S >= 2 ? std::max(scratch(2), S >= 3 ? small + hb_small : 0) : 0);
+        const size_t sh = sizeof(double) * (size_t)dg.lds_total;
+        const unsigned grid = (unsigned)(dg.nsx * dg.nsy);
+#define RM_DENSE_LAUNCH(NW, RPW)                                                                                                         \
+        do {                                                                                                                             \
+            if (sh > 64 * 1024)                                                                                                          \
+                HIP_TRY(hipFuncSetAttribute((const void *)k_dense_sum<NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));   \
+            hipLaunchKernelGGL((k_dense_sum<NW, RPW>), dim3(grid), dim3(64 * NW), sh, s, cp.cS, g, dg, cp.t0, cp.t1, st, thr, heat_sum,  \
+                               avg_T, tile_nkept, stats_dev, (unsigned)cp.npairs);                                                       \
+        } while (0)
+        if (rows == 64) RM_DENSE_LAUNCH(4, 16); else if (rows == 32) RM_DENSE_LAUNCH(2, 16); else RM_DENSE_LAUNCH(4, 4);
+#undef RM_DENSE_LAUNCH
+        LAUNCH_CHECK();
+        ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;
+        return RM_OK;
+    }
     // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
 #ifdef RM_HIPEMU
     const int nworkers = std::min(cp.ntiles * MS_Q, 24);    // (host emulation: fewer, looping workgroups compute the same thing)
@@ -1184,7 +1273,8 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
 #endif
     hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
-                       cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers);
+                       cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, stats_dev,
+                       (unsigned)cp.npairs);
     LAUNCH_CHECK();
     ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;   // the constant tiles of this heatmap (or partial heat sum of a frame shard) are known
     return RM_OK;

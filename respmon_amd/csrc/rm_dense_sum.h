@@ -1,0 +1,250 @@
+// respmon_amd/csrc/rm_dense_sum.h -- the masked time sum of a DENSE stream (round 2)
+//
+//   heat_sum[y, x] = sum_t (raw[t, y, x] >= top ? min : raw[t, y, x])        transforms.py:184-192 + base.py:562
+//
+// The sparse path (k_select_pairs -> k_eval_pairs -> k_masked_sum_tiles, rm_kernels.h) evaluates the few (tile, frame) pairs
+// that can hold a value below `top`, parks their values in the value store and sums them afterwards.  When most pairs are
+// such pairs -- skip_levels_at_top = 2 on a noisy video: every 64x16 tile of every frame -- that is one 8 KB round trip
+// through memory per pair on top of single-wave workgroups whose pyrUp steps use a third of their lanes: 12.4 + 5.2 ms at
+// 4K x 512, 0.33 + 0.22 ms at 720p x 128.  Here the exact extrema come first, from the pairs that can hold them alone (C pairs,
+// k_eval_pairs without a store), and then ONE kernel recomputes the full-resolution values frame after frame and adds them up in
+// registers: a workgroup owns a 64 x (16 NW) super-tile of the heatmap for all frames, its NW waves run the pyrUp chain of the
+// super-tile's footprint together (same per-pixel arithmetic as chain_step / level0_rows: bit-identical values), wave w keeps
+// rows 16 w .. 16 w + 15, lane = column, 16 running sums per lane.  Nothing but C_S is read, nothing but the heatmap is written.
+// A pruned pair needs no special case: all of its values are >= top, so every pixel adds `min`, exactly what the sparse
+// path adds for it.
+#pragma once
+
+namespace rm {
+
+// the dense kernel is chosen when the previous selection kept more than one pair in DENSE_ONE_IN (measured crossover)
+constexpr unsigned long long DENSE_ONE_IN = 16;
+
+struct DenseGeom {
+    int rows;                    // super-tile rows (waves per workgroup x rows per wave)
+    int nsx, nsy;                // super-tiles across / down
+    int lds_off[MAX_CHAIN];      // level k's footprint buffer, k = 1 .. S
+    int lds_hb[MAX_CHAIN];       // scratch of the horizontal pass of step k -> k-1
+    int lds_total;               // doubles
+};
+
+// footprint of super-tile (sxi, syi) at level k (0 = the super-tile itself): the recurrence of tile_region
+__host__ __device__ __forceinline__ Region super_region(const ChainGeom &g, int rows, int sxi, int syi, int k)
+{
+    Region R;
+    R.y0 = syi * rows; R.y1 = min(R.y0 + rows, g.h[0]) - 1;
+    R.x0 = sxi * CT_W; R.x1 = min(R.x0 + CT_W, g.w[0]) - 1;
+    for (int i = 1; i <= k; ++i) {
+        R.y0 = max(0, floordiv2(R.y0) - 1);
+        R.y1 = min(g.h[i] - 1, floordiv2(R.y1) + 1);
+        R.x0 = max(0, floordiv2(R.x0) - 1);
+        R.x1 = min(g.w[i] - 1, floordiv2(R.x1) + 1);
+    }
+    return R;
+}
+
+// one pyrUp step of the footprint inside LDS, level k (Rk) -> level k-1 (Rd): chain_step's arithmetic, regions handed in.
+// Rows go to the waves in batches of DS_U whose LDS reads are issued together: one read-to-write round trip per batch instead
+// of one per row (the compiler cannot reorder the loads of a row past the previous row's store).
+constexpr int DS_U = 4;
+__device__ __forceinline__ void dense_step(const ChainGeom &g, const double *src, double *hb, double *dst, int k, const Region &Rk,
+                                           const Region &Rd)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    const int sp = Rk.x1 - Rk.x0 + 1, srows = Rk.y1 - Rk.y0 + 1;
+    const int dw = Rd.x1 - Rd.x0 + 1, drows = Rd.y1 - Rd.y0 + 1;
+    const int sh = g.h[k], sw = g.w[k];
+    for (int c = lane; c < dw; c += 64) {
+        const HTap t = make_htap(Rd.x0 + c, sw);
+        const int oa = t.ia - Rk.x0, ob = t.ib - Rk.x0, oc = t.ic - Rk.x0;
+        for (int rb = wave; rb < srows; rb += nwaves * DS_U) {
+            double a[DS_U], b[DS_U], cc[DS_U];
+#pragma unroll
+            for (int u = 0; u < DS_U; ++u) {
+                const int r = rb + u * nwaves;
+                const double *row = src + (r < srows ? r : rb) * sp;
+                a[u] = row[oa]; b[u] = row[ob]; cc[u] = row[oc];
+            }
+#pragma unroll
+            for (int u = 0; u < DS_U; ++u) {
+                const int r = rb + u * nwaves;
+                if (r < srows) hb[r * dw + c] = (a[u] * t.wa + b[u] * t.wb) + cc[u] * t.wc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = lane; c < dw; c += 64) {
+        for (int rb = wave; rb < drows; rb += nwaves * DS_U) {
+            double h0[DS_U], h1[DS_U], h2[DS_U];
+#pragma unroll
+            for (int u = 0; u < DS_U; ++u) {
+                const int r = min(rb + u * nwaves, drows - 1);
+                const int y = Rd.y0 + r, i = y >> 1;                         // uniform per wave
+                const int r2 = ((i == sh - 1) ? i : i + 1) - Rk.y0, r1 = i - Rk.y0;
+                const int r0 = (y & 1) ? r1 : ((i == 0) ? (sh > 1 ? 1 : 0) : i - 1) - Rk.y0;   // (odd rows: unused)
+                h0[u] = hb[r0 * dw + c]; h1[u] = hb[r1 * dw + c]; h2[u] = hb[r2 * dw + c];
+            }
+#pragma unroll
+            for (int u = 0; u < DS_U; ++u) {
+                const int r = rb + u * nwaves;
+                if (r < drows) {
+                    const int y = Rd.y0 + r;
+                    dst[r * dw + c] = (y & 1) ? ((h1[u] + h2[u]) * 4) * (1.0 / 64) : (h0[u] + h1[u] * 6 + h2[u]) * (1.0 / 64);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// level 1 (LDS, footprint R1) -> level 0 rows y_first .. y_first + NR - 1 of column x (y_first, NR even): level0_rows' arithmetic
+template <int NR>
+__device__ __forceinline__ void dense_level0(const ChainGeom &g, const double *src, const Region &R1, int x, int y_first, double (&out)[NR])
+{
+    const int sp = R1.x1 - R1.x0 + 1;
+    const int sh = g.h[1], sw = g.w[1];
+    const HTap t = make_htap(x, sw);
+    const int oa = t.ia - R1.x0, ob = t.ib - R1.x0, oc = t.ic - R1.x0;
+    const int i0 = y_first >> 1;
+    double hv[NR / 2 + 2];
+#pragma unroll
+    for (int k = 0; k < NR / 2 + 2; ++k) {
+        int i = i0 - 1 + k;
+        int r = (i < 0) ? (sh > 1 ? 1 : 0) : (i > sh - 1 ? sh - 1 : i);
+        r = min(max(r, R1.y0), R1.y1);   // rows past the image end are computed and dropped: keep their reads inside the footprint
+        const double *row = src + (r - R1.y0) * sp;
+        hv[k] = (row[oa] * t.wa + row[ob] * t.wb) + row[oc] * t.wc;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        int k = (j >> 1) + 1;
+        if (j & 1) out[j] = ((hv[k] + hv[k + 1]) * 4) * (1.0 / 64);
+        else out[j] = (hv[k - 1] + hv[k] * 6 + hv[k + 1]) * (1.0 / 64);
+    }
+}
+
+// stats_host (pinned, nullable): {pairs kept for the sum by the selection, pairs} of this call -- what the next call's choice
+// between this kernel and the sparse path goes by
+// NW waves per workgroup, RPW rows of the heatmap per wave: a 64 x (NW RPW) super-tile.  <4,16> and <2,16> for images with
+// super-tiles to spare; <4,4> gives one 64x16 tile to four waves when tiles are few and the per-frame latency is what counts.
+template <int NW, int RPW>
+__global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGeom g, DenseGeom dg, int t_first, int t_end, CollapseState *st,
+                                                        double threshold, double *heat_sum, int avg_T, int *tile_nkept, unsigned int *stats_host,
+                                                        unsigned int npairs)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = g.S;
+    const int syi = (int)blockIdx.x / dg.nsx, sxi = (int)blockIdx.x - syi * dg.nsx;
+    constexpr int ROWS = RPW * NW;
+    // transforms.py:184-189: min, max, top = max - (max - min) * threshold
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;
+    if (blockIdx.x == 0 && tid == 0) {
+        st->min_val = min_val; st->max_val = max_val; st->top = top;
+        if (stats_host) { stats_host[0] = st->n_slots; stats_host[1] = npairs; }
+    }
+    const Region R0 = super_region(g, ROWS, sxi, syi, 0), RS = super_region(g, ROWS, sxi, syi, S);
+    const int nwS = RS.x1 - RS.x0 + 1, nS = (RS.y1 - RS.y0 + 1) * nwS, wS = g.w[S];
+    const float inv_nwS = 1.0f / (float)nwS;
+    const size_t fs = (size_t)g.h[S] * wS;
+    double *dS = lds + dg.lds_off[S];
+    const int x = R0.x0 + lane;
+    const int y_first = R0.y0 + wave * RPW;
+    const bool col_ok = x <= R0.x1 && y_first <= R0.y1;
+    const int rows = min(R0.y1 - y_first + 1, RPW);   // <= 0 for a wave below the image
+    double acc[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) acc[j] = 0.0;
+    // the footprint's own elements of C_S: position fixed for all frames
+    constexpr int PF = 4;   // staged elements per thread ...
+    constexpr int PD = 3;   // ... held in registers PD frames ahead: a footprint is a few short rows gathered from L2 / HBM, and
+                            // one frame of arithmetic (~1 us) does not cover that latency
+    int off_g[PF], off_l[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int i = tid + p * 64 * NW;
+        int r, c;
+        split_rc(i < nS ? i : 0, nwS, inv_nwS, r, c);
+        off_g[p] = (RS.y0 + r) * wS + RS.x0 + c;
+        off_l[p] = i < nS ? i : -1;
+    }
+    const bool small = nS <= PF * 64 * NW;
+    double nxt[PD][PF];
+    auto compute = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        Region Rk = RS;   // (the footprints are recomputed per step on the scalar unit: keeping all of them live costs registers)
+        for (int k = S; k >= 2; --k) {
+            const Region Rd = super_region(g, ROWS, sxi, syi, k - 1);
+            dense_step(g, lds + dg.lds_off[k], lds + dg.lds_hb[k], lds + dg.lds_off[k - 1], k, Rk, Rd);
+            Rk = Rd;
+        }
+        if (col_ok) {
+            double v[RPW];
+            dense_level0<RPW>(g, lds + dg.lds_off[1], Rk, x, y_first, v);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
+        }
+        if (S == 1) __syncthreads();   // (S >= 2: the barriers of the next frame's first step stand between these reads and its writes)
+    };
+    if (small) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int t = t_first + d;
+            const double *src = cS + (size_t)(t < t_end ? t : t_first) * fs;
+#pragma unroll
+            for (int p = 0; p < PF; ++p) nxt[d][p] = (off_l[p] >= 0 && t < t_end) ? src[off_g[p]] : 0.0;
+        }
+        for (int tb = t_first; tb < t_end; tb += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int t = tb + d;
+                if (t < t_end) {   // (uniform)
+#pragma unroll
+                    for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) dS[off_l[p]] = nxt[d][p];
+                    const int tn = t + PD;
+                    const double *src = cS + (size_t)(tn < t_end ? tn : t_first) * fs;
+#pragma unroll
+                    for (int p = 0; p < PF; ++p) nxt[d][p] = (off_l[p] >= 0 && tn < t_end) ? src[off_g[p]] : 0.0;
+                    compute();
+                }
+            }
+        }
+    } else {
+        for (int t = t_first; t < t_end; ++t) {
+            const double *src = cS + (size_t)t * fs;
+            for (int i = tid; i < nS; i += 64 * NW) {
+                int r, c;
+                split_rc(i, nwS, inv_nwS, r, c);
+                dS[i] = src[(size_t)(RS.y0 + r) * wS + RS.x0 + c];
+            }
+            compute();
+        }
+    }
+    // base.py:562: np.average = sum / T when the whole buffer was summed here; the heatmap's extrema for base.py:563
+    const double cnt = (double)avg_T;
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+    if (col_ok) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            if (j < rows) {
+                const double v = avg_T > 0 ? acc[j] / cnt : acc[j];
+                heat_sum[(size_t)(y_first + j) * g.w[0] + x] = v;
+                hmn = (v < hmn) ? v : hmn; hmx = (v > hmx) ? v : hmx;
+            }
+        }
+    }
+    if (tile_nkept && lane == 0 && y_first <= R0.y1 && y_first % CT_H == 0)   // (the sparse heatmap exchange: no tile is known to be the constant)
+        tile_nkept[(y_first / CT_H) * g.tiles_x + sxi] = t_end - t_first;
+    if (avg_T > 0) {
+        block_minmax(hmn, hmx);
+        if (tid == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp = blockIdx.x & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+        }
+    }
+}
+
+}  // namespace rm

@@ -1181,7 +1181,7 @@ constexpr int SEL_U = 4;   // pairs per lane: their bound loads are issued toget
 __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
                                                       unsigned int *list, int *slot_of, int no_prune,
                                                       double thr, int first_pair, int end_pair, int ntiles, int *sel_cnt,
-                                                      unsigned int *heavy)
+                                                      unsigned int *heavy, int dense)
 {
     RM_TRACE_SCOPE(4);
     __shared__ unsigned int s_cnt[2][SEL_U][4];   // [kept | listed][k][wave]
@@ -1230,8 +1230,9 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
             isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
             isD[k] = no_prune || (l[k] - m < top_ub);
         }
-        // listed = evaluated by k_eval_pairs: C pairs (exact extrema) and every kept pair
-        isL[k] = isC || isD[k];
+        // listed = evaluated by k_eval_pairs: C pairs (exact extrema) and every kept pair -- C pairs alone when the dense sum
+        // kernel (rm_dense_sum.h) follows: it recomputes every value itself and wants no store (n_slots still counts the D pairs)
+        isL[k] = isC || (isD[k] && !dense);
         mD[k] = __ballot(isD[k]);
         mL[k] = __ballot(isL[k]);
         if (lane == 0) { s_cnt[0][k][wave] = (unsigned)__popcll(mD[k]); s_cnt[1][k][wave] = (unsigned)__popcll(mL[k]); }
@@ -1260,11 +1261,11 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
             myL += (w < wave) ? cL : 0;
             offL += cL;
         }
-        if (isD[k]) {
+        if (isD[k] && !dense) {
             const int t = i / ntiles, tile = i - t * ntiles;
             if (atomicAdd(&sel_cnt[tile], 1) == 0) heavy[atomicAdd(&st->n_heavy, 1u)] = (unsigned)tile;
         }
-        if (i < n) slot_of[i] = isD[k] ? SLOT_KEPT : SLOT_PRUNED;
+        if (i < n) slot_of[i] = (isD[k] && !dense) ? SLOT_KEPT : SLOT_PRUNED;
         if (isL[k]) list[myL + (unsigned)__popcll(mL[k] & below)] = (unsigned)i;
     }
 }
@@ -1474,7 +1475,8 @@ constexpr int MS_B = 16;             // kept frames per batch
 __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int t_end, int T, int ntiles, int W0, int H0,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
-                                                          int *tile_nkept, const int *sel_cnt, const unsigned int *heavy, int nworkers)
+                                                          int *tile_nkept, const int *sel_cnt, const unsigned int *heavy, int nworkers,
+                                                          unsigned int *stats_host, unsigned int npairs)
 {
     RM_TRACE_SCOPE(6);
     HIP_DYNAMIC_SHARED(int, s_kt)     // kept frames of the tile, in order
@@ -1491,7 +1493,12 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;
     RM_TRACE_MARK(6, 0);
-    if (blockIdx.x == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    if (blockIdx.x == 0 && tid == 0) {
+        st->min_val = min_val; st->max_val = max_val; st->top = top;
+        // (pinned host words, nullable: how many pairs the selection kept -- the next call chooses between this path and the
+        //  dense sum kernel by it)
+        if (stats_host) { stats_host[0] = st->n_slots; stats_host[1] = npairs; }
+    }
     // avg_T > 0 (the whole buffer is summed here): write np.average = sum / T (base.py:562) and reduce the
     // heatmap's min / max for the normalisation (base.py:563) on the way out
     const double cnt = (double)avg_T;
