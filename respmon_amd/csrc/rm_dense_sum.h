@@ -17,8 +17,11 @@
 
 namespace rm {
 
-// the dense kernel is chosen when the previous selection kept more than one pair in DENSE_ONE_IN (measured crossover)
-constexpr unsigned long long DENSE_ONE_IN = 16;
+// The dense kernel is chosen when the previous selection kept more than one pair in DENSE_ONE_IN.  Measured per pair of the
+// geometry (MI355X): sparse path 3.7-4.8 ns per KEPT pair, dense kernel 1.6 ns (4K x 512, skip 2), 3.6 ns (720p x 128, skip 2:
+// 900 tiles, latency bound) and 4.6 ns (1080p x 256, skip 4: three pyrUp steps per frame) per pair, kept or not -- the crossover
+// lies between 40 % and never; streams are either sparse (1-4 % kept) or keep every pair, so one half separates them.
+constexpr unsigned long long DENSE_ONE_IN = 2;
 
 struct DenseGeom {
     int rows;                    // super-tile rows (waves per workgroup x rows per wave)

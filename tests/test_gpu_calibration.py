@@ -605,3 +605,74 @@ def test_bpm_estimate_config1_on_the_gpu(hip, golden):
     assert len(mon.freq) > 0 and abs(mon.freq[-1] - 24.0) < 1.0
     assert abs(mon.freq[-1] - float(g["freq0"][-1])) <= 1e-9 * float(g["freq0"][-1])
     assert list(mon.peak_indices) == list(g["peaks0"])
+
+
+def test_dense_sum_equals_sparse_path(hip, oracle, monkeypatch):
+    """rm_dense_sum.h against the selection / value-store path, bit for bit: random geometries, every frame dtype, every
+    super-tile shape, config Q at full size (every pair kept: the automatic choice takes the dense kernel from the second call on)
+    and the breathing video of config P (1 % of the pairs kept: the automatic choice stays sparse)."""
+    import ctypes
+    import torch
+    from respmon_amd import _capi, device, dist, synth
+    rng = np.random.default_rng(11)
+
+    def sum_path():
+        dbg = (ctypes.c_longlong * 4)()
+        _capi.check(hip, hip.rm_debug_counters(device.ctx(), dbg, device.stream_ptr()), "rm_debug_counters")
+        return "dense" if dbg[3] == 0 else "sparse"
+
+    for n, (T, H, W, L, S) in enumerate([(5, 64, 96, 4, 2), (3, 67, 131, 5, 3), (4, 135, 240, 6, 4), (6, 48, 64, 3, 1), (2, 200, 320, 7, 5),
+                                         (16, 270, 480, 9, 4), (8, 360, 640, 4, 2), (4, 540, 1936, 8, 4), (3, 300, 2000, 6, 3), (7, 700, 1300, 4, 1)]):
+        dt = (np.float64, np.uint8, np.float32, np.float16)[n % 4]
+        v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
+        buf = torch.from_numpy(v).cuda()
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+        monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
+        sparse = dist.hip_calibrate(buf, 10, flags=256, **kw)
+        assert sum_path() == "sparse"
+        for rows in (None, "16", "32", "64"):
+            if rows is None:
+                monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
+            else:
+                monkeypatch.setenv("RM_DENSE_ROWS", rows)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows)
+            assert sum_path() == "dense"
+        assert torch.equal(dist.hip_calibrate(buf, 10, flags=128 | 1, **kw), sparse), (dt, T, H, W, L, S)
+    monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
+    # config Q: dense by itself from the second call of the geometry on
+    T, H, W, L, S = 128, 720, 1280, 4, 2
+    buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=1234)).cuda()
+    kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+    sparse = dist.hip_calibrate(buf, 10, flags=256, **kw)
+    torch.cuda.synchronize()
+    auto = dist.hip_calibrate(buf, 10, **kw)
+    assert sum_path() == "dense" and torch.equal(auto, sparse)
+    assert dist.hip_heatmap_to_roi(auto, 20) == dist.hip_heatmap_to_roi(sparse, 20)
+    # config P's video: sparse stays sparse, and the forced dense kernel agrees
+    T, H, W = 256, 1080, 1920
+    buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=1234)).cuda()
+    a = dist.hip_calibrate(buf, 10)
+    torch.cuda.synchronize()
+    b = dist.hip_calibrate(buf, 10)
+    assert sum_path() == "sparse" and torch.equal(a, b)
+    assert torch.equal(dist.hip_calibrate(buf, 10, flags=128), a)
+
+
+def test_filter_first_per_level_equals_fused(hip, monkeypatch):
+    """Levels too large for LDS (4K, skip 2) take the filter-first small pyramid with one launch per level: forced here on
+    geometries that also fit the one-kernel form, the two must agree bit for bit; the 4K geometry itself against the
+    reference's operation order (flags=2) to rounding."""
+    import torch
+    from respmon_amd import dist
+    rng = np.random.default_rng(13)
+    for (T, H, W, L, S) in [(5, 64, 96, 4, 2), (3, 67, 131, 5, 3), (16, 270, 480, 9, 4), (6, 48, 64, 3, 1), (2, 200, 320, 7, 5), (4, 540, 1936, 8, 4)]:
+        buf = torch.from_numpy(rng.random((T, H, W))).cuda()
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+        monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
+        fused = dist.hip_calibrate(buf, 10, **kw)
+        monkeypatch.setenv("RM_FF_PER_LEVEL", "1")
+        assert torch.equal(dist.hip_calibrate(buf, 10, **kw), fused), (T, H, W, L, S)
+    monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
+    buf = torch.from_numpy(rng.random((6, 2160, 3840)).astype(np.float16)).cuda()
+    kw = dict(pyramid_levels=6, skip_levels_at_top=2)
+    assert _close(dist.hip_calibrate(buf, 10, **kw), dist.hip_calibrate(buf, 10, flags=2, **kw))
