@@ -63,6 +63,7 @@ struct CollapsePlan {
     const double *cS = nullptr;
     int T = 0, t0 = 0, t1 = 0, H = 0, W = 0, S = 0;
     bool valid = false;
+    bool no_prune = false;
     bool dense = false;    // the sum is taken by k_dense_sum (rm_dense_sum.h): no value store, C pairs only in `list`
 };
 
@@ -1128,9 +1129,9 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
         HIP_TRY(hipHostMalloc((void **)&ctx->h_stats, 2 * sizeof(unsigned int), hipHostMallocDefault));
         ctx->h_stats[0] = ctx->h_stats[1] = 0;
     }
-    cp.dense = false;
+    cp.dense = false; cp.no_prune = no_prune != 0;
     if (flags & RM_FLAG_DENSE_SUM) cp.dense = true;
-    else if (!(flags & RM_FLAG_SPARSE_SUM)) {
+    else if (!(flags & RM_FLAG_SPARSE_SUM) && !no_prune) {   // (RM_FLAG_NO_PRUNE is the exhaustive-evaluation baseline: sparse path)
         const bool same = ctx->stats_T == T && ctx->stats_H == cp.H && ctx->stats_W == cp.W && ctx->stats_S == sl.S;
         const unsigned int kept = *(volatile unsigned int *)&ctx->h_stats[0], of = *(volatile unsigned int *)&ctx->h_stats[1];
         cp.dense = (same && of == (unsigned)npairs && (unsigned long long)kept * DENSE_ONE_IN > (unsigned long long)of);
@@ -1224,8 +1225,8 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
-    unsigned int *stats_dev = nullptr;
-    if (ctx->h_stats) HIP_TRY(hipHostGetDevicePointer((void **)&stats_dev, ctx->h_stats, 0));
+    unsigned int *stats_dev = nullptr;   // (an exhaustive-evaluation call keeps every pair by decree: it leaves the record alone)
+    if (ctx->h_stats && !cp.no_prune) HIP_TRY(hipHostGetDevicePointer((void **)&stats_dev, ctx->h_stats, 0));
     if (cp.dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
         // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts

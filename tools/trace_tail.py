@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = {0: "k_down_chain", 1: "k_small_pyramid", 2: "k_temporal_mfma", 3: "k_small_collapse_bounds", 4: "k_select_pairs",
+NAMES = {0: "k_down_chain", 1: "k_small_pyramid", 2: "k_temporal_mfma", 3: "k_small_filter_first (or k_small_collapse_bounds)", 4: "k_select_pairs",
          5: "k_eval_pairs", 6: "k_masked_sum_tiles", 7: "k_heat_to_u8", 8: "k_extra8", 9: "k_extra9"}
 KERNELS, BLOCKS = 16, 20480
 
