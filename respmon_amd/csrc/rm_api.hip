@@ -1261,7 +1261,19 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
             hipLaunchKernelGGL((k_dense_sum<NW, RPW>), dim3(grid), dim3(64 * NW), sh, s, cp.cS, g, dg, cp.t0, cp.t1, st, thr, heat_sum,  \
                                avg_T, tile_nkept, stats_dev, (unsigned)cp.npairs);                                                       \
         } while (0)
-        if (rows == 64) RM_DENSE_LAUNCH(4, 16); else if (rows == 32) RM_DENSE_LAUNCH(2, 16); else RM_DENSE_LAUNCH(4, 4);
+#define RM_DENSE_LAUNCH_S2(NW, RPW)                                                                                                      \
+        do {                                                                                                                             \
+            if (sh > 64 * 1024)                                                                                                          \
+                HIP_TRY(hipFuncSetAttribute((const void *)k_dense_sum_s2<NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));\
+            hipLaunchKernelGGL((k_dense_sum_s2<NW, RPW>), dim3(grid), dim3(64 * NW), sh, s, cp.cS, g, dg, cp.t0, cp.t1, st, thr,         \
+                               heat_sum, avg_T, tile_nkept, stats_dev, (unsigned)cp.npairs);                                             \
+        } while (0)
+        if (S <= 2 && !getenv("RM_DENSE_GENERAL")) {   // table-driven form (env: test hook for the general kernel)
+            if (rows == 64) RM_DENSE_LAUNCH_S2(4, 16); else if (rows == 32) RM_DENSE_LAUNCH_S2(2, 16); else RM_DENSE_LAUNCH_S2(4, 4);
+        } else {
+            if (rows == 64) RM_DENSE_LAUNCH(4, 16); else if (rows == 32) RM_DENSE_LAUNCH(2, 16); else RM_DENSE_LAUNCH(4, 4);
+        }
+#undef RM_DENSE_LAUNCH_S2
 #undef RM_DENSE_LAUNCH
         LAUNCH_CHECK();
         ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;

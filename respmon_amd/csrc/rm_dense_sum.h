@@ -250,4 +250,205 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGe
     }
 }
 
+// ---- the same kernel for skip_levels_at_top <= 2 (the reference's module defaults L=4, S=2; 4K L=6, S=2), table driven -----------
+// k_dense_sum above is bound by instruction issue: ~600 VALU + ~400 scalar instructions per wave and frame, nearly all of them
+// index arithmetic, border rules and tap weights that do not depend on the frame.  With at most ONE pyrUp step between the staged
+// level and level 1, everything frame-invariant fits in registers: every thread owns a fixed list of outputs per stage (flat
+// index over the stage's rows x columns, so all lanes work, not just the 35 of 64 that own a column) and keeps, per output, the
+// three LDS offsets it reads, the offset it writes and its three tap weights.  A frame is then: store the prefetched footprint,
+// barrier, NH x (3 LDS reads, 5 flops, 1 write), barrier, NV x (3 reads, 6 flops, 1 write), barrier, the level-0 rows from
+// precomputed row offsets, 2 flops + a select per running sum.  Same expressions, same operand order: bit-identical values.
+template <int NW, int RPW> struct DenseS2 {
+    static constexpr int ROWS = NW * RPW, NT = 64 * NW;
+    static constexpr int R2 = ROWS == 64 ? 21 : (ROWS == 32 ? 13 : 9);    // chain_extent(ROWS, 2) + 1
+    static constexpr int R1 = ROWS == 64 ? 35 : (ROWS == 32 ? 19 : 11);   // chain_extent(ROWS, 1) + 1
+    static constexpr int C1 = 35;                                          // chain_extent(CT_W, 1) + 1
+    static constexpr int NH = (R2 * C1 + NT - 1) / NT;                     // horizontal-pass outputs per thread
+    static constexpr int NV = (R1 * C1 + NT - 1) / NT;                     // vertical-pass outputs (= level-1 elements) per thread
+};
+
+template <int NW, int RPW>
+__global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, ChainGeom g, DenseGeom dg, int t_first, int t_end, CollapseState *st,
+                                                           double threshold, double *heat_sum, int avg_T, int *tile_nkept, unsigned int *stats_host,
+                                                           unsigned int npairs)
+{
+    using G = DenseS2<NW, RPW>;
+    constexpr int NT = G::NT, NH = G::NH, NV = G::NV, PF = G::NV, ROWS = G::ROWS;
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = g.S;   // 1 or 2
+    const int syi = (int)blockIdx.x / dg.nsx, sxi = (int)blockIdx.x - syi * dg.nsx;
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
+    if (blockIdx.x == 0 && tid == 0) {
+        st->min_val = min_val; st->max_val = max_val; st->top = top;
+        if (stats_host) { stats_host[0] = st->n_slots; stats_host[1] = npairs; }
+    }
+    const Region R0 = super_region(g, ROWS, sxi, syi, 0), R1 = super_region(g, ROWS, sxi, syi, 1), R2 = super_region(g, ROWS, sxi, syi, 2 <= S ? 2 : 1);
+    const Region RS = S == 2 ? R2 : R1;
+    const int nwS = RS.x1 - RS.x0 + 1, nS = (RS.y1 - RS.y0 + 1) * nwS, wS = g.w[S];
+    const size_t fs = (size_t)g.h[S] * wS;
+    double *dS = lds + dg.lds_off[S];
+    const double *l1 = lds + dg.lds_off[1];
+    // staged elements of this thread (position fixed for all frames)
+    int off_g[PF], off_l[PF];
+    {
+        const float inv = 1.0f / (float)nwS;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int i = tid + p * NT;
+            int r, c;
+            split_rc(i < nS ? i : 0, nwS, inv, r, c);
+            off_g[p] = (RS.y0 + r) * wS + RS.x0 + c;
+            off_l[p] = i < nS ? i : -1;
+        }
+    }
+    // horizontal pass of step 2 -> 1: output i = r * dw + c of the scratch buffer, r = level-2 row, c = level-1 column
+    const int sp2 = R2.x1 - R2.x0 + 1, srows = R2.y1 - R2.y0 + 1;
+    const int dw = R1.x1 - R1.x0 + 1, drows = R1.y1 - R1.y0 + 1;
+    int h_src[NH][3], h_dst[NH];
+    float h_w[NH][3];
+    int v_src[NV][3], v_dst[NV];   // vertical pass: output i = r * dw + c of level 1; v_src[n][0] < 0: odd row
+    if (S == 2) {
+        const float inv = 1.0f / (float)dw;
+        const int sh = g.h[2], sw = g.w[2];
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+            const int i = tid + n * NT;
+            const bool ok = i < srows * dw;
+            int r, c;
+            split_rc(ok ? i : 0, dw, inv, r, c);
+            const HTap t = make_htap(R1.x0 + c, sw);
+            h_src[n][0] = r * sp2 + t.ia - R2.x0; h_src[n][1] = r * sp2 + t.ib - R2.x0; h_src[n][2] = r * sp2 + t.ic - R2.x0;
+            h_w[n][0] = (float)t.wa; h_w[n][1] = (float)t.wb; h_w[n][2] = (float)t.wc;   // 0, 1, 2, 4, 6, 7: exact
+            h_dst[n] = ok ? i : -1;
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int i = tid + n * NT;
+            const bool ok = i < drows * dw;
+            int r, c;
+            split_rc(ok ? i : 0, dw, inv, r, c);
+            const int y = R1.y0 + r, ii = y >> 1;
+            const int r1 = ii - R2.y0, r2 = ((ii == sh - 1) ? ii : ii + 1) - R2.y0;
+            const int r0 = ((ii == 0) ? (sh > 1 ? 1 : 0) : ii - 1) - R2.y0;
+            v_src[n][0] = (y & 1) ? -1 : r0 * dw + c; v_src[n][1] = r1 * dw + c; v_src[n][2] = r2 * dw + c;
+            v_dst[n] = ok ? i : -1;
+        }
+    }
+    // level 1 -> level 0: rows y_first .. y_first + RPW - 1 of column x (dense_level0's arithmetic with the row offsets fixed)
+    const int x = R0.x0 + lane;
+    const int y_first = R0.y0 + wave * RPW;
+    const bool col_ok = x <= R0.x1 && y_first <= R0.y1;
+    const int rows = min(R0.y1 - y_first + 1, RPW);
+    int l0_row[RPW / 2 + 2], l0_b, l0_c;
+    double l0_wa, l0_wb, l0_wc;
+    {
+        const int sp = R1.x1 - R1.x0 + 1, sh = g.h[1];
+        const HTap t = make_htap(col_ok ? x : R0.x0, g.w[1]);
+        const int oa = t.ia - R1.x0;
+        l0_b = t.ib - t.ia; l0_c = t.ic - t.ia;
+        l0_wa = t.wa; l0_wb = t.wb; l0_wc = t.wc;
+        const int i0 = y_first >> 1;
+#pragma unroll
+        for (int k = 0; k < RPW / 2 + 2; ++k) {
+            const int i = i0 - 1 + k;
+            int r = (i < 0) ? (sh > 1 ? 1 : 0) : (i > sh - 1 ? sh - 1 : i);
+            r = min(max(r, R1.y0), R1.y1);
+            l0_row[k] = (r - R1.y0) * sp + oa;
+        }
+    }
+    double acc[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) acc[j] = 0.0;
+    const double *hb = lds + dg.lds_hb[2];
+    double *hbw = lds + dg.lds_hb[2], *l1w = lds + dg.lds_off[1];
+    const double *l2 = lds + dg.lds_off[2];
+    const bool small = nS <= PF * NT;
+    double nxt[PF];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const double *src = cS + (size_t)(t < t_end ? t : t_first) * fs;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) nxt[p] = (off_l[p] >= 0 && t < t_end) ? src[off_g[p]] : 0.0;
+    };
+    if (small) fetch(t_first);
+    for (int t = t_first; t < t_end; ++t) {
+        if (small) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) dS[off_l[p]] = nxt[p];
+            fetch(t + 1);
+        } else {
+            const double *src = cS + (size_t)t * fs;
+            const float inv = 1.0f / (float)nwS;
+            for (int i = tid; i < nS; i += NT) {
+                int r, c;
+                split_rc(i, nwS, inv, r, c);
+                dS[i] = src[(size_t)(RS.y0 + r) * wS + RS.x0 + c];
+            }
+        }
+        __syncthreads();
+        if (S == 2) {
+            double a[NH], b[NH], c[NH];
+#pragma unroll
+            for (int n = 0; n < NH; ++n) { a[n] = l2[h_src[n][0]]; b[n] = l2[h_src[n][1]]; c[n] = l2[h_src[n][2]]; }
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+                if (h_dst[n] >= 0) hbw[h_dst[n]] = (a[n] * (double)h_w[n][0] + b[n] * (double)h_w[n][1]) + c[n] * (double)h_w[n][2];
+            __syncthreads();
+            double h0[NV], h1[NV], h2[NV];
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int o0 = v_src[n][0] < 0 ? v_src[n][1] : v_src[n][0];
+                h0[n] = hb[o0]; h1[n] = hb[v_src[n][1]]; h2[n] = hb[v_src[n][2]];
+            }
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                if (v_dst[n] >= 0) {
+                    const double odd = (h1[n] + h2[n]) * 4, even = h0[n] + h1[n] * 6 + h2[n];
+                    l1w[v_dst[n]] = ((v_src[n][0] < 0) ? odd : even) * (1.0 / 64);
+                }
+            }
+            __syncthreads();
+        }
+        if (col_ok) {
+            double hv[RPW / 2 + 2];
+#pragma unroll
+            for (int k = 0; k < RPW / 2 + 2; ++k) {
+                const double *row = l1 + l0_row[k];
+                hv[k] = (row[0] * l0_wa + row[l0_b] * l0_wb) + row[l0_c] * l0_wc;
+            }
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int k = (j >> 1) + 1;
+                const double v = (j & 1) ? ((hv[k] + hv[k + 1]) * 4) * (1.0 / 64) : (hv[k - 1] + hv[k] * 6 + hv[k + 1]) * (1.0 / 64);
+                acc[j] = acc[j] + ((v >= top) ? min_val : v);
+            }
+        }
+        if (S == 1) __syncthreads();
+    }
+    const double cnt = (double)avg_T;   // base.py:562-563
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+    if (col_ok) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            if (j < rows) {
+                const double v = avg_T > 0 ? acc[j] / cnt : acc[j];
+                heat_sum[(size_t)(y_first + j) * g.w[0] + x] = v;
+                hmn = (v < hmn) ? v : hmn; hmx = (v > hmx) ? v : hmx;
+            }
+        }
+    }
+    if (tile_nkept && lane == 0 && y_first <= R0.y1 && y_first % CT_H == 0)
+        tile_nkept[(y_first / CT_H) * g.tiles_x + sxi] = t_end - t_first;
+    if (avg_T > 0) {
+        block_minmax(hmn, hmx);
+        if (tid == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp = blockIdx.x & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+        }
+    }
+}
+
 }  // namespace rm

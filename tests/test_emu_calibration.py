@@ -419,6 +419,11 @@ def test_emu_dense_sum_equals_sparse_path(emu, monkeypatch):
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, rows)
         dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128 | 1)
         assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "no_prune")
+        if S <= 2:      # skip <= 2 takes the table-driven kernel: the general one must agree there too
+            monkeypatch.setenv("RM_DENSE_GENERAL", "1")
+            dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+            monkeypatch.delenv("RM_DENSE_GENERAL")
+            assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "general kernel")
         auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)        # uniform noise keeps every pair: dense from the second call on
         assert np.array_equal(auto, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "auto")
     monkeypatch.delenv("RM_DENSE_ROWS", raising=False)

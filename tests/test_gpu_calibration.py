@@ -638,6 +638,13 @@ def test_dense_sum_equals_sparse_path(hip, oracle, monkeypatch):
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows)
             assert sum_path() == "dense"
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=128 | 1, **kw), sparse), (dt, T, H, W, L, S)
+        if S <= 2:      # skip <= 2 takes the table-driven kernel: the general one must agree there too
+            for rows in ("16", "32", "64"):
+                monkeypatch.setenv("RM_DENSE_ROWS", rows)
+                monkeypatch.setenv("RM_DENSE_GENERAL", "1")
+                assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows, "general")
+            monkeypatch.delenv("RM_DENSE_GENERAL")
+            monkeypatch.delenv("RM_DENSE_ROWS")
     monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
     # config Q: dense by itself from the second call of the geometry on
     T, H, W, L, S = 128, 720, 1280, 4, 2

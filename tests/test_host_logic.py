@@ -225,3 +225,16 @@ def test_run_reports_bpm_for_config1(golden):
     assert len(mon.data) == 64 and len(mon.freq) > 0
     assert abs(mon.freq[-1] - float(g["freq0"][-1])) <= 1e-9 * float(g["freq0"][-1])
     assert abs(mon.freq[-1] - 24.0) < 1.0
+
+
+def test_flag_constants_match_the_header():
+    """respmon_amd/_capi.py mirrors the RM_FLAG_* values of include/respmon_hip.h (the ctypes boundary has no compiler to do it)."""
+    import re
+    from respmon_amd import _capi
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "respmon_hip.h")).read()
+    flags = dict(re.findall(r"#define\s+(RM_FLAG_\w+)\s+(\d+)u", text))
+    assert len(flags) >= 9
+    for name, value in flags.items():
+        assert getattr(_capi, name) == int(value), name
+    assert len(set(flags.values())) == len(flags)          # one bit each
+    assert all(int(v) & (int(v) - 1) == 0 for v in flags.values())
