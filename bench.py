@@ -245,6 +245,10 @@ def main():
     _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
     pairs = {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3],
              "sum_path": "dense (every pair recomputed by the sum kernel, no value store)" if dbg[3] == 0 and dbg[0] else "sparse"}
+    cn, cl = ctypes.c_int(0), ctypes.c_int(0)
+    _capi.check(lib, lib.rm_contour_stats(ctx, ctypes.byref(cn), ctypes.byref(cl)), "rm_contour_stats")
+    contour_stage = {"components": cn.value,
+                     "path": "device labelling + host border following of the candidates" if cl.value else "host border following"}
     # phase breakdown: separate untimed pass (bracketing every phase costs ~10 us of stream idle time each)
     _capi.check(lib, lib.rm_profile_enable(ctx, 2), "rm_profile_enable")
     for _ in range(3):
@@ -384,6 +388,7 @@ def main():
             "alt_uint8_buffer": alt,
             "roi_flow": roi_flow,
             "collapse_pairs": pairs,
+            "contour_stage": contour_stage,
             "no_prune": no_prune,
             "dense_stream": dense,
         }

@@ -254,6 +254,16 @@ int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gr
  *      RM_FLAG_CONTOUR_CLIP_FRAME. */
 int rm_set_contour_clip_frame(rm_ctx *ctx, int on);
 
+/* ---- base.py:568-575 on noisy thresholded images.  locate() keeps ONE contour (max contourArea -> boundingRect); when the
+ *      image holds thousands of specks (BASELINE configs 2 / 5) the device labels the 8-connected components, reduces their
+ *      bounding boxes and the host follows only the borders whose (w-1)*(h-1) bound can reach the best area -- same contour,
+ *      same tie rule, no per-speck border following (csrc/rm_ccl.h).
+ *      mode = -1 (default): taken when the previous ROI extraction of this geometry met more than 512 components;
+ *      0: never (every border is followed on the host); 1: always.  The ROI does not depend on the mode.
+ *      rm_contour_stats: components / contours met by the last ROI extraction and whether it ran labelled (diagnostics). */
+int rm_set_contour_labelling(rm_ctx *ctx, int mode);
+int rm_contour_stats(rm_ctx *ctx, int *n_components, int *labelled);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,8 @@ SIGNATURES = {
     "rm_ctx_workspace_bytes": (_sz, [_vp]),
     "rm_profile_enable": (_i, [_vp, _i]),
     "rm_set_contour_clip_frame": (_i, [_vp, _i]),
+    "rm_set_contour_labelling": (_i, [_vp, _i]),
+    "rm_contour_stats": (_i, [_vp, _vp, _vp]),
     "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_debug_counters": (_i, [_vp, _vp, _vp]),
     "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),

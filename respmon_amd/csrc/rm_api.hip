@@ -21,6 +21,7 @@
 #include "rm_down_chain.h"
 #include "rm_down_chain_u8.h"
 #include "rm_dense_sum.h"
+#include "rm_ccl.h"
 #include "rm_flow.h"
 
 using namespace rm;
@@ -76,6 +77,10 @@ struct rm_ctx {
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned: bit-packed thresholded image + H row flags (k_heat_to_u8)
     bool clip_frame = false, clip_frame_once = false;      // cv2.findContours of OpenCV <= 3.1 (rm_set_contour_clip_frame / RM_FLAG_CONTOUR_CLIP_FRAME)
     uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
+    // device labelling of the thresholded image (rm_ccl.h): taken when the previous ROI extraction of this geometry met
+    // more than LABEL_MIN_CONTOURS components (label_mode -1 = that rule, 0 = never, 1 = always: rm_set_contour_labelling)
+    int label_mode = -1, label_H = 0, label_W = 0, label_last_n = 0, label_used = 0;
+    CclComp *h_comps = nullptr; size_t h_comps_cap = 0;    // pinned: [0] = {count, -, -, -}, then one record per component
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     bool state_fresh = false;   // d_state was reset by the last kernel of front_pyramid and nothing has reduced into it since
@@ -172,6 +177,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
+    if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
@@ -1470,6 +1476,9 @@ __global__ __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st)
     if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
 }
 
+constexpr int LABEL_MIN_CONTOURS = 512;   // ~0.13 us per followed border on the host against ~40 us of labelling kernels
+static_assert(sizeof(CclComp) == sizeof(LabelComp), "record layout shared by rm_ccl.h and rm_contour.h");
+
 static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
                                uint8_t *binary, void *stream, bool have_minmax)
 {
@@ -1503,9 +1512,50 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         hipLaunchKernelGGL(k_heat_minmax, dim3(nblk(npix, 256, 256)), dim3(256), 0, s, heat, npix, st);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
-                       (unsigned long long *)dev_bin, dev_bin + nwords * 8);
-    LAUNCH_CHECK();
+    // noisy images: label the components on the device so that the host follows only borders that can win (rm_ccl.h)
+    const bool clip = ctx->clip_frame || ctx->clip_frame_once;
+    const bool same_geom = ctx->label_H == H && ctx->label_W == W;
+    const bool label = !clip && npix < (size_t)0x7fffffff &&
+                       (ctx->label_mode == 1 || (ctx->label_mode < 0 && same_geom && ctx->label_last_n > LABEL_MIN_CONTOURS));
+    unsigned long long *d_bits = nullptr;
+    const size_t comps_cap = std::min<size_t>(npix / 4 + 2, (size_t)1 << 18);
+    if (label) {
+        int *d_label = nullptr; CclBox *d_box = nullptr; unsigned int *d_cnt = nullptr; CclComp *d_list = nullptr;
+        RM_TRY(ws(ctx, "ccl_list", comps_cap, &d_list));
+        RM_TRY(ws(ctx, "ccl_bits", nwords, &d_bits));
+        RM_TRY(ws(ctx, "ccl_label", npix, &d_label));
+        RM_TRY(ws(ctx, "ccl_box", npix, &d_box));
+        RM_TRY(ws(ctx, "ccl_counters", (size_t)2, &d_cnt));
+        if (ctx->h_comps_cap < comps_cap + 1) {
+            if (ctx->h_comps) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(ctx->h_comps)); }
+            ctx->h_comps = nullptr; ctx->h_comps_cap = 0;
+            HIP_TRY(hipHostMalloc((void **)&ctx->h_comps, (comps_cap + 1) * sizeof(CclComp), hipHostMallocDefault));
+            ctx->h_comps_cap = comps_cap + 1;
+        }
+        CclComp *dev_comps = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, ctx->h_comps, 0));
+        hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
+                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits);
+        LAUNCH_CHECK();
+        const dim3 grid((unsigned)((npix + 255) / 256));
+        hipLaunchKernelGGL(k_ccl_init, grid, dim3(256), 0, s, d_bits, npix, W, d_label, d_box, d_cnt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_ccl_union, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_ccl_bbox, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label, d_box);
+        LAUNCH_CHECK();
+        const int groups = (int)std::max<size_t>(1, (npix + (size_t)256 * 1024 - 1) / ((size_t)256 * 1024));   // ~1 000 workgroups
+        const dim3 egrid((unsigned)((npix + (size_t)256 * groups - 1) / ((size_t)256 * groups)));
+        hipLaunchKernelGGL(k_ccl_emit, egrid, dim3(256), 0, s, d_bits, npix, d_label, d_box, W, groups, d_cnt, d_list,
+                           (unsigned int)comps_cap);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_ccl_publish, dim3(64), dim3(256), 0, s, d_list, d_cnt, (unsigned int)comps_cap, dev_comps);
+        LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
+                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, (unsigned long long *)nullptr);
+        LAUNCH_CHECK();
+    }
     delete pt_roi; pt_roi = nullptr;
     HIP_TRY(stream_wait(s));
     RoiResult r;
@@ -1525,7 +1575,13 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
             }
         }
         ctx->clip_frame_once = false;
-        largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
+        const size_t ncomp = label ? (size_t)(unsigned int)ctx->h_comps[0].root : 0;
+        ctx->label_used = label && ncomp <= comps_cap;
+        if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
+            largest_external_contour_labelled((const uint64_t *)ctx->h_bin, H, W, (const LabelComp *)(ctx->h_comps + 1), ncomp, &r);
+        else
+            largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
+        ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
         if (y1 >= y0) {   // restore the all-zero image: the words that cover rows y0 .. y1
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
             std::memset(ctx->h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
@@ -1604,6 +1660,21 @@ extern "C" int rm_heat_sparse_tiles_needed(rm_ctx *ctx, int *tiles)
 {
     if (!ctx || !tiles) return fail(RM_E_BADARG, "rm_heat_sparse_tiles_needed: bad argument");
     *tiles = ctx->h_flag ? ctx->h_flag[1] : 0;
+    return RM_OK;
+}
+
+extern "C" int rm_set_contour_labelling(rm_ctx *ctx, int mode)
+{
+    if (!ctx) return fail(RM_E_BADARG, "rm_set_contour_labelling: ctx is NULL");
+    ctx->label_mode = mode < 0 ? -1 : mode > 0 ? 1 : 0;
+    return RM_OK;
+}
+
+extern "C" int rm_contour_stats(rm_ctx *ctx, int *n_components, int *labelled)
+{
+    if (!ctx) return fail(RM_E_BADARG, "rm_contour_stats: ctx is NULL");
+    if (n_components) *n_components = ctx->label_last_n;
+    if (labelled) *labelled = ctx->label_used;
     return RM_OK;
 }
 

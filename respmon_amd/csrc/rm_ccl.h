@@ -1,0 +1,172 @@
+// respmon_amd/csrc/rm_ccl.h -- device half of the ROI stage for NOISY thresholded images (base.py:568-575).
+//
+//   cv2.findContours(thresh, RETR_EXTERNAL, ...) -> max(contours, key=cv2.contourArea) -> cv2.boundingRect
+//
+// locate() consumes ONE contour.  On a noisy heatmap (BASELINE configs 2 / 5: level 2 of a 4-level pyramid is noise
+// dominated) the thresholded image holds thousands of specks, and following every one of their borders on the host was half
+// of the step (7 466 borders, 0.94 ms at 720p; 4.5 ms at 4K).  None of them can win:
+//   * an external contour is the outer border of one 8-connected component, its boundingRect is the component's bounding
+//     box, and its shoelace area (a polygon through pixel centres inside that box) is at most (w-1)*(h-1);
+//   * a component nested in a hole of another one (which RETR_EXTERNAL does not list) lies strictly inside the enclosing
+//     outer border, so its area is strictly smaller and it can never be the maximum either way.
+// So the device labels the components (union-find over the bit-packed image, root = smallest pixel index = the pixel
+// Suzuki-Abe starts the outer border at), reduces a bounding box per root and hands the host one 16-byte record per
+// component; the host follows only borders whose bound can reach the best area found so far (rm_contour.cpp,
+// largest_external_contour_labelled) -- typically one.  Exact: same contour, same ties (last discovered = largest root).
+//
+// Four launches over the H*W bits (and a small copy kernel), one thread per pixel (84 % of the threads of a 16 %-foreground image leave at once):
+//   k_ccl_init    label = first pixel of the pixel's run inside its 64-bit word (rows break runs), bounding boxes reset
+//   k_ccl_union   joins with the row above / the word to the left, lock-free (atomicMin on the larger root)
+//   k_ccl_bbox    every run end / bottom pixel folds its coordinates into its root's box
+//   k_ccl_emit    roots -> {root, minx, width-1, height-1} records, wave-aggregated slot reservation
+//   k_ccl_publish the record list and its length -> pinned host memory, in whole cache lines
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rm {
+
+struct CclComp { int root, minx, w1, h1; };   // box: x = minx, y = root / W, width w1 + 1, height h1 + 1
+struct alignas(16) CclBox { int minx, maxx, maxy, pad; };
+
+__device__ inline bool ccl_bit(const unsigned long long *bits, size_t p) { return (bits[p >> 6] >> (p & 63)) & 1ull; }
+
+__device__ inline int ccl_find(const int *label, int a)
+{
+    int l = label[a];
+    while (l != a) { a = l; l = label[a]; }
+    return a;
+}
+
+__device__ inline void ccl_union(int *label, int a, int b)
+{
+    for (;;) {
+        a = ccl_find(label, a);
+        b = ccl_find(label, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }   // a < b: b's tree hangs under a
+        const int old = atomicMin(&label[b], a);
+        if (old == b) return;
+        b = old;                                         // somebody re-rooted b meanwhile: join with what it points to now
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(const unsigned long long *bits, size_t npix, int W, int *label, CclBox *box,
+                                                  unsigned int *counters)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p == 0) { counters[0] = 0; counters[1] = 0; }
+    if (p >= npix) return;
+    const unsigned long long w = bits[p >> 6];
+    const int b = (int)(p & 63);
+    if (!((w >> b) & 1ull)) return;
+    // first bit of the run of ones that ends at bit b (inside this word), not crossing the start of pixel p's image row
+    const unsigned long long zeros_below = ~w & ((1ull << b) - 1ull);
+    int run0 = zeros_below ? 64 - __builtin_clzll(zeros_below) : 0;
+    const int x = (int)(p % (size_t)W);
+    if (b - run0 > x) run0 = b - x;
+    label[p] = (int)(p - (size_t)(b - run0));
+    // the box of the component this pixel may end up the root of starts at the pixel itself: single pixels (most of a noise
+    // image) never need an atomic in k_ccl_bbox
+    CclBox e; e.minx = x; e.maxx = x; e.maxy = (int)(p / (size_t)W); e.pad = 0;
+    box[p] = e;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits, size_t npix, int H, int W, int *label)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix || !ccl_bit(bits, p)) return;
+    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
+    const bool w_fg = x > 0 && ccl_bit(bits, p - 1);
+    // a run that continues from the previous word of the same row
+    if (w_fg && (p & 63) == 0) ccl_union(label, (int)p, (int)p - 1);
+    if (y == 0) return;
+    const size_t up = p - (size_t)W;
+    const bool n_fg = ccl_bit(bits, up);
+    const bool nw_fg = x > 0 && ccl_bit(bits, up - 1);
+    if (n_fg) {
+        // west neighbour joined with its own north (= our north-west), which touches our north: already one component
+        if (!(w_fg && nw_fg)) ccl_union(label, (int)p, (int)up);
+        return;
+    }
+    if (nw_fg && !w_fg) ccl_union(label, (int)p, (int)(up - 1));   // otherwise west joins with it (it is west's north)
+    if (x + 1 < W && ccl_bit(bits, up + 1)) {
+        const bool e_fg = ccl_bit(bits, p + 1);
+        if (!e_fg) ccl_union(label, (int)p, (int)(up + 1));        // otherwise east joins with it (it is east's north)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_bbox(const unsigned long long *bits, size_t npix, int H, int W, int *label, CclBox *box)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix || !ccl_bit(bits, p)) return;
+    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
+    const bool run_first = !(x > 0 && ccl_bit(bits, p - 1));
+    const bool run_last = !(x + 1 < W && ccl_bit(bits, p + 1));
+    // a pixel of the component's bottom row has no foreground straight below it
+    const bool bottom = !(y + 1 < H && ccl_bit(bits, p + (size_t)W));
+    if (!(run_first || run_last || bottom)) return;
+    const int r = ccl_find(label, (int)p);
+    if (r == (int)p) return;                 // the root's own coordinates are in its box since k_ccl_init
+    int *b = (int *)&box[r];
+    // the box only ever grows: a (possibly stale) value that already covers this pixel makes the atomic unnecessary
+    const CclBox cur = box[r];
+    if (run_first && x < cur.minx) atomicMin(b + 0, x);
+    if (run_last && x > cur.maxx) atomicMax(b + 1, x);
+    if (bottom && y > cur.maxy) atomicMax(b + 2, y);
+}
+
+// counters[0]: records reserved.  `out` is a device list: 16-byte records scattered one by one into pinned host memory cost a
+// PCIe write each (136 us for 7 466 records); k_ccl_publish moves the list in full cache lines instead.
+// Every atomicAdd on the one counter takes ~10 ns of the L2's atomic unit whatever the grid does meanwhile (one per wave:
+// 5 700 of them, 70 us at 720p), so a workgroup counts the roots of 4 x `groups` 64-pixel groups first and reserves its
+// slots with ONE atomic; the second sweep re-evaluates the predicate (bits and labels are cache hits) and stores.
+__global__ __launch_bounds__(256) void k_ccl_emit(const unsigned long long *bits, size_t npix, const int *label, const CclBox *box,
+                                                  int W, int groups, unsigned int *counters, CclComp *out, unsigned int cap)
+{
+    __shared__ unsigned int wave_cnt[4];
+    __shared__ unsigned int block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t first = ((size_t)blockIdx.x * 4 + wave) * (size_t)groups * 64;
+    unsigned int mine = 0;
+    for (int k = 0; k < groups; ++k) {
+        const size_t p = first + (size_t)k * 64 + lane;
+        const bool root = p < npix && ccl_bit(bits, p) && label[p] == (int)p;
+        mine += (unsigned int)__popcll(__ballot(root));
+    }
+    if (lane == 0) wave_cnt[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        block_base = total ? atomicAdd(&counters[0], total) : 0u;
+    }
+    __syncthreads();
+    unsigned int slot0 = block_base;
+    for (int w = 0; w < wave; ++w) slot0 += wave_cnt[w];
+    for (int k = 0; k < groups; ++k) {
+        const size_t p = first + (size_t)k * 64 + lane;
+        const bool root = p < npix && ccl_bit(bits, p) && label[p] == (int)p;
+        const unsigned long long m = __ballot(root);
+        if (root) {
+            const unsigned int slot = slot0 + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                const CclBox bb = box[p];
+                CclComp c; c.root = (int)p; c.minx = bb.minx; c.w1 = bb.maxx - bb.minx; c.h1 = bb.maxy - (int)(p / (size_t)W);
+                out[slot] = c;
+            }
+        }
+        slot0 += (unsigned int)__popcll(m);
+    }
+}
+
+// device list -> pinned host memory; host[0].root = the number of components (> cap: the list overflowed and the host follows
+// every border itself), records from host[1] on
+__global__ __launch_bounds__(256) void k_ccl_publish(const CclComp *list, const unsigned int *counters, unsigned int cap, CclComp *host)
+{
+    const unsigned int total = counters[0];
+    const unsigned int n = total < cap ? total : cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { CclComp h; h.root = (int)total; h.minx = 0; h.w1 = 0; h.h1 = 0; host[0] = h; }
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) host[1 + i] = list[i];
+}
+
+}  // namespace rm

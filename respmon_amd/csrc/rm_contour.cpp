@@ -291,6 +291,85 @@ int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y
     return scan_runs(g_tracer, bits, H, W, out, y0, y1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Labelled variant.  The outer border of a component starts at its smallest pixel index (top row, leftmost pixel), its
+// bounding box is the component's, and twice its area is at most 2 (w-1)(h-1); components nested in a hole have a strictly
+// smaller area than the enclosing border, so it does not matter that RETR_EXTERNAL would not list them.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BitImage {
+    const uint64_t *bits; int H, W;
+    inline bool fg(int x, int y) const
+    {
+        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return false;
+        const size_t p = (size_t)y * W + x;
+        return (bits[p >> 6] >> (p & 63)) & 1ull;
+    }
+};
+
+// twice the signed shoelace area of the outer border that starts at (sx, sy): Tracer::follow without marks
+long long follow_bits(const BitImage &im, int sx, int sy)
+{
+    static const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    static const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int dir = 4, fx, fy;
+    do {
+        dir = (dir - 1) & 7;
+        fx = sx + dx[dir]; fy = sy + dy[dir];
+    } while (!im.fg(fx, fy) && dir != 4);
+    if (dir == 4) return 0;   // isolated pixel
+    long long twice_area = 0;
+    int cx = sx, cy = sy;
+    for (;;) {
+        int nx, ny;
+        for (;;) {
+            ++dir;
+            nx = cx + dx[dir & 7]; ny = cy + dy[dir & 7];
+            if (im.fg(nx, ny)) break;
+        }
+        dir &= 7;
+        twice_area += (long long)cx * ny - (long long)nx * cy;
+        if (nx == sx && ny == sy && cx == fx && cy == fy) break;
+        cx = nx; cy = ny;
+        dir = (dir + 4) & 7;
+    }
+    return twice_area;
+}
+}  // namespace
+
+int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const LabelComp *comps, size_t n, RoiResult *out)
+{
+    out->found = 0; out->n_contours = (int)n; out->area = 0.0;
+    out->x = out->y = out->w = out->h = 0;
+    if (H <= 0 || W <= 0 || n == 0) return 0;
+    const BitImage im{bits, H, W};
+    auto bound2 = [](const LabelComp &c) { return 2ll * (long long)c.w1 * (long long)c.h1; };   // twice the largest area inside the box
+    long long best2 = -1; size_t best_i = 0;
+    auto consider = [&](size_t i) {
+        const LabelComp &c = comps[i];
+        long long a2 = 0;
+        if (c.w1 > 0 && c.h1 > 0) { a2 = follow_bits(im, c.root % W, c.root / W); if (a2 < 0) a2 = -a2; }
+        // max() over cv2's reversed list keeps, among equal areas, the border discovered last = the largest start index
+        if (a2 > best2 || (a2 == best2 && c.root > comps[best_i].root)) { best2 = a2; best_i = i; }
+    };
+    // the component with the largest bound sets the bar (on a blob in noise it is the winner) ...
+    long long top = -1; size_t top_i = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const long long b = bound2(comps[i]);
+        if (b > top) { top = b; top_i = i; }
+    }
+    consider(top_i);
+    // ... then everything that can still reach (or tie with) the best area so far; the bar rises as borders are followed
+    for (size_t i = 0; i < n; ++i)
+        if (i != top_i && bound2(comps[i]) >= best2) consider(i);
+    const LabelComp &c = comps[best_i];
+    out->found = 1;
+    out->x = c.minx; out->y = c.root / W;
+    out->w = c.w1 + 1; out->h = c.h1 + 1;
+    out->area = 0.5 * (double)best2;
+    return 0;
+}
+
 // `have_ranges`: pixels left of row_x0 / right of row_x1 are background without marks (borders only visit
 // foreground pixels), so the raster scan of a row may start at its first and stop after its last foreground pixel
 static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out, bool have_ranges)

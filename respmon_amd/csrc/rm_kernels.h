@@ -1728,7 +1728,8 @@ __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t 
 // makes the NEXT launch ~100 us slower.)
 __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
-                                                    unsigned long long *bits, uint8_t *row_any)
+                                                    unsigned long long *bits, uint8_t *row_any,
+                                                    unsigned long long *bits_dev)
 {
     RM_TRACE_SCOPE(7);
     const int lane = threadIdx.x & 63;
@@ -1761,6 +1762,7 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                 if (binary) binary[i] = b;
             }
             const unsigned long long m = __ballot(b != 0);
+            if (lane == 0 && bits_dev) bits_dev[base >> 6] = m;   // device copy for the labelling kernels (rm_ccl.h): every word
             if (lane == 0 && bits && m) {   // the host keeps the image all-zero between calls: only set words travel
                 bits[base >> 6] = m;
                 if (row_any) {   // the group may straddle row ends: flag every row it touches (a superset is fine)

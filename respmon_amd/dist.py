@@ -74,20 +74,36 @@ def hip_calibrate(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyram
     return heat
 
 
-def hip_heatmap_to_roi(heat, threshold=20, clip_frame=False):
-    """base.py:563-575 on a device heatmap.  clip_frame=True: cv2.findContours as OpenCV <= 3.1 did it (rm_set_contour_clip_frame)."""
+def hip_heatmap_to_roi(heat, threshold=20, clip_frame=False, labelling=None):
+    """base.py:563-575 on a device heatmap.  clip_frame=True: cv2.findContours as OpenCV <= 3.1 did it (rm_set_contour_clip_frame).
+    labelling: None = the library's rule, False / True = follow every border on the host / label the components on the device
+    first (rm_set_contour_labelling); the ROI is the same."""
     import ctypes
     from . import _capi, device
     lib = _capi.load()
     H, W = heat.shape
     xywh = (ctypes.c_int32 * 4)()
     _capi.check(lib, lib.rm_set_contour_clip_frame(device.ctx(), 1 if clip_frame else 0), "rm_set_contour_clip_frame")
+    if labelling is not None:
+        _capi.check(lib, lib.rm_set_contour_labelling(device.ctx(), 1 if labelling else 0), "rm_set_contour_labelling")
     try:
         rc = _capi.check(lib, lib.rm_heatmap_to_roi(device.ctx(), device.ptr(heat), H, W, int(threshold), xywh, None, None,
                                                     device.stream_ptr()), "rm_heatmap_to_roi")
     finally:
         lib.rm_set_contour_clip_frame(device.ctx(), 0)
+        if labelling is not None:
+            lib.rm_set_contour_labelling(device.ctx(), -1)
     return None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
+
+
+def contour_stats():
+    """(components / contours the last ROI extraction of this process's context met, whether it ran on the labelled path)."""
+    import ctypes
+    from . import _capi, device
+    lib = _capi.load()
+    n, lab = ctypes.c_int(), ctypes.c_int()
+    _capi.check(lib, lib.rm_contour_stats(device.ctx(), ctypes.byref(n), ctypes.byref(lab)), "rm_contour_stats")
+    return n.value, bool(lab.value)
 
 
 LAST_EXCHANGE = None      # "sparse" / "dense": how the last locate_streams summed the heatmaps (bench.py reports it)

@@ -90,14 +90,21 @@ class Emu:
                                       flags, ptr(heat), ptr(mm), None), "calibrate")
         return heat, mm
 
-    def heatmap_to_roi(self, heat, threshold=20, clip_frame=False):
+    def heatmap_to_roi(self, heat, threshold=20, clip_frame=False, labelling=-1):
         heat = np.ascontiguousarray(heat, dtype=np.float64)
         H, W = heat.shape
         xywh = np.zeros(4, np.int32); u8 = np.empty((H, W), np.uint8); b = np.empty((H, W), np.uint8)
         self.ck(self.lib.rm_set_contour_clip_frame(self.ctx, 1 if clip_frame else 0), "clip_frame")
+        self.ck(self.lib.rm_set_contour_labelling(self.ctx, labelling), "labelling")
         rc = self.ck(self.lib.rm_heatmap_to_roi(self.ctx, ptr(heat), H, W, threshold, ptr(xywh), ptr(u8), ptr(b), None), "roi")
         self.lib.rm_set_contour_clip_frame(self.ctx, 0)
+        self.lib.rm_set_contour_labelling(self.ctx, -1)
         return (None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)), u8, b
+
+    def contour_stats(self):
+        n, lab = ctypes.c_int(), ctypes.c_int()
+        self.ck(self.lib.rm_contour_stats(self.ctx, ctypes.byref(n), ctypes.byref(lab)), "contour_stats")
+        return n.value, lab.value
 
     def locate(self, frames, fps, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, threshold=20, flags=0):
         frames = np.ascontiguousarray(frames)

@@ -448,3 +448,60 @@ def test_emu_filter_first_per_level_equals_fused(emu, monkeypatch):
         assert np.array_equal(per_level, fused) and tuple(mm) == tuple(mm2), (T, H, W, L, S)
         assert np.abs(fused - ref).max() <= 1e-12 * np.abs(ref).max(), (T, H, W, L, S)
     monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
+
+
+def test_emu_contour_stage_device_labelling(emu, oracle):
+    """rm_ccl.h: the device labels the 8-connected components of the thresholded image and the host follows only the borders
+    whose bounding-box bound can win.  Same ROI as following every border (mode 0) and as the oracle's findContours
+    restatement: noise at several densities, widths that are not multiples of the 64-pixel words (runs must not cross row
+    ends), nested components, equal-area ties (the LAST discovered border wins), zero-area components only, empty image."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(77)
+    masks = []
+    for (h, w, dens) in [(40, 131, 0.15), (64, 64, 0.35), (57, 200, 0.5), (33, 129, 0.62), (20, 70, 0.05), (48, 192, 0.45),
+                         (31, 63, 0.3), (9, 257, 0.4), (70, 5, 0.5), (1, 90, 0.5), (50, 1, 0.5), (2, 2, 1.0)]:
+        masks.append(rng.random((h, w)) < dens)
+    for k in range(6):   # a blob in noise: what configs 2 / 5 look like
+        m = rng.random((60, 150)) < 0.16
+        blob = ndi.gaussian_filter(rng.standard_normal((60, 150)), 4.0) > 0.06
+        masks.append(m | blob)
+    ring = np.zeros((60, 150), bool)
+    ring[5:55, 10:90] = True; ring[12:48, 20:80] = False; ring[20:40, 30:70] = True; ring[25:35, 40:60] = False
+    ring[28:32, 45:55] = True
+    ring[:, 100:] = rng.random((60, 50)) < 0.3
+    masks.append(ring)
+    ties = np.zeros((40, 100), bool)          # three 6x6 squares (equal areas) and a diagonal line with a larger box, area 0
+    for (y, x) in [(3, 5), (3, 40), (20, 22)]:
+        ties[y:y + 6, x:x + 6] = True
+    ties[np.arange(10, 30), np.arange(60, 80)] = True
+    masks.append(ties)
+    dots = np.zeros((20, 70), bool); dots[::3, ::5] = True     # isolated pixels only: every area is 0
+    masks.append(dots)
+    lines = np.zeros((20, 70), bool); lines[4, 3:40] = True; lines[9, 10:66] = True; lines[12:19, 68] = True
+    masks.append(lines)
+    full = np.ones((17, 66), bool); full[8, 33] = False
+    masks.append(full)
+    masks.append(np.zeros((12, 40), bool))
+    for m in masks:
+        heat = m.astype(np.float64)
+        if not m.any() or m.all():
+            heat = heat + 0.0   # flat heatmap: NaN normalisation -> nothing above the threshold
+        roi_l, u8, binary = emu.heatmap_to_roi(heat, threshold=20, labelling=1)
+        n_l, used = emu.contour_stats()
+        roi_h, _, _ = emu.heatmap_to_roi(heat, threshold=20, labelling=0)
+        n_h, used_h = emu.contour_stats()
+        assert used == 1 and used_h == 0
+        assert roi_l == roi_h, (m.shape, roi_l, roi_h)
+        if m.any() and not m.all():
+            assert np.array_equal(binary != 0, m)
+            assert roi_l == oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20), m.shape
+            import scipy.ndimage as ndi2
+            assert n_l == ndi2.label(m, structure=np.ones((3, 3)))[1]      # every 8-connected component has one record
+            assert n_h <= n_l                                              # RETR_EXTERNAL skips nested components
+    # the automatic rule: a geometry whose last extraction met many components switches to the labelled path
+    noisy = (rng.random((64, 256)) < 0.2).astype(np.float64)
+    emu.heatmap_to_roi(noisy, threshold=20)
+    assert emu.contour_stats()[1] == 0 and emu.contour_stats()[0] > 512
+    r2 = emu.heatmap_to_roi(noisy, threshold=20)[0]
+    assert emu.contour_stats()[1] == 1
+    assert r2 == emu.heatmap_to_roi(noisy, threshold=20, labelling=0)[0]

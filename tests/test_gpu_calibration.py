@@ -683,3 +683,51 @@ def test_filter_first_per_level_equals_fused(hip, monkeypatch):
     buf = torch.from_numpy(rng.random((6, 2160, 3840)).astype(np.float16)).cuda()
     kw = dict(pyramid_levels=6, skip_levels_at_top=2)
     assert _close(dist.hip_calibrate(buf, 10, **kw), dist.hip_calibrate(buf, 10, flags=2, **kw))
+
+
+def test_contour_stage_device_labelling(hip, oracle):
+    """rm_ccl.h on the GPU (lock-free union-find with thousands of waves in flight): labelled ROI == ROI from following every
+    border == the oracle's findContours restatement; one record per 8-connected component (scipy.ndimage.label).  Sizes up to
+    4K, noise densities around and beyond the percolation threshold (one component snaking through the whole image), a blob in
+    16 % noise (what BASELINE configs 2 / 5 threshold to), rows that straddle the 64-pixel words."""
+    import torch
+    import scipy.ndimage as ndi
+    from respmon_amd import dist
+    rng = np.random.default_rng(2024)
+    cases = []
+    for (h, w, dens) in [(720, 1280, 0.16), (720, 1280, 0.45), (1080, 1920, 0.30), (2160, 3840, 0.02), (2160, 3840, 0.62),
+                         (333, 1001, 0.5), (97, 4099, 0.4), (1500, 63, 0.55), (64, 64, 0.9)]:
+        cases.append(rng.random((h, w)) < dens)
+    for (h, w, dens) in [(720, 1280, 0.16), (2160, 3840, 0.03), (411, 777, 0.16)]:
+        m = rng.random((h, w)) < dens
+        yy, xx = np.mgrid[0:h, 0:w]
+        m |= ((yy - 0.45 * h) / (0.11 * h)) ** 2 + ((xx - 0.6 * w) / (0.06 * w)) ** 2 < 1.0
+        cases.append(m)
+    spiral = np.zeros((600, 600), bool)                 # one long thin component: deep union-find chains
+    for k in range(0, 290, 4):
+        spiral[k, k:600 - k] = True; spiral[k:600 - k, 599 - k] = True
+        spiral[599 - k, k + 2:600 - k] = True; spiral[k + 4:600 - k, k + 2] = True
+    cases.append(spiral)
+    for m in cases:
+        heat = torch.from_numpy(m.astype(np.float64)).cuda()
+        roi_l = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
+        n_l, used = dist.contour_stats()
+        assert used
+        roi_h = dist.hip_heatmap_to_roi(heat, 20, labelling=False)
+        assert not dist.contour_stats()[1]
+        assert roi_l == roi_h, (m.shape, roi_l, roi_h)
+        assert n_l == ndi.label(m, structure=np.ones((3, 3)))[1], m.shape
+        if m.size <= 1300 * 800:
+            assert roi_l == oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20), m.shape
+    # more components than the record list holds (2^18): the host follows every border of the image it has anyway
+    m = rng.random((2160, 3840)) < 0.16
+    heat = torch.from_numpy(m.astype(np.float64)).cuda()
+    roi_l = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
+    assert not dist.contour_stats()[1] and roi_l == dist.hip_heatmap_to_roi(heat, 20, labelling=False)
+    # the automatic rule switches a noisy geometry to the labelled path from its second extraction on, and back
+    noisy = torch.from_numpy((rng.random((720, 1280)) < 0.16).astype(np.float64)).cuda()
+    clean = torch.zeros((720, 1280), dtype=torch.float64, device="cuda"); clean[100:300, 200:500] = 1.0
+    r0 = dist.hip_heatmap_to_roi(noisy, 20); assert not dist.contour_stats()[1]
+    r1 = dist.hip_heatmap_to_roi(noisy, 20); assert dist.contour_stats()[1] and r1 == r0
+    assert dist.hip_heatmap_to_roi(clean, 20) == (200, 100, 300, 200) and dist.contour_stats()[1]
+    assert dist.hip_heatmap_to_roi(clean, 20) == (200, 100, 300, 200) and not dist.contour_stats()[1]
