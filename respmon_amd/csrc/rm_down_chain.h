@@ -37,6 +37,7 @@ struct DownGeom {
     int seg_split;                   // > 0: TWO uneven segments, [y_begin, seg_split) and [seg_split, y_end) (see k_down_chain)
     int y_begin, y_end;              // level-S rows [y_begin, y_end) covered by this launch
     int strips, segs;                // per frame
+    int sw;                          // level-S columns per strip: the row split evenly over `strips` (<= StripWidth<S>::SW)
     int wpg;                         // waves (= adjacent strips of one segment) per workgroup, marching in lockstep
     int T;
     int vec;                         // 1: 16-byte aligned vector loads are legal for this buffer
@@ -553,7 +554,7 @@ struct DownChain {
     __device__ __forceinline__ void run(const Tin *frame, double *out_t, int strip, int seg)
     {
         // ranges, from level S back to 0
-        cx0[S] = strip * SW; cx1[S] = min(cx0[S] + SW, g.w[S]) - 1;
+        cx0[S] = strip * g.sw; cx1[S] = min(cx0[S] + g.sw, g.w[S]) - 1;
         if (g.seg_split > 0) { next[S] = seg ? g.seg_split : g.y_begin; last[S] = (seg ? g.y_end : g.seg_split) - 1; }
         else { next[S] = g.y_begin + seg * g.seg_h; last[S] = min(next[S] + g.seg_h, g.y_end) - 1; }
 #pragma unroll
@@ -677,6 +678,7 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
     const int SW = S == 1 ? StripWidth<1>::SW : S == 2 ? StripWidth<2>::SW : S == 3 ? StripWidth<3>::SW
                  : S == 4 ? StripWidth<4>::SW : StripWidth<5>::SW;
     g.strips = (g.w[S] + SW - 1) / SW;
+    g.sw = (g.w[S] + g.strips - 1) / g.strips;   // even split: 320 columns = 4 x 80, not 88 + 88 + 88 + 56 (the lockstep group waits for its widest strip)
     // segments: ONE resident round of waves (12 per CU at ~147 VGPRs = 3072 on the chip).  Every extra segment
     // re-reads 2*(2^(S+1)-2) input rows from HBM (measured: 4 segments = 1.23x the algorithmic bytes at 1080p),
     // so take the fewest segments that fill the machine, and never let the halo exceed ~25 % of a segment.
