@@ -300,6 +300,12 @@ static int launch_pyr_up(const double *src, int T, int sh, int sw, double *dst, 
     if (!other_fs) other_fs = (size_t)dh * dw;
     if (!((dw == 2 * sw || dw == 2 * sw - 1) && (dh == 2 * sh || dh == 2 * sh - 1)))
         return fail(RM_E_BADARG, "pyrUp: dstsize (%d,%d) incompatible with source (%d,%d)", dw, dh, sw, sh);
+    if (dw >= 128 && dh >= 8 && dst != src) {   // large levels: 2 x 2 outputs per thread
+        dim3 grid((dw + 127) / 128, (dh + 7) / 8, T), block(256);
+        hipLaunchKernelGGL(k_pyr_up_2x2, grid, block, 0, s, src, sh, sw, src_fs, dst, dh, dw, dst_fs, mode, other, other_fs);
+        LAUNCH_CHECK();
+        return RM_OK;
+    }
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, T), block(256);
     hipLaunchKernelGGL(k_pyr_up, grid, block, 0, s, src, sh, sw, src_fs, dst, dh, dw, dst_fs, mode, other, other_fs);
     LAUNCH_CHECK();

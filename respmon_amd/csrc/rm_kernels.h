@@ -276,6 +276,36 @@ __global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int s
     dst[(size_t)t * dst_fs + o] = u;
 }
 
+// The same for large levels: a thread produces the 2 x 2 outputs that hang under source pixel (i, j).  Their taps all lie
+// in its 3 x 3 neighbourhood, so the four up_at() calls share 9 loads (instead of 9 + 6 + 6 + 4 for four threads), the
+// address arithmetic is paid once, and a lane stores 16 contiguous bytes per row.  Same expressions per output, same bits.
+__global__ __launch_bounds__(256) void k_pyr_up_2x2(const double *__restrict__ src, int sh, int sw, size_t src_fs,
+                                                    double *dst, int dh, int dw, size_t dst_fs, int mode,
+                                                    const double *other, size_t other_fs)
+{
+    const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int t = blockIdx.z;
+    if (x >= dw || y >= dh) return;
+    const bool x1 = x + 1 < dw, y1 = y + 1 < dh;
+    GlobalImg s{src + (size_t)t * src_fs, sw};
+    double u00 = up_at(s, y, x, sh, sw);
+    double u01 = x1 ? up_at(s, y, x + 1, sh, sw) : 0.0;
+    double u10 = y1 ? up_at(s, y + 1, x, sh, sw) : 0.0;
+    double u11 = (x1 && y1) ? up_at(s, y + 1, x + 1, sh, sw) : 0.0;
+    const size_t o0 = (size_t)y * dw + x, o1 = o0 + dw;
+    if (mode != 0) {
+        const double *op = other + (size_t)t * other_fs;
+        const double a00 = op[o0], a01 = x1 ? op[o0 + 1] : 0.0, a10 = y1 ? op[o1] : 0.0, a11 = (x1 && y1) ? op[o1 + 1] : 0.0;
+        if (mode == 1) { u00 = a00 - u00; u01 = a01 - u01; u10 = a10 - u10; u11 = a11 - u11; }
+        else { u00 = u00 + a00; u01 = u01 + a01; u10 = u10 + a10; u11 = u11 + a11; }
+    }
+    double *dp = dst + (size_t)t * dst_fs;
+    dp[o0] = u00;
+    if (x1) dp[o0 + 1] = u01;
+    if (y1) { dp[o1] = u10; if (x1) dp[o1 + 1] = u11; }
+}
+
 // ----------------------------------------------------------------------------------------
 // K5-K8  temporal band-pass (transforms.py:82-102): packed rfft -> index mask -> Re(ifft) -> *amp,
 //        a fixed real linear operator along T, applied in its two-stage form.
@@ -911,10 +941,20 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
         const double *row = p + (size_t)(y_lo + y) * wS;
         double mn = row[R.x0], mx = mn;
         int xn = R.x0, xx = R.x0;
-        for (int x = R.x0 + 1; x <= R.x1; ++x) {
-            const double v = row[x];
-            if (v < mn) { mn = v; xn = x; }
-            if (v > mx) { mx = v; xx = x; }
+        // FB_CHUNK loads in flight per thread (the plain loop waited for every element in turn: ~20 dependent round trips per
+        // footprint row at skip 2).  Columns past the footprint repeat its last one: a repeated value changes neither the
+        // extrema nor the first position they were met at, so the result is that of the element-by-element scan.
+        constexpr int FB_CHUNK = 10;
+        for (int x = R.x0 + 1; x <= R.x1; x += FB_CHUNK) {
+            double v[FB_CHUNK];
+#pragma unroll
+            for (int j = 0; j < FB_CHUNK; ++j) v[j] = row[min(x + j, R.x1)];
+#pragma unroll
+            for (int j = 0; j < FB_CHUNK; ++j) {
+                const int xj = min(x + j, R.x1);
+                if (v[j] < mn) { mn = v[j]; xn = xj; }
+                if (v[j] > mx) { mx = v[j]; xx = xj; }
+            }
         }
         rmin[i] = mn; rmax[i] = mx;
         // (where this thread has seen the lowest / highest C_S so far: its lattice samples are taken there)
