@@ -1541,11 +1541,9 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         CclComp *dev_comps = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, ctx->h_comps, 0));
         hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
-                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits);
+                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits, d_label, d_box, d_cnt);
         LAUNCH_CHECK();
         const dim3 grid((unsigned)((npix + 255) / 256));
-        hipLaunchKernelGGL(k_ccl_init, grid, dim3(256), 0, s, d_bits, npix, W, d_label, d_box, d_cnt);
-        LAUNCH_CHECK();
         hipLaunchKernelGGL(k_ccl_union, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_ccl_bbox, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label, d_box);
@@ -1559,7 +1557,8 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
-                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, (unsigned long long *)nullptr);
+                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, (unsigned long long *)nullptr, (int *)nullptr,
+                           (CclBox *)nullptr, (unsigned int *)nullptr);
         LAUNCH_CHECK();
     }
     delete pt_roi; pt_roi = nullptr;

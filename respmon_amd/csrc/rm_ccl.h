@@ -14,8 +14,9 @@
 // component; the host follows only borders whose bound can reach the best area found so far (rm_contour.cpp,
 // largest_external_contour_labelled) -- typically one.  Exact: same contour, same ties (last discovered = largest root).
 //
-// Four launches over the H*W bits (and a small copy kernel), one thread per pixel (84 % of the threads of a 16 %-foreground image leave at once):
-//   k_ccl_init    label = first pixel of the pixel's run inside its 64-bit word (rows break runs), bounding boxes reset
+// Three launches over the H*W bits (and a small copy kernel), one thread per pixel (84 % of the threads of a 16 %-foreground
+// image leave at once); their start state comes from k_heat_to_u8, whose ballot is the pixel's word:
+//   (k_heat_to_u8) label = first pixel of the pixel's run inside its 64-bit word (rows break runs), box = the pixel itself
 //   k_ccl_union   joins with the row above / the word to the left, lock-free (atomicMin on the larger root)
 //   k_ccl_bbox    every run end / bottom pixel folds its coordinates into its root's box
 //   k_ccl_emit    roots -> {root, minx, width-1, height-1} records, wave-aggregated slot reservation
@@ -27,7 +28,7 @@
 namespace rm {
 
 struct CclComp { int root, minx, w1, h1; };   // box: x = minx, y = root / W, width w1 + 1, height h1 + 1
-struct alignas(16) CclBox { int minx, maxx, maxy, pad; };
+// (CclBox, the per-root bounding box, is declared next to k_heat_to_u8 in rm_kernels.h)
 
 __device__ inline bool ccl_bit(const unsigned long long *bits, size_t p) { return (bits[p >> 6] >> (p & 63)) & 1ull; }
 
@@ -49,27 +50,6 @@ __device__ inline void ccl_union(int *label, int a, int b)
         if (old == b) return;
         b = old;                                         // somebody re-rooted b meanwhile: join with what it points to now
     }
-}
-
-__global__ __launch_bounds__(256) void k_ccl_init(const unsigned long long *bits, size_t npix, int W, int *label, CclBox *box,
-                                                  unsigned int *counters)
-{
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p == 0) { counters[0] = 0; counters[1] = 0; }
-    if (p >= npix) return;
-    const unsigned long long w = bits[p >> 6];
-    const int b = (int)(p & 63);
-    if (!((w >> b) & 1ull)) return;
-    // first bit of the run of ones that ends at bit b (inside this word), not crossing the start of pixel p's image row
-    const unsigned long long zeros_below = ~w & ((1ull << b) - 1ull);
-    int run0 = zeros_below ? 64 - __builtin_clzll(zeros_below) : 0;
-    const int x = (int)(p % (size_t)W);
-    if (b - run0 > x) run0 = b - x;
-    label[p] = (int)(p - (size_t)(b - run0));
-    // the box of the component this pixel may end up the root of starts at the pixel itself: single pixels (most of a noise
-    // image) never need an atomic in k_ccl_bbox
-    CclBox e; e.minx = x; e.maxx = x; e.maxy = (int)(p / (size_t)W); e.pad = 0;
-    box[p] = e;
 }
 
 __global__ __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits, size_t npix, int H, int W, int *label)

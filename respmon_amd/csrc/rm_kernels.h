@@ -1766,12 +1766,16 @@ __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t 
 // have a bit set (~12 KB instead of 259 KB over PCIe: the launch's end-of-kernel flush of host-memory writes shrinks with it).  (Tried and dropped: a sparse list of the non-zero words with a `done` word the host spins on instead of the
 // runtime's completion query -- the kernel's own hand-off cost 14 us more, and a stream the runtime never sees complete
 // makes the NEXT launch ~100 us slower.)
+struct alignas(16) CclBox { int minx, maxx, maxy, pad; };   // bounding box of a labelled component (rm_ccl.h), indexed by its root
+
 __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
                                                     unsigned long long *bits, uint8_t *row_any,
-                                                    unsigned long long *bits_dev)
+                                                    unsigned long long *bits_dev, int *ccl_label, CclBox *ccl_box,
+                                                    unsigned int *ccl_counters)
 {
     RM_TRACE_SCOPE(7);
+    if (ccl_counters && blockIdx.x == 0 && threadIdx.x == 0) ccl_counters[0] = 0;   // k_ccl_emit reserves record slots there
     const int lane = threadIdx.x & 63;
     // `base` is the first pixel of this wave's 64-pixel group: the same for all lanes, so the ballot is complete.
     // HU groups per trip: their heat values are requested together and BEFORE the extrema are folded from the state
@@ -1802,7 +1806,21 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                 if (binary) binary[i] = b;
             }
             const unsigned long long m = __ballot(b != 0);
-            if (lane == 0 && bits_dev) bits_dev[base >> 6] = m;   // device copy for the labelling kernels (rm_ccl.h): every word
+            if (bits_dev) {   // device labelling of the components (rm_ccl.h) follows: every word, and the start state of its
+                              // union-find -- the ballot IS the pixel's word, so no separate pass has to read it back
+                if (lane == 0) bits_dev[base >> 6] = m;
+                if (b) {
+                    // label = first pixel of the run of ones that ends here (inside this word, not crossing the row start);
+                    // the box of the component this pixel may end up the root of starts at the pixel itself
+                    const unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);
+                    int run0 = zeros_below ? 64 - __builtin_clzll(zeros_below) : 0;
+                    const unsigned int y = (unsigned int)i / (unsigned int)W, x = (unsigned int)i - y * (unsigned int)W;
+                    if (lane - run0 > (int)x) run0 = lane - (int)x;
+                    ccl_label[i] = (int)i - (lane - run0);
+                    CclBox e; e.minx = (int)x; e.maxx = (int)x; e.maxy = (int)y; e.pad = 0;
+                    ccl_box[i] = e;
+                }
+            }
             if (lane == 0 && bits && m) {   // the host keeps the image all-zero between calls: only set words travel
                 bits[base >> 6] = m;
                 if (row_any) {   // the group may straddle row ends: flag every row it touches (a superset is fine)
