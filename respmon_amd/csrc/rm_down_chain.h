@@ -49,7 +49,10 @@ struct DownGeom {
 #endif
 template <int S> struct StripWidth;
 template <> struct StripWidth<1> { static constexpr int SW = 160; };
-template <> struct StripWidth<2> { static constexpr int SW = 88; };
+#ifndef RM_DC_SW2
+#define RM_DC_SW2 88
+#endif
+template <> struct StripWidth<2> { static constexpr int SW = RM_DC_SW2; };
 template <> struct StripWidth<3> { static constexpr int SW = 44; };
 template <> struct StripWidth<4> { static constexpr int SW = RM_DC_SW4; };
 template <> struct StripWidth<5> { static constexpr int SW = 8; };

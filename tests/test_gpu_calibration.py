@@ -320,6 +320,12 @@ def test_config_q_720p_full_size_vs_oracle(hip, oracle):
     ref, mid = oracle.locate(frames, 10, pyramid_levels=L, skip_levels_at_top=S, return_intermediates=True)
     buf = torch.from_numpy(frames).cuda()
     assert RespiratoryMonitor.locate(buf, 10, pyramid_levels=L, skip_levels_at_top=S) == ref
+    n0, labelled0 = dist.contour_stats()
+    # this heatmap thresholds to thousands of specks: the second locate() of the geometry labels the components on the device and
+    # follows only the borders that can win (rm_ccl.h) -- same ROI
+    assert n0 > 512 and not labelled0
+    assert RespiratoryMonitor.locate(buf, 10, pyramid_levels=L, skip_levels_at_top=S) == ref
+    assert dist.contour_stats()[1]
     heat = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
     assert _rel(heat.cpu().numpy(), mid["avg_frame"]) <= 1e-12          # north_star gate is 1e-4
     assert torch.equal(heat, dist.hip_calibrate(torch.from_numpy(v8).cuda(), 10, pyramid_levels=L, skip_levels_at_top=S))
