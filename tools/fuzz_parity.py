@@ -325,6 +325,8 @@ def fuzz_roi(budget, seed):
     n = bad = 0
     while time.time() < t_end:
         H = int(rng.integers(1, 300)); W = int(rng.integers(1, 500))
+        if rng.random() < 0.1:
+            H = int(rng.integers(300, 1200)); W = int(rng.integers(500, 2000))   # several workgroups per labelling kernel
         kind = int(rng.integers(0, 3))
         if kind == 0:
             heat = (rng.random((H, W)) < rng.uniform(0.02, 0.7)).astype(np.float64)
@@ -336,11 +338,13 @@ def fuzz_roi(budget, seed):
         with np.errstate(all="ignore"):
             u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min()))
         ref = oracle.roi_from_heatmap_u8(u8, thr)
-        got = rdist.hip_heatmap_to_roi(torch.from_numpy(heat).cuda(), thr)
+        dev = torch.from_numpy(heat).cuda()
+        got = rdist.hip_heatmap_to_roi(dev, thr, labelling=False)
+        lab = rdist.hip_heatmap_to_roi(dev, thr, labelling=True)     # components labelled on the device first (rm_ccl.h)
         n += 1
-        if got != ref:
+        if got != ref or lab != ref:
             bad += 1
-            print("ROI MISMATCH", dict(H=H, W=W, kind=kind, thr=thr), got, ref, flush=True)
+            print("ROI MISMATCH", dict(H=H, W=W, kind=kind, thr=thr), got, lab, ref, flush=True)
     print("fuzz roi: %d cases, %d mismatches" % (n, bad))
     return bad
 
