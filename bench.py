@@ -302,8 +302,26 @@ def main():
                     backend.pca_reduce(np.array(motion, dtype=np.float32))
             torch.cuda.synchronize()
             dtf = (time.perf_counter() - tf) / max(n_fl, 1)
-            roi_flow = {"roi": [x, y, w, h], "corners": int(len(pts)), "frames": n_fl, "ms_per_frame": dtf * 1e3,
-                        "frames_per_s": 1.0 / dtf if dtf > 0 else None, "budget_ms_at_30fps": 33.3}
+            # the same frames through rm_flow_begin / rm_flow_step: crop + LK + mean flow in ONE call per frame, crops and points
+            # resident on the device (what RespiratoryMonitor.extract_motion('flow') runs); same numbers as the four calls above
+            grays = [torch.from_numpy(vid_u8[i]).cuda() for i in range(n_fl + 1)]
+            backend.flow_begin(grays[0], x, y, w, h, 100, 0.3, 7, 7)
+            motion2 = []
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for i in range(n_fl):
+                mean, n_good = backend.flow_step(grays[i + 1], x, y, w, h, (15, 15), 2, (3, 10, 0.03))
+                if n_good:
+                    motion2.append([mean[0], mean[1]])
+                if len(motion2) >= 2:
+                    backend.pca_reduce(np.array(motion2, dtype=np.float32))
+            torch.cuda.synchronize()
+            dtr = (time.perf_counter() - tf) / max(n_fl, 1)
+            roi_flow = {"roi": [x, y, w, h], "corners": int(len(pts)), "frames": n_fl, "ms_per_frame": dtr * 1e3,
+                        "frames_per_s": 1.0 / dtr if dtr > 0 else None, "budget_ms_at_30fps": 33.3,
+                        "path": "rm_flow_step: crop + pyramidal LK + mean flow per call, state resident on the device; + rm_pca_reduce",
+                        "four_calls_ms_per_frame": dtf * 1e3,
+                        "equal_to_four_calls": bool(np.array_equal(np.array(motion2, dtype=np.float32), np.array(motion, dtype=np.float32)))}
         else:
             roi_flow = {"roi": [x, y, w, h], "corners": 0}
     # Data dependence of the headline: the collapse passes skip every (frame, tile) pair that provably cannot

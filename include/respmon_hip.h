@@ -242,6 +242,22 @@ int rm_mean_flow(rm_ctx *ctx, const float *old_host, const float *new_host, cons
                  int npts, float *mean_xy_host, int *n_good_host, void *stream);
 int rm_pca_reduce(rm_ctx *ctx, const float *motion_host, int n, double *out_host, void *stream);
 
+/* ---- base.py:363-388 as ONE call per frame (SURVEY 8b "rm_flow_step"): the ROI crop, its pyramids, the tracked points and
+ *      their status never leave the device between two frames.
+ *      rm_flow_begin = base.py:364-366: crop + float_to_uint8 of the ROI, cv2.goodFeaturesToTrack on it; the corners are
+ *        returned (pts_host, capacity max(max_corners, 1) float32 pairs; *n_host = 0 <=> cv2 returns None) and kept on the device.
+ *      rm_flow_step  = base.py:371-388: crop of the new frame, cv2.calcOpticalFlowPyrLK from the previous crop and the kept
+ *        points, np.mean(good_old - good_new, axis=0) over status == 1 (float32, point order) -> mean_xy_host[2], *n_good_host;
+ *        the new crop and p1[st == 1] become the state the next call starts from (base.py:381-382).  With no points left the
+ *        call only advances the previous image (mean 0, n_good 0: the caller returns NaN, base.py:385-386).
+ *      rm_flow_points: the points the next step will track (what the reference holds in self.motion_key_points).
+ *      Bit-identical to rm_roi_to_uint8 + rm_calc_optical_flow_pyr_lk + rm_mean_flow called in turn. */
+int rm_flow_begin(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int max_corners,
+                  double quality_level, double min_distance, int block_size, float *pts_host, int *n_host, void *stream);
+int rm_flow_step(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int win_w, int win_h,
+                 int max_level, int max_count, double epsilon, float *mean_xy_host, int *n_good_host, void *stream);
+int rm_flow_points(rm_ctx *ctx, float *pts_host, int cap, int *n_host, void *stream);
+
 /* ---- base.py:230-231: cv2.cvtColor(BGR2GRAY) then uint8_to_float, on device ("next" row f3) */
 int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gray_dev, void *stream);
 

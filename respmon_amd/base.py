@@ -140,6 +140,42 @@ class _Backend:
                                                     ctypes.byref(ng), device.stream_ptr()), "rm_mean_flow")
         return mean, ng.value
 
+    # -- extract_motion('flow') with the crops and points resident on the device: one C-ABI call per frame --------------------
+    def flow_begin(self, gray_u8, x, y, w, h, maxCorners, qualityLevel, minDistance, blockSize):
+        import ctypes
+        H, W = gray_u8.shape
+        pts = np.empty((max(int(maxCorners), 1), 2), dtype=np.float32)
+        n = ctypes.c_int()
+        _capi.check(self.lib, self.lib.rm_flow_begin(device.ctx(), device.ptr(gray_u8), device.dtype_code(gray_u8), H, W, x, y, w, h,
+                                                     int(maxCorners), float(qualityLevel), float(minDistance), int(blockSize),
+                                                     ctypes.c_void_p(pts.ctypes.data), ctypes.byref(n), device.stream_ptr()),
+                    "rm_flow_begin")
+        return None if n.value == 0 else pts[:n.value].reshape(-1, 1, 2).copy()
+
+    def flow_step(self, gray_u8, x, y, w, h, winSize, maxLevel, criteria):
+        import ctypes
+        H, W = gray_u8.shape
+        ctype, max_count, eps = criteria
+        if not (ctype & 1):
+            max_count = 30
+        if not (ctype & 2):
+            eps = 0.01
+        mean = np.empty(2, dtype=np.float32)
+        ng = ctypes.c_int()
+        _capi.check(self.lib, self.lib.rm_flow_step(device.ctx(), device.ptr(gray_u8), device.dtype_code(gray_u8), H, W, x, y, w, h,
+                                                    int(winSize[0]), int(winSize[1]), int(maxLevel), int(max_count), float(eps),
+                                                    ctypes.c_void_p(mean.ctypes.data), ctypes.byref(ng), device.stream_ptr()),
+                    "rm_flow_step")
+        return mean, ng.value
+
+    def flow_points(self, cap):
+        import ctypes
+        pts = np.empty((max(int(cap), 1), 2), dtype=np.float32)
+        n = ctypes.c_int()
+        _capi.check(self.lib, self.lib.rm_flow_points(device.ctx(), ctypes.c_void_p(pts.ctypes.data), len(pts), ctypes.byref(n),
+                                                      device.stream_ptr()), "rm_flow_points")
+        return pts[:min(n.value, len(pts))].reshape(-1, 1, 2).copy()
+
     def pca_reduce(self, motion_data):
         import ctypes
         m = np.ascontiguousarray(motion_data, dtype=np.float32).reshape(-1, 2)
@@ -371,6 +407,8 @@ class RespiratoryMonitor:
         if self.motion_extraction_method == "average":
             return self._backend.roi_mean(self._frame_u8, x, y, w, h)       # np.average(crop), base.py:357
         be = self._backend
+        if self.fused_flow_step and hasattr(be, "flow_step"):
+            return self._extract_motion_flow_resident(be, x, y, w, h)
         if self.previous_cropped_image is None:                            # base.py:363-369
             self.previous_cropped_image = be.roi_to_uint8(self._frame_u8, x, y, w, h)
             self.motion_key_points = be.good_features_to_track(self.previous_cropped_image, **self.feature_params)
@@ -390,6 +428,49 @@ class RespiratoryMonitor:
         if len(self.motion_data) >= 2:
             return be.pca_reduce(np.array(self.motion_data, dtype=np.float32))  # base.py:396-405
         return 0.0
+
+    # One C-ABI call per frame (rm_flow_begin / rm_flow_step): the previous crop and the tracked points stay on the device, so
+    # `previous_cropped_image` only marks that tracking has begun and `motion_key_points` is fetched when somebody reads it.
+    # False: the reference's four steps as four calls, points and status through host memory (same numbers).
+    fused_flow_step = True
+    _RESIDENT = "on the device (rm_flow_step)"
+
+    def _extract_motion_flow_resident(self, be, x, y, w, h):
+        if self.previous_cropped_image is None:                            # base.py:363-369
+            self.motion_key_points = be.flow_begin(self._frame_u8, x, y, w, h, **self.feature_params)
+            self.previous_cropped_image = self._RESIDENT
+            self._flow_cap = max(int(self.feature_params["maxCorners"]), 1)
+            self._flow_n = 0 if self.motion_key_points is None else len(self.motion_key_points)
+            if self._flow_n < 1:
+                self.trigger_error("No motion key points found.")
+            return 0.0
+        if self.previous_cropped_image is not self._RESIDENT:              # tracking was begun by the four-call path
+            self.fused_flow_step = False
+            return self.extract_motion()
+        if self._flow_n == 0:
+            be.flow_step(self._frame_u8, x, y, w, h, **self.lk_params)     # (the previous image still advances, base.py:381)
+            return np.nan
+        mean, n_good = be.flow_step(self._frame_u8, x, y, w, h, **self.lk_params)   # base.py:371-388
+        self._flow_n = n_good
+        self._points_stale = True
+        if n_good == 0:
+            return np.nan                                                   # base.py:385-386
+        self.motion_data.append([mean[0], mean[1]])                         # base.py:389
+        if len(self.motion_data) >= 2:
+            return be.pca_reduce(np.array(self.motion_data, dtype=np.float32))  # base.py:396-405
+        return 0.0
+
+    @property
+    def motion_key_points(self):
+        if getattr(self, "_points_stale", False):
+            self._motion_key_points = self._backend.flow_points(self._flow_cap)
+            self._points_stale = False
+        return getattr(self, "_motion_key_points", None)
+
+    @motion_key_points.setter
+    def motion_key_points(self, value):
+        self._motion_key_points = value
+        self._points_stale = False
 
     # Which cv2.findContours the ROI stage reproduces (the reference pins no OpenCV version, README.md:12): False = OpenCV >= 3.2
     # (pixels on the image frame count), True = OpenCV <= 3.1 (the 1-pixel frame is zeroed before tracing; base.py:567's

@@ -86,6 +86,9 @@ struct rm_ctx {
     bool state_fresh = false;   // d_state was reset by the last kernel of front_pyramid and nothing has reduced into it since
     int op_mfma = 0;        // > 0: the cached operator also exists in the fragment-major form of k_temporal_mfma, with this many 16-row tiles
     FlowWorkspace flow;
+    // device-resident state of rm_flow_begin / rm_flow_step: previous ROI crop, the points tracked from it, pinned result words
+    int fs_w = 0, fs_h = 0, fs_npts = 0, fs_cap = 0, fs_flip = 0;
+    float *fs_res = nullptr;   // pinned {mean_x, mean_y, n_good}
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
     // pinned {pairs the selection kept, pairs} written by the last sum kernel, and the geometry they belong to: the next call
@@ -178,6 +181,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
     if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
+    if (ctx->fs_res) (void)hipHostFree(ctx->fs_res);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
@@ -1792,6 +1796,98 @@ extern "C" int rm_pca_reduce(rm_ctx *ctx, const float *motion, int n, double *ou
     int rc = flow_pca(ctx->flow, motion, n, out, (hipStream_t)stream, err);
     if (rc < 0) return fail(rc, "%s", err.c_str());
     return rc;
+}
+
+// ---- one C-ABI call per frame of extract_motion('flow') (base.py:363-388); crops and points stay on the device ----------
+static int flow_crop(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, uint8_t *dst, hipStream_t s)
+{
+    return rm_roi_to_uint8(ctx, frame, dtype, H, W, x, y, w, h, dst, (void *)s);
+}
+
+static int flow_state_bufs(rm_ctx *ctx, int w, int h, int cap, uint8_t **crop_a, uint8_t **crop_b, float **pts_a, float **pts_b)
+{
+    std::string err;
+    int rc;
+    if ((rc = ctx->flow.get("fs_crop_a", (size_t)w * h, (void **)crop_a, err)) < 0) return fail(rc, "%s", err.c_str());
+    if ((rc = ctx->flow.get("fs_crop_b", (size_t)w * h, (void **)crop_b, err)) < 0) return fail(rc, "%s", err.c_str());
+    if ((rc = ctx->flow.get("fs_pts_a", sizeof(float) * 2 * (size_t)cap, (void **)pts_a, err)) < 0) return fail(rc, "%s", err.c_str());
+    if ((rc = ctx->flow.get("fs_pts_b", sizeof(float) * 2 * (size_t)cap, (void **)pts_b, err)) < 0) return fail(rc, "%s", err.c_str());
+    return RM_OK;
+}
+
+extern "C" int rm_flow_begin(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, int max_corners,
+                             double quality, double min_distance, int block_size, float *pts_host, int *n_host, void *stream)
+{
+    if (!ctx || !frame || !pts_host || !n_host || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h) || h < 3 || w < 3 || block_size < 1 ||
+        (block_size & 1) == 0)
+        return fail(RM_E_BADARG, "rm_flow_begin: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int cap = std::max(max_corners, 1);
+    uint8_t *ca = nullptr, *cb = nullptr; float *pa = nullptr, *pb = nullptr;
+    RM_TRY(flow_state_bufs(ctx, w, h, cap, &ca, &cb, &pa, &pb));
+    if (!ctx->fs_res) HIP_TRY(hipHostMalloc((void **)&ctx->fs_res, 4 * sizeof(float), hipHostMallocDefault));
+    ctx->fs_w = w; ctx->fs_h = h; ctx->fs_cap = cap; ctx->fs_flip = 0; ctx->fs_npts = 0;
+    RM_TRY(flow_crop(ctx, frame, dtype, H, W, x, y, w, h, ca, s));
+    std::string err;
+    int rc = flow_good_features(ctx->flow, ca, h, w, max_corners, quality, min_distance, block_size, pts_host, n_host, s, err);
+    if (rc < 0) return fail(rc, "%s", err.c_str());
+    ctx->fs_npts = *n_host;
+    if (*n_host > 0) {
+        HIP_TRY(hipMemcpyAsync(pa, pts_host, sizeof(float) * 2 * (size_t)*n_host, hipMemcpyHostToDevice, s));
+        HIP_TRY(stream_wait(s));   // pts_host is the caller's again
+    }
+    return RM_OK;
+}
+
+extern "C" int rm_flow_step(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, int win_w, int win_h,
+                            int max_level, int max_count, double epsilon, float *mean_xy_host, int *n_good_host, void *stream)
+{
+    if (!ctx || !frame || !mean_xy_host || !n_good_host || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h) || win_w < 3 || win_h < 3 ||
+        max_level < 0)
+        return fail(RM_E_BADARG, "rm_flow_step: bad argument");
+    if (!ctx->fs_res || w != ctx->fs_w || h != ctx->fs_h) return fail(RM_E_BADARG, "rm_flow_step: rm_flow_begin has not been called for this ROI size");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t *ca = nullptr, *cb = nullptr; float *pa = nullptr, *pb = nullptr;
+    RM_TRY(flow_state_bufs(ctx, w, h, ctx->fs_cap, &ca, &cb, &pa, &pb));
+    uint8_t *prev = ctx->fs_flip ? cb : ca, *cur = ctx->fs_flip ? ca : cb;
+    float *pts = ctx->fs_flip ? pb : pa, *pts_next = ctx->fs_flip ? pa : pb;
+    RM_TRY(flow_crop(ctx, frame, dtype, H, W, x, y, w, h, cur, s));
+    const int npts = ctx->fs_npts;
+    mean_xy_host[0] = mean_xy_host[1] = 0.f; *n_good_host = 0;
+    if (npts > 0) {
+        std::string err;
+        float *d_out = nullptr; uint8_t *d_st = nullptr; float *dev_res = nullptr;
+        int rc;
+        if ((rc = ctx->flow.get("lk_pts_out", sizeof(float) * 2 * (size_t)npts, (void **)&d_out, err)) < 0) return fail(rc, "%s", err.c_str());
+        if ((rc = ctx->flow.get("lk_status", (size_t)npts, (void **)&d_st, err)) < 0) return fail(rc, "%s", err.c_str());
+        rc = flow_pyr_lk_dev(ctx->flow, prev, cur, h, w, pts, npts, win_w, win_h, max_level, max_count, epsilon, d_out, d_st, s, err);
+        if (rc < 0) return fail(rc, "%s", err.c_str());
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev_res, ctx->fs_res, 0));
+        hipLaunchKernelGGL(k_flow_finish, dim3(1), dim3(1), 0, s, pts, d_out, d_st, npts, dev_res, pts_next);
+        LAUNCH_CHECK();
+        HIP_TRY(stream_wait(s));
+        mean_xy_host[0] = ctx->fs_res[0]; mean_xy_host[1] = ctx->fs_res[1]; *n_good_host = (int)ctx->fs_res[2];
+        ctx->fs_npts = *n_good_host;
+    }
+    ctx->fs_flip ^= 1;   // the crop just made is the next call's previous image, the packed points its input (base.py:381-382)
+    return RM_OK;
+}
+
+extern "C" int rm_flow_points(rm_ctx *ctx, float *pts_host, int cap, int *n_host, void *stream)
+{
+    if (!ctx || !n_host || cap < 0 || (cap > 0 && !pts_host)) return fail(RM_E_BADARG, "rm_flow_points: bad argument");
+    *n_host = ctx->fs_npts;
+    if (ctx->fs_npts == 0 || cap == 0) return RM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t *ca = nullptr, *cb = nullptr; float *pa = nullptr, *pb = nullptr;
+    RM_TRY(flow_state_bufs(ctx, ctx->fs_w, ctx->fs_h, ctx->fs_cap, &ca, &cb, &pa, &pb));
+    const int n = std::min(cap, ctx->fs_npts);
+    HIP_TRY(hipMemcpyAsync(pts_host, ctx->fs_flip ? pb : pa, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(stream_wait(s));
+    return RM_OK;
 }
 
 // ------------------------------------------------------------------------------------------

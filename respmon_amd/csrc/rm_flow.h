@@ -385,11 +385,12 @@ inline int lk_max_level(int h, int w, int win_w, int win_h, int max_level)
     return max_level;
 }
 
-inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *next, int h, int w, const float *pts_in, int npts, int win_w,
-                       int win_h, int max_level, int max_count, double epsilon, float *pts_out, uint8_t *status, hipStream_t s,
-                       std::string &err)
+// device half of flow_pyr_lk: pyramids, derivatives and the tracking kernel; points in / out and status stay on the device,
+// nothing is copied and the stream is not waited for.  Returns the number of pyramid levels above level 0 that were used.
+inline int flow_pyr_lk_dev(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *next, int h, int w, const float *d_in, int npts,
+                           int win_w, int win_h, int max_level, int max_count, double epsilon, float *d_out, uint8_t *d_st,
+                           hipStream_t s, std::string &err)
 {
-    if (npts == 0) return RM_OK;
     if (win_w * win_h > LK_MAX_WIN) { err = "winSize too large"; return RM_E_UNSUPPORTED; }
     if (max_count < 0) max_count = 0;
     if (max_count > 100) max_count = 100;
@@ -419,18 +420,46 @@ inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *ne
         L.prev[l] = pp; L.next[l] = nn; L.deriv[l] = dd;
         sh = (sh + 1) / 2; sw = (sw + 1) / 2;
     }
+    hipLaunchKernelGGL(k_lk_track, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
+    FLOW_HIP(hipGetLastError());
+    return max_level;
+}
+
+inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *next, int h, int w, const float *pts_in, int npts, int win_w,
+                       int win_h, int max_level, int max_count, double epsilon, float *pts_out, uint8_t *status, hipStream_t s,
+                       std::string &err)
+{
+    if (npts == 0) return RM_OK;
     float *d_in = nullptr, *d_out = nullptr;
     uint8_t *d_st = nullptr;
     FLOW_TRY(ws.get("lk_pts_in", sizeof(float) * 2 * npts, (void **)&d_in, err));
     FLOW_TRY(ws.get("lk_pts_out", sizeof(float) * 2 * npts, (void **)&d_out, err));
     FLOW_TRY(ws.get("lk_status", npts, (void **)&d_st, err));
     FLOW_HIP(hipMemcpyAsync(d_in, pts_in, sizeof(float) * 2 * npts, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_lk_track, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
-    FLOW_HIP(hipGetLastError());
+    const int used = flow_pyr_lk_dev(ws, prev, next, h, w, d_in, npts, win_w, win_h, max_level, max_count, epsilon, d_out, d_st, s, err);
+    if (used < 0) return used;
     FLOW_HIP(hipMemcpyAsync(pts_out, d_out, sizeof(float) * 2 * npts, hipMemcpyDeviceToHost, s));
     FLOW_HIP(hipMemcpyAsync(status, d_st, npts, hipMemcpyDeviceToHost, s));
     FLOW_HIP(stream_wait(s));
-    return max_level;
+    return used;
+}
+
+// One frame of extract_motion('flow') without a host round trip in the middle (base.py:377-388): the mean of old - new over
+// the points with status == 1 (float32, in point order: k_mean_flow's arithmetic) AND p1[st == 1] packed in order into the
+// buffer the next frame tracks from.  res (pinned host memory): {mean_x, mean_y, (float) n_good}.
+__global__ void k_flow_finish(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
+{
+    float sx = 0.f, sy = 0.f;
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (st[i] == 1) {
+            sx += o[2 * i] - nw[2 * i]; sy += o[2 * i + 1] - nw[2 * i + 1];
+            next_pts[2 * m] = nw[2 * i]; next_pts[2 * m + 1] = nw[2 * i + 1];
+            ++m;
+        }
+    res[0] = m ? sx / (float)m : 0.f;
+    res[1] = m ? sy / (float)m : 0.f;
+    res[2] = (float)m;
 }
 
 // ----------------------------------------------------------------------------------------

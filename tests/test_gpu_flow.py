@@ -133,3 +133,44 @@ def test_flow_against_float64_brute_force_and_component_boxes(be, oracle):
         # region is largest -- its box must not be smaller than HALF the largest component's (a gross mis-selection would be)
         sizes = ndi.sum(np.ones_like(lab), lab, index=np.arange(1, n + 1))
         assert sizes[boxes.index(roi)] >= 0.5 * sizes.max()
+
+
+def test_flow_step_resident_equals_four_calls(oracle):
+    """rm_flow_begin / rm_flow_step (crops, points and status resident on the device, one C-ABI call per frame) against the four
+    calls of the reference's order (rm_roi_to_uint8, rm_calc_optical_flow_pyr_lk, rm_mean_flow with points through host memory):
+    identical data trace, motion_data and surviving points, frame after frame -- also while points are being lost (large shifts
+    push corners out of the ROI) and after all of them are gone (NaN from then on, base.py:385-386)."""
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    render = synth.synth_texture(120, 160, seed=11)
+    T = 36
+    for amp, roi in [(1.5, (30, 20, 90, 70)), (9.0, (40, 30, 60, 50)), (40.0, (50, 40, 24, 20))]:
+        frames = np.stack([render(amp * np.sin(2 * np.pi * 0.4 * t / 10), 0.6 * amp * np.sin(2 * np.pi * 0.4 * t / 10 + 1.0))
+                           for t in range(T)])
+        traces = []
+        for fused in (True, False):
+            mon = RespiratoryMonitor(capture_target=synth.FakeCapture(frames, fps=10), visualize=None, save_all_data=False,
+                                     motion_extraction_method="flow", run_on_init=False)
+            mon.fused_flow_step = fused
+            mon.sync_to_fps = lambda: None
+            mon.skip_calibration(*roi)
+            pts_per_frame = []
+            step = mon.extract_motion
+            def spy(step=step, mon=mon, out=pts_per_frame):
+                v = step()
+                p = mon.motion_key_points
+                out.append(None if p is None else np.array(p, dtype=np.float32).reshape(-1, 2).copy())
+                return v
+            mon.extract_motion = spy
+            mon.run()
+            traces.append((np.array(mon.data, dtype=np.float64), np.array(mon.motion_data, dtype=np.float32), pts_per_frame))
+        (d1, m1, p1), (d0, m0, p0) = traces
+        assert len(d1) == T and np.array_equal(d1, d0, equal_nan=True), amp
+        assert np.array_equal(m1, m0), amp
+        assert len(p1) == len(p0)
+        for a, b in zip(p1, p0):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), amp
+        x, y, w, h = roi
+        state = oracle.FlowState()
+        ref = np.array([oracle.extract_motion_flow(state, oracle.uint8_to_float(frames[t])[y:y + h, x:x + w]) for t in range(T)])
+        assert np.allclose(d1, ref, rtol=1e-9, atol=1e-12, equal_nan=True), amp
