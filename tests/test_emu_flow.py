@@ -75,3 +75,34 @@ def test_emu_roi_mean(emu):
         f = (rng.random((60, 80)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((60, 80))
         ref = (f[12:43, 9:70] * (1. / 255)).mean() if dt == np.uint8 else f[12:43, 9:70].mean()
         assert abs(emu.roi_mean(f, 9, 12, 61, 31) - ref) <= 1e-13 * abs(ref)
+
+
+def test_emu_flow_step_resident_equals_four_calls(emu, oracle):
+    """rm_flow_begin / rm_flow_step (state resident on the device, one call per frame) against the reference's four steps run
+    through the single entry points, and against the oracle's calcOpticalFlowPyrLK: same corners, same mean flow, same surviving
+    points frame after frame, also while large shifts push points out of the ROI."""
+    render = synth.synth_texture(80, 100, seed=99)
+    x, y, w, h = 12, 9, 70, 51
+    for amp in (1.0, 14.0):
+        frames = [render(amp * np.sin(0.5 * t), 0.5 * amp * np.cos(0.4 * t)) for t in range(7)]
+        # the crop is float_to_uint8(uint8_to_float(frame)[roi]) (base.py:364, 371: truncation loses 24 of the 256 levels)
+        crop = lambda f: np.ascontiguousarray(oracle.float_to_uint8(oracle.uint8_to_float(f)[y:y + h, x:x + w]))
+        p = emu.flow_begin(frames[0], x, y, w, h, 100, 0.3, 7, 7)
+        q = emu.good_features(crop(frames[0]), 100, 0.3, 7, 7)
+        assert (p is None) == (q is None) and (p is None or np.array_equal(p, q))
+        if p is None:
+            continue
+        assert np.array_equal(emu.flow_points(), q)
+        for t in range(1, 7):
+            m, ng = emu.flow_step(frames[t], x, y, w, h)
+            if len(q) == 0:
+                assert ng == 0
+                continue
+            p1, st = emu.pyr_lk(crop(frames[t - 1]), crop(frames[t]), q)
+            po, so, _ = oracle.calcOpticalFlowPyrLK(crop(frames[t - 1]), crop(frames[t]), q, None, winSize=(15, 15), maxLevel=2,
+                                                    criteria=(3, 10, 0.03))
+            assert np.array_equal(st, so)
+            m4, ng4 = emu.mean_flow(q, p1, st)
+            assert ng == ng4 and np.array_equal(m, m4), (amp, t)
+            q = p1[st.ravel() == 1].reshape(-1, 1, 2)
+            assert np.array_equal(emu.flow_points(), q), (amp, t)
