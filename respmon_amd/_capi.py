@@ -20,6 +20,7 @@ RM_FLAG_CONTOUR_CLIP_FRAME = 32
 RM_FLAG_FILTER_LAPLACIANS = 64
 RM_FLAG_DENSE_SUM = 128
 RM_FLAG_SPARSE_SUM = 256
+RM_FLAG_FF_PER_LEVEL = 512
 
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint
@@ -31,6 +32,7 @@ SIGNATURES = {
     "rm_last_error_string": (_c.c_char_p, []),
     "rm_abi_version": (_i, []),
     "rm_ctx_workspace_bytes": (_sz, [_vp]),
+    "rm_debug_set": (_i, [_vp, _c.c_char_p, _c.c_longlong]),
     "rm_profile_enable": (_i, [_vp, _i]),
     "rm_set_contour_clip_frame": (_i, [_vp, _i]),
     "rm_set_contour_labelling": (_i, [_vp, _i]),

@@ -56,21 +56,35 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 // what the collapse passes share (see collapse_eval / collapse_sum below)
 struct CollapsePlan {
     ChainGeom g;
-    int ntiles = 0, npairs = 0;
+    int ntiles = 0, npairs = 0;            // npairs: unique (tile, frame) pairs = ntiles * sym_frames(T)
     double *lo = nullptr, *hi = nullptr, *store = nullptr;
-    unsigned int *list = nullptr, *heavy = nullptr;
+    unsigned int *list_a = nullptr, *list_b = nullptr, *heavy = nullptr;
     int *slot_of = nullptr, *sel_cnt = nullptr;
     size_t shmem = 0;
     const double *cS = nullptr;
     int T = 0, t0 = 0, t1 = 0, H = 0, W = 0, S = 0;
     bool valid = false;
     bool no_prune = false;
-    bool dense = false;    // the sum is taken by k_dense_sum (rm_dense_sum.h): no value store, C pairs only in `list`
+    SumPlan sp{0, 0, 0, 0};                // sparse or dense sum: decided on the device (rm_kernels.h sum_is_dense)
 };
 
 
+// developer / test switches (rm_debug_set): they select between implementations that produce identical results, or shrink a
+// tuning constant so that a test reaches a rare code path.  The library never reads the process environment.
+struct DebugKnobs {
+    int temporal_valu = 0;        // 1: the two-stage VALU temporal kernels instead of k_temporal_sym
+    int dc_lds_front_end = 0;     // 1: narrow frame buffers through the LDS front end of k_down_chain instead of rm_down_chain_u8.h
+    int no_fused_bounds = 0;      // 1: k_small_collapse + k_frame_bounds instead of k_small_collapse_bounds
+    long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
+    int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
+    int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2
+    int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
+    long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
+};
+
 struct rm_ctx {
     int device = 0;
+    DebugKnobs dbg;
     std::map<std::string, DevBuf> bufs;
     CollapseState *d_state = nullptr;
     CollapseState *h_state = nullptr;  // pinned
@@ -91,14 +105,10 @@ struct rm_ctx {
     float *fs_res = nullptr;   // pinned {mean_x, mean_y, n_good}
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
-    // pinned {pairs the selection kept, pairs} written by the last sum kernel, and the geometry they belong to: the next call
-    // of the same geometry takes the dense sum kernel when more than 1 / DENSE_ONE_IN of its pairs were kept
-    unsigned int *h_stats = nullptr;
-    int stats_T = 0, stats_H = 0, stats_W = 0, stats_S = 0;
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     // measurement hook (rm_profile_*)
-    long long dbg_pairs = 0, dbg_cap = 0;
+    long long dbg_pairs = 0, dbg_cap = 0, dbg_mine = 0; int dbg_mode = 0, dbg_auto_dense = 0;   // the SumPlan of the last collapse (host copy)
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
     bool prof_on = false;
     int prof_calls = 0, prof_sampled = 0;
@@ -183,11 +193,28 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
     if (ctx->fs_res) (void)hipHostFree(ctx->fs_res);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
-    if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
+    return RM_OK;
+}
+
+extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
+{
+    if (!ctx || !key) return fail(RM_E_BADARG, "rm_debug_set: bad argument");
+    DebugKnobs &d = ctx->dbg;
+    const std::string k(key);
+    if (k == "temporal_valu") d.temporal_valu = (int)value;
+    else if (k == "dc_lds_front_end") d.dc_lds_front_end = (int)value;
+    else if (k == "no_fused_bounds") d.no_fused_bounds = (int)value;
+    else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
+    else if (k == "dense_rows") d.dense_rows = (int)value;
+    else if (k == "dense_general") d.dense_general = (int)value;
+    else if (k == "dc_segs") d.dc_segs = (int)value;
+    else if (k == "dc_wpg") d.dc_wpg = (int)value;
+    else if (k == "store_slots") d.store_slots = value;
+    else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
     return RM_OK;
 }
 
@@ -228,7 +255,11 @@ extern "C" int rm_debug_counters(rm_ctx *ctx, long long *out, void *stream)
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
     HIP_TRY(stream_wait(s));
-    out[0] = ctx->dbg_pairs; out[1] = ctx->h_state->n_list; out[2] = ctx->h_state->n_slots; out[3] = ctx->dbg_cap;
+    const CollapseState &h = *ctx->h_state;
+    const bool dense = ctx->dbg_mode == 1 || (long long)h.n_slots > ctx->dbg_cap ||
+                       (ctx->dbg_mode == 0 && ctx->dbg_auto_dense && (unsigned long long)h.n_slots * DENSE_ONE_IN > (unsigned long long)ctx->dbg_mine);
+    out[0] = ctx->dbg_pairs; out[1] = (long long)h.n_list_a + (dense ? 0 : (long long)h.n_list_b); out[2] = h.n_slots;
+    out[3] = dense ? 0 : ctx->dbg_cap;
     return RM_OK;
 }
 
@@ -491,72 +522,104 @@ static void kept_packed_indices(int n, double fps, double fmin, double fmax, std
         if (keep[k]) kept.push_back(k);
 }
 
-// two-stage form of the operator: R[nk,T] = surviving rows of the packed real FFT, C[T,nk] = the columns of
-// Re(ifft) that multiply them (1/n included)
-static void two_stage_operator(int n, const std::vector<int> &kept, std::vector<double> &R, std::vector<double> &C)
+// Two-stage form of the operator, MERGED and for the UNIQUE output frames (rm_kernels.h sym_frames):
+//   packed index k contributes  Re(ifft)[s] += cos(2 pi k s / n) / n * y[k]  (transforms.py:98 on the packed array), and
+//   cos(2 pi (n - k) s / n) == cos(2 pi k s / n): the kept indices k and n - k share their inverse column, so their forward rows
+//   are added here once and for all.  m = min(k, n - k) names the merged row;
+//     Rz[i][t] = R[m_i][t] (if kept) + R[n - m_i][t] (if kept, and a different index)      i < nm, t < n
+//     Cz[s][i] = cos(2 pi m_i s / n) / n                                                   s < n / 2 + 1
+//   The rows s > n / 2 of the inverse are the mirror images of these (out[n - s] == out[s], as in the reference: scipy's ifft of
+//   a real array is exactly Hermitian), so they are never computed.
+static double packed_row(int n, int k, int t)
 {
     const double two_pi = 6.283185307179586476925286766559;
-    const int nk = (int)kept.size();
-    R.assign((size_t)nk * n, 0.0);
-    C.assign((size_t)n * nk, 0.0);
-    for (int i = 0; i < nk; ++i) {
-        const int k = kept[i];
+    if (k == 0) return 1.0;
+    if ((n % 2 == 0) && k == n - 1) return (t % 2 == 0) ? 1.0 : -1.0;
+    const int j = (k + 1) / 2;
+    const long long jt = ((long long)j * t) % n;  // exact argument reduction
+    const double ang = two_pi * (double)jt / (double)n;
+    return (k % 2 == 1) ? std::cos(ang) : -std::sin(ang);
+}
+
+static void merged_operator(int n, const std::vector<int> &kept, std::vector<int> &ms, std::vector<double> &Rz, std::vector<double> &Cz)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    std::vector<char> is_kept(n, 0);
+    for (int k : kept) is_kept[k] = 1;
+    ms.clear();
+    for (int m = 0; m <= n / 2; ++m) {
+        const int k2 = n - m;
+        if (is_kept[m] || (m != 0 && k2 < n && is_kept[k2])) ms.push_back(m);
+    }
+    const int nm = (int)ms.size(), Th = n / 2 + 1;
+    Rz.assign((size_t)nm * n, 0.0);
+    Cz.assign((size_t)Th * nm, 0.0);
+    for (int i = 0; i < nm; ++i) {
+        const int m = ms[i], k2 = n - m;
+        const bool second = m != 0 && k2 != m && k2 < n && is_kept[k2];
         for (int t = 0; t < n; ++t) {
-            double v;
-            if (k == 0) v = 1.0;
-            else if ((n % 2 == 0) && k == n - 1) v = (t % 2 == 0) ? 1.0 : -1.0;
-            else {
-                int j = (k + 1) / 2;
-                long long jt = ((long long)j * t) % n;  // exact argument reduction
-                double ang = two_pi * (double)jt / (double)n;
-                v = (k % 2 == 1) ? std::cos(ang) : -std::sin(ang);
-            }
-            R[(size_t)i * n + t] = v;
+            double v = is_kept[m] ? packed_row(n, m, t) : 0.0;
+            if (second) v = is_kept[m] ? v + packed_row(n, k2, t) : packed_row(n, k2, t);
+            Rz[(size_t)i * n + t] = v;
         }
-        for (int sidx = 0; sidx < n; ++sidx) {
-            long long ks = ((long long)k * sidx) % n;
-            C[(size_t)sidx * nk + i] = std::cos(two_pi * (double)ks / (double)n) / (double)n;
+        for (int sidx = 0; sidx < Th; ++sidx) {
+            const long long ks = ((long long)m * sidx) % n;
+            Cz[(size_t)sidx * nm + i] = std::cos(two_pi * (double)ks / (double)n) / (double)n;
         }
     }
 }
 
-struct TemporalOp { const double *R = nullptr, *C = nullptr, *Rf = nullptr, *Cf = nullptr; int nk = 0, tiles = 0; };  // Rf / Cf: fragment-major copies for k_temporal_mfma
+// symmetry class of merged row m when n is even: rows 0, odd m (cosine rows, and (-1)^t for k = n - 1) are even in t, even m > 0
+// (sine rows) odd in t; the partner n - m has the parity of m, so a merged row never mixes the classes
+static bool merged_row_is_even(int m) { return m == 0 || (m & 1); }
+
+struct TemporalOp { const double *R = nullptr, *C = nullptr, *Rf = nullptr, *Cf = nullptr; int nk = 0, tiles = 0; };  // nk: merged rows; Rf / Cf: fragment-major copies for k_temporal_sym<tiles>
 
 static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax, TemporalOp *op, hipStream_t s)
 {
+    const int Th = T / 2 + 1, nks = (Th + 3) / 4, mt = (Th + 15) / 16;
     if (!(ctx->op_T == T && ctx->op_fps == fps && ctx->op_fmin == fmin && ctx->op_fmax == fmax)) {
-        std::vector<int> kept;
+        std::vector<int> kept, ms;
         kept_packed_indices(T, fps, fmin, fmax, kept);
         std::vector<double> R, C;
-        two_stage_operator(T, kept, R, C);
-        ctx->op_nk = (int)kept.size();
+        merged_operator(T, kept, ms, R, C);
+        const int nm = (int)ms.size();
+        ctx->op_nk = nm;
         double *dR = nullptr, *dC = nullptr;
         RM_TRY(ws(ctx, "temporal_R", R.size() + 1, &dR));
         RM_TRY(ws(ctx, "temporal_C", C.size() + 1, &dC));
-        // fragment-major copies for the matrix-core kernel (k_temporal_mfma), zero padded to NT tiles of 16 rows of R /
-        // columns of C; NT = 3 covers the calibration defaults (46 rows at n = 256), 6 the long buffers (92 at n = 512)
-        const int nk = ctx->op_nk;
-        const int NT = nk <= 48 ? 3 : 6;
-        const bool mf = nk >= 1 && nk <= 16 * TM_MAX_TILES && T % (4 * (NT == 3 ? TemporalWaves<3>::W : TemporalWaves<6>::W)) == 0;
-        std::vector<double> Rf(mf ? (size_t)(T / 4) * NT * 64 : 1, 0.0), Cf(mf ? (size_t)(T / 16) * 4 * NT * 64 : 1, 0.0);
+        // fragment-major copies for the matrix-core kernel (k_temporal_sym): class-pure tiles of 16 merged rows, NH "even" tiles
+        // then NH "odd" ones, zero padded; frames folded to t <= n / 2 (needs an even n)
+        std::vector<int> rows_e, rows_o;
+        for (int i = 0; i < nm; ++i) (merged_row_is_even(ms[i]) ? rows_e : rows_o).push_back(i);
+        const int NH = std::max(1, (int)std::max((rows_e.size() + 15) / 16, (rows_o.size() + 15) / 16));
+        const bool mf = nm >= 1 && T % 2 == 0 && T >= 8 && NH <= TM_MAX_HALF;
+        const int NT = 2 * NH;
+        std::vector<double> Rf(mf ? (size_t)nks * NT * 64 : 1, 0.0), Cf(mf ? (size_t)mt * 4 * NT * 64 : 1, 0.0);
         if (mf) {
-            for (int t0 = 0; t0 < T; t0 += 4)
-                for (int ti = 0; ti < NT; ++ti)
+            auto row_of = [&](int q, int i) -> int {   // merged row held by row i of tile q, or -1
+                const std::vector<int> &v = q < NH ? rows_e : rows_o;
+                const size_t j = (size_t)(q < NH ? q : q - NH) * 16 + i;
+                return j < v.size() ? v[j] : -1;
+            };
+            for (int ks = 0; ks < nks; ++ks)
+                for (int q = 0; q < NT; ++q)
                     for (int l = 0; l < 64; ++l) {
-                        const int k = 16 * ti + (l & 15), t = t0 + (l >> 4);
-                        Rf[((size_t)(t0 / 4) * NT + ti) * 64 + l] = k < nk ? R[(size_t)k * T + t] : 0.0;
+                        const int r = row_of(q, l & 15), t = 4 * ks + (l >> 4);
+                        Rf[((size_t)ks * NT + q) * 64 + l] = (r >= 0 && t < Th) ? R[(size_t)r * T + t] : 0.0;
                     }
-            for (int m = 0; m < T / 16; ++m)
-                for (int q = 0; q < 4 * NT; ++q)
-                    for (int l = 0; l < 64; ++l) {
-                        const int sI = 16 * m + (l & 15), k = 16 * (q / 4) + 4 * (q % 4) + (l >> 4);
-                        Cf[((size_t)m * 4 * NT + q) * 64 + l] = k < nk ? C[(size_t)sI * nk + k] : 0.0;
-                    }
+            for (int m = 0; m < mt; ++m)
+                for (int q = 0; q < NT; ++q)
+                    for (int rr = 0; rr < 4; ++rr)
+                        for (int l = 0; l < 64; ++l) {
+                            const int sI = 16 * m + (l & 15), r = row_of(q, 4 * rr + (l >> 4));
+                            Cf[(((size_t)m * NT + q) * 4 + rr) * 64 + l] = (r >= 0 && sI < Th) ? C[(size_t)sI * nm + r] : 0.0;
+                        }
         }
         double *dRf = nullptr, *dCf = nullptr;
         RM_TRY(ws(ctx, "temporal_Rf", Rf.size(), &dRf));
         RM_TRY(ws(ctx, "temporal_Cf", Cf.size(), &dCf));
-        ctx->op_mfma = mf ? NT : 0;
+        ctx->op_mfma = mf ? NH : 0;
         if (!R.empty()) {
             HIP_TRY(hipMemcpyAsync(dR, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(dC, C.data(), sizeof(double) * C.size(), hipMemcpyHostToDevice, s));
@@ -568,31 +631,35 @@ static int get_operator(rm_ctx *ctx, int T, double fps, double fmin, double fmax
     }
     double *dR = nullptr, *dC = nullptr;
     RM_TRY(ws(ctx, "temporal_R", (size_t)ctx->op_nk * T + 1, &dR));
-    RM_TRY(ws(ctx, "temporal_C", (size_t)ctx->op_nk * T + 1, &dC));
+    RM_TRY(ws(ctx, "temporal_C", (size_t)ctx->op_nk * Th + 1, &dC));
     op->R = dR; op->C = dC; op->nk = ctx->op_nk;
     if (ctx->op_mfma) {
         double *dRf = nullptr, *dCf = nullptr;
-        RM_TRY(ws(ctx, "temporal_Rf", (size_t)(T / 4) * ctx->op_mfma * 64, &dRf));
-        RM_TRY(ws(ctx, "temporal_Cf", (size_t)(T / 16) * 4 * ctx->op_mfma * 64, &dCf));
+        RM_TRY(ws(ctx, "temporal_Rf", (size_t)nks * 2 * ctx->op_mfma * 64, &dRf));
+        RM_TRY(ws(ctx, "temporal_Cf", (size_t)mt * 8 * ctx->op_mfma * 64, &dCf));
         op->Rf = dRf; op->Cf = dCf; op->tiles = ctx->op_mfma;
     }
     return RM_OK;
 }
 
-// out[T, NP] = amp * C (R x), x[T, NP]   (transforms.py:86-99)
+// out[Th, NP] = amp * Cz (Rz x), x[T, NP]: the Th = T / 2 + 1 unique frames of the band-passed signal (transforms.py:86-99);
+// full = true: out is [T, NP] and the mirrored frames are stored as well
 static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const TemporalOp &op, double amp, double *out, hipStream_t s,
-                           CollapseState *st_init = nullptr)
+                           CollapseState *st_init = nullptr, bool full = false)
 {
+    const int Th = sym_frames(T);
     if (op.nk == 0) {  // nothing survives the mask
-        HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * (size_t)T * NP, s));
+        HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(full ? T : Th) * NP, s));
         if (st_init) { hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st_init); LAUNCH_CHECK(); }
         return RM_OK;
     }
+    const int mirror_n = full ? T : 0;
 #ifndef RM_HIPEMU
-    static const int env_valu = [] { const char *e = getenv("RM_TEMPORAL_VALU"); return e ? atoi(e) : 0; }();  // developer A/B knob
-    if (op.Rf && !env_valu) {
-        if (op.tiles == 3) hipLaunchKernelGGL((k_temporal_mfma<3>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<3>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out, st_init);
-        else hipLaunchKernelGGL((k_temporal_mfma<6>), dim3((unsigned)((NP + 15) / 16)), dim3(64 * TemporalWaves<6>::W), 0, s, x, T, NP, op.Rf, op.Cf, amp, out, st_init);
+    if (op.Rf && !ctx->dbg.temporal_valu) {
+        const dim3 grid((unsigned)((NP + 15) / 16)), block(64 * TM_W);
+        if (op.tiles == 1) hipLaunchKernelGGL((k_temporal_sym<1>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
+        else if (op.tiles == 2) hipLaunchKernelGGL((k_temporal_sym<2>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
+        else hipLaunchKernelGGL((k_temporal_sym<3>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
         LAUNCH_CHECK();
         return RM_OK;
     }
@@ -601,10 +668,10 @@ static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const
     if (sh1 > 64 * 1024 || sh2 > 64 * 1024) return fail(RM_E_UNSUPPORTED, "temporal filter: T=%d exceeds the LDS-staged operator (T <= 2048)", T);
     double *y = nullptr;
     RM_TRY(ws(ctx, "temporal_y", (size_t)op.nk * NP, &y));
-    dim3 g1((unsigned)((NP + 63) / 64), (op.nk + TF_KC - 1) / TF_KC), g2((unsigned)((NP + 63) / 64), (T + TF_SC - 1) / TF_SC);
+    dim3 g1((unsigned)((NP + 63) / 64), (op.nk + TF_KC - 1) / TF_KC), g2((unsigned)((NP + 63) / 64), (Th + TF_SC - 1) / TF_SC);
     hipLaunchKernelGGL(k_temporal_fwd, g1, dim3(64), sh1, s, x, T, NP, op.R, op.nk, y, st_init);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_temporal_inv, g2, dim3(64), sh2, s, y, op.nk, NP, op.C, T, amp, out);
+    hipLaunchKernelGGL(k_temporal_inv, g2, dim3(64), sh2, s, y, op.nk, NP, op.C, Th, amp, out, mirror_n);
     LAUNCH_CHECK();
     return RM_OK;
 }
@@ -618,7 +685,7 @@ extern "C" int rm_temporal_bandpass_filter_fft(rm_ctx *ctx, const double *data, 
     hipStream_t s = (hipStream_t)stream;
     TemporalOp op;
     RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
-    return launch_temporal(ctx, data, T, npix, op, amp, out, s);
+    return launch_temporal(ctx, data, T, npix, op, amp, out, s, nullptr, true);
 }
 
 extern "C" int rm_time_average(rm_ctx *ctx, const void *data, int dtype, int T, size_t npix, double *out, void *stream)
@@ -713,10 +780,9 @@ template <typename Tin>
 static int launch_down_chain_t(rm_ctx *ctx, const void *frames, int T, const std::vector<int> &h, const std::vector<int> &w, int S, int vec_ok,
                                double *out, hipStream_t s, bool tiny)
 {
-    (void)ctx;
     const Tin *f = (const Tin *)frames;
     DownGeom g;
-    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny, ctx->dbg.dc_segs, ctx->dbg.dc_wpg)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
     if (down_chain_hot_ok(S, h.data())) return launch_down_chain_g<Tin, false>(f, T, g, out, s);
     return launch_down_chain_g<Tin, true>(f, T, g, out, s);
 }
@@ -733,8 +799,7 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
     const bool vec_ok = (w[0] % V == 0) && (((size_t)h[0] * w[0] * esz) % 16 == 0) && (((uintptr_t)frames) % 16 == 0);
     if (S < 1 || S > 5) return fail(RM_E_UNSUPPORTED, "fused pyrDown chain supports 1..5 levels, got %d", S);
     const int vo = vec_ok ? 1 : 0;
-    static const unsigned flags_dev = [] { const char *e = getenv("RM_DC_LDS_FRONT_END"); return (unsigned)(e ? atoi(e) : 0); }();  // developer A/B knob
-    if ((dtype == RM_U8 || dtype == RM_F16 || dtype == RM_F32) && vec_ok && !(flags_dev & 1u)) {
+    if ((dtype == RM_U8 || dtype == RM_F16 || dtype == RM_F32) && vec_ok && !ctx->dbg.dc_lds_front_end) {
         // all-register variant for narrow frame buffers (rm_down_chain_u8.h): a lane owns 16 adjacent pixels
         DownGeom g8;
         if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny)) {
@@ -824,12 +889,12 @@ static void pyr_geom(int H, int W, int levels, int skip, unsigned flags, PyrGeom
             const size_t nS = (size_t)pg.h[S] * pg.w[S];
             const size_t tiles_x = (size_t)(W + CT_W - 1) / CT_W;
             const size_t need = sizeof(double) * (pg.lds_levels + 2 * (size_t)pg.h[S] * tiles_x);
-            if (need <= LDS_LIMIT && !getenv("RM_FF_PER_LEVEL")) { pg.filter_first = true; pg.NP = nS; }   // (env: test hook)
+            if (need <= LDS_LIMIT && !(flags & RM_FLAG_FF_PER_LEVEL)) { pg.filter_first = true; pg.NP = nS; }   // (flag: test hook)
         }
     }
     // the same form with one launch per pyramid level when the levels are too large for LDS (4K, skip 2): the temporal filter
     // runs over G_S only and the Laplacian levels are never materialised
-    if (pg.chain && !pg.filter_first && (!pg.fuse_small || getenv("RM_FF_PER_LEVEL")) &&
+    if (pg.chain && !pg.filter_first && (!pg.fuse_small || (flags & RM_FLAG_FF_PER_LEVEL)) &&
         !(flags & (RM_FLAG_FILTER_LAPLACIANS | RM_FLAG_UNFUSED_SMALL)) && S >= 1 && S < MAX_CHAIN) {
         pg.ff_levels = true; pg.fuse_small = false; pg.NP = (size_t)pg.h[S] * pg.w[S];
     }
@@ -909,6 +974,7 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
     const std::vector<int> &h = pg.h, &w = pg.w;
     const int L = pg.L, S = pg.S;
     const size_t NP = pg.NP;
+    const int Th = sym_frames(T);   // the band-passed signal is even in time: everything below handles the unique frames only
     out.h = pg.h; out.w = pg.w; out.S = S; out.all_zero = false;
     // consumed here, on every path: whatever follows reduces into d_state, so the reset by front_pyramid's last kernel
     // vouches for this call only (a later rm_shard_collapse with a foreign lap buffer must reset the state itself)
@@ -918,26 +984,26 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
     RM_TRY(get_operator(ctx, T, fps, fmin, fmax, &op, s));
     PhaseTimer pt_small(ctx, 1, s);
     double *bp = nullptr;
-    RM_TRY(ws(ctx, "bp_all", (size_t)T * NP, &bp));
+    RM_TRY(ws(ctx, "bp_all", (size_t)Th * NP, &bp));
     if (pg.filter_first) {
-        // X = B(G_S) for all frames (its workgroup 0 resets the reduction state), then ONE per-frame kernel: Gaussian levels of X,
-        // Laplacians, collapse to C_S, tile bounds and lattice samples
+        // X = B(G_S) for the unique frames (its workgroup 0 resets the reduction state), then ONE per-frame kernel: Gaussian levels
+        // of X, Laplacians, collapse to C_S, tile bounds and lattice samples
         RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s, ctx->d_state));
         ChainGeom cg;
         SmallLevels probe; probe.h = pg.h; probe.w = pg.w; probe.S = S;
         RM_TRY(make_geom(probe, cg));
-        const long long npairs = (long long)cg.tiles_x * cg.tiles_y * T;
+        const long long npairs = (long long)cg.tiles_x * cg.tiles_y * Th;
         if (npairs >= (1ll << 31)) return fail(RM_E_UNSUPPORTED, "calibration: %lld (tile, frame) pairs exceed 2^31", npairs);
         double *dst = nullptr, *lo = nullptr, *hi = nullptr;
         int *sel_cnt = nullptr;
-        RM_TRY(ws(ctx, "cS", (size_t)T * NP, &dst));
+        RM_TRY(ws(ctx, "cS", (size_t)Th * NP, &dst));
         RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
         RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &hi));
         RM_TRY(ws(ctx, "sel_cnt", (size_t)cg.tiles_x * cg.tiles_y, &sel_cnt));
         const size_t sh = sizeof(double) * (pg.lds_levels + 2 * (size_t)h[S] * cg.tiles_x);
         if (sh > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_filter_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_small_filter_first, dim3(T), dim3(SMALL_NT), sh, s, (const double *)bp, pg.sg, (int)pg.lds_levels, dst, ctx->d_state, cg,
+        hipLaunchKernelGGL(k_small_filter_first, dim3(Th), dim3(SMALL_NT), sh, s, (const double *)bp, pg.sg, (int)pg.lds_levels, dst, ctx->d_state, cg,
                            cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt);
         LAUNCH_CHECK();
         out.state_ready = true; out.bounds_ready = true;
@@ -945,33 +1011,38 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         return RM_OK;
     }
     if (pg.ff_levels) {
-        // X_S = B(G_S); X_l = pyrDown(X_{l-1}); U_{L-1} = X_{L-1}, U_l = pyrUp(U_{l+1}); C_S = X_S - pyrUp(U_{S+1})
-        // (rm_kernels.h k_small_filter_first: the telescoped collapse, here with the per-level kernels)
+        // X_S = B(G_S); X_{L-1} = pyrDown^(L-1-S)(X_S); U_{L-1} = X_{L-1}, U_l = pyrUp(U_{l+1}); C_S = X_S - pyrUp(U_{S+1})
+        // (rm_kernels.h k_small_filter_first: the telescoped collapse, here with one launch per step): only the COARSEST level of
+        // the filtered pyramid is needed, so the way down is the fused pyrDown chain (rm_down_chain.h) on the float64 level X_S
         RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
         std::vector<double *> x(L, nullptr);
         x[S] = bp;
-        for (int l = S + 1; l < L; ++l) {
-            RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)T * h[l] * w[l], &x[l]));
-            RM_TRY(launch_pyr_down(x[l - 1], RM_F64, T, h[l - 1], w[l - 1], x[l], s));
+        for (int l = S + 1; l < L; ++l) RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)Th * h[l] * w[l], &x[l]));
+        const int depth = L - 1 - S;
+        if (depth >= 1 && depth <= 5) {
+            std::vector<int> hh(h.begin() + S, h.end()), ww(w.begin() + S, w.end());
+            RM_TRY(launch_down_chain(ctx, bp, RM_F64, Th, hh, ww, depth, x[L - 1], s, false));
+        } else {
+            for (int l = S + 1; l < L; ++l) RM_TRY(launch_pyr_down(x[l - 1], RM_F64, Th, h[l - 1], w[l - 1], x[l], s));
         }
-        for (int l = L - 2; l > S; --l)   // over the dead X_l
-            RM_TRY(launch_pyr_up(x[l + 1], T, h[l + 1], w[l + 1], x[l], h[l], w[l], 0, nullptr, s));
+        for (int l = L - 2; l > S; --l)
+            RM_TRY(launch_pyr_up(x[l + 1], Th, h[l + 1], w[l + 1], x[l], h[l], w[l], 0, nullptr, s));
         double *dst = nullptr;
-        RM_TRY(ws(ctx, "cS", (size_t)T * NP, &dst));
-        RM_TRY(launch_pyr_up(x[S + 1], T, h[S + 1], w[S + 1], dst, h[S], w[S], 1, bp, s));
+        RM_TRY(ws(ctx, "cS", (size_t)Th * NP, &dst));
+        RM_TRY(launch_pyr_up(x[S + 1], Th, h[S + 1], w[S + 1], dst, h[S], w[S], 1, bp, s));
         out.cS = dst;
         return RM_OK;
     }
     // temporal band-pass of every level at once (transforms.py:162,169)
     RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
     // collapse of the band-passed levels L-2 .. S (pyramid.py:51-57; the coarsest level is zeros: 0 + x == x);
-    // the result is a contiguous [T,h_S,w_S] array for the full-resolution passes
+    // the result is a contiguous [Th,h_S,w_S] array for the full-resolution passes
     const double *c = bp + pg.off[L - 2];
     if (L - 2 == S) {
         // single filtered level: NP == h_S*w_S, bp_all is already C_S
     } else if (pg.fuse_small) {
         double *dst = nullptr;
-        RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
+        RM_TRY(ws(ctx, "cS", (size_t)Th * h[S] * w[S], &dst));
         const size_t shmem = NP * sizeof(double);
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -981,8 +1052,8 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         SmallLevels probe; probe.h = pg.h; probe.w = pg.w; probe.S = S;
         const bool geom_ok = S >= 1 && S < MAX_CHAIN && make_geom(probe, cg) == RM_OK;
         const size_t tbl = geom_ok ? 2 * sizeof(double) * (size_t)h[S] * cg.tiles_x : 0;
-        const long long npairs = geom_ok ? (long long)cg.tiles_x * cg.tiles_y * T : 0;
-        if (geom_ok && shmem + tbl <= 150 * 1024 && npairs < (1ll << 31) && !getenv("RM_NO_FUSED_BOUNDS")) {
+        const long long npairs = geom_ok ? (long long)cg.tiles_x * cg.tiles_y * Th : 0;
+        if (geom_ok && shmem + tbl <= 150 * 1024 && npairs < (1ll << 31) && !ctx->dbg.no_fused_bounds) {
             double *lo = nullptr, *hi = nullptr;
             int *sel_cnt = nullptr;
             RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &lo));
@@ -995,11 +1066,11 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
             const size_t sh2 = shmem + tbl;
             if (sh2 > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void *)k_small_collapse_bounds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
-            hipLaunchKernelGGL(k_small_collapse_bounds, dim3(T), dim3(SMALL_NT), sh2, s, (const double *)bp, pg.sg, dst, ctx->d_state, cg,
+            hipLaunchKernelGGL(k_small_collapse_bounds, dim3(Th), dim3(SMALL_NT), sh2, s, (const double *)bp, pg.sg, dst, ctx->d_state, cg,
                                cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt);
             out.state_ready = true; out.bounds_ready = true;
         } else {
-            hipLaunchKernelGGL(k_small_collapse, dim3(T), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
+            hipLaunchKernelGGL(k_small_collapse, dim3(Th), dim3(SMALL_NT), shmem, s, (const double *)bp, pg.sg, dst, ctx->d_state);
             out.state_ready = true;
         }
         LAUNCH_CHECK();
@@ -1010,10 +1081,10 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
             double *dst = bp + pg.off[l];
             size_t dst_fs = NP;
             if (l == S) {
-                RM_TRY(ws(ctx, "cS", (size_t)T * h[S] * w[S], &dst));
+                RM_TRY(ws(ctx, "cS", (size_t)Th * h[S] * w[S], &dst));
                 dst_fs = (size_t)h[S] * w[S];
             }
-            RM_TRY(launch_pyr_up(c, T, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + pg.off[l], s, c_fs, dst_fs, NP));
+            RM_TRY(launch_pyr_up(c, Th, h[l + 1], w[l + 1], dst, h[l], w[l], 2, bp + pg.off[l], s, c_fs, dst_fs, NP));
             c = dst; c_fs = dst_fs;
         }
     }
@@ -1114,6 +1185,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     cp.valid = false;
     cp.cS = sl.cS; cp.T = T; cp.t0 = t0; cp.t1 = t1; cp.H = sl.h[0]; cp.W = sl.w[0]; cp.S = sl.S;
     const size_t npix = (size_t)cp.H * cp.W;
+    const int Th = sym_frames(T);   // C_S, the bounds and the pairs exist for the unique frames only (rm_kernels.h sym_frame)
     if (!sl.state_ready) {
         hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
         LAUNCH_CHECK();
@@ -1121,7 +1193,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     const int no_prune = (flags & RM_FLAG_NO_PRUNE) ? 1 : 0;
     if (sl.S == 0) {
         if (t0 != 0 || t1 != T) return fail(RM_E_UNSUPPORTED, "frame-sharded calibration needs skip_levels_at_top >= 1");
-        size_t n = (size_t)T * npix;
+        size_t n = (size_t)Th * npix;
         hipLaunchKernelGGL(k_minmax_plain, dim3(nblk(n, 256, 1024)), dim3(256), 0, s, sl.cS, n, st);
         LAUNCH_CHECK();
         cp.valid = true;
@@ -1130,31 +1202,36 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     ChainGeom &g = cp.g;
     RM_TRY(make_geom(sl, g));
     const int ntiles = g.tiles_x * g.tiles_y;
-    const int npairs = ntiles * T;
+    const long long npairs_ll = (long long)ntiles * Th;
+    if (npairs_ll >= (1ll << 31)) return fail(RM_E_UNSUPPORTED, "calibration: %lld (tile, frame) pairs exceed 2^31", npairs_ll);
+    const int npairs = (int)npairs_ll;
     cp.ntiles = ntiles; cp.npairs = npairs;
-    // value store: one slot per (tile, frame) pair, tile-major (rm_kernels.h SLOT_KEPT) -- the size of ONE float64 [T,H,W]
-    // array (rounded up to whole tiles), of which only the kept pairs are ever written or read
-    ctx->dbg_pairs = npairs; ctx->dbg_cap = (long long)npairs;
+    int mine_frames = 0;   // unique frames this rank's frame range [t0, t1) holds
+    for (int u = 0; u < Th; ++u) mine_frames += sym_in_range(u, T, t0, t1) ? 1 : 0;
+    const long long npairs_mine = (long long)ntiles * mine_frames;
     RM_TRY(ws(ctx, "tile_lo", (size_t)npairs, &cp.lo));
     RM_TRY(ws(ctx, "tile_hi", (size_t)npairs, &cp.hi));
-    RM_TRY(ws(ctx, "pair_list", (size_t)npairs, &cp.list));
+    RM_TRY(ws(ctx, "pair_list_a", (size_t)npairs, &cp.list_a));
+    RM_TRY(ws(ctx, "pair_list_b", (size_t)npairs, &cp.list_b));
     RM_TRY(ws(ctx, "pair_slot", (size_t)npairs, &cp.slot_of));
-    // sparse or dense sum (bit-identical results): forced by a flag, else by what the selection of the previous call of this
-    // geometry on this context kept -- the first call of a geometry is sparse
-    if (!ctx->h_stats) {
-        HIP_TRY(hipHostMalloc((void **)&ctx->h_stats, 2 * sizeof(unsigned int), hipHostMallocDefault));
-        ctx->h_stats[0] = ctx->h_stats[1] = 0;
-    }
-    cp.dense = false; cp.no_prune = no_prune != 0;
-    if (flags & RM_FLAG_DENSE_SUM) cp.dense = true;
-    else if (!(flags & RM_FLAG_SPARSE_SUM) && !no_prune) {   // (RM_FLAG_NO_PRUNE is the exhaustive-evaluation baseline: sparse path)
-        const bool same = ctx->stats_T == T && ctx->stats_H == cp.H && ctx->stats_W == cp.W && ctx->stats_S == sl.S;
-        const unsigned int kept = *(volatile unsigned int *)&ctx->h_stats[0], of = *(volatile unsigned int *)&ctx->h_stats[1];
-        cp.dense = (same && of == (unsigned)npairs && (unsigned long long)kept * DENSE_ONE_IN > (unsigned long long)of);
-    }
-    ctx->stats_T = T; ctx->stats_H = cp.H; ctx->stats_W = cp.W; ctx->stats_S = sl.S;
-    if (!cp.dense) RM_TRY(ws(ctx, "value_store", (size_t)npairs * CT_H * CT_W, &cp.store));
-    ctx->dbg_cap = cp.dense ? 0 : (long long)npairs;
+    // The value store: 8 KB slots for the pairs the selection keeps, handed out tile by tile (rm_kernels.h k_select_pairs).
+    // Capped at STORE_BUDGET_SLOTS (1 GiB): a selection that keeps more takes the dense sum kernel, which needs no store --
+    // decided on the device, in this same call (sum_is_dense).  The exhaustive-evaluation baseline (RM_FLAG_NO_PRUNE) and a
+    // forced sparse path park every pair they are told to, so they get a slot per pair.
+    constexpr long long STORE_BUDGET_SLOTS = 131072;
+    cp.no_prune = no_prune != 0;
+    SumPlan &sp = cp.sp;
+    sp.mode = (flags & RM_FLAG_DENSE_SUM) ? 1 : ((flags & RM_FLAG_SPARSE_SUM) || no_prune) ? 2 : 0;
+    sp.auto_dense_ok = sl.S <= 2 ? 1 : 0;
+    sp.npairs_mine = (unsigned)npairs_mine;
+    long long cap = sp.mode == 2 ? npairs_mine : std::min(npairs_mine, STORE_BUDGET_SLOTS);
+    if (flags & RM_FLAG_TINY_STORE) cap = std::min(cap, (long long)8);   // test hook: nearly every selection overflows
+    if (ctx->dbg.store_slots > 0) cap = std::min(npairs_mine, ctx->dbg.store_slots);
+    if (sp.mode == 1) cap = 0;
+    sp.cap_slots = (unsigned)cap;
+    cp.store = nullptr;
+    if (cap > 0) RM_TRY(ws(ctx, "value_store", (size_t)cap * CT_H * CT_W, &cp.store));
+    ctx->dbg_pairs = npairs; ctx->dbg_cap = cap; ctx->dbg_mine = npairs_mine; ctx->dbg_mode = sp.mode; ctx->dbg_auto_dense = sp.auto_dense_ok;
     RM_TRY(ws(ctx, "sel_cnt", (size_t)ntiles, &cp.sel_cnt));
     RM_TRY(ws(ctx, "heavy_tiles", (size_t)ntiles, &cp.heavy));
     if (!sl.bounds_ready) {
@@ -1171,26 +1248,26 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
             return most;
         };
         size_t tbl_max = 64 * 1024;
-        if (const char *e = getenv("RM_BOUNDS_TABLE_BYTES")) tbl_max = (size_t)atol(e);   // test hook: force small bands
+        if (ctx->dbg.bounds_table_bytes > 0) tbl_max = (size_t)ctx->dbg.bounds_table_bytes;   // test hook: force small bands
         while (band > 1 && (size_t)tbl_rows_of(band) * row_bytes > tbl_max) band = (band + 1) / 2;
         // ... and enough workgroups to fill the chip: one workgroup per frame leaves half of it idle at T = 128
-        while (band > 4 && (long long)T * ((g.tiles_y + band - 1) / band) < 1024) band = (band + 1) / 2;
+        while (band > 4 && (long long)Th * ((g.tiles_y + band - 1) / band) < 1024) band = (band + 1) / 2;
         const int tbl_rows = tbl_rows_of(band);
         const size_t tbl = (size_t)tbl_rows * row_bytes;
         if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
             const unsigned nbands = (unsigned)((g.tiles_y + band - 1) / band);
-            hipLaunchKernelGGL(k_frame_bounds, dim3(T, nbands), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, band, tbl_rows, cp.sel_cnt);
+            hipLaunchKernelGGL(k_frame_bounds, dim3(Th, nbands), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, band, tbl_rows, cp.sel_cnt);
         } else {
-            hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, T, ntiles, cp.lo, cp.hi, st, cp.sel_cnt);
+            hipLaunchKernelGGL(k_tile_bounds, dim3((npairs + 255) / 256), dim3(256), 0, s, sl.cS, g, Th, ntiles, cp.lo, cp.hi, st, cp.sel_cnt);
         }
         LAUNCH_CHECK();
     }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
-    hipLaunchKernelGGL(k_select_pairs, dim3((npairs + 256 * SEL_U - 1) / (256 * SEL_U)), dim3(256), 0, s, cp.lo, cp.hi, npairs, st, cp.list, cp.slot_of,
-                       prune_ok ? 0 : 1, thr, t0 * ntiles, t1 * ntiles, ntiles, cp.sel_cnt, cp.heavy, cp.dense ? 1 : 0);
+    hipLaunchKernelGGL(k_select_pairs, dim3((ntiles + SEL_TILES - 1) / SEL_TILES, (Th + SEL_PH * SEL_U - 1) / (SEL_PH * SEL_U)), dim3(256), 0, s,
+                       cp.lo, cp.hi, ntiles, Th, T, t0, t1, st, cp.list_a, cp.list_b, cp.slot_of, prune_ok ? 0 : 1, thr, cp.sel_cnt, cp.heavy);
     LAUNCH_CHECK();
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
-    // one resident round of single-wave workgroups that loop over the list: the list length lives on the device, and
+    // one resident round of single-wave workgroups that loop over the lists: their lengths live on the device, and
     // dispatching thousands of workgroups that find nothing to do costs more than the loop.  "Resident" is what the
     // kernel's registers and this geometry's LDS footprint allow per CU (asked of the runtime once per footprint).
     unsigned egrid = 64;   // (host emulation: a fiber per lane -- few, looping workgroups compute the same thing)
@@ -1208,13 +1285,13 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
 #endif
             cached_per_cu = per_cu < 1 ? 1 : per_cu; cached_cus = cus < 1 ? 1 : cus; cached_shmem = cp.shmem;
         }
-        const long long cap = (long long)cached_per_cu * cached_cus;
-        egrid = (unsigned)(npairs < cap ? npairs : cap);
+        const long long capw = (long long)cached_per_cu * cached_cus;
+        egrid = (unsigned)(npairs < capw ? npairs : capw);
     }
 #else
     if ((long long)egrid > npairs) egrid = (unsigned)npairs;
 #endif
-    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, T, ntiles, cp.list, cp.slot_of, st, cp.store);
+    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp);
     LAUNCH_CHECK();
     cp.valid = true;
     return RM_OK;
@@ -1241,9 +1318,24 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
-    unsigned int *stats_dev = nullptr;   // (an exhaustive-evaluation call keeps every pair by decree: it leaves the record alone)
-    if (ctx->h_stats && !cp.no_prune) HIP_TRY(hipHostGetDevicePointer((void **)&stats_dev, ctx->h_stats, 0));
-    if (cp.dense) {
+    const SumPlan &sp = cp.sp;
+    // Both sum kernels are enqueued and the one whose turn it is not returns at once (sum_is_dense, decided from this call's own
+    // selection); a launch that can never be chosen is left out: the sparse one when the dense kernel is forced, the dense one when
+    // the store has a slot for every pair and the automatic rule cannot pick it.
+    const bool may_sparse = sp.mode != 1;
+    const bool may_dense = sp.mode == 1 || sp.cap_slots < sp.npairs_mine || (sp.mode == 0 && sp.auto_dense_ok);
+    if (may_sparse) {
+        // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
+#ifdef RM_HIPEMU
+        const int nworkers = std::min(cp.ntiles * MS_Q, 24);    // (host emulation: fewer, looping workgroups compute the same thing)
+#else
+        const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
+#endif
+        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), 2 * sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
+                           cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, sp);
+        LAUNCH_CHECK();
+    }
+    if (may_dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
         // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts
         int cus = 256;
@@ -1253,7 +1345,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         const ChainGeom &g = cp.g;
         int rows = 64;
         while (rows > 16 && (long long)g.tiles_x * ((cp.H + rows - 1) / rows) < 2ll * cus) rows >>= 1;
-        if (const char *e = getenv("RM_DENSE_ROWS")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) rows = v; }   // test hook
+        { const int v = ctx->dbg.dense_rows; if (v == 16 || v == 32 || v == 64) rows = v; }   // test hook
         DenseGeom dg;
         dg.rows = rows; dg.nsx = g.tiles_x; dg.nsy = (cp.H + rows - 1) / rows;
         const int S = cp.S;
@@ -1270,41 +1362,21 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         dg.lds_total = B + (S >= 2 ? std::max(scratch(2), S >= 3 ? small + hb_small : 0) : 0);
         const size_t sh = sizeof(double) * (size_t)dg.lds_total;
         const unsigned grid = (unsigned)(dg.nsx * dg.nsy);
-#define RM_DENSE_LAUNCH(NW, RPW)                                                                                                         \
+#define RM_DENSE_LAUNCH(KERNEL, NW, RPW)                                                                                                 \
         do {                                                                                                                             \
             if (sh > 64 * 1024)                                                                                                          \
-                HIP_TRY(hipFuncSetAttribute((const void *)k_dense_sum<NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));   \
-            hipLaunchKernelGGL((k_dense_sum<NW, RPW>), dim3(grid), dim3(64 * NW), sh, s, cp.cS, g, dg, cp.t0, cp.t1, st, thr, heat_sum,  \
-                               avg_T, tile_nkept, stats_dev, (unsigned)cp.npairs);                                                       \
+                HIP_TRY(hipFuncSetAttribute((const void *)KERNEL<NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));       \
+            hipLaunchKernelGGL((KERNEL<NW, RPW>), dim3(grid), dim3(64 * NW), sh, s, cp.cS, g, dg, cp.t0, cp.t1, cp.T, st, thr, heat_sum, \
+                               avg_T, tile_nkept, sp);                                                                                   \
         } while (0)
-#define RM_DENSE_LAUNCH_S2(NW, RPW)                                                                                                      \
-        do {                                                                                                                             \
-            if (sh > 64 * 1024)                                                                                                          \
-                HIP_TRY(hipFuncSetAttribute((const void *)k_dense_sum_s2<NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));\
-            hipLaunchKernelGGL((k_dense_sum_s2<NW, RPW>), dim3(grid), dim3(64 * NW), sh, s, cp.cS, g, dg, cp.t0, cp.t1, st, thr,         \
-                               heat_sum, avg_T, tile_nkept, stats_dev, (unsigned)cp.npairs);                                             \
-        } while (0)
-        if (S <= 2 && !getenv("RM_DENSE_GENERAL")) {   // table-driven form (env: test hook for the general kernel)
-            if (rows == 64) RM_DENSE_LAUNCH_S2(4, 16); else if (rows == 32) RM_DENSE_LAUNCH_S2(2, 16); else RM_DENSE_LAUNCH_S2(4, 4);
+        if (S <= 2 && !ctx->dbg.dense_general) {   // table-driven form (knob: test hook for the general kernel)
+            if (rows == 64) RM_DENSE_LAUNCH(k_dense_sum_s2, 4, 16); else if (rows == 32) RM_DENSE_LAUNCH(k_dense_sum_s2, 2, 16); else RM_DENSE_LAUNCH(k_dense_sum_s2, 4, 4);
         } else {
-            if (rows == 64) RM_DENSE_LAUNCH(4, 16); else if (rows == 32) RM_DENSE_LAUNCH(2, 16); else RM_DENSE_LAUNCH(4, 4);
+            if (rows == 64) RM_DENSE_LAUNCH(k_dense_sum, 4, 16); else if (rows == 32) RM_DENSE_LAUNCH(k_dense_sum, 2, 16); else RM_DENSE_LAUNCH(k_dense_sum, 4, 4);
         }
-#undef RM_DENSE_LAUNCH_S2
 #undef RM_DENSE_LAUNCH
         LAUNCH_CHECK();
-        ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;
-        return RM_OK;
     }
-    // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
-#ifdef RM_HIPEMU
-    const int nworkers = std::min(cp.ntiles * MS_Q, 24);    // (host emulation: fewer, looping workgroups compute the same thing)
-#else
-    const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
-#endif
-    hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
-                       cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, stats_dev,
-                       (unsigned)cp.npairs);
-    LAUNCH_CHECK();
     ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;   // the constant tiles of this heatmap (or partial heat sum of a frame shard) are known
     return RM_OK;
 }
@@ -1450,16 +1522,22 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
     }
     double *raw_buf = raw;
     if (!raw_buf) RM_TRY(ws(ctx, "raw_full", n, &raw_buf));
-    // materialised collapse of the all-zero levels below `skip` (pyramid.py:55 with zero levels)
+    // materialised collapse of the all-zero levels below `skip` (pyramid.py:55 with zero levels), for the unique frames; the
+    // frames past T / 2 are their mirror images (rm_kernels.h sym_frame)
+    const int Th = sym_frames(T);
     const double *cur = sl.cS;
     for (int l = sl.S - 1; l >= 0; --l) {
         double *dst = nullptr;
         if (l == 0) dst = raw_buf;
-        else RM_TRY(ws(ctx, (l & 1) ? "collapse_a" : "collapse_b", (size_t)T * sl.h[l] * sl.w[l], &dst));
-        RM_TRY(launch_pyr_up(cur, T, sl.h[l + 1], sl.w[l + 1], dst, sl.h[l], sl.w[l], 0, nullptr, s));
+        else RM_TRY(ws(ctx, (l & 1) ? "collapse_a" : "collapse_b", (size_t)Th * sl.h[l] * sl.w[l], &dst));
+        RM_TRY(launch_pyr_up(cur, Th, sl.h[l + 1], sl.w[l + 1], dst, sl.h[l], sl.w[l], 0, nullptr, s));
         cur = dst;
     }
-    if (sl.S == 0) HIP_TRY(hipMemcpyAsync(raw_buf, sl.cS, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    if (sl.S == 0) HIP_TRY(hipMemcpyAsync(raw_buf, sl.cS, sizeof(double) * (size_t)Th * H * W, hipMemcpyDeviceToDevice, s));
+    if (T > Th) {
+        hipLaunchKernelGGL(k_mirror_frames, dim3(nblk((size_t)H * W, 256, 1024), (unsigned)(T - Th)), dim3(256), 0, s, raw_buf, T, (size_t)H * W);
+        LAUNCH_CHECK();
+    }
     CollapseState *st = ctx->d_state;
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(NSTRIPE), 0, s, st);
     LAUNCH_CHECK();

@@ -17,11 +17,8 @@
 
 namespace rm {
 
-// The dense kernel is chosen when the previous selection kept more than one pair in DENSE_ONE_IN.  Measured per pair of the
-// geometry (MI355X): sparse path 3.7-4.8 ns per KEPT pair, dense kernel 1.6 ns (4K x 512, skip 2), 3.6 ns (720p x 128, skip 2:
-// 900 tiles, latency bound) and 4.6 ns (1080p x 256, skip 4: three pyrUp steps per frame) per pair, kept or not -- the crossover
-// lies between 40 % and never; streams are either sparse (1-4 % kept) or keep every pair, so one half separates them.
-constexpr unsigned long long DENSE_ONE_IN = 2;
+// Which path takes the sum is decided on the device from this call's own selection: sum_is_dense() in rm_kernels.h.  Both sum
+// kernels are enqueued; the one whose turn it is not returns at once.
 
 struct DenseGeom {
     int rows;                    // super-tile rows (waves per workgroup x rows per wave)
@@ -126,16 +123,14 @@ __device__ __forceinline__ void dense_level0(const ChainGeom &g, const double *s
     }
 }
 
-// stats_host (pinned, nullable): {pairs kept for the sum by the selection, pairs} of this call -- what the next call's choice
-// between this kernel and the sparse path goes by
 // NW waves per workgroup, RPW rows of the heatmap per wave: a 64 x (NW RPW) super-tile.  <4,16> and <2,16> for images with
 // super-tiles to spare; <4,4> gives one 64x16 tile to four waves when tiles are few and the per-frame latency is what counts.
 template <int NW, int RPW>
-__global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGeom g, DenseGeom dg, int t_first, int t_end, CollapseState *st,
-                                                        double threshold, double *heat_sum, int avg_T, int *tile_nkept, unsigned int *stats_host,
-                                                        unsigned int npairs)
+__global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGeom g, DenseGeom dg, int t_first, int t_end, int T, CollapseState *st,
+                                                        double threshold, double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp)
 {
     HIP_DYNAMIC_SHARED(double, lds)
+    if (!sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse path took the sum)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = g.S;
     const int syi = (int)blockIdx.x / dg.nsx, sxi = (int)blockIdx.x - syi * dg.nsx;
@@ -145,7 +140,6 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGe
     const double top = max_val - (max_val - min_val) * threshold;
     if (blockIdx.x == 0 && tid == 0) {
         st->min_val = min_val; st->max_val = max_val; st->top = top;
-        if (stats_host) { stats_host[0] = st->n_slots; stats_host[1] = npairs; }
     }
     const Region R0 = super_region(g, ROWS, sxi, syi, 0), RS = super_region(g, ROWS, sxi, syi, S);
     const int nwS = RS.x1 - RS.x0 + 1, nS = (RS.y1 - RS.y0 + 1) * nwS, wS = g.w[S];
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGe
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
             const int t = t_first + d;
-            const double *src = cS + (size_t)(t < t_end ? t : t_first) * fs;
+            const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
 #pragma unroll
             for (int p = 0; p < PF; ++p) nxt[d][p] = (off_l[p] >= 0 && t < t_end) ? src[off_g[p]] : 0.0;
         }
@@ -206,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGe
 #pragma unroll
                     for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) dS[off_l[p]] = nxt[d][p];
                     const int tn = t + PD;
-                    const double *src = cS + (size_t)(tn < t_end ? tn : t_first) * fs;
+                    const double *src = cS + (size_t)sym_frame(tn < t_end ? tn : t_first, T) * fs;
 #pragma unroll
                     for (int p = 0; p < PF; ++p) nxt[d][p] = (off_l[p] >= 0 && tn < t_end) ? src[off_g[p]] : 0.0;
                     compute();
@@ -215,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGe
         }
     } else {
         for (int t = t_first; t < t_end; ++t) {
-            const double *src = cS + (size_t)t * fs;
+            const double *src = cS + (size_t)sym_frame(t, T) * fs;
             for (int i = tid; i < nS; i += 64 * NW) {
                 int r, c;
                 split_rc(i, nwS, inv_nwS, r, c);
@@ -268,13 +262,13 @@ template <int NW, int RPW> struct DenseS2 {
 };
 
 template <int NW, int RPW>
-__global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, ChainGeom g, DenseGeom dg, int t_first, int t_end, CollapseState *st,
-                                                           double threshold, double *heat_sum, int avg_T, int *tile_nkept, unsigned int *stats_host,
-                                                           unsigned int npairs)
+__global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, ChainGeom g, DenseGeom dg, int t_first, int t_end, int T, CollapseState *st,
+                                                           double threshold, double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp)
 {
     using G = DenseS2<NW, RPW>;
     constexpr int NT = G::NT, NH = G::NH, NV = G::NV, PF = G::NV, ROWS = G::ROWS;
     HIP_DYNAMIC_SHARED(double, lds)
+    if (!sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse path took the sum)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = g.S;   // 1 or 2
     const int syi = (int)blockIdx.x / dg.nsx, sxi = (int)blockIdx.x - syi * dg.nsx;
@@ -282,7 +276,6 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, Chai
     const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
     if (blockIdx.x == 0 && tid == 0) {
         st->min_val = min_val; st->max_val = max_val; st->top = top;
-        if (stats_host) { stats_host[0] = st->n_slots; stats_host[1] = npairs; }
     }
     const Region R0 = super_region(g, ROWS, sxi, syi, 0), R1 = super_region(g, ROWS, sxi, syi, 1), R2 = super_region(g, ROWS, sxi, syi, 2 <= S ? 2 : 1);
     const Region RS = S == 2 ? R2 : R1;
@@ -367,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, Chai
     const bool small = nS <= PF * NT;
     double nxt[PF];
     auto fetch = [&](int t) __attribute__((always_inline)) {
-        const double *src = cS + (size_t)(t < t_end ? t : t_first) * fs;
+        const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
 #pragma unroll
         for (int p = 0; p < PF; ++p) nxt[p] = (off_l[p] >= 0 && t < t_end) ? src[off_g[p]] : 0.0;
     };
@@ -378,7 +371,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, Chai
             for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) dS[off_l[p]] = nxt[p];
             fetch(t + 1);
         } else {
-            const double *src = cS + (size_t)t * fs;
+            const double *src = cS + (size_t)sym_frame(t, T) * fs;
             const float inv = 1.0f / (float)nwS;
             for (int i = tid; i < nS; i += NT) {
                 int r, c;

@@ -673,7 +673,9 @@ inline bool down_chain_hot_ok(int S, const int *h)
 }
 
 // geometry of one launch over level-S rows [y_begin, y_end)
-inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok, int y_begin, int y_end, DownGeom &g, bool tiny = false)
+// force_segs / force_wpg > 0: developer overrides (rm_debug_set "dc_segs" / "dc_wpg")
+inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok, int y_begin, int y_end, DownGeom &g, bool tiny = false,
+                           int force_segs = 0, int force_wpg = 0)
 {
     if (S < 1 || S > 5 || y_end <= y_begin) return false;
     g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end;
@@ -695,10 +697,7 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
 #ifdef RM_DC_SEGS  // developer experiment
     segs = RM_DC_SEGS;
 #endif
-    {   // developer A/B knob, read once: RM_DC_SEGS=<n> overrides the segment count
-        static const int env_segs = [] { const char *e = getenv("RM_DC_SEGS"); return e ? atoi(e) : 0; }();
-        if (env_segs >= 1 && env_segs <= rows) segs = env_segs;
-    }
+    if (force_segs >= 1 && force_segs <= rows) segs = force_segs;
     g.seg_h = (rows + segs - 1) / segs;
     if (tiny) g.seg_h = rows < 2 ? rows : 2;  // test hook: many small segments
     g.segs = (rows + g.seg_h - 1) / g.seg_h;
@@ -715,10 +714,7 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
 #ifdef RM_DC_WPG  // developer experiment
     g.wpg = RM_DC_WPG;
 #endif
-    {   // developer A/B knob, read once: RM_DC_WPG=<n> overrides the waves per workgroup
-        static const int env_wpg = [] { const char *e = getenv("RM_DC_WPG"); return e ? atoi(e) : 0; }();
-        if (env_wpg >= 1 && env_wpg <= DC_MAX_WPG) g.wpg = env_wpg;
-    }
+    if (force_wpg >= 1 && force_wpg <= DC_MAX_WPG) g.wpg = force_wpg;
 #ifdef RM_HIPEMU
     g.wpg = 1;
 #endif

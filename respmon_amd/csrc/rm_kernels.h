@@ -82,6 +82,19 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// The band-passed video is EVEN in time.  transforms.py:98 takes Re(ifft(.)) of a REAL (packed-rfft) array, so the filter output
+// satisfies out[s] == out[n - s] for 0 < s < n -- bit for bit in the reference (scipy's ifft of a real sequence is exactly
+// Hermitian) and here (the stage-2 operator is evaluated for s <= n / 2 only, rm_api.hip get_operator).  Every per-frame stage
+// after the filter is a function of the frame alone, so C_S, the tile bounds and raw inherit the symmetry: the library computes and
+// stores the T / 2 + 1 UNIQUE frames and the time-ordered consumers (the masked sum) read frame t through sym_frame().
+__host__ __device__ __forceinline__ int sym_frames(int T) { return T / 2 + 1; }
+__host__ __device__ __forceinline__ int sym_frame(int t, int T) { return 2 * t <= T ? t : T - t; }
+// does the frame range [t0, t1) of a T-frame buffer hold a frame whose unique frame is u?
+__host__ __device__ __forceinline__ bool sym_in_range(int u, int T, int t0, int t1)
+{
+    return (u >= t0 && u < t1) || (u > 0 && T - u >= t0 && T - u < t1);
+}
+
 // widening loads; uint8 applies uint8_to_float's  k * (1./255)  (transforms.py:20-23)
 __device__ __forceinline__ double load_px(const uint8_t *p, size_t i) { return (double)p[i] * (1.0 / 255); }
 __device__ __forceinline__ double load_px(const __half *p, size_t i) { return (double)__half2float(p[i]); }
@@ -362,8 +375,10 @@ __global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, siz
         if (k0 + k < nk) y[(size_t)(k0 + k) * NP + p] = acc[k];
 }
 
+// T = rows of C / frames written (the unique frames: sym_frames(n)); mirror_n > 0: also store row s as row mirror_n - s
+// (0 < s, 2 s < mirror_n) -- the full [n, NP] array of the module-level filter call
 __global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, size_t NP, const double *C, int T, double amp,
-                                                     double *out)
+                                                     double *out, int mirror_n)
 {
     HIP_DYNAMIC_SHARED(double, s_c)  // [nk][TF_SC]
     const int s0 = blockIdx.y * TF_SC;
@@ -392,82 +407,97 @@ __global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, si
     }
 #pragma unroll
     for (int j = 0; j < TF_SC; ++j)
-        if (s0 + j < T) out[(size_t)(s0 + j) * NP + p] = acc[j] * amp;
+        if (s0 + j < T) {
+            const int sr = s0 + j;
+            const double v = acc[j] * amp;
+            out[(size_t)sr * NP + p] = v;
+            if (mirror_n > 0 && sr > 0 && 2 * sr < mirror_n) out[(size_t)(mirror_n - sr) * NP + p] = v;
+        }
 }
 
-// Matrix-core form of the two stages for the hot shapes (T a multiple of 16, at most 16 * TM_MAX_TILES = 96 surviving rows).
-// The band-pass IS a dense contraction along T -- y = R x, out = amp * C y with R [nk x T], C [T x nk] -- and the only
-// place on this path where MFMA fits.  v_mfma_f64_16x16x4_f64 runs at the fp64 vector rate on gfx950, so the gain is
-// not flops but operand reuse: a workgroup owns 16 pixel columns and reads its x[T, 16] tile ONCE (the VALU form
-// re-reads x once per group of 4 rows of R: 12 x 22 MB through L2), keeps all of y in NT accumulator tiles and feeds them
-// straight back as B operands of the second product -- the D layout of the first product (row = (lane >> 4) + 4 * reg,
-// col = lane & 15) is exactly the B layout the second one needs for K-step (tile, reg) -- so y never leaves registers.
-// The TM_W wavefronts of a workgroup share the 16 columns: wave w contracts its quarter of T in stage 1 (the partial y
-// tiles meet in LDS, summed in wave order) and produces every TM_W-th tile of 16 output frames in stage 2.
-// The operators arrive "fragment major" (built on the host, zero padded to 16 NT rows), so that every A operand is one
-// coalesced 512-byte load (layouts beside the kernel).
-// fused == materialised == per-level stays bit for bit: every path through the library uses this same kernel.
-// waves per workgroup: 8 when the accumulators are 3 tiles (each wave then has T / 32 K-steps -- 8 at T = 256 -- and requests
-// ALL its operands before the first product: one memory round trip instead of a chain), 4 for the 6-tile form (LDS: the
-// partial y tiles of 8 waves would be 98 KB)
-template <int NT> struct TemporalWaves { static constexpr int W = 4; static constexpr int MINW = NT <= 3 ? 3 : 2; };   // MINW: waves per SIMD the register budget must allow (3 workgroups per CU for NT = 3)
-constexpr int TM_MAX_TILES = 6;   // up to 96 surviving rows (n = 512 at 10 fps has 92); NT = tiles of 16 rows actually used
+// Matrix-core form of the two stages (even n, at most 48 merged rows of either symmetry class).
+// The band-pass IS a dense contraction along T -- z = Rz x, out = amp * Cz z -- and the only place on this path where MFMA fits.
+// v_mfma_f64_16x16x4_f64 runs at the fp64 vector rate on gfx950, so what counts is the number of products and operand reuse:
+//   * merged rows (host, get_operator): packed indices k and n - k multiply the same inverse column cos(2 pi k s / n), so their
+//     forward rows are added once on the host: about half the rows of R and the columns of C;
+//   * folded frames: a merged row is a cosine row (even in t) or a sine row (odd in t), never a mix (n even), so
+//         z_even = sum_{t <= n/2} Rz[., t] e[t],   e[t] = x[t] + x[n - t]   (x[t] alone for t = 0 and t = n / 2)
+//         z_odd  = sum_{t <  n/2} Rz[., t] o[t],   o[t] = x[t] - x[n - t]   (0 there)
+//     -- half the K-steps; the tiles of 16 rows are class-pure (NH "even" tiles, then NH "odd" tiles, zero padded);
+//   * unique output frames: only s <= n / 2 is produced (sym_frames): half the products of stage 2.
+// 6 x fewer products than the plain two-stage form at n = 256 / 512.  A workgroup owns 16 pixel columns and reads its x[T, 16] tile
+// ONCE, keeps z in 2 NH accumulator tiles and feeds them straight back as the B operands of the second product -- the D layout of
+// the first product (row = (lane >> 4) + 4 * reg, col = lane & 15) is exactly the B layout the second one needs for K-step
+// (tile, reg) -- so z never leaves registers.  The W wavefronts of a workgroup share the 16 columns: wave w contracts every W-th
+// K-step of stage 1 (the partial z tiles meet in LDS, summed in wave order) and produces every W-th tile of 16 output frames.
+// The operators arrive "fragment major" (built on the host), so that every A operand is one coalesced 512-byte load:
+//   Rf[(ks * 2 NH + q) * 64 + lane] = Rz[row(q, lane & 15)][4 ks + (lane >> 4)]
+//   Cf[(m * 8 NH + 4 q + r) * 64 + lane] = Cz[16 m + (lane & 15)][row(q, 4 r + (lane >> 4))]
+// fused == materialised == per-level stays bit for bit: every path through the library uses this same kernel for a given n.
+constexpr int TM_W = 4;            // waves per workgroup
+constexpr int TM_MAX_HALF = 3;     // up to 48 merged rows per symmetry class (n = 1024 at 10 fps has 47 + 47)
 
 #ifndef RM_HIPEMU   // (the host emulation of tests/emu runs the two-stage VALU kernels above)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// Rf[(t0/4 * NT + ti) * 64 + lane] = R[16 ti + (lane & 15)][t0 + (lane >> 4)]
-// Cf[((s0/16) * 4 NT + 4 ti + r) * 64 + lane] = C[s0 + (lane & 15)][16 ti + 4 r + (lane >> 4)]
-template <int NT>
-__global__ __launch_bounds__(64 * TemporalWaves<NT>::W, TemporalWaves<NT>::MINW) void k_temporal_mfma(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
-                                                             const double *__restrict__ Cf, double amp, double *__restrict__ out, struct CollapseState *st_init)
+// mirror_n > 0: also store output frame s as frame mirror_n - s (the full [n, NP] array of the module-level filter call)
+template <int NH>
+__global__ __launch_bounds__(64 * TM_W, NH == 1 ? 3 : 2) void k_temporal_sym(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
+                                                             const double *__restrict__ Cf, double amp, double *__restrict__ out, int mirror_n,
+                                                             struct CollapseState *st_init)
 {
     RM_TRACE_SCOPE(2);
     if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
-    constexpr int TM_W = TemporalWaves<NT>::W;
+    constexpr int NT = 2 * NH;
     __shared__ double s_y[TM_W][4 * NT][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const size_t p = (size_t)blockIdx.x * 16 + lo;
     const size_t pc = p < NP ? p : NP - 1;     // columns past the end repeat the last one (never stored)
-    const int per = T / TM_W;                  // T % (4 TM_W) == 0: a multiple of 4 frames per wave
+    const int Th = sym_frames(T), nks = (Th + 3) >> 2;
     v4f64 acc[NT];
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti) acc[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NT; ++q) acc[q] = (v4f64){0.0, 0.0, 0.0, 0.0};
     RM_TRACE_MARK(2, 0);
-    const double *xr = x + (size_t)hi * NP + pc;
     // The operands of TM_U K-steps are requested together, then consumed in order: a loop that loads one step's operands,
-    // waits and multiplies is a chain of T / 16 L2 round trips per wave (16 at T = 256: most of the kernel's 18 us).
-    // The order of the products into each accumulator is unchanged.
-    constexpr int TM_U = NT <= 3 ? 8 : 4;
-    const int t_end = (wave + 1) * per;
-    for (int t0 = wave * per; t0 < t_end; t0 += 4 * TM_U) {
-        double bb[TM_U], rr[TM_U][NT];
+    // waits and multiplies is a chain of L2 round trips.  The order of the products into each accumulator is fixed.
+    constexpr int TM_U = NH == 1 ? 8 : 4;
+    for (int k0 = wave; k0 < nks; k0 += TM_W * TM_U) {
+        double xa[TM_U], xb[TM_U], rr[TM_U][NT];
 #pragma unroll
         for (int u = 0; u < TM_U; ++u) {
-            const int tu = t0 + 4 * u;
-            if (tu < t_end) {
-                bb[u] = xr[(size_t)tu * NP];
-                const double *rf = Rf + (size_t)(tu >> 2) * NT * 64 + lane;
+            const int ks = k0 + u * TM_W;
+            if (ks < nks) {   // (wave-uniform)
+                const int t = 4 * ks + hi, tc = t < Th ? t : Th - 1, tp = tc == 0 ? 0 : T - tc;
+                xa[u] = x[(size_t)tc * NP + pc];
+                xb[u] = x[(size_t)tp * NP + pc];
+                const double *rf = Rf + (size_t)ks * NT * 64 + lane;
 #pragma unroll
-                for (int ti = 0; ti < NT; ++ti) rr[u][ti] = rf[ti * 64];
+                for (int q = 0; q < NT; ++q) rr[u][q] = rf[q * 64];
             }
         }
 #pragma unroll
         for (int u = 0; u < TM_U; ++u) {
-            if (t0 + 4 * u < t_end) {
+            const int ks = k0 + u * TM_W;
+            if (ks < nks) {
+                const int t = 4 * ks + hi;
+                const bool self = t == 0 || 2 * t == T, valid = t < Th;
+                double e = self ? xa[u] : xa[u] + xb[u], o = self ? 0.0 : xa[u] - xb[u];
+                if (!valid) { e = 0.0; o = 0.0; }
 #pragma unroll
-                for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][ti], bb[u], acc[ti], 0, 0, 0);
+                for (int q = 0; q < NH; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], e, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = NH; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], o, acc[q], 0, 0, 0);
             }
         }
-        RM_TRACE_MARK(2, 8 + (t0 - wave * per) / (4 * TM_U));
+        RM_TRACE_MARK(2, 8 + (k0 - wave) / (TM_W * TM_U));
     }
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
+    for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_y[wave][4 * ti + r][lane] = acc[ti][r];
+        for (int r = 0; r < 4; ++r) s_y[wave][4 * q + r][lane] = acc[q][r];
     RM_TRACE_MARK(2, 1);
-    const int mt = T / 16;                     // output tiles of 16 frames, dealt round-robin to the waves
-    // the A operands of this wave's first output tile travel while the partial y tiles meet in LDS
+    const int mt = (Th + 15) >> 4;             // output tiles of 16 frames, dealt round-robin to the waves
+    // the A operands of this wave's first output tile travel while the partial z tiles meet in LDS
     double cfv[4 * NT];
     if (wave < mt) {
         const double *cf = Cf + (size_t)wave * 4 * NT * 64 + lane;
@@ -476,22 +506,22 @@ __global__ __launch_bounds__(64 * TemporalWaves<NT>::W, TemporalWaves<NT>::MINW)
     }
     __syncthreads();
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
+    for (int q = 0; q < NT; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double v = s_y[0][4 * ti + r][lane];
+            double v = s_y[0][4 * q + r][lane];
 #pragma unroll
-            for (int w = 1; w < TM_W; ++w) v = v + s_y[w][4 * ti + r][lane];
-            acc[ti][r] = v;
+            for (int w = 1; w < TM_W; ++w) v = v + s_y[w][4 * q + r][lane];
+            acc[q][r] = v;
         }
     RM_TRACE_MARK(2, 2);
     for (int m = wave; m < mt; m += TM_W) {
         const int s0 = 16 * m;
         v4f64 o = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
+        for (int q = 0; q < NT; ++q) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cfv[4 * ti + r], acc[ti][r], o, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cfv[4 * q + r], acc[q][r], o, 0, 0, 0);
         }
         if (m + TM_W < mt) {   // the next tile's operands travel while this one is stored
             const double *cf = Cf + (size_t)(m + TM_W) * 4 * NT * 64 + lane;
@@ -500,7 +530,14 @@ __global__ __launch_bounds__(64 * TemporalWaves<NT>::W, TemporalWaves<NT>::MINW)
         }
         if (p < NP) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(size_t)(s0 + hi + 4 * r) * NP + p] = o[r] * amp;
+            for (int r = 0; r < 4; ++r) {
+                const int sr = s0 + hi + 4 * r;
+                if (sr < Th) {
+                    const double v = o[r] * amp;
+                    out[(size_t)sr * NP + p] = v;
+                    if (mirror_n > 0 && sr > 0 && 2 * sr < mirror_n) out[(size_t)(mirror_n - sr) * NP + p] = v;
+                }
+            }
         }
     }
     RM_TRACE_MARK(2, 3);
@@ -813,8 +850,9 @@ struct CollapseState {
     unsigned long long min_keys[NSTRIPE], max_keys[NSTRIPE];  // stripes of the six words above
     unsigned long long heat_min_keys[NSTRIPE], heat_max_keys[NSTRIPE];  // stripes of heat_min_key / heat_max_key
     unsigned long long smp_min_keys[NSTRIPE], smp_max_keys[NSTRIPE];    // extrema of the lattice samples (true raw values)
-    unsigned int n_list;            // (frame, tile) pairs that must be evaluated
-    unsigned int n_slots;           // pairs whose values are kept for the masked time sum
+    unsigned int n_list_a;          // (frame, tile) pairs that may hold raw.min() / raw.max(): always evaluated (k_select_pairs -> list_a)
+    unsigned int n_list_b;          // pairs kept for the masked time sum that are not in list_a: evaluated on the sparse path only
+    unsigned int n_slots;           // pairs whose values are kept for the masked time sum = slots of the value store handed out
     unsigned int n_heavy;           // tiles with at least one such pair among this rank's frames (k_select_pairs -> heavy[])
     double margin;                  // absolute safety margin of the bounds
     double top_ub;                  // upper bound of `top`, from the bounds alone
@@ -832,7 +870,7 @@ __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIP
     st->smp_min_keys[i] = ~0ull; st->smp_max_keys[i] = 0ull;
     if (i != 0) return;
     st->lb_max_key = 0ull; st->ub_min_key = ~0ull; st->ub_max_key = 0ull; st->lb_min_key = ~0ull;
-    st->min_key = ~0ull; st->max_key = 0ull; st->n_list = 0; st->n_slots = 0; st->n_heavy = 0;
+    st->min_key = ~0ull; st->max_key = 0ull; st->n_list_a = 0; st->n_list_b = 0; st->n_slots = 0; st->n_heavy = 0;
     st->margin = 0; st->top_ub = 0; st->min_val = 0; st->max_val = 0; st->top = 0;
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
 }
@@ -1202,40 +1240,83 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *x
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
 
 constexpr int SLOT_PRUNED = -1;    // every value of the pair is provably >= top: contributes `min`
-constexpr int SLOT_KEPT = 0;       // the pair's values are parked in the value store for the masked time sum
-// The value store is indexed by the pair itself -- store[(tile * T + t)][CT_H][CT_W], i.e. one (sparsely touched) float64
-// [T,H,W] array in tile-major order: a tile's kept frames sit in ONE contiguous T x 8 KB region, which is what the sum
-// pass walks (slots handed out by an atomic counter scattered a tile's frames over the whole store: every batch of the
-// sum pass paid a TLB / DRAM-page miss per frame, ~3.5 us per batch of 12), and there is no capacity to overflow.
+// slot >= 0: the pair's 16 x 64 values are parked in slot `slot` of the value store for the masked time sum.  k_select_pairs hands
+// the slots out so that the kept frames of a tile are NEIGHBOURS in the store (one contiguous run per tile and frame chunk): the
+// sum pass walks a tile's frames, and slots scattered over the store cost it a TLB / DRAM-page miss per frame.
+//
+// Sparse or dense sum?  (rm_dense_sum.h)  Decided ON THE DEVICE from what this call's own selection kept -- every kernel that
+// cares evaluates sum_is_dense() on the counters k_select_pairs left in the state, so the first call of a geometry behaves like
+// the hundredth and nothing is remembered between calls:
+//   * more kept pairs than the value store has slots -> dense (the store is capped: rm_api.hip collapse_eval);
+//   * skip <= 2 and more than one pair in DENSE_ONE_IN kept -> dense (measured per pair of the geometry on MI355X: sparse 3.7-4.8 ns
+//     per KEPT pair; dense 1.6 ns at 4K x 512 skip 2, 3.6 ns at 720p x 128 skip 2, 4.6 ns at 1080p x 256 skip 4 -- slower than
+//     sparse even with everything kept, so deeper chains go dense only on overflow);
+//   * RM_FLAG_DENSE_SUM / RM_FLAG_SPARSE_SUM force it (an overflowing store still goes dense).
+constexpr unsigned long long DENSE_ONE_IN = 2;
+struct SumPlan {
+    int mode;                  // 0 automatic, 1 dense, 2 sparse
+    unsigned int cap_slots;    // slots of the value store
+    unsigned int npairs_mine;  // unique (tile, frame) pairs among this rank's frames
+    int auto_dense_ok;         // the automatic rule may choose the dense kernel (skip <= 2)
+};
+__device__ __forceinline__ bool sum_is_dense(const CollapseState *st, const SumPlan &sp)
+{
+    const unsigned int kept = st->n_slots;
+    if (sp.mode == 1 || kept > sp.cap_slots) return true;
+    if (sp.mode == 2) return false;
+    return sp.auto_dense_ok && (unsigned long long)kept * DENSE_ONE_IN > (unsigned long long)sp.npairs_mine;
+}
+
+// exclusive prefix sum over the 256 threads of a workgroup (thread order); s_wave: 4 words of LDS.  total = sum over all threads.
+__device__ __forceinline__ unsigned long long block_excl_scan_256(unsigned long long v, unsigned long long *s_wave, unsigned long long &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const unsigned long long c = s_wave[w]; base += (w < wave) ? c : 0; tot += c; }
+    total = tot;
+    return base + inc - v;
+}
 
 // which pairs need their full-resolution values:
-//   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max
-//   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum
-constexpr int SEL_U = 4;   // pairs per lane: their bound loads are issued together (the kernel is latency bound)
-// Slot / list positions: ballots + prefix popcounts inside the workgroup, then ONE returning atomic per counter and
-// workgroup, both issued together (a wave-level atomic per counter and per k was a chain of up to eight dependent
-// ~2.5 us round trips in the workgroups that select anything: 20 us of a 21 us kernel).
-// sel_cnt[tile] counts the kept pairs of a tile among this rank's frames (zeroed by the bounds kernel that ran before);
-// the first pair of a tile appends it to heavy[]: k_masked_sum_tiles gives those tiles to its worker workgroups and
+//   C: may hold raw.max() or raw.min()                        -> evaluated for the exact min/max      (list_a)
+//   D: may hold a value below top (lo - margin < top_ub)      -> values kept for the masked sum       (list_b unless also C)
+// Pairs are [u][tile] over the UNIQUE frames u < Th (sym_frames).  A workgroup takes SEL_TILES adjacent tiles (16 lanes = one
+// 128-byte row of bounds) and a chunk of SEL_PH x SEL_U unique frames; thread (tile, phase) owns the frames phase, phase + 16, ...
+// of its tile, whose bound loads are issued together (the kernel is latency bound).  Everything the workgroup hands out -- value
+// store slots, list positions -- is counted in LDS (one block-wide prefix sum in (tile, phase) order over three packed 20-bit
+// counts) and reserved with ONE returning atomic per counter, so a tile's kept frames get consecutive slots.
+// sel_cnt[tile] counts the kept pairs of a tile among this rank's frames (zeroed by the bounds kernel that ran before); the
+// chunk that adds the first ones appends the tile to heavy[]: k_masked_sum_tiles gives those tiles to its worker workgroups and
 // finishes every other tile with a constant fill.
-__global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int n, CollapseState *st,
-                                                      unsigned int *list, int *slot_of, int no_prune,
-                                                      double thr, int first_pair, int end_pair, int ntiles, int *sel_cnt,
-                                                      unsigned int *heavy, int dense)
+// A frame shard [t0, t1) of the T-frame buffer owns unique frame u when it holds t = u or t = T - u (sym_in_range).
+constexpr int SEL_TILES = 16, SEL_PH = 16, SEL_U = 9;   // 16 x 9 = 144 unique frames per chunk: one chunk at T = 256
+__global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int ntiles, int Th, int T, int t0, int t1,
+                                                      CollapseState *st, unsigned int *list_a, unsigned int *list_b, int *slot_of,
+                                                      int no_prune, double thr, int *sel_cnt, unsigned int *heavy)
 {
     RM_TRACE_SCOPE(4);
-    __shared__ unsigned int s_cnt[2][SEL_U][4];   // [kept | listed][k][wave]
-    __shared__ unsigned int s_base[2];
-    const int i0 = blockIdx.x * (256 * SEL_U) + threadIdx.x;
+    __shared__ unsigned long long s_cnt[256], s_off[257], s_wave[4];
+    __shared__ unsigned int s_base[3];
+    const int ti = threadIdx.x & (SEL_TILES - 1), ph = threadIdx.x / SEL_TILES;
+    const int tile = blockIdx.x * SEL_TILES + ti;
+    const int u0 = blockIdx.y * (SEL_PH * SEL_U) + ph;
     // the pairs' bounds first: nothing below depends on them until the comparisons
     double l[SEL_U], h[SEL_U];
     bool mine[SEL_U];
 #pragma unroll
     for (int k = 0; k < SEL_U; ++k) {
-        const int i = i0 + 256 * k;
-        // frame shard (pairs are [t][tile]): the bounds below cover every frame, the evaluation only this
-        // rank's frames [first_pair, end_pair) / ntiles
-        mine[k] = i < n && i >= first_pair && i < end_pair;
+        const int u = u0 + SEL_PH * k;
+        mine[k] = tile < ntiles && u < Th && sym_in_range(u, T, t0, t1);
+        const size_t i = (size_t)u * ntiles + tile;
         l[k] = mine[k] ? lo[i] : 0.0;
         h[k] = mine[k] ? hi[i] : 0.0;
     }
@@ -1257,56 +1338,47 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
     }
     const double mx_ = ub_max + m, mn_ = ub_min + m;
     const double top_ub = (mx_ - (mx_ - mn_) * thr) + m;
-    if (i0 == 0) { st->margin = m; st->top_ub = top_ub; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    bool isD[SEL_U], isL[SEL_U];
-    unsigned long long mD[SEL_U], mL[SEL_U];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { st->margin = m; st->top_ub = top_ub; }
+    unsigned int fC = 0, fD = 0;   // bit k: pair k is C / D
+    unsigned long long cnt = 0;    // D | A << 20 | B << 40
 #pragma unroll
     for (int k = 0; k < SEL_U; ++k) {
-        bool isC = false;
-        isD[k] = false;
-        if (mine[k]) {
-            isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
-            isD[k] = no_prune || (l[k] - m < top_ub);
-        }
-        // listed = evaluated by k_eval_pairs: C pairs (exact extrema) and every kept pair -- C pairs alone when the dense sum
-        // kernel (rm_dense_sum.h) follows: it recomputes every value itself and wants no store (n_slots still counts the D pairs)
-        isL[k] = isC || (isD[k] && !dense);
-        mD[k] = __ballot(isD[k]);
-        mL[k] = __ballot(isL[k]);
-        if (lane == 0) { s_cnt[0][k][wave] = (unsigned)__popcll(mD[k]); s_cnt[1][k][wave] = (unsigned)__popcll(mL[k]); }
+        if (!mine[k]) continue;
+        const bool isC = no_prune || !(h[k] + m < lb_max - m) || !(l[k] - m > ub_min + m);
+        const bool isD = no_prune || (l[k] - m < top_ub);
+        fC |= (isC ? 1u : 0u) << k; fD |= (isD ? 1u : 0u) << k;
+        cnt += (isD ? 1ull : 0ull) + (isC ? 1ull << 20 : 0ull) + ((isD && !isC) ? 1ull << 40 : 0ull);
     }
+    // prefix sums in (tile, phase) order: thread j of the scan stands for tile j / 16, phase j % 16
+    s_cnt[ti * SEL_PH + ph] = cnt;
     __syncthreads();
+    unsigned long long total = 0;
+    const unsigned long long ex = block_excl_scan_256(s_cnt[threadIdx.x], s_wave, total);
+    s_off[threadIdx.x] = ex;
     if (threadIdx.x == 0) {
-        unsigned totD = 0, totL = 0;
-#pragma unroll
-        for (int k = 0; k < SEL_U; ++k)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { totD += s_cnt[0][k][w]; totL += s_cnt[1][k][w]; }
-        unsigned bL = 0;
-        if (totD) atomicAdd(&st->n_slots, totD);      // reported only (rm_debug_counters)
-        if (totL) bL = atomicAdd(&st->n_list, totL);
-        s_base[1] = bL;
+        s_off[256] = total;
+        const unsigned int totD = (unsigned)(total & 0xfffffu), totA = (unsigned)((total >> 20) & 0xfffffu), totB = (unsigned)(total >> 40);
+        s_base[0] = totD ? atomicAdd(&st->n_slots, totD) : 0u;
+        s_base[1] = totA ? atomicAdd(&st->n_list_a, totA) : 0u;
+        s_base[2] = totB ? atomicAdd(&st->n_list_b, totB) : 0u;
     }
     __syncthreads();
-    unsigned offL = s_base[1];
+    const unsigned long long mo = s_off[ti * SEL_PH + ph];
+    unsigned int oD = s_base[0] + (unsigned)(mo & 0xfffffu), oA = s_base[1] + (unsigned)((mo >> 20) & 0xfffffu), oB = s_base[2] + (unsigned)(mo >> 40);
+    if (ph == 0 && tile < ntiles) {   // kept pairs of this tile in this chunk
+        const unsigned int tot = (unsigned)((s_off[(ti + 1) * SEL_PH] - s_off[ti * SEL_PH]) & 0xfffffu);
+        if (tot && atomicAdd(&sel_cnt[tile], (int)tot) == 0) heavy[atomicAdd(&st->n_heavy, 1u)] = (unsigned)tile;
+    }
 #pragma unroll
     for (int k = 0; k < SEL_U; ++k) {
-        const int i = i0 + 256 * k;
-        unsigned myL = offL;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned cL = s_cnt[1][k][w];
-            myL += (w < wave) ? cL : 0;
-            offL += cL;
-        }
-        if (isD[k] && !dense) {
-            const int t = i / ntiles, tile = i - t * ntiles;
-            if (atomicAdd(&sel_cnt[tile], 1) == 0) heavy[atomicAdd(&st->n_heavy, 1u)] = (unsigned)tile;
-        }
-        if (i < n) slot_of[i] = (isD[k] && !dense) ? SLOT_KEPT : SLOT_PRUNED;
-        if (isL[k]) list[myL + (unsigned)__popcll(mL[k] & below)] = (unsigned)i;
+        if (!mine[k]) continue;
+        const int u = u0 + SEL_PH * k;
+        const unsigned int i = (unsigned)u * (unsigned)ntiles + (unsigned)tile;
+        const bool isC = (fC >> k) & 1u, isD = (fD >> k) & 1u;
+        slot_of[i] = isD ? (int)oD : SLOT_PRUNED;
+        if (isD) ++oD;
+        if (isC) list_a[oA++] = i;
+        else if (isD) list_b[oB++] = i;
     }
 }
 
@@ -1400,30 +1472,34 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
     }
 }
 
-// the one evaluation pass: full-resolution values of every listed (frame, tile) pair, once.
-// Exact raw.min()/raw.max() (transforms.py:185,187) come from here; values of pairs that can fall
-// below `top` are parked in `store` ([tile][t][row][lane], coalesced) for the masked time sum.
-__global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int T, int ntiles, const unsigned int *list,
-                                                   int *slot_of, CollapseState *st, double *store)
+// the one evaluation pass: full-resolution values of every listed (unique frame, tile) pair, once.
+// Exact raw.min()/raw.max() (transforms.py:185,187) come from here (list_a); on the sparse path the values of the pairs that can
+// fall below `top` (list_a's kept pairs and all of list_b) are parked in their slot of `store` ([slot][row][lane], coalesced) for
+// the masked time sum.  On the dense path (sum_is_dense) list_b is not touched and nothing is stored.
+__global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, const unsigned int *list_b,
+                                                   int *slot_of, CollapseState *st, double *store, SumPlan sp)
 {
     RM_TRACE_SCOPE(5);
     HIP_DYNAMIC_SHARED(double, lds)
-    // the first list entry is requested together with the list length (the list buffer is valid memory whatever n turns out
+    // the first list entry is requested together with the list lengths (the list buffer is valid memory whatever they turn out
     // to be): one memory round trip less at the head of every workgroup's dependent chain
-    unsigned first_idx = list[blockIdx.x];
-    const unsigned n = st->n_list;
+    const unsigned first_idx = list_a[blockIdx.x];
+    const unsigned nA = st->n_list_a, nB = st->n_list_b;
+    const bool dense = sum_is_dense(st, sp);
+    const unsigned n = nA + (dense ? 0u : nB);
     const int lane = threadIdx.x;
     const double inf = __builtin_huge_val();
     const double top_ub = st->top_ub;   // upper bound of `top` from the tile bounds (k_select_pairs)
     double mn = inf, mx = -inf;
     for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
         RM_TRACE_MARK(5, 0);
-        const unsigned idx = (unsigned)uniform((int)(c == blockIdx.x ? first_idx : list[c]));   // wave-uniform: the tile geometry stays in scalar registers
-        const int slot = uniform(slot_of[idx]);                // (needed after the chain: requested now)
-        const int t = idx / ntiles, tile = idx - t * ntiles;
+        const unsigned raw_idx = c < nA ? (c == blockIdx.x ? first_idx : list_a[c]) : list_b[c - nA];
+        const unsigned idx = (unsigned)uniform((int)raw_idx);   // wave-uniform: the tile geometry stays in scalar registers
+        const int slot = dense ? SLOT_PRUNED : uniform(slot_of[idx]);   // (needed after the chain: requested now)
+        const int u = idx / ntiles, tile = idx - u * ntiles;
         const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
         RM_TRACE_MARK(5, 1);
-        chain_to_level1(g, tile, cS + (size_t)t * g.h[g.S] * g.w[g.S], lds);
+        chain_to_level1(g, tile, cS + (size_t)u * g.h[g.S] * g.w[g.S], lds);
         RM_TRACE_MARK(5, 6);
         int x = R0.x0 + lane;
         double pmn = inf;   // minimum of this pair's tile
@@ -1444,7 +1520,7 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
             if (pmn >= top_ub) {
                 if (lane == 0) slot_of[idx] = SLOT_PRUNED;
             } else if (x <= R0.x1) {
-                double *d = store + ((size_t)tile * T + t) * (CT_H * CT_W) + lane;
+                double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
 #pragma unroll
                 for (int j = 0; j < CT_H; ++j) d[j * CT_W] = v[j];
             }
@@ -1457,9 +1533,9 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
     if (lane == 0 && blockIdx.x < n) {
         // striped, and skipped when they cannot change the result
         const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
-        const int sp = blockIdx.x & (NSTRIPE - 1);
-        if (kmn < *(volatile unsigned long long *)&st->min_keys[sp]) atomicMin(&st->min_keys[sp], kmn);
-        if (kmx > *(volatile unsigned long long *)&st->max_keys[sp]) atomicMax(&st->max_keys[sp], kmx);
+        const int sp_ = blockIdx.x & (NSTRIPE - 1);
+        if (kmn < *(volatile unsigned long long *)&st->min_keys[sp_]) atomicMin(&st->min_keys[sp_], kmn);
+        if (kmx > *(volatile unsigned long long *)&st->max_keys[sp_]) atomicMax(&st->max_keys[sp_], kmx);
     }
 }
 
@@ -1506,7 +1582,9 @@ __global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, co
 //     share.  The workgroups that found no worker item do the filling (they are free at once; separate fill workgroups
 //     queued behind the workers' registers and started 5-14 us late); when every workgroup has items, all of them fill
 //     after their items.
-// Dynamic LDS: s_kt[T], the tile's kept frames in order.
+// Dynamic LDS: s_kt[T] and s_ks[T], the tile's kept frames in order and their value store slots.
+// Frames are walked in time order t = t_first .. t_end - 1 (np.average's order); frame t's pair is that of its unique frame
+// sym_frame(t, T).  On the dense path (sum_is_dense) the kernel returns at once: k_dense_sum takes the sum.
 constexpr int MAX_T = 4096;
 constexpr int MS_Q = 4;              // row groups (worker items) per heavy tile
 constexpr int MS_RQ = CT_H / MS_Q;   // rows per worker == waves per workgroup
@@ -1516,10 +1594,11 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
                                                           int *tile_nkept, const int *sel_cnt, const unsigned int *heavy, int nworkers,
-                                                          unsigned int *stats_host, unsigned int npairs)
+                                                          SumPlan sp)
 {
     RM_TRACE_SCOPE(6);
-    HIP_DYNAMIC_SHARED(int, s_kt)     // kept frames of the tile, in order
+    HIP_DYNAMIC_SHARED(int, s_kt)     // kept frames of the tile, in order; then their slots
+    int *s_ks = s_kt + T;
     __shared__ int s_wcnt[MS_RQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (W0 + CT_W - 1) / CT_W;
@@ -1527,17 +1606,15 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
     // first slot_of column (speculatively: heavy[] and slot_of[] are valid memory whatever n_heavy turns out to be)
     const int tile0 = (int)(heavy[blockIdx.x / MS_Q] % (unsigned)ntiles);
     int slot0 = SLOT_PRUNED;
-    if (t_first + tid < t_end) slot0 = slot_of[(size_t)(t_first + tid) * ntiles + tile0];
+    if (t_first + tid < t_end) slot0 = slot_of[(size_t)sym_frame(t_first + tid, T) * ntiles + tile0];
     const int nitems = (int)st->n_heavy * MS_Q;
+    if (sum_is_dense(st, sp)) return;   // (uniform over the grid: k_dense_sum takes the sum)
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;
     RM_TRACE_MARK(6, 0);
     if (blockIdx.x == 0 && tid == 0) {
         st->min_val = min_val; st->max_val = max_val; st->top = top;
-        // (pinned host words, nullable: how many pairs the selection kept -- the next call chooses between this path and the
-        //  dense sum kernel by it)
-        if (stats_host) { stats_host[0] = st->n_slots; stats_host[1] = npairs; }
     }
     // avg_T > 0 (the whole buffer is summed here): write np.average = sum / T (base.py:562) and reduce the
     // heatmap's min / max for the normalisation (base.py:563) on the way out
@@ -1554,7 +1631,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
             const int t = c0 + tid;
             int slot = SLOT_PRUNED;
             if (first && c0 == t_first) slot = slot0;
-            else if (t < t_end) slot = slot_of[(size_t)t * ntiles + tile];
+            else if (t < t_end) slot = slot_of[(size_t)sym_frame(t, T) * ntiles + tile];
             const bool kept = slot != SLOT_PRUNED;
             const unsigned long long m = __ballot(kept);
             if (lane == 0) s_wcnt[wave] = __popcll(m);
@@ -1562,7 +1639,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
             int off = nkept, tot = 0;
 #pragma unroll
             for (int w = 0; w < MS_RQ; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
-            if (kept) s_kt[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
+            if (kept) { const int pos = off + __popcll(m & ((1ull << lane) - 1ull)); s_kt[pos] = t; s_ks[pos] = slot; }
             nkept += tot;
             __syncthreads();
         }
@@ -1571,7 +1648,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
         const int x = tx * CT_W + lane;
         const int row = q * MS_RQ + wave, y = ty * CT_H + row;
         const bool active = x < W0 && y < H0;
-        const double *mine = store + (size_t)tile * T * (CT_H * CT_W) + (size_t)row * CT_W + lane;   // + t * 1024: this pixel in frame t
+        const double *mine = store + (size_t)row * CT_W + lane;   // + slot * 1024: this pixel in the pair parked in `slot`
         double acc = 0.0;
         // a batch = MS_B kept frames: their frame numbers and (one batch ahead) values sit in registers, so the serial
         // part below touches neither LDS nor memory (per-frame LDS look-ups were 2/3 of the heaviest worker's time)
@@ -1585,7 +1662,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
                 const int i = ib + b;
                 const bool ok = i < nkept;
                 ktn[b] = ok ? s_kt[i] : t_end;
-                if (ok && active) nxt[b] = mine[(size_t)ktn[b] * (CT_H * CT_W)];
+                if (ok && active) nxt[b] = mine[(size_t)s_ks[i] * (CT_H * CT_W)];
             }
         };
         fetch(0);
@@ -1694,7 +1771,7 @@ __global__ __launch_bounds__(256) void k_mask_plain(const double *raw, size_t n,
     }
 }
 
-// heat_sum[p] = sum_t (raw[t,p] >= top ? min : raw[t,p])   (sequential in t)
+// heat_sum[p] = sum_t (raw[t,p] >= top ? min : raw[t,p])   (sequential in t); raw holds the sym_frames(T) unique frames
 __global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int T, size_t npix, const CollapseState *st,
                                                           double *heat_sum)
 {
@@ -1703,10 +1780,19 @@ __global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int
     const double top = st->top, mn = st->min_val;
     double acc = 0.0;
     for (int t = 0; t < T; ++t) {
-        double v = raw[(size_t)t * npix + p];
+        double v = raw[(size_t)sym_frame(t, T) * npix + p];
         acc = acc + ((v >= top) ? mn : v);
     }
     heat_sum[p] = acc;
+}
+
+// frames T/2+1 .. T-1 of a [T, npix] array from their mirror images (sym_frame): dst[t] = dst[T - t]
+__global__ __launch_bounds__(256) void k_mirror_frames(double *a, int T, size_t npix)
+{
+    const int t = sym_frames(T) + (int)blockIdx.y;   // t in (T/2, T)
+    const double *src = a + (size_t)(T - t) * npix;
+    double *dst = a + (size_t)t * npix;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // np.average(video, axis=0) of a [T, npix] array of any frame dtype (base.py:562, 579, 587, 589): float64 sum in t

@@ -38,6 +38,12 @@ def ctx(device_index=None):
     return _CTX[device_index]
 
 
+def debug_set(key, value, device_index=None):
+    """Developer / test switch of this GPU's library context (include/respmon_hip.h rm_debug_set)."""
+    lib = _capi.load()
+    _capi.check(lib, lib.rm_debug_set(ctx(device_index), key.encode(), int(value)), "rm_debug_set")
+
+
 def stream_ptr():
     t = torch()
     return ctypes.c_void_p(t.cuda.current_stream().cuda_stream)

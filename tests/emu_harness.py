@@ -29,6 +29,9 @@ class Emu:
     def ck(self, rc, what):
         return _capi.check(self.lib, rc, what)
 
+    def debug_set(self, key, value):
+        self.ck(self.lib.rm_debug_set(self.ctx, key.encode(), int(value)), "debug_set")
+
     def pyr_down(self, src):
         src = np.ascontiguousarray(src)
         T, h, w = src.shape

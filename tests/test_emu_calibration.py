@@ -384,26 +384,26 @@ def test_emu_contour_stage_many_components_and_nesting(emu, oracle):
         assert roi == oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20), m.shape
 
 
-def test_emu_banded_tile_bounds(emu, oracle, monkeypatch):
+def test_emu_banded_tile_bounds(emu, oracle):
     """k_frame_bounds in bands of tile rows (what 4K levels need: their row-extrema table exceeds LDS): forced here with a
     tiny table budget; the heatmap must not change by a bit."""
     v = oracle.uint8_to_float(synth.synth_breathing(12, 150, 200, seed=17))
     for (L, S) in [(5, 2), (4, 1), (6, 3)]:
-        monkeypatch.delenv("RM_BOUNDS_TABLE_BYTES", raising=False)
-        monkeypatch.delenv("RM_NO_FUSED_BOUNDS", raising=False)
-        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S)          # bounds taken inside the small-collapse kernel
-        monkeypatch.setenv("RM_NO_FUSED_BOUNDS", "1")               # the separate k_frame_bounds, whole frame at once
-        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+        emu.debug_set("bounds_table_bytes", 0)
+        emu.debug_set("no_fused_bounds", 0)
+        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=64)   # reference order: bounds taken inside the small-collapse kernel
+        emu.debug_set("no_fused_bounds", 1)                            # the separate k_frame_bounds, whole frame at once
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=64)
         assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (L, S)
-        for budget in (("600", "1") if L == 5 else ("2000",)):      # a few tile rows per band ... one tile row per band (minimum)
-            monkeypatch.setenv("RM_BOUNDS_TABLE_BYTES", budget)
-            got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+        for budget in ((600, 1) if L == 5 else (2000,)):             # a few tile rows per band ... one tile row per band (minimum)
+            emu.debug_set("bounds_table_bytes", budget)
+            got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=64)
             assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (L, S, budget)
-    monkeypatch.delenv("RM_BOUNDS_TABLE_BYTES", raising=False)
-    monkeypatch.delenv("RM_NO_FUSED_BOUNDS", raising=False)
+    emu.debug_set("bounds_table_bytes", 0)
+    emu.debug_set("no_fused_bounds", 0)
 
 
-def test_emu_dense_sum_equals_sparse_path(emu, monkeypatch):
+def test_emu_dense_sum_equals_sparse_path(emu):
     """rm_dense_sum.h: the masked time sum that recomputes every (tile, frame) pair frame after frame (flags=128) against the
     selection / value-store path (flags=256), bit for bit -- every super-tile shape (RM_DENSE_ROWS), skip 1..5, shards of the
     frame range, exhaustive evaluation (flags | 1), and the automatic choice (second call of a geometry that kept every pair)."""
@@ -411,22 +411,26 @@ def test_emu_dense_sum_equals_sparse_path(emu, monkeypatch):
     for n, (T, H, W, L, S) in enumerate([(5, 64, 96, 4, 2), (3, 67, 131, 5, 3), (3, 135, 130, 6, 4), (4, 48, 64, 3, 1), (2, 100, 160, 7, 5),
                                          (3, 70, 300, 4, 2)]):
         v = rng.random((T, H, W))
-        monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
+        emu.debug_set("dense_rows", 0)
         sparse, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
-        for rows in (("16", "32", "64") if n < 2 else (("16", "32", "64")[n % 3],)):
-            monkeypatch.setenv("RM_DENSE_ROWS", rows)
+        for rows in ((16, 32, 64) if n < 2 else ((16, 32, 64)[n % 3],)):
+            emu.debug_set("dense_rows", rows)
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, rows)
         dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128 | 1)
         assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "no_prune")
         if S <= 2:      # skip <= 2 takes the table-driven kernel: the general one must agree there too
-            monkeypatch.setenv("RM_DENSE_GENERAL", "1")
+            emu.debug_set("dense_general", 1)
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
-            monkeypatch.delenv("RM_DENSE_GENERAL")
+            emu.debug_set("dense_general", 0)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "general kernel")
-        auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)        # uniform noise keeps every pair: dense from the second call on
+        auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)        # decided on the device from this call's own selection
         assert np.array_equal(auto, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "auto")
-    monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
+        tiny, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=4)   # an 8-slot value store overflows: the dense kernel takes over
+        assert np.array_equal(tiny, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "store overflow")
+        tiny, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=4 | 256)
+        assert np.array_equal(tiny, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "store overflow, sparse asked for")
+    emu.debug_set("dense_rows", 0)
     v = rng.random((11, 70, 150))
     for world in (2, 3):                      # frame shards: partial sums over [t0, t1) with the global extrema
         a = emu.locate_sharded(v, world, levels=4, skip=2, flags=256)
@@ -434,20 +438,17 @@ def test_emu_dense_sum_equals_sparse_path(emu, monkeypatch):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]), world
 
 
-def test_emu_filter_first_per_level_equals_fused(emu, monkeypatch):
+def test_emu_filter_first_per_level_equals_fused(emu):
     """The filter-first small pyramid with one launch per level (what levels too large for LDS take: 4K, skip 2) computes what
     k_small_filter_first computes, bit for bit; both agree with the reference's operation order (flags=2) to rounding."""
     rng = np.random.default_rng(7)
     for (T, H, W, L, S) in [(5, 64, 96, 4, 2), (3, 67, 131, 5, 3), (3, 135, 130, 6, 4), (4, 48, 64, 3, 1), (2, 100, 160, 7, 5), (9, 33, 47, 4, 2)]:
         v = rng.random((T, H, W))
-        monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
         fused, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
         ref, _ = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256 | 2)
-        monkeypatch.setenv("RM_FF_PER_LEVEL", "1")
-        per_level, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+        per_level, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256 | 512)
         assert np.array_equal(per_level, fused) and tuple(mm) == tuple(mm2), (T, H, W, L, S)
         assert np.abs(fused - ref).max() <= 1e-12 * np.abs(ref).max(), (T, H, W, L, S)
-    monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
 
 
 def test_emu_contour_stage_device_labelling(emu, oracle):

@@ -613,7 +613,7 @@ def test_bpm_estimate_config1_on_the_gpu(hip, golden):
     assert list(mon.peak_indices) == list(g["peaks0"])
 
 
-def test_dense_sum_equals_sparse_path(hip, oracle, monkeypatch):
+def test_dense_sum_equals_sparse_path(hip, oracle):
     """rm_dense_sum.h against the selection / value-store path, bit for bit: random geometries, every frame dtype, every
     super-tile shape, config Q at full size (every pair kept: the automatic choice takes the dense kernel from the second call on)
     and the breathing video of config P (1 % of the pairs kept: the automatic choice stays sparse)."""
@@ -633,34 +633,44 @@ def test_dense_sum_equals_sparse_path(hip, oracle, monkeypatch):
         v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
         buf = torch.from_numpy(v).cuda()
         kw = dict(pyramid_levels=L, skip_levels_at_top=S)
-        monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
+        device.debug_set("dense_rows", 0)
         sparse = dist.hip_calibrate(buf, 10, flags=256, **kw)
         assert sum_path() == "sparse"
-        for rows in (None, "16", "32", "64"):
-            if rows is None:
-                monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
-            else:
-                monkeypatch.setenv("RM_DENSE_ROWS", rows)
+        for rows in (0, 16, 32, 64):
+            device.debug_set("dense_rows", rows)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows)
             assert sum_path() == "dense"
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=128 | 1, **kw), sparse), (dt, T, H, W, L, S)
         if S <= 2:      # skip <= 2 takes the table-driven kernel: the general one must agree there too
-            for rows in ("16", "32", "64"):
-                monkeypatch.setenv("RM_DENSE_ROWS", rows)
-                monkeypatch.setenv("RM_DENSE_GENERAL", "1")
+            for rows in (16, 32, 64):
+                device.debug_set("dense_rows", rows)
+                device.debug_set("dense_general", 1)
                 assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows, "general")
-            monkeypatch.delenv("RM_DENSE_GENERAL")
-            monkeypatch.delenv("RM_DENSE_ROWS")
-    monkeypatch.delenv("RM_DENSE_ROWS", raising=False)
-    # config Q: dense by itself from the second call of the geometry on
+            device.debug_set("dense_general", 0)
+        device.debug_set("dense_rows", 0)
+        # an 8-slot value store (RM_FLAG_TINY_STORE) overflows: the dense kernel takes over inside the same call, asked for or not
+        for fl in (4, 4 | 256):
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=fl, **kw), sparse), (dt, T, H, W, L, S, "store overflow", fl)
+            assert sum_path() == "dense"
+    device.debug_set("dense_rows", 0)
+    # config Q: dense by itself, on the FIRST call of the geometry (a fresh library context: nothing is remembered between calls)
     T, H, W, L, S = 128, 720, 1280, 4, 2
     buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=1234)).cuda()
     kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+    fresh = ctypes.c_void_p()
+    _capi.check(hip, hip.rm_ctx_create(torch.cuda.current_device(), ctypes.byref(fresh)), "rm_ctx_create")
+    heat = torch.empty((H, W), dtype=torch.float64, device=buf.device)
+    _capi.check(hip, hip.rm_calibrate(fresh, device.ptr(buf), device.dtype_code(buf), T, H, W, 10.0, 0.1, 1.0, 500.0, L, S, 0.7, 0,
+                                      device.ptr(heat), None, device.stream_ptr()), "rm_calibrate")
+    dbg = (ctypes.c_longlong * 4)()
+    _capi.check(hip, hip.rm_debug_counters(fresh, dbg, device.stream_ptr()), "rm_debug_counters")
+    assert dbg[3] == 0, "first call of the geometry must already take the dense kernel"
     sparse = dist.hip_calibrate(buf, 10, flags=256, **kw)
-    torch.cuda.synchronize()
+    assert sum_path() == "sparse" and torch.equal(heat, sparse)
     auto = dist.hip_calibrate(buf, 10, **kw)
     assert sum_path() == "dense" and torch.equal(auto, sparse)
     assert dist.hip_heatmap_to_roi(auto, 20) == dist.hip_heatmap_to_roi(sparse, 20)
+    _capi.check(hip, hip.rm_ctx_destroy(fresh), "rm_ctx_destroy")
     # config P's video: sparse stays sparse, and the forced dense kernel agrees
     T, H, W = 256, 1080, 1920
     buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=1234)).cuda()
@@ -669,9 +679,14 @@ def test_dense_sum_equals_sparse_path(hip, oracle, monkeypatch):
     b = dist.hip_calibrate(buf, 10)
     assert sum_path() == "sparse" and torch.equal(a, b)
     assert torch.equal(dist.hip_calibrate(buf, 10, flags=128), a)
+    # ... and a value store too small for what the selection keeps (5 078 pairs) hands the sum to the dense kernel: same bits
+    device.debug_set("store_slots", 1000)
+    assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "dense"
+    device.debug_set("store_slots", 0)
+    assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "sparse"
 
 
-def test_filter_first_per_level_equals_fused(hip, monkeypatch):
+def test_filter_first_per_level_equals_fused(hip):
     """Levels too large for LDS (4K, skip 2) take the filter-first small pyramid with one launch per level: forced here on
     geometries that also fit the one-kernel form, the two must agree bit for bit; the 4K geometry itself against the
     reference's operation order (flags=2) to rounding."""
@@ -681,11 +696,8 @@ def test_filter_first_per_level_equals_fused(hip, monkeypatch):
     for (T, H, W, L, S) in [(5, 64, 96, 4, 2), (3, 67, 131, 5, 3), (16, 270, 480, 9, 4), (6, 48, 64, 3, 1), (2, 200, 320, 7, 5), (4, 540, 1936, 8, 4)]:
         buf = torch.from_numpy(rng.random((T, H, W))).cuda()
         kw = dict(pyramid_levels=L, skip_levels_at_top=S)
-        monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
         fused = dist.hip_calibrate(buf, 10, **kw)
-        monkeypatch.setenv("RM_FF_PER_LEVEL", "1")
-        assert torch.equal(dist.hip_calibrate(buf, 10, **kw), fused), (T, H, W, L, S)
-    monkeypatch.delenv("RM_FF_PER_LEVEL", raising=False)
+        assert torch.equal(dist.hip_calibrate(buf, 10, flags=512, **kw), fused), (T, H, W, L, S)
     buf = torch.from_numpy(rng.random((6, 2160, 3840)).astype(np.float16)).cuda()
     kw = dict(pyramid_levels=6, skip_levels_at_top=2)
     assert _close(dist.hip_calibrate(buf, 10, **kw), dist.hip_calibrate(buf, 10, flags=2, **kw))
