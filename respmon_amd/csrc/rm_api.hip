@@ -78,6 +78,7 @@ struct DebugKnobs {
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
     int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
     int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2
+    int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
 };
@@ -107,6 +108,7 @@ struct rm_ctx {
     size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
+    int *h_unserved = nullptr;      // pinned: set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0, dbg_mine = 0; int dbg_mode = 0, dbg_auto_dense = 0;   // the SumPlan of the last collapse (host copy)
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
@@ -193,6 +195,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
     if (ctx->fs_res) (void)hipHostFree(ctx->fs_res);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    if (ctx->h_unserved) (void)hipHostFree(ctx->h_unserved);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -211,6 +214,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
     else if (k == "dense_rows") d.dense_rows = (int)value;
     else if (k == "dense_general") d.dense_general = (int)value;
+    else if (k == "dense_wave") d.dense_wave = (int)value;
     else if (k == "dc_segs") d.dc_segs = (int)value;
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
     else if (k == "store_slots") d.store_slots = value;
@@ -1017,19 +1021,36 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         RM_TRY(launch_temporal(ctx, lap, T, NP, op, amp, bp, s));
         std::vector<double *> x(L, nullptr);
         x[S] = bp;
-        for (int l = S + 1; l < L; ++l) RM_TRY(ws(ctx, "g" + std::to_string(l), (size_t)Th * h[l] * w[l], &x[l]));
         const int depth = L - 1 - S;
-        if (depth >= 1 && depth <= 5) {
+        const bool fused_down = depth >= 1 && depth <= 5;
+        auto level_buf = [&](int l) { return x[l] ? RM_OK : ws(ctx, "g" + std::to_string(l), (size_t)Th * h[l] * w[l], &x[l]); };
+        RM_TRY(level_buf(L - 1));
+        if (fused_down) {
             std::vector<int> hh(h.begin() + S, h.end()), ww(w.begin() + S, w.end());
             RM_TRY(launch_down_chain(ctx, bp, RM_F64, Th, hh, ww, depth, x[L - 1], s, false));
         } else {
-            for (int l = S + 1; l < L; ++l) RM_TRY(launch_pyr_down(x[l - 1], RM_F64, Th, h[l - 1], w[l - 1], x[l], s));
+            for (int l = S + 1; l < L; ++l) { RM_TRY(level_buf(l)); RM_TRY(launch_pyr_down(x[l - 1], RM_F64, Th, h[l - 1], w[l - 1], x[l], s)); }
         }
-        for (int l = L - 2; l > S; --l)
-            RM_TRY(launch_pyr_up(x[l + 1], Th, h[l + 1], w[l + 1], x[l], h[l], w[l], 0, nullptr, s));
         double *dst = nullptr;
         RM_TRY(ws(ctx, "cS", (size_t)Th * NP, &dst));
-        RM_TRY(launch_pyr_up(x[S + 1], Th, h[S + 1], w[S + 1], dst, h[S], w[S], 1, bp, s));
+        // the way back up and the subtraction in one launch (k_ff_collapse): levels S .. L-1 as a pyrUp chain of `depth` steps
+        SmallLevels up; up.S = depth;
+        up.h.assign(h.begin() + S, h.end()); up.w.assign(w.begin() + S, w.end());
+        ChainGeom ug;
+        if (depth >= 1 && depth < MAX_CHAIN && make_geom(up, ug) == RM_OK && (long long)ug.tiles_x * ug.tiles_y * Th < (1ll << 31)) {
+            const int utiles = ug.tiles_x * ug.tiles_y, nitems = utiles * Th;
+            const size_t sh = sizeof(double) * (size_t)ug.lds_total;
+            if (sh > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_ff_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(k_ff_collapse, dim3((unsigned)std::min(nitems, 256 * 64)), dim3(64), sh, s, (const double *)bp, (const double *)x[L - 1],
+                               ug, utiles, nitems, dst);
+            LAUNCH_CHECK();
+        } else {
+            for (int l = L - 2; l > S; --l) {
+                RM_TRY(level_buf(l));
+                RM_TRY(launch_pyr_up(x[l + 1], Th, h[l + 1], w[l + 1], x[l], h[l], w[l], 0, nullptr, s));
+            }
+            RM_TRY(launch_pyr_up(x[S + 1], Th, h[S + 1], w[S + 1], dst, h[S], w[S], 1, bp, s));
+        }
         out.cS = dst;
         return RM_OK;
     }
@@ -1299,7 +1320,9 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
 
 // heat_sum[H*W] = sum over t in [t0, t1) of (raw >= top ? min : raw), with min/max as they stand in the state
 // avg_T > 0: the sum covers the whole buffer, write heat = sum / avg_T and leave the heatmap's min / max in the state
-static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_sum, hipStream_t s, int avg_T = 0)
+// host_rescue: the caller synchronises the stream soon and looks at ctx->h_unserved (rm_locate): a dense kernel that could only
+// be chosen because the value store overflowed is then not enqueued here
+static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_sum, hipStream_t s, int avg_T = 0, bool host_rescue = false)
 {
     CollapseState *st = ctx->d_state;
     const size_t npix = (size_t)cp.H * cp.W;
@@ -1323,7 +1346,15 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     // selection); a launch that can never be chosen is left out: the sparse one when the dense kernel is forced, the dense one when
     // the store has a slot for every pair and the automatic rule cannot pick it.
     const bool may_sparse = sp.mode != 1;
-    const bool may_dense = sp.mode == 1 || sp.cap_slots < sp.npairs_mine || (sp.mode == 0 && sp.auto_dense_ok);
+    const bool auto_dense = sp.mode == 0 && sp.auto_dense_ok;
+    const bool overflow_only = !auto_dense && sp.mode != 1 && sp.cap_slots < sp.npairs_mine;
+    const bool may_dense = sp.mode == 1 || auto_dense || (overflow_only && !host_rescue);
+    int *unserved_dev = nullptr;
+    if (overflow_only && host_rescue) {
+        if (!ctx->h_unserved) HIP_TRY(hipHostMalloc((void **)&ctx->h_unserved, sizeof(int), hipHostMallocDefault));
+        *ctx->h_unserved = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **)&unserved_dev, ctx->h_unserved, 0));
+    }
     if (may_sparse) {
         // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
 #ifdef RM_HIPEMU
@@ -1332,10 +1363,20 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
 #endif
         hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), 2 * sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
-                           cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, sp);
+                           cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, sp, unserved_dev);
         LAUNCH_CHECK();
     }
-    if (may_dense) {
+    if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
+        // one wave per 64 x 16 tile, no barriers (rm_dense_sum.h k_dense_sum_w)
+        const ChainGeom &g = cp.g;
+        if (cp.S == 2)
+            hipLaunchKernelGGL((k_dense_sum_w<2>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<2>::TOTAL, s, cp.cS, g, cp.t0, cp.t1, cp.T, st,
+                               thr, heat_sum, avg_T, tile_nkept, sp);
+        else
+            hipLaunchKernelGGL((k_dense_sum_w<1>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<1>::TOTAL, s, cp.cS, g, cp.t0, cp.t1, cp.T, st,
+                               thr, heat_sum, avg_T, tile_nkept, sp);
+        LAUNCH_CHECK();
+    } else if (may_dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
         // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts
         int cus = 256;
@@ -1381,9 +1422,9 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     return RM_OK;
 }
 
-extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin,
-                            double fmax, double amp, int levels, int skip, double thr, unsigned flags, double *heat,
-                            double *minmax_host, void *stream)
+static int calibrate_impl(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin,
+                          double fmax, double amp, int levels, int skip, double thr, unsigned flags, double *heat,
+                          double *minmax_host, void *stream, CollapsePlan *plan_out)
 {
     if (!ctx || !frames || !heat || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_dtype(dtype))
         return fail(RM_E_BADARG, "rm_calibrate: bad argument");
@@ -1401,7 +1442,8 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_collapse};
     CollapsePlan cp;
     RM_TRY(collapse_eval(ctx, sl, T, 0, T, thr, flags, cp, s));
-    RM_TRY(collapse_sum(ctx, cp, thr, heat, s, T));   // time average and heatmap extrema ride the sum kernel
+    RM_TRY(collapse_sum(ctx, cp, thr, heat, s, T, plan_out != nullptr));   // time average and heatmap extrema ride the sum kernel
+    if (plan_out) *plan_out = cp;
     delete pt_collapse; pt_collapse = nullptr;
     if (minmax_host) {
         HIP_TRY(hipMemcpyAsync(ctx->h_state, st, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
@@ -1410,6 +1452,13 @@ extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, i
         minmax_host[1] = ctx->h_state->max_val;
     }
     return RM_OK;
+}
+
+extern "C" int rm_calibrate(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin,
+                            double fmax, double amp, int levels, int skip, double thr, unsigned flags, double *heat,
+                            double *minmax_host, void *stream)
+{
+    return calibrate_impl(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, thr, flags, heat, minmax_host, stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1785,9 +1834,25 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     if (!ctx || !xywh) return fail(RM_E_BADARG, "rm_locate: bad argument");
     double *heat = nullptr;
     RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
-    RM_TRY(rm_calibrate(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream));
-    ctx->clip_frame_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
-    return heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
+    CollapsePlan cp;
+    RM_TRY(calibrate_impl(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream, &cp));
+    const bool clip_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
+    ctx->clip_frame_once = clip_once;
+    int rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
+    if (rc >= 0 && cp.valid && ctx->h_unserved && *ctx->h_unserved) {
+        // the selection kept more pairs than the value store holds and the sparse sum kernel stood down (the ROI stage above ran on
+        // a heatmap nobody wrote): take the sum with the dense kernel, now that the stream is idle, and extract the ROI again
+        *ctx->h_unserved = 0;
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
+        LAUNCH_CHECK();
+        CollapsePlan dense = cp;
+        dense.sp.mode = 1;
+        RM_TRY(collapse_sum(ctx, dense, temporal_thr, heat, s, T));
+        ctx->clip_frame_once = clip_once;
+        rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -444,4 +444,192 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, Chai
     }
 }
 
+// ---- wave-private tiles (round 3): the dense sum for skip_levels_at_top <= 2 -------------------------------------------------------
+// k_dense_sum_s2 above holds four waves on three barriers per frame at 184 VGPRs (two waves per SIMD): at 4K x 512 the chip's
+// fp64 units are 37 % busy, the rest is LDS latency nobody covers.  Here ONE wave owns a 64 x 16 tile of the heatmap for all
+// frames, with a private 4 KB slice of LDS: no s_barrier anywhere (a wave's DS instructions execute in order: wave_sync() only
+// fences the compiler), four to five independent waves per SIMD, and every index, border rule and tap weight is settled before
+// the frame loop:
+//   * VIRTUAL footprints.  The tile's level-1 footprint is always the 10 rows 8 ty - 1 .. 8 ty + 8 by 34 columns 32 tx - 1 ..
+//     32 tx + 32, its level-2 footprint the 7 rows 4 ty - 1 .. 4 ty + 5 by 20 columns 16 tx - 2 .. 16 tx + 17.  Rows outside
+//     the image are MATERIALISED as the rows OpenCV's border rules substitute for them (row -1 := row 1, row h := row h - 1:
+//     up_at()'s r0 / r2), by address at staging time for the staged level and by a copy for the level computed here; columns
+//     outside the image hold finite values that the column weights multiply by zero.  After that every read is base +
+//     immediate offset and the row structure (which rows are even, which three values meet) is compile-time.
+//   * column taps are always the three neighbours (j - 1, j, j + 1) with per-LANE weights: interior 1,6,1 / 0,4,4, left edge
+//     0,6,2, right edge 1,7,0 / 0,8,0 -- make_htap()'s five shapes with the same operand order, bit for bit.
+//   * level 2 -> 1: lane = level-1 column; the horizontal values of the 7 staged rows stay in REGISTERS and the 10 level-1 rows
+//     are formed from them (odd row (a + b) / 16, even row (a + 6 b + c) / 64: the exact power-of-two scalings merged).
+//   * level 1 -> 0: lane = (column pair, row half): 2 columns x 8 rows, so the three level-1 taps of a source row serve both
+//     columns and six source rows serve eight output rows.
+// Same expressions per value as chain_step / level0_rows (additions of the same operands, commuted at most): bit-identical to the
+// sparse path.  Needs >= 2 rows and columns at levels 1 .. S; smaller images take k_dense_sum_s2.
+template <int S> struct DenseW {
+    static constexpr int R2 = 7, P2 = 20;            // staged level-2 footprint (virtual rows x virtual columns)
+    static constexpr int R1 = 10, P1 = 34;           // level-1 footprint
+    static constexpr int L1_OFF = S == 2 ? R2 * P2 : 0;
+    static constexpr int TOTAL = L1_OFF + R1 * P1;   // doubles of LDS per wave
+    static constexpr int NST = S == 2 ? R2 * P2 : R1 * P1;   // staged elements
+    static constexpr int PF = (NST + 63) / 64;
+    static constexpr int PD = 2;                     // frames the staged elements are requested ahead
+};
+
+// the row OpenCV substitutes for virtual row y of an image with h >= 2 rows (pyrUp: top reflect-101, bottom replicate)
+__host__ __device__ __forceinline__ int up_virtual_row(int y, int h) { return y < 0 ? 1 : (y > h - 1 ? h - 1 : y); }
+
+inline bool dense_wave_ok(const ChainGeom &g)
+{
+    if (g.S < 1 || g.S > 2) return false;
+    for (int k = 1; k <= g.S; ++k) if (g.h[k] < 2 || g.w[k] < 2) return false;
+    return true;
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom g, int t_first, int t_end, int T, CollapseState *st, double threshold,
+                                                    double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp)
+{
+    using G = DenseW<S>;
+    constexpr int R1 = G::R1, P1 = G::P1, R2 = G::R2, P2 = G::P2, PF = G::PF, PD = G::PD;
+    HIP_DYNAMIC_SHARED(double, lds)
+    if (!sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse path took the sum)
+    const int lane = threadIdx.x;
+    const int tile = (int)blockIdx.x, ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
+    if (blockIdx.x == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    const int H0 = g.h[0], W0 = g.w[0], sh1 = g.h[1], sw1 = g.w[1];
+    const int yv1 = 8 * ty - 1, xv1 = 32 * tx - 1;   // first virtual row / column of the level-1 footprint
+    double *l1 = lds + G::L1_OFF;
+    // ---- staged elements of this lane (position fixed for all frames): virtual rows / columns resolved to addresses here
+    const int hS = g.h[S], wS = g.w[S];
+    const size_t fs = (size_t)hS * wS;
+    int off_g[PF], off_l[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int i = lane + 64 * p;
+        const int pitch = S == 2 ? P2 : P1;
+        const int r = i / pitch, c = i - r * pitch;
+        const int yv = (S == 2 ? 4 * ty - 1 : yv1) + r, xv = (S == 2 ? 16 * tx - 2 : xv1) + c;
+        const int ya = up_virtual_row(yv, hS), xa = min(max(xv, 0), wS - 1);
+        off_g[p] = ya * wS + xa;
+        off_l[p] = i < G::NST ? i : -1;
+    }
+    // ---- level 2 -> 1: lane c < 34 owns level-1 column xv1 + c
+    double hw_a = 0.0, hw_b = 0.0, hw_c = 0.0;
+    int h_base = 0;
+    if (S == 2) {
+        const int sw2 = g.w[2];
+        const int xv = xv1 + (lane < P1 ? lane : 0);
+        if (lane < P1 && xv >= 0 && xv < sw1) {
+            const int j = xv >> 1;
+            const bool left = j == 0, right = j == sw2 - 1;
+            if (xv & 1) { hw_b = right ? 8.0 : 4.0; hw_c = right ? 0.0 : 4.0; }
+            else { hw_a = left ? 0.0 : 1.0; hw_b = right ? 7.0 : 6.0; hw_c = left ? 2.0 : (right ? 0.0 : 1.0); }
+        }
+        // taps j - 1, j, j + 1 of staged row q sit at h_base + q P2 + {0, 1, 2}: virtual column (xv >> 1) - 1 - (16 tx - 2)
+        h_base = ((xv >> 1) - 1) - (16 * tx - 2);
+        h_base = min(max(h_base, 0), P2 - 3);   // (lanes >= 34 and out-of-image columns: any valid address, weights are zero)
+    }
+    // ---- level 1 -> 0: lane = (column pair cp, row half rh): columns X, X + 1, rows Y0 .. Y0 + 7
+    const int cp = lane & 31, rh = lane >> 5;
+    const int X = 64 * tx + 2 * cp, Y0 = 16 * ty + 8 * rh;
+    double we_a, we_b, we_c, wo_b, wo_c;
+    {
+        const int j = X >> 1;                       // = 32 tx + cp
+        const bool left = j == 0, right = j >= sw1 - 1;
+        we_a = left ? 0.0 : 1.0; we_b = right ? 7.0 : 6.0; we_c = left ? 2.0 : (right ? 0.0 : 1.0);
+        wo_b = right ? 8.0 : 4.0; wo_c = right ? 0.0 : 4.0;
+    }
+    const double *l0src = l1 + (4 * rh) * P1 + cp;   // taps of source row k: l0src[k P1 + {0, 1, 2}]
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    double nxt[PD][PF];
+    auto fetch = [&](int d, int t) __attribute__((always_inline)) {
+        const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) nxt[d][p] = src[off_g[p]];
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch(d, t_first + d);
+    for (int tb = t_first; tb < t_end; tb += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int t = tb + d;
+            if (t >= t_end) break;   // (uniform)
+            wave_sync();             // the previous frame's reads of this buffer are behind us
+#pragma unroll
+            for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) lds[off_l[p]] = nxt[d][p];
+            fetch(d, t + PD);
+            wave_sync();
+            if (S == 2) {
+                // horizontal values of the 7 staged rows at this lane's level-1 column, in registers
+                double hq[R2];
+#pragma unroll
+                for (int q = 0; q < R2; ++q) {
+                    const double *row = lds + h_base + q * P2;
+                    hq[q] = (row[0] * hw_a + row[1] * hw_b) + row[2] * hw_c;
+                }
+                // level-1 rows p = 0 .. 9 <-> virtual rows 8 ty - 1 + p: p even is an odd row (values of level-2 rows 4 ty - 1 + p / 2
+                // and the next one), p odd an even row (the three rows around 4 ty + (p - 1) / 2); hq[q] <-> level-2 row 4 ty - 1 + q
+                double prev = 0.0;
+#pragma unroll
+                for (int p = 0; p < R1; ++p) {
+                    const int q = p >> 1;
+                    double v = (p & 1) ? (hq[q] + hq[q + 1] * 6 + hq[q + 2]) * (1.0 / 64) : (hq[q] + hq[q + 1]) * (1.0 / 16);
+                    if (yv1 + p > sh1 - 1) v = prev;   // (uniform) virtual row past the bottom: the last row again (up_at()'s r2)
+                    prev = v;
+                    if (lane < P1) l1[p * P1 + lane] = v;
+                }
+                wave_sync();
+            }
+            double hve[6], hvo[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double *row = l0src + k * P1;
+                const double a = row[0], b = row[1], c = row[2];
+                hve[k] = (a * we_a + b * we_b) + c * we_c;
+                hvo[k] = b * wo_b + c * wo_c;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double e0 = (hve[m] + hve[m + 1] * 6 + hve[m + 2]) * (1.0 / 64), e1 = (hve[m + 1] + hve[m + 2]) * (1.0 / 16);
+                const double o0 = (hvo[m] + hvo[m + 1] * 6 + hvo[m + 2]) * (1.0 / 64), o1 = (hvo[m + 1] + hvo[m + 2]) * (1.0 / 16);
+                acc[2 * m] = acc[2 * m] + ((e0 >= top) ? min_val : e0);
+                acc[2 * m + 1] = acc[2 * m + 1] + ((e1 >= top) ? min_val : e1);
+                acc[8 + 2 * m] = acc[8 + 2 * m] + ((o0 >= top) ? min_val : o0);
+                acc[8 + 2 * m + 1] = acc[8 + 2 * m + 1] + ((o1 >= top) ? min_val : o1);
+            }
+        }
+    }
+    // base.py:562: np.average = sum / T when the whole buffer was summed here; the heatmap's extrema for base.py:563
+    const double cnt = (double)avg_T;
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = Y0 + r;
+        if (y < H0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                if (X + o < W0) {
+                    const double a = acc[8 * o + r];
+                    const double v = avg_T > 0 ? a / cnt : a;
+                    heat_sum[(size_t)y * W0 + X + o] = v;
+                    hmn = (v < hmn) ? v : hmn; hmx = (v > hmx) ? v : hmx;
+                }
+            }
+        }
+    }
+    if (tile_nkept && lane == 0) tile_nkept[tile] = t_end - t_first;   // (the sparse heatmap exchange: no tile is known to be the constant)
+    if (avg_T > 0) {
+        hmn = wave_min(hmn); hmx = wave_max(hmx);
+        if (lane == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp_ = blockIdx.x & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+        }
+    }
+}
+
 }  // namespace rm

@@ -458,38 +458,53 @@ __global__ __launch_bounds__(64 * TM_W, NH == 1 ? 3 : 2) void k_temporal_sym(con
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[q] = (v4f64){0.0, 0.0, 0.0, 0.0};
     RM_TRACE_MARK(2, 0);
-    // The operands of TM_U K-steps are requested together, then consumed in order: a loop that loads one step's operands,
-    // waits and multiplies is a chain of L2 round trips.  The order of the products into each accumulator is fixed.
+    // x comes from HBM (one round trip ~2 us under load), the operator fragments from L2: a chunk of up to TM_XPF K-steps has ALL
+    // its x operands requested up front (two doubles per K-step and lane), then the K-steps run in batches of TM_U whose operator
+    // fragments are requested together.  A loop that loads one step's operands, waits and multiplies is a chain of round trips, and
+    // at 2-3 waves per SIMD nothing hides them (4K x 512: 2.75 -> 1.16 ms with the symmetric operator, -> this).
+    // The order of the products into each accumulator is fixed: K-steps wave, wave + W, ... in increasing order.
     constexpr int TM_U = NH == 1 ? 8 : 4;
-    for (int k0 = wave; k0 < nks; k0 += TM_W * TM_U) {
-        double xa[TM_U], xb[TM_U], rr[TM_U][NT];
+    constexpr int TM_XPF = NH == 3 ? 8 : 16;
+    for (int kc = wave; kc < nks; kc += TM_W * TM_XPF) {
+        double xa[TM_XPF], xb[TM_XPF];
 #pragma unroll
-        for (int u = 0; u < TM_U; ++u) {
-            const int ks = k0 + u * TM_W;
+        for (int i = 0; i < TM_XPF; ++i) {
+            const int ks = kc + i * TM_W;
             if (ks < nks) {   // (wave-uniform)
                 const int t = 4 * ks + hi, tc = t < Th ? t : Th - 1, tp = tc == 0 ? 0 : T - tc;
-                xa[u] = x[(size_t)tc * NP + pc];
-                xb[u] = x[(size_t)tp * NP + pc];
-                const double *rf = Rf + (size_t)ks * NT * 64 + lane;
-#pragma unroll
-                for (int q = 0; q < NT; ++q) rr[u][q] = rf[q * 64];
+                xa[i] = x[(size_t)tc * NP + pc];
+                xb[i] = x[(size_t)tp * NP + pc];
             }
         }
 #pragma unroll
-        for (int u = 0; u < TM_U; ++u) {
-            const int ks = k0 + u * TM_W;
-            if (ks < nks) {
-                const int t = 4 * ks + hi;
-                const bool self = t == 0 || 2 * t == T, valid = t < Th;
-                double e = self ? xa[u] : xa[u] + xb[u], o = self ? 0.0 : xa[u] - xb[u];
-                if (!valid) { e = 0.0; o = 0.0; }
+        for (int i0 = 0; i0 < TM_XPF; i0 += TM_U) {
+            if (kc + i0 * TM_W >= nks) break;   // (wave-uniform)
+            double rr[TM_U][NT];
 #pragma unroll
-                for (int q = 0; q < NH; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], e, acc[q], 0, 0, 0);
+            for (int u = 0; u < TM_U; ++u) {
+                const int ks = kc + (i0 + u) * TM_W;
+                if (ks < nks) {
+                    const double *rf = Rf + (size_t)ks * NT * 64 + lane;
 #pragma unroll
-                for (int q = NH; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], o, acc[q], 0, 0, 0);
+                    for (int q = 0; q < NT; ++q) rr[u][q] = rf[q * 64];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TM_U; ++u) {
+                const int ks = kc + (i0 + u) * TM_W;
+                if (ks < nks) {
+                    const int t = 4 * ks + hi;
+                    const bool self = t == 0 || 2 * t == T, valid = t < Th;
+                    double e = self ? xa[i0 + u] : xa[i0 + u] + xb[i0 + u], o = self ? 0.0 : xa[i0 + u] - xb[i0 + u];
+                    if (!valid) { e = 0.0; o = 0.0; }
+#pragma unroll
+                    for (int q = 0; q < NH; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], e, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = NH; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], o, acc[q], 0, 0, 0);
+                }
             }
         }
-        RM_TRACE_MARK(2, 8 + (k0 - wave) / (TM_W * TM_U));
+        RM_TRACE_MARK(2, 8 + (kc - wave) / (TM_W * TM_XPF));
     }
 #pragma unroll
     for (int q = 0; q < NT; ++q)
@@ -1472,6 +1487,41 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
     }
 }
 
+// Filter-first collapse of levels too large for LDS (4K, skip 2; rm_api.hip front_filter): with X_l the band-passed Gaussian levels,
+//     C_S = X_S - pyrUp^n(X_{L-1}),  n = L - 1 - S        (the telescoped collapse, see k_small_filter_first)
+// for one 64 x 16 tile of level S per work item: the footprint of the tile at the coarsest level is staged in LDS, the pyrUp chain
+// runs there exactly as in k_eval_pairs (`g` describes levels S .. L-1 as its levels 0 .. n), the last step lands in registers
+// (lane = column, 16 rows) and is subtracted from the tile of X_S, requested before the chain starts.  X_S is read once, C_S
+// written once, the intermediate levels U_l never exist (three k_pyr_up launches over the 2.1 GB level at 4K x 512 did 1.05 ms).
+// Same per-pixel arithmetic as k_pyr_up (modes 0 and 1): bit-identical.
+__global__ __launch_bounds__(64) void k_ff_collapse(const double *xS, const double *xL, ChainGeom g, int ntiles, int nitems, double *cS)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int lane = threadIdx.x;
+    const int w0 = g.w[0];
+    const size_t fs0 = (size_t)g.h[0] * w0, fsL = (size_t)g.h[g.S] * g.w[g.S];
+    for (int c = blockIdx.x; c < nitems; c += gridDim.x) {
+        const int u = c / ntiles, tile = c - u * ntiles;   // (wave-uniform)
+        const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
+        const int x = R0.x0 + lane, rows = R0.y1 - R0.y0 + 1;
+        const bool col = x <= R0.x1;
+        const double *src = xS + (size_t)u * fs0 + (size_t)R0.y0 * w0 + x;
+        double xs[CT_H];
+#pragma unroll
+        for (int j = 0; j < CT_H; ++j) xs[j] = (col && j < rows) ? src[(size_t)j * w0] : 0.0;
+        chain_to_level1(g, tile, xL + (size_t)u * fsL, lds);
+        if (col) {
+            double v[CT_H];
+            level0_rows<CT_H>(g, R0, R1, lds, x, 0, v);
+            double *dst = cS + (size_t)u * fs0 + (size_t)R0.y0 * w0 + x;
+#pragma unroll
+            for (int j = 0; j < CT_H; ++j)
+                if (j < rows) dst[(size_t)j * w0] = xs[j] - v[j];
+        }
+        __syncthreads();
+    }
+}
+
 // the one evaluation pass: full-resolution values of every listed (unique frame, tile) pair, once.
 // Exact raw.min()/raw.max() (transforms.py:185,187) come from here (list_a); on the sparse path the values of the pairs that can
 // fall below `top` (list_a's kept pairs and all of list_b) are parked in their slot of `store` ([slot][row][lane], coalesced) for
@@ -1594,7 +1644,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
                                                           int *tile_nkept, const int *sel_cnt, const unsigned int *heavy, int nworkers,
-                                                          SumPlan sp)
+                                                          SumPlan sp, int *unserved_host)
 {
     RM_TRACE_SCOPE(6);
     HIP_DYNAMIC_SHARED(int, s_kt)     // kept frames of the tile, in order; then their slots
@@ -1608,7 +1658,12 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
     int slot0 = SLOT_PRUNED;
     if (t_first + tid < t_end) slot0 = slot_of[(size_t)sym_frame(t_first + tid, T) * ntiles + tile0];
     const int nitems = (int)st->n_heavy * MS_Q;
-    if (sum_is_dense(st, sp)) return;   // (uniform over the grid: k_dense_sum takes the sum)
+    if (sum_is_dense(st, sp)) {   // (uniform over the grid: k_dense_sum takes the sum)
+        // unserved_host (pinned, nullable): no dense kernel follows on the stream -- the caller synchronises anyway and enqueues it
+        // itself when it finds this word set (rm_locate: the rare value-store overflow costs the common case no launch)
+        if (unserved_host && blockIdx.x == 0 && tid == 0) *unserved_host = 1;
+        return;
+    }
     // transforms.py:184-189: min, max, top = max - (max - min) * threshold
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;

@@ -417,8 +417,15 @@ def test_emu_dense_sum_equals_sparse_path(emu):
             emu.debug_set("dense_rows", rows)
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, rows)
+        emu.debug_set("dense_rows", 0)                              # skip <= 2: the wave-private kernel (k_dense_sum_w)
+        dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+        assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "wave-private tiles")
         dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128 | 1)
         assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "no_prune")
+        emu.debug_set("dense_wave", 0)
+        dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+        emu.debug_set("dense_wave", 1)
+        assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "workgroup kernel, automatic shape")
         if S <= 2:      # skip <= 2 takes the table-driven kernel: the general one must agree there too
             emu.debug_set("dense_general", 1)
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
@@ -431,6 +438,22 @@ def test_emu_dense_sum_equals_sparse_path(emu):
         tiny, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=4 | 256)
         assert np.array_equal(tiny, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "store overflow, sparse asked for")
     emu.debug_set("dense_rows", 0)
+    # k_dense_sum_w on ragged geometries: widths / heights that are not multiples of the 64 x 16 tiles, odd level sizes (the
+    # virtual rows / columns of the footprints meet every border rule), single-tile images, levels of 2 rows
+    for (T, H, W, L, S) in [(3, 33, 70, 4, 2), (4, 17, 129, 3, 1), (2, 5, 7, 4, 2), (3, 64, 64, 3, 1), (3, 31, 193, 4, 2), (2, 8, 8, 4, 2),
+                            (5, 50, 66, 5, 2), (2, 3, 3, 3, 1), (3, 47, 65, 3, 2)]:
+        v = rng.random((T, H, W))
+        sparse, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+        dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+        assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "wave-private tiles, ragged")
+    # rm_locate leaves the overflow rescue to the host: the sparse kernel stands down, the ROI stage's synchronisation finds the
+    # pinned word set, the dense kernel is enqueued then and the ROI extracted again (skip 3: dense is never the automatic choice)
+    v = synth.synth_breathing(10, 120, 160, seed=5).astype(np.float64) / 255
+    want = emu.locate(v, 10.0, levels=5, skip=3)
+    emu.debug_set("store_slots", 2)
+    got = emu.locate(v, 10.0, levels=5, skip=3)
+    emu.debug_set("store_slots", 0)
+    assert want is not None and got == want
     v = rng.random((11, 70, 150))
     for world in (2, 3):                      # frame shards: partial sums over [t0, t1) with the global extrema
         a = emu.locate_sharded(v, world, levels=4, skip=2, flags=256)

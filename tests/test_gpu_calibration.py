@@ -640,6 +640,10 @@ def test_dense_sum_equals_sparse_path(hip, oracle):
             device.debug_set("dense_rows", rows)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows)
             assert sum_path() == "dense"
+        device.debug_set("dense_rows", 0)        # (rows 0 above: skip <= 2 takes the wave-private k_dense_sum_w; here the workgroup kernel)
+        device.debug_set("dense_wave", 0)
+        assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, "workgroup kernel")
+        device.debug_set("dense_wave", 1)
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=128 | 1, **kw), sparse), (dt, T, H, W, L, S)
         if S <= 2:      # skip <= 2 takes the table-driven kernel: the general one must agree there too
             for rows in (16, 32, 64):
