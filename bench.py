@@ -57,6 +57,8 @@ def parse():
                     "independent [T,H,W] stream per GPU + one heatmap exchange, weak scaling.  sharded: ONE [T,H,W] buffer split by frame "
                     "index over the GPUs (respmon_amd.dist.locate_sharded), strong scaling")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="developer switch of the library context "
+                    "(include/respmon_hip.h rm_debug_set), e.g. temporal_wide=0; listed in the JSON line as debug_set")
     ap.add_argument("--no-extras", action="store_true", help="skip everything outside the contract line: uint8-buffer variant, ROI "
                     "flow, no-prune / dense-stream data-dependence figures")
     ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
@@ -175,6 +177,9 @@ def main():
 
     lib = _capi.load()
     ctx = device.ctx()
+    for kv in a.debug_set:
+        k, v = kv.split("=", 1)
+        device.debug_set(k, int(v))
     flags = _capi.RM_FLAG_NO_PRUNE if a.no_prune else 0
     kw = dict(pyramid_levels=a.levels, skip_levels_at_top=a.skip, flags=flags)
 
@@ -380,6 +385,7 @@ def main():
                        "preset": a.config, "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "levels": a.levels,
                        "skip": a.skip, "prune": not a.no_prune, "mode": a.mode if world > 1 else "single"},
             "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
+            "debug_set": a.debug_set,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"

@@ -73,11 +73,13 @@ struct CollapsePlan {
 // tuning constant so that a test reaches a rare code path.  The library never reads the process environment.
 struct DebugKnobs {
     int temporal_valu = 0;        // 1: the two-stage VALU temporal kernels instead of k_temporal_sym
+    int temporal_wide = -1;       // 0 / 1: k_temporal_sym / k_temporal_sym_px whatever the level size (-1: by size)
     int dc_lds_front_end = 0;     // 1: narrow frame buffers through the LDS front end of k_down_chain instead of rm_down_chain_u8.h
     int no_fused_bounds = 0;      // 1: k_small_collapse + k_frame_bounds instead of k_small_collapse_bounds
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
     int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
     int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2
+    int dense_frames = 0;         // 1 / 2: frames per trip of k_dense_sum_w (0: by the number of tiles)
     int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
@@ -209,12 +211,14 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     DebugKnobs &d = ctx->dbg;
     const std::string k(key);
     if (k == "temporal_valu") d.temporal_valu = (int)value;
+    else if (k == "temporal_wide") d.temporal_wide = (int)value;
     else if (k == "dc_lds_front_end") d.dc_lds_front_end = (int)value;
     else if (k == "no_fused_bounds") d.no_fused_bounds = (int)value;
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
     else if (k == "dense_rows") d.dense_rows = (int)value;
     else if (k == "dense_general") d.dense_general = (int)value;
     else if (k == "dense_wave") d.dense_wave = (int)value;
+    else if (k == "dense_frames") d.dense_frames = (int)value;
     else if (k == "dc_segs") d.dc_segs = (int)value;
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
     else if (k == "store_slots") d.store_slots = value;
@@ -659,6 +663,18 @@ static int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const
     }
     const int mirror_n = full ? T : 0;
 #ifndef RM_HIPEMU
+    // large levels: one wave per 16 pixel columns, no K-split (k_temporal_sym_px); the choice depends on (T, NP) only
+    int cus_t = 256;
+    (void)hipDeviceGetAttribute(&cus_t, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const bool wide = ctx->dbg.temporal_wide >= 0 ? ctx->dbg.temporal_wide != 0 : NP >= (size_t)64 * 4 * cus_t;
+    if (op.Rf && !ctx->dbg.temporal_valu && wide) {
+        const dim3 grid((unsigned)((NP + 63) / 64)), block(256);
+        if (op.tiles == 1) hipLaunchKernelGGL((k_temporal_sym_px<1>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
+        else if (op.tiles == 2) hipLaunchKernelGGL((k_temporal_sym_px<2>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
+        else hipLaunchKernelGGL((k_temporal_sym_px<3>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
+        LAUNCH_CHECK();
+        return RM_OK;
+    }
     if (op.Rf && !ctx->dbg.temporal_valu) {
         const dim3 grid((unsigned)((NP + 15) / 16)), block(64 * TM_W);
         if (op.tiles == 1) hipLaunchKernelGGL((k_temporal_sym<1>), grid, block, 0, s, x, T, NP, op.Rf, op.Cf, amp, out, mirror_n, st_init);
@@ -1369,12 +1385,19 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
         // one wave per 64 x 16 tile, no barriers (rm_dense_sum.h k_dense_sum_w)
         const ChainGeom &g = cp.g;
-        if (cp.S == 2)
-            hipLaunchKernelGGL((k_dense_sum_w<2>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<2>::TOTAL, s, cp.cS, g, cp.t0, cp.t1, cp.T, st,
-                               thr, heat_sum, avg_T, tile_nkept, sp);
-        else
-            hipLaunchKernelGGL((k_dense_sum_w<1>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<1>::TOTAL, s, cp.cS, g, cp.t0, cp.t1, cp.T, st,
-                               thr, heat_sum, avg_T, tile_nkept, sp);
+        int cus = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+#endif
+        // fewer than two waves per SIMD: two frames per trip, interleaved (the lone wave's dependency chain is what takes the time)
+        int fr = cp.ntiles < 8 * cus ? 2 : 1;
+        if (ctx->dbg.dense_frames == 1 || ctx->dbg.dense_frames == 2) fr = ctx->dbg.dense_frames;
+#define RM_DENSE_W(SS, FF)                                                                                                                \
+        hipLaunchKernelGGL((k_dense_sum_w<SS, FF>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<SS>::TOTAL * FF, s, cp.cS, g, cp.t0, \
+                           cp.t1, cp.T, st, thr, heat_sum, avg_T, tile_nkept, sp)
+        if (cp.S == 2) { if (fr == 2) RM_DENSE_W(2, 2); else RM_DENSE_W(2, 1); }
+        else { if (fr == 2) RM_DENSE_W(1, 2); else RM_DENSE_W(1, 1); }
+#undef RM_DENSE_W
         LAUNCH_CHECK();
     } else if (may_dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two

@@ -477,6 +477,14 @@ template <int S> struct DenseW {
 // the row OpenCV substitutes for virtual row y of an image with h >= 2 rows (pyrUp: top reflect-101, bottom replicate)
 __host__ __device__ __forceinline__ int up_virtual_row(int y, int h) { return y < 0 ? 1 : (y > h - 1 ? h - 1 : y); }
 
+// (a wa + b wb) + c wc with wa in {0, 1} and wc in {0, 1, 2}: those two products are EXACT, so each addition of one of them
+// may be written as a fused multiply-add without changing a bit (round(t + a wa) either way) -- three instructions instead of
+// five on the fp64 units this kernel is bound by.  (b wb is inexact for wb = 6, 7: it stays a separate, rounded product.)
+__device__ __forceinline__ double dw_tap3(double a, double b, double c, double wa, double wb, double wc)
+{
+    return __builtin_fma(c, wc, __builtin_fma(a, wa, b * wb));
+}
+
 inline bool dense_wave_ok(const ChainGeom &g)
 {
     if (g.S < 1 || g.S > 2) return false;
@@ -484,7 +492,11 @@ inline bool dense_wave_ok(const ChainGeom &g)
     return true;
 }
 
-template <int S>
+// FR frames per trip of the frame loop, each with its own LDS slice: their stages interleave (stage both, first pyrUp step of
+// both, ...), which gives a LONE wave two independent dependency chains -- for images with fewer tiles than the chip has SIMDs
+// to fill (720p: 900 tiles on 1 024 SIMDs) the kernel is bound by the latency of one wave's chain, not by issue.  The running
+// sums still take frame t before frame t + 1.
+template <int S, int FR>
 __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom g, int t_first, int t_end, int T, CollapseState *st, double threshold,
                                                     double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp)
 {
@@ -499,7 +511,6 @@ __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom 
     if (blockIdx.x == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     const int H0 = g.h[0], W0 = g.w[0], sh1 = g.h[1], sw1 = g.w[1];
     const int yv1 = 8 * ty - 1, xv1 = 32 * tx - 1;   // first virtual row / column of the level-1 footprint
-    double *l1 = lds + G::L1_OFF;
     // ---- staged elements of this lane (position fixed for all frames): virtual rows / columns resolved to addresses here
     const int hS = g.h[S], wS = g.w[S];
     const size_t fs = (size_t)hS * wS;
@@ -540,65 +551,78 @@ __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom 
         we_a = left ? 0.0 : 1.0; we_b = right ? 7.0 : 6.0; we_c = left ? 2.0 : (right ? 0.0 : 1.0);
         wo_b = right ? 8.0 : 4.0; wo_c = right ? 0.0 : 4.0;
     }
-    const double *l0src = l1 + (4 * rh) * P1 + cp;   // taps of source row k: l0src[k P1 + {0, 1, 2}]
+    const int l0off = G::L1_OFF + (4 * rh) * P1 + cp;   // taps of source row k: slice[l0off + k P1 + {0, 1, 2}]
     double acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-    double nxt[PD][PF];
+    constexpr int NB = PD * FR;   // frames in flight (registers): trip i uses buffers 0 .. NB - 1 in frame order
+    double nxt[NB][PF];
     auto fetch = [&](int d, int t) __attribute__((always_inline)) {
         const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
 #pragma unroll
         for (int p = 0; p < PF; ++p) nxt[d][p] = src[off_g[p]];
     };
 #pragma unroll
-    for (int d = 0; d < PD; ++d) fetch(d, t_first + d);
-    for (int tb = t_first; tb < t_end; tb += PD) {
+    for (int d = 0; d < NB; ++d) fetch(d, t_first + d);
+    for (int tb = t_first; tb < t_end; tb += NB) {
 #pragma unroll
-        for (int d = 0; d < PD; ++d) {
-            const int t = tb + d;
-            if (t >= t_end) break;   // (uniform)
-            wave_sync();             // the previous frame's reads of this buffer are behind us
+        for (int d0 = 0; d0 < NB; d0 += FR) {
+            if (tb + d0 >= t_end) break;   // (uniform)
+            wave_sync();                   // the previous trip's reads of these slices are behind us
 #pragma unroll
-            for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) lds[off_l[p]] = nxt[d][p];
-            fetch(d, t + PD);
+            for (int f = 0; f < FR; ++f) {
+                double *sl = lds + f * G::TOTAL;
+#pragma unroll
+                for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) sl[off_l[p]] = nxt[d0 + f][p];
+                fetch(d0 + f, tb + d0 + f + NB);
+            }
             wave_sync();
             if (S == 2) {
-                // horizontal values of the 7 staged rows at this lane's level-1 column, in registers
-                double hq[R2];
 #pragma unroll
-                for (int q = 0; q < R2; ++q) {
-                    const double *row = lds + h_base + q * P2;
-                    hq[q] = (row[0] * hw_a + row[1] * hw_b) + row[2] * hw_c;
-                }
-                // level-1 rows p = 0 .. 9 <-> virtual rows 8 ty - 1 + p: p even is an odd row (values of level-2 rows 4 ty - 1 + p / 2
-                // and the next one), p odd an even row (the three rows around 4 ty + (p - 1) / 2); hq[q] <-> level-2 row 4 ty - 1 + q
-                double prev = 0.0;
+                for (int f = 0; f < FR; ++f) {
+                    double *sl = lds + f * G::TOTAL, *l1 = sl + G::L1_OFF;
+                    // horizontal values of the 7 staged rows at this lane's level-1 column, in registers
+                    double hq[R2];
 #pragma unroll
-                for (int p = 0; p < R1; ++p) {
-                    const int q = p >> 1;
-                    double v = (p & 1) ? (hq[q] + hq[q + 1] * 6 + hq[q + 2]) * (1.0 / 64) : (hq[q] + hq[q + 1]) * (1.0 / 16);
-                    if (yv1 + p > sh1 - 1) v = prev;   // (uniform) virtual row past the bottom: the last row again (up_at()'s r2)
-                    prev = v;
-                    if (lane < P1) l1[p * P1 + lane] = v;
+                    for (int q = 0; q < R2; ++q) {
+                        const double *row = sl + h_base + q * P2;
+                        hq[q] = dw_tap3(row[0], row[1], row[2], hw_a, hw_b, hw_c);
+                    }
+                    // level-1 rows p = 0 .. 9 <-> virtual rows 8 ty - 1 + p: p even is an odd row (values of level-2 rows 4 ty - 1 + p / 2
+                    // and the next one), p odd an even row (the three rows around 4 ty + (p - 1) / 2); hq[q] <-> level-2 row 4 ty - 1 + q
+                    double prev = 0.0;
+#pragma unroll
+                    for (int p = 0; p < R1; ++p) {
+                        const int q = p >> 1;
+                        double v = (p & 1) ? (hq[q] + hq[q + 1] * 6 + hq[q + 2]) * (1.0 / 64) : (hq[q] + hq[q + 1]) * (1.0 / 16);
+                        if (yv1 + p > sh1 - 1) v = prev;   // (uniform) virtual row past the bottom: the last row again (up_at()'s r2)
+                        prev = v;
+                        if (lane < P1) l1[p * P1 + lane] = v;
+                    }
                 }
                 wave_sync();
             }
-            double hve[6], hvo[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const double *row = l0src + k * P1;
-                const double a = row[0], b = row[1], c = row[2];
-                hve[k] = (a * we_a + b * we_b) + c * we_c;
-                hvo[k] = b * wo_b + c * wo_c;
-            }
+            for (int f = 0; f < FR; ++f) {
+                if (tb + d0 + f >= t_end) break;   // (uniform: a trip past the last frame computed on a repeated frame, nothing is added)
+                const double *l0src = lds + f * G::TOTAL + l0off;
+                double hve[6], hvo[6];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const double e0 = (hve[m] + hve[m + 1] * 6 + hve[m + 2]) * (1.0 / 64), e1 = (hve[m + 1] + hve[m + 2]) * (1.0 / 16);
-                const double o0 = (hvo[m] + hvo[m + 1] * 6 + hvo[m + 2]) * (1.0 / 64), o1 = (hvo[m + 1] + hvo[m + 2]) * (1.0 / 16);
-                acc[2 * m] = acc[2 * m] + ((e0 >= top) ? min_val : e0);
-                acc[2 * m + 1] = acc[2 * m + 1] + ((e1 >= top) ? min_val : e1);
-                acc[8 + 2 * m] = acc[8 + 2 * m] + ((o0 >= top) ? min_val : o0);
-                acc[8 + 2 * m + 1] = acc[8 + 2 * m + 1] + ((o1 >= top) ? min_val : o1);
+                for (int k = 0; k < 6; ++k) {
+                    const double *row = l0src + k * P1;
+                    const double a = row[0], b = row[1], c = row[2];
+                    hve[k] = dw_tap3(a, b, c, we_a, we_b, we_c);
+                    hvo[k] = __builtin_fma(c, wo_c, b * wo_b);   // b * 4 + c * 4 (or b * 8 + c * 0): both products exact
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double e0 = (hve[m] + hve[m + 1] * 6 + hve[m + 2]) * (1.0 / 64), e1 = (hve[m + 1] + hve[m + 2]) * (1.0 / 16);
+                    const double o0 = (hvo[m] + hvo[m + 1] * 6 + hvo[m + 2]) * (1.0 / 64), o1 = (hvo[m + 1] + hvo[m + 2]) * (1.0 / 16);
+                    acc[2 * m] = acc[2 * m] + ((e0 >= top) ? min_val : e0);
+                    acc[2 * m + 1] = acc[2 * m + 1] + ((e1 >= top) ? min_val : e1);
+                    acc[8 + 2 * m] = acc[8 + 2 * m] + ((o0 >= top) ? min_val : o0);
+                    acc[8 + 2 * m + 1] = acc[8 + 2 * m + 1] + ((o1 >= top) ? min_val : o1);
+                }
             }
         }
     }

@@ -559,6 +559,110 @@ __global__ __launch_bounds__(64 * TM_W, NH == 1 ? 3 : 2) void k_temporal_sym(con
 }
 #endif
 
+#ifndef RM_HIPEMU
+// The same products for LARGE levels (4K x 512, skip 2: 518 400 pixels per frame, 2.1 GB in, 1.07 GB out): throughput, not
+// latency, is what counts there, and k_temporal_sym's K-split costs it an LDS exchange plus a barrier per 16 pixels and a
+// frontier of only 128 contiguous bytes per frame and workgroup in DRAM.  Here a WAVE owns 16 pixel columns for the whole
+// contraction (no LDS, no barrier; the four waves of a workgroup sit on adjacent columns: 512 contiguous bytes per frame), x
+// streams through two register buffers of TP_XC K-steps (the next chunk is requested before the current one is multiplied),
+// and stage 2 walks all output tiles with the next tile's operator fragments in flight.  The products into each accumulator
+// happen in the same order as in k_temporal_sym?  No: there the partial sums of the four K-phases are added in wave order --
+// here K runs straight through.  The two kernels agree to rounding (~1e-16), and a given (T, level size) always takes the same one.
+template <int NH>
+__global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
+                                                            const double *__restrict__ Cf, double amp, double *__restrict__ out, int mirror_n,
+                                                            struct CollapseState *st_init)
+{
+    if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
+    constexpr int NT = 2 * NH;
+    constexpr int TP_XC = 8;   // K-steps per x chunk
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
+    const size_t p = ((size_t)blockIdx.x * 4 + wave) * 16 + lo;
+    if (((size_t)blockIdx.x * 4 + wave) * 16 >= NP) return;   // (wave-uniform; no barrier in this kernel)
+    const size_t pc = p < NP ? p : NP - 1;
+    const int Th = sym_frames(T), nks = (Th + 3) >> 2;
+    v4f64 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double xa[2][TP_XC], xb[2][TP_XC];
+    auto load_x = [&](int buf, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TP_XC; ++i) {
+            const int ks = k0 + i;
+            const int t = 4 * (ks < nks ? ks : nks - 1) + hi, tc = t < Th ? t : Th - 1, tp = tc == 0 ? 0 : T - tc;
+            xa[buf][i] = x[(size_t)tc * NP + pc];
+            xb[buf][i] = x[(size_t)tp * NP + pc];
+        }
+    };
+    load_x(0, 0);
+    for (int k0 = 0; k0 < nks; k0 += 2 * TP_XC) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int kb = k0 + b * TP_XC;
+            if (kb >= nks) break;   // (uniform)
+            load_x(b ^ 1, kb + TP_XC);
+#pragma unroll
+            for (int i0 = 0; i0 < TP_XC; i0 += 4) {
+                double rr[4][NT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = kb + i0 + u;
+                    const double *rf = Rf + (size_t)(ks < nks ? ks : nks - 1) * NT * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) rr[u][q] = rf[q * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ks = kb + i0 + u;
+                    if (ks < nks) {   // (uniform)
+                        const int t = 4 * ks + hi;
+                        const bool self = t == 0 || 2 * t == T, valid = t < Th;
+                        double e = self ? xa[b][i0 + u] : xa[b][i0 + u] + xb[b][i0 + u], o = self ? 0.0 : xa[b][i0 + u] - xb[b][i0 + u];
+                        if (!valid) { e = 0.0; o = 0.0; }
+#pragma unroll
+                        for (int q = 0; q < NH; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], e, acc[q], 0, 0, 0);
+#pragma unroll
+                        for (int q = NH; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], o, acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const int mt = (Th + 15) >> 4;
+    double cfv[4 * NT];
+    {
+        const double *cf = Cf + lane;
+#pragma unroll
+        for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
+    }
+    for (int m = 0; m < mt; ++m) {
+        const int s0 = 16 * m;
+        v4f64 o = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cfv[4 * q + r], acc[q][r], o, 0, 0, 0);
+        }
+        if (m + 1 < mt) {   // the next tile's operands travel while this one is stored
+            const double *cf = Cf + (size_t)(m + 1) * 4 * NT * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
+        }
+        if (p < NP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sr = s0 + hi + 4 * r;
+                if (sr < Th) {
+                    const double v = o[r] * amp;
+                    out[(size_t)sr * NP + p] = v;
+                    if (mirror_n > 0 && sr > 0 && 2 * sr < mirror_n) out[(size_t)(mirror_n - sr) * NP + p] = v;
+                }
+            }
+        }
+    }
+}
+#endif
+
 // ----------------------------------------------------------------------------------------
 // transforms.py:72-79 temporal_bandpass_filter (the IIR alternative to the FFT filter, selectable through
 // eulerian_magnification_bandpass(temporal_filter_function=...)): scipy.signal.lfilter(b, a, data, axis=0) * amp.

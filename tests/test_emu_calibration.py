@@ -444,8 +444,11 @@ def test_emu_dense_sum_equals_sparse_path(emu):
                             (5, 50, 66, 5, 2), (2, 3, 3, 3, 1), (3, 47, 65, 3, 2)]:
         v = rng.random((T, H, W))
         sparse, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
-        dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
-        assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "wave-private tiles, ragged")
+        for fr in (1, 2):                                           # one frame per trip / two interleaved
+            emu.debug_set("dense_frames", fr)
+            dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+            assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, fr, "wave-private tiles, ragged")
+        emu.debug_set("dense_frames", 0)
     # rm_locate leaves the overflow rescue to the host: the sparse kernel stands down, the ROI stage's synchronisation finds the
     # pinned word set, the dense kernel is enqueued then and the ROI extracted again (skip 3: dense is never the automatic choice)
     v = synth.synth_breathing(10, 120, 160, seed=5).astype(np.float64) / 255
