@@ -10,6 +10,10 @@ by the launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one ra
 [H,W] heatmaps per step (an all-gather of sparse packets; dense all-reduce(sum) as the fallback).  --mode sharded: ONE
 buffer split by frame index over the GPUs (Mode A, strong scaling).  Rank 0 prints ONE JSON line.
 
+The default single-GPU P line also carries `configs`: summaries of BASELINE configs 2 (Q), 5 (R), 3 (F: LK on a 256x256 ROI with
+1000 points) and of P with a float32 frame buffer, each measured in the same process after the headline and checked against the
+CPU oracle (--no-configs skips them).
+
 --config picks the workload (SURVEY 8 sizes):  P = 256 x 1080p, L=9, S=4, float64 buffer (the metric's own configuration,
 default);  Q = 128 x 720p, L=4, S=2, float64 (BASELINE config 2);  R = 512 x 4K, L=6, S=2, float16 buffer (config 5).
 """
@@ -64,6 +68,9 @@ def parse():
     ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
     ap.add_argument("--no-roi-flow", action="store_true", help="skip the per-frame ROI optical-flow measurement")
     ap.add_argument("--no-data-dependence", action="store_true", help="skip the no-prune and dense-stream measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the summaries of the other BASELINE configs (Q, R, F, and P with a "
+                    "float32 frame buffer) that the default single-GPU P line carries under `configs`")
+    ap.add_argument("--configs", default="Q,R,F,P32", help="which of those summaries to run (comma separated)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T "
                     "frames if host memory allows, else 64)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="threads of the all-cores CPU figure (0 = skip, -1 = min(64, host cores))")
@@ -124,6 +131,20 @@ def cpu_baseline(vid_u8, n_frames, levels, skip, in_dtype, workers):
     return out
 
 
+def mode_b_exchange(rdist, need):
+    """What respmon_amd.dist.ExchangePolicy does with a stream whose sparse packet needs `need` tiles: first step and steady state."""
+    if need is None:
+        return "dense all-reduce (no pruning bookkeeping)"
+    pol = rdist.ExchangePolicy()
+    if need <= pol.cap:
+        return "sparse (%d-tile packets)" % pol.cap
+    pol.overflowed(need)
+    if pol.dense_left:
+        return "first step: sparse attempt refused, dense all-reduce; then dense all-reduce for %d steps before the next sparse attempt" % pol.dense_left
+    return "first step: sparse attempt refused, dense all-reduce; from the second step on sparse with the cap grown to %d tiles (%.1f MB packets)" % (
+        pol.cap, 8e-6 * (4 + pol.cap * 1025))
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -162,14 +183,16 @@ def main():
     if sharded:
         t_lo, t_hi = rdist.shard_frames(T, rank, world)
         vid_u8 = vid_u8[t_lo:t_hi]
-    tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[a.in_dtype]
+    TORCH_DT = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}
 
-    def to_device(v8):
-        if a.in_dtype == "u8":
+    def to_device(v8, dt_name=None):
+        dt_name = dt_name or a.in_dtype
+        if dt_name == "u8":
             return torch.from_numpy(v8).cuda()
-        b = torch.empty(tuple(v8.shape), dtype=tdt, device="cuda")
+        td = TORCH_DT[dt_name]
+        b = torch.empty(tuple(v8.shape), dtype=td, device="cuda")
         for t0 in range(0, b.shape[0], 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype
-            b[t0:t0 + 16] = (torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)).to(tdt)
+            b[t0:t0 + 16] = (torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)).to(td)
         return b
 
     buf = to_device(vid_u8)
@@ -347,9 +370,112 @@ def main():
                  "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3],
                                     "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
                  "mode_b_sparse_tiles_needed": need, "mode_b_sparse_tile_cap": rdist.SPARSE_CAP_TILES,
-                 "mode_b_exchange": "sparse" if need is not None and need <= rdist.SPARSE_CAP_TILES else "dense fallback"}
+                 "mode_b_exchange": mode_b_exchange(rdist, need)}
         del dbuf, heat_d
         torch.cuda.empty_cache()
+
+    # The other BASELINE configs as driver-verifiable summaries inside the default P line (config 2 = Q, config 5 = R,
+    # config 3 = F; P32 = the headline workload with the float32 frame buffer BASELINE.md quotes its time on).  Each one is
+    # measured like the headline (resident buffer, HIP events around the frame-buffer kernel inside the timed loop) and its ROI
+    # is compared with the CPU oracle run on ALL frames of the same video.
+    other = None
+    if extras and a.config == "P" and not a.no_configs and not a.no_prune and not a.debug_set:
+        other = {}
+        try:
+            del buf
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        which = [c for c in a.configs.split(",") if c]
+
+        def calib_summary(cT, cH, cW, cL, cS, cdt, n_steps, n_warm, check):
+            cbig = cT * cH * cW > 1 << 30
+            v8 = (synth.synth_breathing_blocks if cbig else synth.synth_breathing)(cT, cH, cW, seed=1234)
+            cbuf = to_device(v8, cdt)
+            fn = lambda: backend.locate(cbuf, 10, 0.1, 1.0, 500, cL, cS, 0.7, 20, 0)
+            for _ in range(n_warm):
+                c_roi = fn()
+            torch.cuda.synchronize()
+            _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
+            c_roi, c_ms = timed(fn, n_steps)
+            _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
+            _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+            ck_ms = ms[0] / max(ncalls.value, 1)
+            _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
+            _capi.check(lib, lib.rm_contour_stats(ctx, ctypes.byref(cn), ctypes.byref(cl)), "rm_contour_stats")
+            cb = cT * cH * cW * DT_BYTES[cdt] + cH * cW * 8
+            d = {"workload": "%dx%dx%d %s frame buffer, %d-level pyramid, skip %d" % (cT, cH, cW, cdt, cL, cS),
+                 "steps": n_steps, "ms_per_step": c_ms, "frames_per_s": cT / c_ms * 1e3, "kernel_ms": ck_ms,
+                 "algorithmic_bytes": cb, "frac": cb / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ck_ms > 0 else None,
+                 "step_frac": cb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "roi": c_roi,
+                 "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2],
+                                    "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
+                 "contour_components": cn.value, "contour_labelled": bool(cl.value)}
+            del cbuf
+            torch.cuda.empty_cache()
+            if check:
+                import psutil
+                from oracle import respmon_oracle as oracle
+                oracle.build()
+                if psutil.virtual_memory().available > 1.3 * 6.0 * cT * cH * cW * 8:
+                    fr = oracle.uint8_to_float(v8)
+                    if cdt in ("f32", "f16"):
+                        fr = fr.astype({"f32": np.float32, "f16": np.float16}[cdt]).astype(np.float64)
+                    t_or = time.perf_counter()
+                    r_or = oracle.locate_parallel(fr, 10, pyramid_levels=cL, skip_levels_at_top=cS, workers=min(64, os.cpu_count() or 1))
+                    d["oracle_roi"] = r_or
+                    d["oracle_seconds"] = time.perf_counter() - t_or
+                    d["roi_equals_oracle"] = list(r_or or []) == list(c_roi or [])
+                    del fr
+                else:
+                    d["roi_equals_oracle"] = None
+                    d["oracle_skipped"] = "host memory"
+            return d
+
+        if "Q" in which:
+            other["Q"] = calib_summary(*CONFIGS["Q"], 100, 10, True)
+        if "P32" in which:
+            other["P32"] = calib_summary(T, H, W, a.levels, a.skip, "f32", 50, 10, False)
+            other["P32"]["roi_equals_headline"] = list(other["P32"]["roi"] or []) == list(roi or [])
+        if "R" in which:
+            other["R"] = calib_summary(*CONFIGS["R"], 10, 4, True)
+        if "F" in which:
+            # config 3: pyramidal LK on a 256x256 ROI, 1000 Shi-Tomasi points, one rm_flow_step per frame (30 fps stream)
+            from oracle import respmon_oracle as oracle
+            oracle.build()
+            render = synth.synth_texture(256, 256, seed=4321)
+            n_fr = 60
+            fr8 = [render(1.5 * np.sin(2 * np.pi * 0.4 * t / 30), 0.5 * np.sin(2 * np.pi * 0.4 * t / 30 + np.pi / 3)) for t in range(n_fr + 1)]
+            dev = [torch.from_numpy(f).cuda() for f in fr8]
+            pts0 = backend.flow_begin(dev[0], 0, 0, 256, 256, 1000, 0.01, 3, 7)
+            n0 = 0 if pts0 is None else len(pts0)
+            means = []
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for i in range(n_fr):
+                mean, n_good = backend.flow_step(dev[i + 1], 0, 0, 256, 256, (15, 15), 2, (3, 10, 0.03))
+                means.append((float(mean[0]), float(mean[1]), int(n_good)))
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - tf) / n_fr
+            # the oracle on the first 5 frames: corners, then LK + mean flow frame after frame
+            # (the monitor's frames are float: base.py:231 uint8_to_float, then base.py:364 float_to_uint8 of the crop, which loses
+            #  24 of the 256 levels -- the oracle sees the same round trip)
+            fr8 = [oracle.float_to_uint8(oracle.uint8_to_float(f)) for f in fr8[:6]]
+            ref = oracle.goodFeaturesToTrack(fr8[0], 1000, 0.01, 3, blockSize=7)
+            ok = ref is not None and pts0 is not None and np.array_equal(np.asarray(pts0).reshape(-1, 2), ref.reshape(-1, 2))
+            p = ref
+            for i in range(5):
+                if not ok:
+                    break
+                r1, rs, _ = oracle.calcOpticalFlowPyrLK(fr8[i], fr8[i + 1], p, None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+                good = rs.ravel() == 1
+                m = np.mean(p[rs == 1] - r1[rs == 1], axis=0) if good.any() else np.zeros(2, np.float32)
+                ok = ok and means[i][2] == int(good.sum()) and np.array_equal(np.array(means[i][:2], np.float32), m.astype(np.float32))
+                p = r1[rs == 1].reshape(-1, 1, 2)
+            other["F"] = {"workload": "pyramidal LK on a 256x256 ROI, maxCorners=1000 (qualityLevel 0.01, minDistance 3), winSize 15, maxLevel 2; "
+                                      "one rm_flow_step per frame", "corners": n0, "frames": n_fr, "ms_per_frame": dtf * 1e3,
+                          "frames_per_s": 1.0 / dtf, "budget_ms_at_30fps": 33.3, "points_at_end": means[-1][2],
+                          "first_5_frames_equal_oracle": bool(ok)}
 
     if rank == 0:
         frames_total = (1 if sharded else world) * T * a.steps
@@ -407,6 +533,7 @@ def main():
             "contour_stage": contour_stage,
             "no_prune": no_prune,
             "dense_stream": dense,
+            "configs": other,
         }
         if world == 1 and a.cpu_frames != 0:
             n_cpu = a.cpu_frames

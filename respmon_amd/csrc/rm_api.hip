@@ -825,15 +825,15 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
         if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny)) {
             const size_t fs = (size_t)h[0] * w[0];
             const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
-#define RM_REG_CASE(SS, TT, ptr) case SS: hipLaunchKernelGGL((k_down_chain_u8<SS, TT>), dim3(grid), dim3(64), 0, s, ptr, fs, g8, out); break;
-#define RM_REG_SWITCH(TT)                                                                                   \
+#define RM_REG_CASE(KK, SS, TT, ptr) case SS: hipLaunchKernelGGL((KK<SS, TT>), dim3(grid), dim3(64), 0, s, ptr, fs, g8, out); break;
+#define RM_REG_SWITCH(KK, TT)                                                                               \
             {                                                                                               \
                 const TT *f = (const TT *)frames;                                                           \
-                switch (S) { RM_REG_CASE(1, TT, f) RM_REG_CASE(2, TT, f) RM_REG_CASE(3, TT, f) default: hipLaunchKernelGGL((k_down_chain_u8<4, TT>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break; } \
+                switch (S) { RM_REG_CASE(KK, 1, TT, f) RM_REG_CASE(KK, 2, TT, f) RM_REG_CASE(KK, 3, TT, f) default: hipLaunchKernelGGL((KK<4, TT>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break; } \
             }
-            if (dtype == RM_U8) RM_REG_SWITCH(uint8_t)
-            else if (dtype == RM_F16) RM_REG_SWITCH(__half)
-            else RM_REG_SWITCH(float)
+            if (dtype == RM_U8) RM_REG_SWITCH(k_down_chain_u8, uint8_t)
+            else if (dtype == RM_F16) RM_REG_SWITCH(k_down_chain_u8, __half)
+            else RM_REG_SWITCH(k_down_chain_narrow, float)
 #undef RM_REG_SWITCH
 #undef RM_REG_CASE
             LAUNCH_CHECK();

@@ -26,24 +26,61 @@ constexpr int U8_STRIP_PX = 16 * U8_VALID_LANES;  // 960 exact input columns per
 #ifndef RM_U8_PREFETCH
 #define RM_U8_PREFETCH 4
 #endif
+// developer knobs (bench_micro/dc8_bench.hip): register budget of the kernel, hot blocks on / off, scheduling fence between rows
+#ifndef RM_NARROW_WAVES
+#define RM_NARROW_WAVES 2
+#endif
+#if RM_NARROW_WAVES > 0
+#define RM_NARROW_OCC __attribute__((amdgpu_waves_per_eu(RM_NARROW_WAVES, RM_NARROW_WAVES)))
+#else
+#define RM_NARROW_OCC
+#endif
+#ifndef RM_NARROW_HOT
+#define RM_NARROW_HOT 1
+#endif
+#ifndef RM_NARROW_FENCE
+#define RM_NARROW_FENCE 1
+#endif
 
 template <int S, int K> struct VStateU8 : VStateU8<S, K + 1> {
     double a[(16 >> K) / 2], b[(16 >> K) / 2], c[(16 >> K) / 2], t[(16 >> K) / 2];
 };
 template <int S> struct VStateU8<S, S> {};
 
-template <typename Tin> struct RegTraits;   // NLD: 16-byte loads per lane and row; PF: rows in flight
-template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8_PREFETCH; };
-template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = 3; };
-template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = 2; };
+template <typename Tin> struct RegTraits;   // NLD: 16-byte loads per lane and row; PF: rows in flight (a divisor of the hot block, 4)
+// HOT: the static steady-state blocks of RegChain pay (measured, bench_micro/dc8_bench.hip, kernel ms old -> new): uint8 1080p x 256
+// 0.365 -> 0.30, float16 4K x 512 2.19 -> 2.03; the float32 chain is bound by bytes in flight, not by instruction issue, and
+// keeps the row-at-a-time form without a register cap (0.42 ms; 0.47 with hot blocks, 1.1 under a 256-register cap)
+template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8_PREFETCH; static constexpr bool HOT = RM_NARROW_HOT != 0; };
+#ifndef RM_F16_PREFETCH
+#define RM_F16_PREFETCH 2
+#endif
+template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16_PREFETCH; static constexpr bool HOT = RM_NARROW_HOT != 0; };
+template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = 2; static constexpr bool HOT = false; };
 
 template <int S, typename Tin = uint8_t>
 struct RegChain {
     static_assert(S >= 1 && S <= 4, "a lane owns 16 >> K columns of level K");
-    static constexpr int NLD = RegTraits<Tin>::NLD, PF = RegTraits<Tin>::PF, VPER = 16 / NLD;  // VPER pixels per 16-byte load
+    static constexpr int NLD = RegTraits<Tin>::NLD, VPER = 16 / NLD;  // VPER pixels per 16-byte load
+    // Levels 0 .. D-1 have a STATIC steady state ("hot blocks" of B = 2^D input rows): away from the image top / bottom and
+    // once a level's (a, b, c, t) state is warm, the even / odd role of every row of these levels inside an aligned block is
+    // known at compile time, so the block is straight-line code -- no parity test, no border select, no state copies (the
+    // generic row-at-a-time form below spends more instructions on those than on arithmetic).  Levels D .. S-1 (1/16 of the
+    // pixels and less) and every row near a segment start, the image top or the image bottom take the generic form.
+    static constexpr bool HOT = RegTraits<Tin>::HOT;
+    static constexpr int D = S < 2 ? S : 2;
+    static constexpr int B = 1 << D;
+    static constexpr int PF = !HOT ? RegTraits<Tin>::PF : RegTraits<Tin>::PF < B ? RegTraits<Tin>::PF : B;
+    static_assert(!HOT || B % PF == 0, "a row's prefetch slot must be static inside a hot block");
+    // Every pyrDown ends with an exact scaling by 1/256 (pyramid.py:14 -> cv2.pyrDown); it commutes with the roundings of the
+    // levels above it (powers of two, magnitudes nowhere near the exponent limits for uint8 / float16 / float32 data), so the
+    // chain carries UNSCALED values and the store applies 2^(-8 S) once.
+    static constexpr double OUT_SCALE = S == 1 ? 1.0 / 256 : S == 2 ? 1.0 / 65536 : S == 3 ? 1.0 / 16777216 : 1.0 / 4294967296.0;
     const DownGeom &g;
     const int lane;
     int next[S + 1], last[S + 1];
+    int p_first, p_last, W;
+    const Tin *src;
     bool left_lane, last_lane;   // this lane holds column 0 / the last column of every level
     int col_S;                   // level-S column of this lane's first owned column
     bool store_ok;               // lane is exact (2..61)
@@ -55,18 +92,19 @@ struct RegChain {
     // horizontal 5-tap of a level-K row held as B = 16>>K columns per lane -> B/2 columns of level K+1
     template <int K> __device__ __forceinline__ void hfilter(const double (&v)[16 >> K], double (&n)[(16 >> K) / 2])
     {
-        constexpr int B = 16 >> K;
-        double pm2 = wave_from_prev(v[B - 2]), pm1 = wave_from_prev(v[B - 1]), nx = wave_from_next(v[0]);
+        constexpr int BW = 16 >> K;
+        double pm2 = wave_from_prev(v[BW - 2]), pm1 = wave_from_prev(v[BW - 1]), nx = wave_from_next(v[0]);
         // BORDER_REFLECT_101: columns -2, -1 -> 2, 1 ; column w -> w-2
-        const double l2 = (B >= 4) ? v[B >= 4 ? 2 : 0] : nx;
+        const double l2 = (BW >= 4) ? v[BW >= 4 ? 2 : 0] : nx;
         pm2 = left_lane ? l2 : pm2;
         pm1 = left_lane ? v[1] : pm1;
-        nx = last_lane ? v[B - 2] : nx;
+        nx = last_lane ? v[BW - 2] : nx;
 #pragma unroll
-        for (int j = 0; j < B / 2; ++j) {
+        for (int j = 0; j < BW / 2; ++j) {
             const double m2 = (j == 0) ? pm2 : v[2 * j - 2], m1 = (j == 0) ? pm1 : v[2 * j - 1];
-            const double p2 = (2 * j + 2 < B) ? v[(2 * j + 2 < B) ? 2 * j + 2 : 0] : nx;
-            n[j] = v[2 * j] * 6 + (m1 + v[2 * j + 1]) * 4 + m2 + p2;
+            const double p2 = (2 * j + 2 < BW) ? v[(2 * j + 2 < BW) ? 2 * j + 2 : 0] : nx;
+            // ((v*6 + (m1 + p1)*4) + m2) + p2: the product by 4 is exact, so it rides an FMA (same rounding, one instruction less)
+            n[j] = __builtin_fma(m1 + v[2 * j + 1], 4.0, v[2 * j] * 6) + m2 + p2;
         }
     }
 
@@ -78,13 +116,11 @@ struct RegChain {
 #pragma unroll
             for (int j = 0; j < NO; ++j) {
                 const int col = col_S + j;
-                if (store_ok && col >= 0 && col < g.w[S]) out_frame[(size_t)y * g.w[S] + col] = v[j] * (1.0 / 256);
+                if (store_ok && col >= 0 && col < g.w[S]) out_frame[(size_t)y * g.w[S] + col] = v[j] * OUT_SCALE;
             }
         } else {
-            double row[NO], n[NO / 2];
-#pragma unroll
-            for (int j = 0; j < NO; ++j) row[j] = v[j] * (1.0 / 256);
-            hfilter<K + 1>(row, n);
+            double n[NO / 2];
+            hfilter<K + 1>(v, n);
             feed<K + 1>(y, n);
         }
     }
@@ -131,7 +167,7 @@ struct RegChain {
             }
 #pragma unroll
             for (int j = 0; j < NO; ++j) {
-                st.t[j] = (st.c[j] * 6 + (be[j] + n[j]) * 4) + ae[j];
+                st.t[j] = __builtin_fma(be[j] + n[j], 4.0, st.c[j] * 6) + ae[j];
                 st.a[j] = st.c[j]; st.b[j] = n[j];
             }
         } else {
@@ -151,10 +187,88 @@ struct RegChain {
         }
     }
 
+    // ---- hot blocks ------------------------------------------------------------------------------------------------------
+    // Row J (compile-time) of level K inside a block that starts on an aligned row: even J emits row J / 2 of level K + 1.
+    template <int K, int J> __device__ __forceinline__ void hot_row(const double (&n)[(16 >> K) / 2])
+    {
+        constexpr int NO = (16 >> K) / 2;
+        VStateU8<S, K> &st = vs;
+        if constexpr (J & 1) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                st.t[j] = __builtin_fma(st.b[j] + n[j], 4.0, st.c[j] * 6) + st.a[j];
+                st.a[j] = st.c[j]; st.b[j] = n[j];
+            }
+        } else {
+            double v[NO];
+#pragma unroll
+            for (int j = 0; j < NO; ++j) { v[j] = st.t[j] + n[j]; st.c[j] = n[j]; }
+            if constexpr (K + 1 == D) {
+                emit<K>(next[D], v);   // level D (or the store, D == S) in the generic form; hot_ok() vouches for the row index
+            } else {
+                double n2[NO / 2];
+                hfilter<K + 1>(v, n2);
+                hot_row<K + 1, J / 2>(n2);
+            }
+        }
+    }
+
+    // may rows [base, base + B) run as a hot block?  (wave-uniform)
+    __device__ __forceinline__ bool hot_ok(int base) const
+    {
+        bool ok = base >= p_first && base + B - 1 <= p_last;
+        int y = base;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int cnt = B >> k;
+            // no top-of-image row forms (rows 1 and 2), the last real row (its virtual successors) is not in the block
+            ok = ok && y >= 3 && y + cnt - 1 < g.h[k] - 1;
+            const int y2 = (y >> 1) - 1;                      // first row of level k + 1 the block emits
+            ok = ok && y2 == next[k + 1] && y2 + (cnt >> 1) - 1 <= last[k + 1];   // level k is warm, and every emission is wanted
+            y = y2;
+        }
+        return ok;
+    }
+
+    // rows are independent instruction streams over the same (a, b, c, t) registers: without a fence between them the scheduler
+    // hoists the unpacking of all B rows of a block to the front (128 more live registers, one wave per SIMD)
+    static __device__ __forceinline__ void row_fence()
+    {
+#if !defined(RM_HIPEMU) && RM_NARROW_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+
+    __device__ __forceinline__ void issue(int row, Raw16 (&r)[NLD]) const
+    {
+        const Tin *rp = src + (size_t)row * W;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(rp + j * VPER);   // (plain: this kernel lives on cache hits for its strip halos -- non-temporal loads measured 0.43 -> 0.70 ms on the float32 buffer)
+    }
+
+    __device__ __forceinline__ void unpack_row(const Raw16 (&r)[NLD], double (&v)[16]) const
+    {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = unpack_px<Tin>(r[e / VPER], e % VPER);
+    }
+
+    template <int I> __device__ __forceinline__ void hot_rows(int base, Raw16 (&regs)[PF][NLD])
+    {
+        if constexpr (I < B) {
+            double v[16], n[8];
+            unpack_row(regs[I % PF], v);
+            issue(min(base + I + PF, p_last), regs[I % PF]);
+            hfilter<0>(v, n);
+            hot_row<0, I>(n);
+            row_fence();
+            hot_rows<I + 1>(base, regs);
+        }
+    }
+
     __device__ __forceinline__ void run(const Tin *frame, double *out_t, int strip, int seg)
     {
         out_frame = out_t;
-        const int W = g.w[0];
+        W = g.w[0];
         next[S] = g.y_begin + seg * g.seg_h; last[S] = min(next[S] + g.seg_h, g.y_end) - 1;
 #pragma unroll
         for (int k = S - 1; k >= 0; --k) { next[k] = max(0, 2 * next[k + 1] - 2); last[k] = min(g.h[k] - 1, 2 * last[k + 1] + 2); }
@@ -164,35 +278,87 @@ struct RegChain {
         last_lane = (c_first + 15 == W - 1);
         store_ok = lane >= 2 && lane <= 61;
         col_S = c_first >> S;                                  // exact: P and 16*lane are multiples of 16 >= 2^S
-        const Tin *src = frame + min(max(c_first, 0), W - 16);
-        const int p_first = next[0], p_last = last[0];
-        Raw16 regs[PF][NLD];
-        auto issue = [&](int row, Raw16 (&r)[NLD]) __attribute__((always_inline)) {
-            const Tin *rp = src + (size_t)row * W;
+        src = frame + min(max(c_first, 0), W - 16);
+        p_first = next[0]; p_last = last[0];
+        if constexpr (!HOT) {
+            // row at a time, PF rows in flight in static register sets
+            Raw16 regs[PF][NLD];
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(rp + j * VPER);   // (plain: this kernel lives on cache hits for its strip halos -- non-temporal loads measured 0.43 -> 0.70 ms on the float32 buffer)
-        };
+            for (int i = 0; i < PF; ++i) issue(min(p_first + i, p_last), regs[i]);
+            for (int base = p_first; base <= p_last; base += PF) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) issue(min(p_first + i, p_last), regs[i]);
-        for (int base = p_first; base <= p_last; base += PF) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int p = base + i;
-                if (p <= p_last) {
-                    double v[16], n[8];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = unpack_px<Tin>(regs[i][e / VPER], e % VPER);
-                    issue(min(p + PF, p_last), regs[i]);
-                    hfilter<0>(v, n);
-                    feed<0>(p, n);
+                for (int i = 0; i < PF; ++i) {
+                    const int p = base + i;
+                    if (p <= p_last) {
+                        double v[16], n[8];
+                        unpack_row(regs[i], v);
+                        issue(min(p + PF, p_last), regs[i]);
+                        hfilter<0>(v, n);
+                        feed<0>(p, n);
+                    }
                 }
             }
+            return;
+        }
+        // rows are taken in chunks of B whose first row is = -2 (mod B): the alignment at which an even row of level 0 emits an
+        // even row of level 1 (hot_row); a row's prefetch slot is its offset from base0 modulo PF (PF divides B)
+        const int base0 = p_first - ((p_first + 2) & (B - 1));
+        Raw16 regs[PF][NLD];
+#pragma unroll
+        for (int i = 0; i < PF; ++i)   // slot i <- the first row >= p_first that belongs to it
+            issue(min(p_first + ((i - (p_first - base0)) & (PF - 1)), p_last), regs[i]);
+        int base = base0;
+        while (base <= p_last) {
+            if (hot_ok(base)) {
+                do {
+                    hot_rows<0>(base, regs);
+#pragma unroll
+                    for (int k = 1; k < D; ++k) next[k] += B >> k;   // (next[D] was set by emit)
+                    base += B;
+                } while (hot_ok(base));
+                continue;
+            }
+            // generic rows of this chunk, one at a time (ONE copy of the row code: the slot is picked by a wave-uniform branch)
+            const int p_end = min(base + B - 1, p_last);
+#pragma nounroll
+            for (int p = max(base, p_first); p <= p_end; ++p) {
+                const int slot = (p - base0) & (PF - 1);
+                Raw16 cur[NLD];
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (slot == i) {
+#pragma unroll
+                        for (int j = 0; j < NLD; ++j) cur[j] = regs[i][j];
+                        issue(min(p + PF, p_last), regs[i]);
+                    }
+                double v[16], n[8];
+                unpack_row(cur, v);
+                hfilter<0>(v, n);
+                feed<0>(p, n);
+                row_fence();
+            }
+            base += B;
         }
     }
 };
 
+template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow_body(const Tin *frames, size_t frame_stride, const DownGeom &g, double *out);
+
+// float32 frame buffers: no register cap (RegTraits<float>::HOT == false)
+template <int S, typename Tin = float>
+__global__ __launch_bounds__(64) void k_down_chain_narrow(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
+{
+    down_chain_narrow_body<S, Tin>(frames, frame_stride, g, out);
+}
+
+// uint8 / float16 frame buffers: two waves per SIMD (256 registers: the hot loop holds its state without spills)
 template <int S, typename Tin = uint8_t>
-__global__ __launch_bounds__(64) void k_down_chain_u8(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
+__global__ __launch_bounds__(64) RM_NARROW_OCC void k_down_chain_u8(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
+{
+    down_chain_narrow_body<S, Tin>(frames, frame_stride, g, out);
+}
+
+template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow_body(const Tin *frames, size_t frame_stride, const DownGeom &g, double *out)
 {
     const int per_frame = g.strips * g.segs;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;

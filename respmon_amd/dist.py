@@ -21,10 +21,24 @@ def _dist():
     return dist
 
 
+# Test / smoke switch: issue every collective of this module even when the group has ONE rank (a sum / max / gather over one
+# rank is the identity, so results must not change).  It lets the un-staged RCCL branches below run on a single-GPU box
+# (tests/test_gpu_rccl.py); never set in production -- at world 1 the collectives are skipped.
+COLLECTIVES_AT_WORLD_1 = False
+
+
+def _collective(group=None):
+    """True when this step's collectives are to be issued: an initialised group of more than one rank (or the switch above)."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or COLLECTIVES_AT_WORLD_1
+
+
 def all_reduce_heatmap(heat, group=None):
     """In-place sum of the [H,W] float64 heatmap over ranks (the single data collective of Mode B)."""
     dist = _dist()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         _all_reduce(heat, dist.ReduceOp.SUM, group)
     return heat
 
@@ -34,7 +48,7 @@ def all_reduce_minmax(mn, mx, like, group=None):
     import torch
     dist = _dist()
     t = torch.tensor([-mn, mx], dtype=torch.float64, device=like.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return -float(t[0]), float(t[1])
 
@@ -83,14 +97,17 @@ def hip_heatmap_to_roi(heat, threshold=20, clip_frame=False, labelling=None):
     lib = _capi.load()
     H, W = heat.shape
     xywh = (ctypes.c_int32 * 4)()
-    _capi.check(lib, lib.rm_set_contour_clip_frame(device.ctx(), 1 if clip_frame else 0), "rm_set_contour_clip_frame")
+    # per-call overrides only: a context-wide rm_set_contour_clip_frame / rm_set_contour_labelling the caller made stays as it is
+    if clip_frame:
+        _capi.check(lib, lib.rm_set_contour_clip_frame(device.ctx(), 1), "rm_set_contour_clip_frame")
     if labelling is not None:
         _capi.check(lib, lib.rm_set_contour_labelling(device.ctx(), 1 if labelling else 0), "rm_set_contour_labelling")
     try:
         rc = _capi.check(lib, lib.rm_heatmap_to_roi(device.ctx(), device.ptr(heat), H, W, int(threshold), xywh, None, None,
                                                     device.stream_ptr()), "rm_heatmap_to_roi")
     finally:
-        lib.rm_set_contour_clip_frame(device.ctx(), 0)
+        if clip_frame:
+            lib.rm_set_contour_clip_frame(device.ctx(), 0)
         if labelling is not None:
             lib.rm_set_contour_labelling(device.ctx(), -1)
     return None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
@@ -127,7 +144,7 @@ def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TI
     packet = _scratch("packet", (pd,), t.float64, heat.device)
     _capi.check(lib, lib.rm_heat_sparse_pack(device.ctx(), device.ptr(heat), H, W, cap_tiles, device.ptr(packet), device.stream_ptr()),
                 "rm_heat_sparse_pack")
-    if world > 1:
+    if _collective(group):
         if _staged(packet, group):
             host = packet.cpu()
             allp = host.new_empty(world * pd)
@@ -147,6 +164,50 @@ def hip_sparse_exchange_roi(heat, threshold, group=None, cap_tiles=SPARSE_CAP_TI
         return False, None, None
     roi = None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
     return True, roi, fused
+
+
+def sparse_tiles_needed():
+    """Largest per-rank tile count the last sparse merge on this context saw (identical on every rank: each one reads all the
+    packet headers), whether or not the packets overflowed."""
+    import ctypes
+    from . import _capi, device
+    lib = _capi.load()
+    n = ctypes.c_int(0)
+    _capi.check(lib, lib.rm_heat_sparse_tiles_needed(device.ctx(), ctypes.byref(n)), "rm_heat_sparse_tiles_needed")
+    return n.value
+
+
+class ExchangePolicy:
+    """What a heatmap exchange remembers from one step to the next (per heatmap geometry).  A packet that overflowed tells every
+    rank how many tiles the fullest rank needed: the cap grows to hold that (packets stay <= SPARSE_MAX_TILES * 8 KB = 4 MB), and a
+    stream that needs more than that goes straight to the dense all-reduce for the next DENSE_HOLD steps instead of paying
+    pack + all-gather + merge for a refusal on every step.  Every rank sees the same figures, so all of them switch together."""
+
+    def __init__(self):
+        self.cap = SPARSE_CAP_TILES
+        self.dense_left = 0
+
+    def use_sparse(self):
+        if self.dense_left > 0:
+            self.dense_left -= 1
+            return False
+        return True
+
+    def overflowed(self, needed):
+        want = (int(needed * 1.25) + 63) // 64 * 64
+        if needed > 0 and want <= SPARSE_MAX_TILES:
+            self.cap = max(self.cap, want)
+        else:
+            self.dense_left = DENSE_HOLD
+
+
+SPARSE_MAX_TILES = 512    # 4 MB packets at most
+DENSE_HOLD = 64           # steps a stream that does not fit stays on the dense all-reduce before the sparse form is tried again
+_POLICY = {}
+
+
+def exchange_policy(H, W, mode):
+    return _POLICY.setdefault((int(H), int(W), mode), ExchangePolicy())
 
 
 def hip_sparse_tiles(heat, cap_tiles=SPARSE_CAP_TILES):
@@ -179,12 +240,15 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
     else:
         heat = calibrate_fn(buf, fps, **kw)
     if sparse is None:
-        sparse = calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and _world(group)[1] > 1
+        sparse = calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and _collective(group)
     if sparse:
-        ok, roi, fused = hip_sparse_exchange_roi(heat, threshold, group, keep_fused=return_heatmap)
-        if ok:
-            LAST_EXCHANGE = "sparse"
-            return (roi, fused) if return_heatmap else roi
+        pol = exchange_policy(heat.shape[0], heat.shape[1], "streams")
+        if pol.use_sparse():
+            ok, roi, fused = hip_sparse_exchange_roi(heat, threshold, group, cap_tiles=pol.cap, keep_fused=return_heatmap)
+            if ok:
+                LAST_EXCHANGE = "sparse"
+                return (roi, fused) if return_heatmap else roi
+            pol.overflowed(sparse_tiles_needed())
     LAST_EXCHANGE = "dense"
     all_reduce_heatmap(heat, group)
     roi = roi_fn(heat, threshold)
@@ -217,7 +281,7 @@ def _staged(tensor, group):
 
 def _all_reduce(tensor, op, group=None):
     dist = _dist()
-    if _world(group)[1] == 1:
+    if not _collective(group):
         return tensor
     if _staged(tensor, group):
         host = tensor.cpu()
@@ -233,7 +297,7 @@ def all_gather_frames(local, T, group=None):
     import torch
     dist = _dist()
     rank, world = _world(group)
-    if world == 1:
+    if not _collective(group):
         return local
     spans = [shard_frames(T, r, world) for r in range(world)]
     counts = [b - a for a, b in spans]
@@ -327,13 +391,16 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
     _all_reduce(mm, dist.ReduceOp.MAX, group)
     heat_sum = st.heat(mm, temporal_threshold, H, W)
     if sparse is None:
-        sparse = stages is None and world > 1
+        sparse = stages is None and _collective(group)
     global LAST_EXCHANGE
     if sparse:   # the partial heat sums are one constant outside a few tiles too: sparse all-gather instead of a 16.6 MB all-reduce
-        ok, roi, heat = hip_sparse_exchange_roi(heat_sum, threshold, group, avg_T=T, keep_fused=return_heatmap)
-        if ok:
-            LAST_EXCHANGE = "sparse"
-            return (roi, heat) if return_heatmap else roi
+        pol = exchange_policy(H, W, "sharded")
+        if pol.use_sparse():
+            ok, roi, heat = hip_sparse_exchange_roi(heat_sum, threshold, group, cap_tiles=pol.cap, avg_T=T, keep_fused=return_heatmap)
+            if ok:
+                LAST_EXCHANGE = "sparse"
+                return (roi, heat) if return_heatmap else roi
+            pol.overflowed(sparse_tiles_needed())
     LAST_EXCHANGE = "dense"
     _all_reduce(heat_sum, dist.ReduceOp.SUM, group)
     roi, heat = st.finish(heat_sum, T, threshold)

@@ -73,6 +73,22 @@ def test_single_rank_is_a_no_op():
     assert rdist.all_reduce_minmax(-1.5, 2.5, h) == (-1.5, 2.5)
 
 
+def test_exchange_policy_remembers_an_overflow():
+    """Mode B / Mode A heatmap exchange (dist.ExchangePolicy): a refused sparse attempt grows the packet cap when the fullest rank
+    fits 4 MB, and otherwise holds the dense all-reduce for DENSE_HOLD steps instead of paying for a refusal on every step."""
+    from respmon_amd import dist as rdist
+    pol = rdist.ExchangePolicy()
+    assert pol.use_sparse() and pol.cap == rdist.SPARSE_CAP_TILES
+    pol.overflowed(391)                       # bench.py's dense stream
+    assert pol.cap == 512 and pol.use_sparse() and pol.dense_left == 0
+    pol.overflowed(2040)                      # every tile of a 1080p heatmap: no packet holds that
+    assert pol.dense_left == rdist.DENSE_HOLD and pol.cap == 512
+    assert [pol.use_sparse() for _ in range(rdist.DENSE_HOLD)] == [False] * rdist.DENSE_HOLD
+    assert pol.use_sparse()                   # ... then one more sparse attempt
+    assert rdist.exchange_policy(1080, 1920, "streams") is rdist.exchange_policy(1080, 1920, "streams")
+    assert rdist.exchange_policy(1080, 1920, "streams") is not rdist.exchange_policy(1080, 1920, "sharded")
+
+
 def test_frame_shards_partition_the_buffer():
     from respmon_amd import dist as rdist
     for T in (1, 7, 128, 256, 513):

@@ -354,7 +354,19 @@ def test_config_r_fp16_buffer(hip, oracle):
     assert storage_err < 0.2     # the half-precision frame buffer perturbs, but does not destroy, the heatmap
 
 
-def test_config_r_4k_512_fp16_full_size(hip, oracle):
+def _note_branch(record_property, key, text):
+    """Make a data- or host-dependent branch of a test visible: a junit property, a warning in the pytest summary (which -q keeps)
+    and a line in gpurun_out/test_branches.log (copied to profiles/ with the round's test log)."""
+    import warnings
+    record_property(key, text)
+    warnings.warn("%s: %s" % (key, text))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "test_branches.log"), "a") as f:
+            f.write("%s: %s\n" % (key, text))
+
+
+def test_config_r_4k_512_fp16_full_size(hip, oracle, record_property):
     """BASELINE config 5 at its stated size: 4K x 512 frames, 6-level pyramid, skip 2, float16 frame buffer (8.5 GB; the
     filtered levels are 2.8 GB per array, n = 512 keeps 92 rfft rows = 6 MFMA tiles, tile bounds in bands).  The oracle
     needs ~6 float64 [T,H,W] arrays on the host (T = 512: 204 GB): where the host has that much, the full buffer is compared with
@@ -398,7 +410,9 @@ def test_config_r_4k_512_fp16_full_size(hip, oracle):
         del full_in
         assert roi == ref_full
         assert _rel(a, mid_full["avg_frame"]) <= 1e-12
-        print("config R: oracle run on all 512 4K frames, ROI", ref_full)
+        _note_branch(record_property, "config_R_full_oracle", "ran: oracle on all 512 4K frames, ROI %s == GPU ROI" % (ref_full,))
+    else:
+        _note_branch(record_property, "config_R_full_oracle", "SKIPPED: host has < 270 GB free; only the first-64-frames oracle run below")
     # complete oracle run on the first 64 frames of the same float16 buffer
     Ts = 64
     assert _host_can_hold(6.0 * Ts * H * W * 8), "host memory too small for the 4K x 64 oracle run"

@@ -45,6 +45,30 @@ def test_corners_and_flow_config3(be, oracle):
         prev, cur_pts = b, r1[rs == 1].reshape(-1, 1, 2)
 
 
+def test_config3_at_1000_points(be, oracle):
+    """BASELINE config 3 at its stated point count: minDistance=3 lets the texture yield maxCorners = 1000 corners (minDistance=7
+    stops at 655); five LK steps on all of them, points, status and mean flow bit-exact against the oracle."""
+    from respmon_amd import synth
+    render = synth.synth_texture(256, 256, seed=4321)
+    a = render(0.0, 0.0)
+    pts = be.good_features_to_track(_dev(a), maxCorners=1000, qualityLevel=0.01, minDistance=3, blockSize=7)
+    ref = oracle.goodFeaturesToTrack(a, 1000, 0.01, 3, blockSize=7)
+    assert pts is not None and len(pts) == 1000 and np.array_equal(pts, ref)
+    prev, cur_pts = a, pts
+    tracked = []
+    for t in range(1, 6):
+        dx, dy = 1.5 * np.sin(2 * np.pi * 0.4 * t / 30), 0.5 * np.sin(2 * np.pi * 0.4 * t / 30 + np.pi / 3)
+        b = render(dx, dy)
+        p1, st = be.calc_optical_flow_pyr_lk(_dev(prev), _dev(b), cur_pts, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        r1, rs, _ = oracle.calcOpticalFlowPyrLK(prev, b, cur_pts, None, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        assert np.array_equal(st, rs) and np.array_equal(p1, r1)
+        mean, ng = be.mean_flow(cur_pts, p1, st)
+        assert ng == int((rs.ravel() == 1).sum()) and np.array_equal(mean, np.mean(cur_pts[rs == 1] - r1[rs == 1], axis=0))
+        tracked.append(ng)
+        prev, cur_pts = b, r1[rs == 1].reshape(-1, 1, 2)
+    assert tracked[0] >= 950, tracked   # (nearly) all of the 1000 points are really tracked
+
+
 def test_small_roi_like_the_reference(be, oracle):
     from respmon_amd import synth
     render = synth.synth_texture(96, 112, seed=99)
