@@ -326,12 +326,13 @@ def main():
             # the same frames through rm_flow_begin / rm_flow_step: crop + LK + mean flow in ONE call per frame, crops and points
             # resident on the device (what RespiratoryMonitor.extract_motion('flow') runs); same numbers as the four calls above
             grays = [torch.from_numpy(vid_u8[i]).cuda() for i in range(n_fl + 1)]
-            backend.flow_begin(grays[0], x, y, w, h, 100, 0.3, 7, 7)
+            fstate = backend.flow_state()
+            backend.flow_begin(fstate, grays[0], x, y, w, h, 100, 0.3, 7, 7)
             motion2 = []
             torch.cuda.synchronize()
             tf = time.perf_counter()
             for i in range(n_fl):
-                mean, n_good = backend.flow_step(grays[i + 1], x, y, w, h, (15, 15), 2, (3, 10, 0.03))
+                mean, n_good = backend.flow_step(fstate, grays[i + 1], x, y, w, h, (15, 15), 2, (3, 10, 0.03))
                 if n_good:
                     motion2.append([mean[0], mean[1]])
                 if len(motion2) >= 2:
@@ -447,13 +448,14 @@ def main():
             n_fr = 60
             fr8 = [render(1.5 * np.sin(2 * np.pi * 0.4 * t / 30), 0.5 * np.sin(2 * np.pi * 0.4 * t / 30 + np.pi / 3)) for t in range(n_fr + 1)]
             dev = [torch.from_numpy(f).cuda() for f in fr8]
-            pts0 = backend.flow_begin(dev[0], 0, 0, 256, 256, 1000, 0.01, 3, 7)
+            fstate3 = backend.flow_state()
+            pts0 = backend.flow_begin(fstate3, dev[0], 0, 0, 256, 256, 1000, 0.01, 3, 7)
             n0 = 0 if pts0 is None else len(pts0)
             means = []
             torch.cuda.synchronize()
             tf = time.perf_counter()
             for i in range(n_fr):
-                mean, n_good = backend.flow_step(dev[i + 1], 0, 0, 256, 256, (15, 15), 2, (3, 10, 0.03))
+                mean, n_good = backend.flow_step(fstate3, dev[i + 1], 0, 0, 256, 256, (15, 15), 2, (3, 10, 0.03))
                 means.append((float(mean[0]), float(mean[1]), int(n_good)))
             torch.cuda.synchronize()
             dtf = (time.perf_counter() - tf) / n_fr

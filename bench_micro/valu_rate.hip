@@ -48,6 +48,12 @@ template <int OP> __global__ __launch_bounds__(64) void k_rate(int iters, double
 #define LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
 #define CNDS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(u[i]) : "v"(u[(i + 1) & 15]) : "s20", "s21");
 #define CNDV(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 15]) : );
+#define CNDV64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 15]) : );
+#define CMPCND(i) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 15]) : "vcc");
+#define CMPCNDS(i) asm volatile("v_cmp_lt_u32_e64 s[22:23], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(u[i]) : "v"(u[(i + 1) & 15]) : "s22", "s23");
+#define CMPONLY(i) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(u[i]), "v"(u[(i + 1) & 15]) : "vcc");
+#define CMPCNDF(i) asm volatile("v_cmp_lt_f64_e32 vcc, %0, %1\n v_cndmask_b32_e32 %2, %2, %3, vcc" : : "v"(d[i]), "v"(d[(i + 1) & 15]), "v"(u[i]), "v"(u[(i + 1) & 15]) : "vcc");
+#define MINF64(i) asm volatile("v_min_f64 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 15]));
 #define PKADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 15]));
 #define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) & 15]));
 #define PKMUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 15]));
@@ -62,7 +68,8 @@ template <int OP> __global__ __launch_bounds__(64) void k_rate(int iters, double
         else if (OP == 20) { REP16(PKFMA) } else if (OP == 21) { REP16(PKMUL) } else if (OP == 22) { REP16(SDWASHL) }
         else if (OP == 23 || OP == 24 || OP == 25) { REP16(LDSRD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         else if (OP == 26) { REP16(LDSRD) REP16(ADD) REP16(MUL) REP16(FMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        else if (OP == 27) { REP16(DEPADD) }
+        else if (OP == 27) { REP16(DEPADD) } else if (OP == 28) { REP16(CNDV64) } else if (OP == 29) { REP16(CMPCND) } else if (OP == 30) { REP16(CMPCNDS) }
+        else if (OP == 31) { REP16(CMPONLY) } else if (OP == 32) { REP16(CMPCNDF) } else if (OP == 33) { REP16(MINF64) }
     }
     long long t1 = __builtin_readcyclecounter();
     double s = 0; float sf = 0; unsigned su = 0;
@@ -101,5 +108,7 @@ int main()
     run<17>("v_cndmask_b32_e64 sgpr mask"); run<18>("v_cndmask_b32_e32 vcc"); run<19>("v_pk_add_f32"); run<20>("v_pk_fma_f32"); run<21>("v_pk_mul_f32");
     run<22>("v_lshlrev_b32_sdwa BYTE_1"); run<23>("ds_read_b64 LUT random"); run<24>("ds_read_b64 LUT camera-like"); run<25>("ds_read_b64 LUT uniform");
     run<26>("16 ds_read_b64 + 48 f64 VALU (cost per 16 = x16)"); run<27>("v_add_f64 dependent chain");
+    run<28>("v_cndmask_b32_e64 vcc"); run<29>("v_cmp_e32 vcc + v_cndmask_e32 (pair)"); run<30>("v_cmp_e64 sgpr + v_cndmask_e64 (pair)"); run<31>("v_cmp_lt_u32_e32 vcc");
+    run<32>("v_cmp_lt_f64 + v_cndmask (pair)"); run<33>("v_min_f64");
     return 0;
 }

@@ -70,7 +70,7 @@ size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
 /* developer / test switches, per context; the library never reads the process environment.  Every switch selects between
  * implementations with identical results or shrinks a tuning constant so that a test reaches a rare path:
  *   "temporal_valu" 0|1, "temporal_wide" -1|0|1, "dc_lds_front_end" 0|1, "no_fused_bounds" 0|1, "bounds_table_bytes" n, "dense_rows" 0|16|32|64,
- *   "dense_general" 0|1, "dense_wave" 1|0, "dense_frames" 0|1|2, "dc_segs" n, "dc_wpg" n, "store_slots" n.  Unknown key -> RM_E_BADARG. */
+ *   "dense_general" 0|1, "dense_wave" 1|0, "dense_frames" 0|1|2, "dense_split" 0|1|2|4, "bounds_scalar" 0|1|2, "dc_segs" n, "dc_wpg" n, "store_slots" n.  Unknown key -> RM_E_BADARG. */
 int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
 
 /* ---- measurement hook for bench.py: mode 1 brackets only the frame-buffer kernel with hipEvents on the
@@ -260,11 +260,18 @@ int rm_pca_reduce(rm_ctx *ctx, const float *motion_host, int n, double *out_host
  *        call only advances the previous image (mean 0, n_good 0: the caller returns NaN, base.py:385-386).
  *      rm_flow_points: the points the next step will track (what the reference holds in self.motion_key_points).
  *      Bit-identical to rm_roi_to_uint8 + rm_calc_optical_flow_pyr_lk + rm_mean_flow called in turn. */
-int rm_flow_begin(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int max_corners,
+/*      The session's state -- previous crop, its LK pyramid and derivatives, the tracked points -- lives in an rm_flow_state the
+ *      caller owns (one per RespiratoryMonitor: self.previous_cropped_image / self.motion_key_points of base.py:111-112 are
+ *      per object), so several monitors share a GPU and an rm_ctx without seeing each other's tracking.  What a step builds for
+ *      the new crop is kept for the next step, which tracks FROM it: one pyramid and one set of derivatives per frame. */
+typedef struct rm_flow_state rm_flow_state;
+int rm_flow_state_create(rm_ctx *ctx, rm_flow_state **out);
+int rm_flow_state_destroy(rm_flow_state *state);
+int rm_flow_begin(rm_ctx *ctx, rm_flow_state *state, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int max_corners,
                   double quality_level, double min_distance, int block_size, float *pts_host, int *n_host, void *stream);
-int rm_flow_step(rm_ctx *ctx, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int win_w, int win_h,
+int rm_flow_step(rm_ctx *ctx, rm_flow_state *state, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int win_w, int win_h,
                  int max_level, int max_count, double epsilon, float *mean_xy_host, int *n_good_host, void *stream);
-int rm_flow_points(rm_ctx *ctx, float *pts_host, int cap, int *n_host, void *stream);
+int rm_flow_points(rm_ctx *ctx, rm_flow_state *state, float *pts_host, int cap, int *n_host, void *stream);
 
 /* ---- base.py:230-231: cv2.cvtColor(BGR2GRAY) then uint8_to_float, on device ("next" row f3) */
 int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gray_dev, void *stream);

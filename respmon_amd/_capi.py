@@ -68,9 +68,11 @@ SIGNATURES = {
     "rm_roi_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rm_good_features_to_track": (_i, [_vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
     "rm_calc_optical_flow_pyr_lk": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
-    "rm_flow_begin": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
-    "rm_flow_step": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
-    "rm_flow_points": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "rm_flow_state_create": (_i, [_vp, _vp]),
+    "rm_flow_state_destroy": (_i, [_vp]),
+    "rm_flow_begin": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
+    "rm_flow_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
+    "rm_flow_points": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "rm_mean_flow": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rm_pca_reduce": (_i, [_vp, _vp, _i, _vp, _vp]),
     "rm_bgr_to_gray": (_i, [_vp, _vp, _sz, _vp, _vp]),

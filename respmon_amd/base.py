@@ -10,7 +10,12 @@ Differences from the reference that are deliberate and documented in DESIGN.md:
     (isOpened / read / get / release); a path or camera index needs cv2 at run time;
   * the calibration buffer lives in HBM (`calibration_buffer` is a CUDA tensor);
   * `run_on_init=True` keeps the reference's "constructor blocks in run()" behaviour
-    (base.py:164); pass False to drive the object step by step.
+    (base.py:164); pass False to drive the object step by step;
+  * `reset()` also forgets the flow state (`previous_cropped_image`, `motion_key_points`): the reference leaves them
+    (base.py:515-533) and overwrites them at the next corner initialisation, before anything reads them;
+  * after a calibration that finds no ROI the retry goes through `update_ui()` / `sync_to_fps()` like every other
+    iteration; the reference `continue`s past them (base.py:451-454) -- no effect on the data path (the UI is a no-op here);
+  * the default operation order of the calibration commutes two linear stages (`reference_operation_order`).
 """
 import logging
 import time
@@ -23,6 +28,27 @@ from .tools import Benchmarker, reduce_bounding_box
 from .transforms import butter_lowpass_filter
 
 THRESH_BINARY = 0  # cv2.THRESH_BINARY
+
+
+class FlowState:
+    """Owner of one rm_flow_state (the device-resident tracking session of extract_motion('flow')); released with the object."""
+
+    def __init__(self, lib):
+        import ctypes
+        self._lib = lib
+        self.handle = ctypes.c_void_p()
+        _capi.check(lib, lib.rm_flow_state_create(device.ctx(), ctypes.byref(self.handle)), "rm_flow_state_create")
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self._lib.rm_flow_state_destroy(self.handle)
+            self.handle.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class _Backend:
@@ -141,18 +167,23 @@ class _Backend:
         return mean, ng.value
 
     # -- extract_motion('flow') with the crops and points resident on the device: one C-ABI call per frame --------------------
-    def flow_begin(self, gray_u8, x, y, w, h, maxCorners, qualityLevel, minDistance, blockSize):
+    # -- resident flow session (include/respmon_hip.h rm_flow_state): one handle per monitor -----------------------------
+    def flow_state(self):
+        """A new rm_flow_state on the current device: previous crop, its LK pyramid, the tracked points of ONE tracking session."""
+        return FlowState(self.lib)
+
+    def flow_begin(self, state, gray_u8, x, y, w, h, maxCorners, qualityLevel, minDistance, blockSize):
         import ctypes
         H, W = gray_u8.shape
         pts = np.empty((max(int(maxCorners), 1), 2), dtype=np.float32)
         n = ctypes.c_int()
-        _capi.check(self.lib, self.lib.rm_flow_begin(device.ctx(), device.ptr(gray_u8), device.dtype_code(gray_u8), H, W, x, y, w, h,
+        _capi.check(self.lib, self.lib.rm_flow_begin(device.ctx(), state.handle, device.ptr(gray_u8), device.dtype_code(gray_u8), H, W, x, y, w, h,
                                                      int(maxCorners), float(qualityLevel), float(minDistance), int(blockSize),
                                                      ctypes.c_void_p(pts.ctypes.data), ctypes.byref(n), device.stream_ptr()),
                     "rm_flow_begin")
         return None if n.value == 0 else pts[:n.value].reshape(-1, 1, 2).copy()
 
-    def flow_step(self, gray_u8, x, y, w, h, winSize, maxLevel, criteria):
+    def flow_step(self, state, gray_u8, x, y, w, h, winSize, maxLevel, criteria):
         import ctypes
         H, W = gray_u8.shape
         ctype, max_count, eps = criteria
@@ -162,17 +193,17 @@ class _Backend:
             eps = 0.01
         mean = np.empty(2, dtype=np.float32)
         ng = ctypes.c_int()
-        _capi.check(self.lib, self.lib.rm_flow_step(device.ctx(), device.ptr(gray_u8), device.dtype_code(gray_u8), H, W, x, y, w, h,
+        _capi.check(self.lib, self.lib.rm_flow_step(device.ctx(), state.handle, device.ptr(gray_u8), device.dtype_code(gray_u8), H, W, x, y, w, h,
                                                     int(winSize[0]), int(winSize[1]), int(maxLevel), int(max_count), float(eps),
                                                     ctypes.c_void_p(mean.ctypes.data), ctypes.byref(ng), device.stream_ptr()),
                     "rm_flow_step")
         return mean, ng.value
 
-    def flow_points(self, cap):
+    def flow_points(self, state, cap):
         import ctypes
         pts = np.empty((max(int(cap), 1), 2), dtype=np.float32)
         n = ctypes.c_int()
-        _capi.check(self.lib, self.lib.rm_flow_points(device.ctx(), ctypes.c_void_p(pts.ctypes.data), len(pts), ctypes.byref(n),
+        _capi.check(self.lib, self.lib.rm_flow_points(device.ctx(), state.handle, ctypes.c_void_p(pts.ctypes.data), len(pts), ctypes.byref(n),
                                                       device.stream_ptr()), "rm_flow_points")
         return pts[:min(n.value, len(pts))].reshape(-1, 1, 2).copy()
 
@@ -437,7 +468,9 @@ class RespiratoryMonitor:
 
     def _extract_motion_flow_resident(self, be, x, y, w, h):
         if self.previous_cropped_image is None:                            # base.py:363-369
-            self.motion_key_points = be.flow_begin(self._frame_u8, x, y, w, h, **self.feature_params)
+            if getattr(self, "_flow_state", None) is None:
+                self._flow_state = be.flow_state()                         # this monitor's own tracking session
+            self.motion_key_points = be.flow_begin(self._flow_state, self._frame_u8, x, y, w, h, **self.feature_params)
             self.previous_cropped_image = self._RESIDENT
             self._flow_cap = max(int(self.feature_params["maxCorners"]), 1)
             self._flow_n = 0 if self.motion_key_points is None else len(self.motion_key_points)
@@ -448,9 +481,9 @@ class RespiratoryMonitor:
             self.fused_flow_step = False
             return self.extract_motion()
         if self._flow_n == 0:
-            be.flow_step(self._frame_u8, x, y, w, h, **self.lk_params)     # (the previous image still advances, base.py:381)
+            be.flow_step(self._flow_state, self._frame_u8, x, y, w, h, **self.lk_params)     # (the previous image still advances, base.py:381)
             return np.nan
-        mean, n_good = be.flow_step(self._frame_u8, x, y, w, h, **self.lk_params)   # base.py:371-388
+        mean, n_good = be.flow_step(self._flow_state, self._frame_u8, x, y, w, h, **self.lk_params)   # base.py:371-388
         self._flow_n = n_good
         self._points_stale = True
         if n_good == 0:
@@ -463,7 +496,7 @@ class RespiratoryMonitor:
     @property
     def motion_key_points(self):
         if getattr(self, "_points_stale", False):
-            self._motion_key_points = self._backend.flow_points(self._flow_cap)
+            self._motion_key_points = self._backend.flow_points(self._flow_state, self._flow_cap)
             self._points_stale = False
         return getattr(self, "_motion_key_points", None)
 
@@ -476,6 +509,12 @@ class RespiratoryMonitor:
     # (pixels on the image frame count), True = OpenCV <= 3.1 (the 1-pixel frame is zeroed before tracing; base.py:567's
     # `thresh_copy` exists because that version mutated its input).  include/respmon_hip.h rm_set_contour_clip_frame.
     opencv_contours_clip_frame = False
+    # Operation order of the calibration.  False (default): the temporal filter runs on the Gaussian level G_S and the Laplacians are
+    # taken of the filtered images -- the linear stages commuted, results within ~1e-15 of the band-passed magnitudes of the
+    # reference's order.  True: the reference's own order (Laplacians first, transforms.py:148-170; RM_FLAG_FILTER_LAPLACIANS),
+    # bit-identical to the per-level kernels, a few per cent slower.  locate() is a static method (as in the reference, base.py:547):
+    # both switches are read from RespiratoryMonitor itself, not from a subclass.
+    reference_operation_order = False
 
     # ------------------------------------------------------------------ hot path A
     @staticmethod
@@ -492,7 +531,8 @@ class RespiratoryMonitor:
         buf = device.to_device(calibration_video_data)
         roi = _Backend().locate(buf, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
                                 temporal_threshold, threshold,
-                                flags=_capi.RM_FLAG_CONTOUR_CLIP_FRAME if RespiratoryMonitor.opencv_contours_clip_frame else 0)
+                                flags=(_capi.RM_FLAG_CONTOUR_CLIP_FRAME if RespiratoryMonitor.opencv_contours_clip_frame else 0) |
+                                      (_capi.RM_FLAG_FILTER_LAPLACIANS if RespiratoryMonitor.reference_operation_order else 0))
         if save_calibration_image and roi is not None:     # base.py:577-596 (the reference returns before it when no contour)
             from . import montage
             logging.info('Creating calibration image.')

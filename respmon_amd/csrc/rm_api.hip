@@ -77,9 +77,11 @@ struct DebugKnobs {
     int dc_lds_front_end = 0;     // 1: narrow frame buffers through the LDS front end of k_down_chain instead of rm_down_chain_u8.h
     int no_fused_bounds = 0;      // 1: k_small_collapse + k_frame_bounds instead of k_small_collapse_bounds
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
+    int bounds_scalar = 0;        // 1: k_frame_bounds (a thread per row and tile column) also for wide levels instead of k_frame_bounds_rows
     int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
     int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2
     int dense_frames = 0;         // 1 / 2: frames per trip of k_dense_sum_w (0: by the number of tiles)
+    int dense_split = 0;          // 1 / 2 / 4: waves per tile (k_dense_sum_wf for 2 and 4; 0: by the number of tiles)
     int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
@@ -103,9 +105,6 @@ struct rm_ctx {
     bool state_fresh = false;   // d_state was reset by the last kernel of front_pyramid and nothing has reduced into it since
     int op_mfma = 0;        // > 0: the cached operator also exists in the fragment-major form of k_temporal_mfma, with this many 16-row tiles
     FlowWorkspace flow;
-    // device-resident state of rm_flow_begin / rm_flow_step: previous ROI crop, the points tracked from it, pinned result words
-    int fs_w = 0, fs_h = 0, fs_npts = 0, fs_cap = 0, fs_flip = 0;
-    float *fs_res = nullptr;   // pinned {mean_x, mean_y, n_good}
     CollapsePlan shard_plan;   // rm_shard_collapse -> rm_shard_heat
     size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
@@ -195,7 +194,6 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
     if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
-    if (ctx->fs_res) (void)hipHostFree(ctx->fs_res);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->h_unserved) (void)hipHostFree(ctx->h_unserved);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
@@ -215,10 +213,12 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dc_lds_front_end") d.dc_lds_front_end = (int)value;
     else if (k == "no_fused_bounds") d.no_fused_bounds = (int)value;
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
+    else if (k == "bounds_scalar") d.bounds_scalar = (int)value;
     else if (k == "dense_rows") d.dense_rows = (int)value;
     else if (k == "dense_general") d.dense_general = (int)value;
     else if (k == "dense_wave") d.dense_wave = (int)value;
     else if (k == "dense_frames") d.dense_frames = (int)value;
+    else if (k == "dense_split") d.dense_split = (int)value;
     else if (k == "dc_segs") d.dc_segs = (int)value;
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
     else if (k == "store_slots") d.store_slots = value;
@@ -1285,13 +1285,22 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
             return most;
         };
         size_t tbl_max = 64 * 1024;
+        // wide levels (>= 256 columns, at most 64 tile columns): a wave per FB_TR tile rows, streaming (k_frame_bounds_rows)
+        const int wS_b = g.w[g.S];
+        const size_t rowbufs = 4 * sizeof(double) * (size_t)fb_row_pitch(wS_b);
+        // (small images -- 720p: 45 tile rows x 65 frames -- have too few waves of 8 tile rows to fill the chip: the table form stays,
+        //  measured 31.7 us against 45 us with 2 tile rows per wave)
+        const bool by_rows = (ctx->dbg.bounds_scalar == 2 || (!ctx->dbg.bounds_scalar && (long long)Th * ((g.tiles_y + 7) / 8) >= 2048)) && wS_b >= 256 &&
+                             wS_b <= 64 * FB_MAXNL && g.tiles_x <= 64 && ntiles < (1 << 24);
         if (ctx->dbg.bounds_table_bytes > 0) tbl_max = (size_t)ctx->dbg.bounds_table_bytes;   // test hook: force small bands
         while (band > 1 && (size_t)tbl_rows_of(band) * row_bytes > tbl_max) band = (band + 1) / 2;
         // ... and enough workgroups to fill the chip: one workgroup per frame leaves half of it idle at T = 128
         while (band > 4 && (long long)Th * ((g.tiles_y + band - 1) / band) < 1024) band = (band + 1) / 2;
         const int tbl_rows = tbl_rows_of(band);
         const size_t tbl = (size_t)tbl_rows * row_bytes;
-        if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
+        if (by_rows) {
+            hipLaunchKernelGGL(k_frame_bounds_rows<8>, dim3(Th, (unsigned)((g.tiles_y + 31) / 32)), dim3(256), rowbufs, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt);
+        } else if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
             const unsigned nbands = (unsigned)((g.tiles_y + band - 1) / band);
             hipLaunchKernelGGL(k_frame_bounds, dim3(Th, nbands), dim3(256), tbl, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, band, tbl_rows, cp.sel_cnt);
         } else {
@@ -1392,6 +1401,21 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         // fewer than two waves per SIMD: two frames per trip, interleaved (the lone wave's dependency chain is what takes the time)
         int fr = cp.ntiles < 8 * cus ? 2 : 1;
         if (ctx->dbg.dense_frames == 1 || ctx->dbg.dense_frames == 2) fr = ctx->dbg.dense_frames;
+        // fewer tiles than SIMDs: NW waves per tile, each evaluating every NW-th frame (k_dense_sum_wf)
+        int split = cp.ntiles < 4 * cus ? 4 : 1;
+        if (ctx->dbg.dense_split == 1 || ctx->dbg.dense_split == 2 || ctx->dbg.dense_split == 4) split = ctx->dbg.dense_split;
+        if (split > 1) {
+#define RM_DENSE_WF(SS, NN)                                                                                                               \
+            do {                                                                                                                          \
+                const size_t shf = sizeof(double) * (size_t)NN * 16 * 64;                                                                 \
+                hipLaunchKernelGGL((k_dense_sum_wf<SS, NN>), dim3((unsigned)cp.ntiles), dim3(64 * NN), shf, s, cp.cS, g, cp.t0, cp.t1, cp.T, st, thr,  \
+                                   heat_sum, avg_T, tile_nkept, sp);                                                                      \
+            } while (0)
+            if (cp.S == 2) { if (split == 4) RM_DENSE_WF(2, 4); else RM_DENSE_WF(2, 2); }
+            else { if (split == 4) RM_DENSE_WF(1, 4); else RM_DENSE_WF(1, 2); }
+#undef RM_DENSE_WF
+            LAUNCH_CHECK();
+        } else {
 #define RM_DENSE_W(SS, FF)                                                                                                                \
         hipLaunchKernelGGL((k_dense_sum_w<SS, FF>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<SS>::TOTAL * FF, s, cp.cS, g, cp.t0, \
                            cp.t1, cp.T, st, thr, heat_sum, avg_T, tile_nkept, sp)
@@ -1399,6 +1423,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         else { if (fr == 2) RM_DENSE_W(1, 2); else RM_DENSE_W(1, 1); }
 #undef RM_DENSE_W
         LAUNCH_CHECK();
+        }
     } else if (may_dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
         // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts
@@ -1970,88 +1995,128 @@ static int flow_crop(rm_ctx *ctx, const void *frame, int dtype, int H, int W, in
     return rm_roi_to_uint8(ctx, frame, dtype, H, W, x, y, w, h, dst, (void *)s);
 }
 
-static int flow_state_bufs(rm_ctx *ctx, int w, int h, int cap, uint8_t **crop_a, uint8_t **crop_b, float **pts_a, float **pts_b)
+struct rm_flow_state {
+    int device = 0;
+    FlowState fs;
+};
+
+extern "C" int rm_flow_state_create(rm_ctx *ctx, rm_flow_state **out)
 {
-    std::string err;
-    int rc;
-    if ((rc = ctx->flow.get("fs_crop_a", (size_t)w * h, (void **)crop_a, err)) < 0) return fail(rc, "%s", err.c_str());
-    if ((rc = ctx->flow.get("fs_crop_b", (size_t)w * h, (void **)crop_b, err)) < 0) return fail(rc, "%s", err.c_str());
-    if ((rc = ctx->flow.get("fs_pts_a", sizeof(float) * 2 * (size_t)cap, (void **)pts_a, err)) < 0) return fail(rc, "%s", err.c_str());
-    if ((rc = ctx->flow.get("fs_pts_b", sizeof(float) * 2 * (size_t)cap, (void **)pts_b, err)) < 0) return fail(rc, "%s", err.c_str());
+    if (!ctx || !out) return fail(RM_E_BADARG, "rm_flow_state_create: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    rm_flow_state *st = new rm_flow_state();
+    st->device = ctx->device;
+    *out = st;
     return RM_OK;
 }
 
-extern "C" int rm_flow_begin(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, int max_corners,
+extern "C" int rm_flow_state_destroy(rm_flow_state *st)
+{
+    if (!st) return RM_OK;
+    (void)hipSetDevice(st->device);
+    delete st;   // (FlowState / FlowWorkspace release their device and pinned memory)
+    return RM_OK;
+}
+
+static int flow_state_pts(FlowState &fs, float **pts_a, float **pts_b)
+{
+    std::string err;
+    int rc;
+    if ((rc = fs.ws.get("pts_a", sizeof(float) * 2 * (size_t)fs.cap, (void **)pts_a, err)) < 0) return fail(rc, "%s", err.c_str());
+    if ((rc = fs.ws.get("pts_b", sizeof(float) * 2 * (size_t)fs.cap, (void **)pts_b, err)) < 0) return fail(rc, "%s", err.c_str());
+    return RM_OK;
+}
+
+static int flow_state_crop(FlowState &fs, int side, uint8_t **crop)
+{
+    std::string err;
+    const int rc = flow_side_buf(fs, side, "pyr", 0, (size_t)fs.w * fs.h, (void **)crop, err);
+    if (rc < 0) return fail(rc, "%s", err.c_str());
+    return RM_OK;
+}
+
+extern "C" int rm_flow_begin(rm_ctx *ctx, rm_flow_state *state, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, int max_corners,
                              double quality, double min_distance, int block_size, float *pts_host, int *n_host, void *stream)
 {
-    if (!ctx || !frame || !pts_host || !n_host || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h) || h < 3 || w < 3 || block_size < 1 ||
+    if (!ctx || !state || !frame || !pts_host || !n_host || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h) || h < 3 || w < 3 || block_size < 1 ||
         (block_size & 1) == 0)
         return fail(RM_E_BADARG, "rm_flow_begin: bad argument");
+    if (state->device != ctx->device) return fail(RM_E_BADARG, "rm_flow_begin: the flow state belongs to device %d, the context to %d", state->device, ctx->device);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    const int cap = std::max(max_corners, 1);
-    uint8_t *ca = nullptr, *cb = nullptr; float *pa = nullptr, *pb = nullptr;
-    RM_TRY(flow_state_bufs(ctx, w, h, cap, &ca, &cb, &pa, &pb));
-    if (!ctx->fs_res) HIP_TRY(hipHostMalloc((void **)&ctx->fs_res, 4 * sizeof(float), hipHostMallocDefault));
-    ctx->fs_w = w; ctx->fs_h = h; ctx->fs_cap = cap; ctx->fs_flip = 0; ctx->fs_npts = 0;
-    RM_TRY(flow_crop(ctx, frame, dtype, H, W, x, y, w, h, ca, s));
+    FlowState &fs = state->fs;
+    fs.w = w; fs.h = h; fs.cap = std::max(max_corners, 1); fs.flip = 0; fs.npts = 0; fs.begun = false;
+    fs.pyr_levels[0] = fs.pyr_levels[1] = -1; fs.deriv_levels[0] = fs.deriv_levels[1] = -1;
+    if (!fs.res) HIP_TRY(hipHostMalloc((void **)&fs.res, 4 * sizeof(float), hipHostMallocDefault));
+    uint8_t *crop = nullptr; float *pa = nullptr, *pb = nullptr;
+    RM_TRY(flow_state_crop(fs, 0, &crop));
+    RM_TRY(flow_state_pts(fs, &pa, &pb));
+    RM_TRY(flow_crop(ctx, frame, dtype, H, W, x, y, w, h, crop, s));
+    fs.pyr_levels[0] = 0;
     std::string err;
-    int rc = flow_good_features(ctx->flow, ca, h, w, max_corners, quality, min_distance, block_size, pts_host, n_host, s, err);
+    int rc = flow_good_features(fs.ws, crop, h, w, max_corners, quality, min_distance, block_size, pts_host, n_host, s, err);
     if (rc < 0) return fail(rc, "%s", err.c_str());
-    ctx->fs_npts = *n_host;
+    fs.npts = *n_host;
     if (*n_host > 0) {
         HIP_TRY(hipMemcpyAsync(pa, pts_host, sizeof(float) * 2 * (size_t)*n_host, hipMemcpyHostToDevice, s));
         HIP_TRY(stream_wait(s));   // pts_host is the caller's again
     }
+    fs.begun = true;
     return RM_OK;
 }
 
-extern "C" int rm_flow_step(rm_ctx *ctx, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, int win_w, int win_h,
-                            int max_level, int max_count, double epsilon, float *mean_xy_host, int *n_good_host, void *stream)
+extern "C" int rm_flow_step(rm_ctx *ctx, rm_flow_state *state, const void *frame, int dtype, int H, int W, int x, int y, int w, int h, int win_w,
+                            int win_h, int max_level, int max_count, double epsilon, float *mean_xy_host, int *n_good_host, void *stream)
 {
-    if (!ctx || !frame || !mean_xy_host || !n_good_host || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h) || win_w < 3 || win_h < 3 ||
+    if (!ctx || !state || !frame || !mean_xy_host || !n_good_host || !valid_dtype(dtype) || !roi_ok(H, W, x, y, w, h) || win_w < 3 || win_h < 3 ||
         max_level < 0)
         return fail(RM_E_BADARG, "rm_flow_step: bad argument");
-    if (!ctx->fs_res || w != ctx->fs_w || h != ctx->fs_h) return fail(RM_E_BADARG, "rm_flow_step: rm_flow_begin has not been called for this ROI size");
+    FlowState &fs = state->fs;
+    if (!fs.begun || w != fs.w || h != fs.h) return fail(RM_E_BADARG, "rm_flow_step: rm_flow_begin has not been called on this state for this ROI size");
+    if (state->device != ctx->device) return fail(RM_E_BADARG, "rm_flow_step: the flow state belongs to another device");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    uint8_t *ca = nullptr, *cb = nullptr; float *pa = nullptr, *pb = nullptr;
-    RM_TRY(flow_state_bufs(ctx, w, h, ctx->fs_cap, &ca, &cb, &pa, &pb));
-    uint8_t *prev = ctx->fs_flip ? cb : ca, *cur = ctx->fs_flip ? ca : cb;
-    float *pts = ctx->fs_flip ? pb : pa, *pts_next = ctx->fs_flip ? pa : pb;
+    const int prev_side = fs.flip, cur_side = fs.flip ^ 1;
+    uint8_t *cur = nullptr; float *pa = nullptr, *pb = nullptr;
+    RM_TRY(flow_state_crop(fs, cur_side, &cur));
+    RM_TRY(flow_state_pts(fs, &pa, &pb));
+    float *pts = fs.flip ? pb : pa, *pts_next = fs.flip ? pa : pb;
     RM_TRY(flow_crop(ctx, frame, dtype, H, W, x, y, w, h, cur, s));
-    const int npts = ctx->fs_npts;
+    fs.pyr_levels[cur_side] = 0; fs.deriv_levels[cur_side] = -1;   // a new image on this side: its old pyramid and derivatives are void
+    const int npts = fs.npts;
     mean_xy_host[0] = mean_xy_host[1] = 0.f; *n_good_host = 0;
     if (npts > 0) {
         std::string err;
         float *d_out = nullptr; uint8_t *d_st = nullptr; float *dev_res = nullptr;
         int rc;
-        if ((rc = ctx->flow.get("lk_pts_out", sizeof(float) * 2 * (size_t)npts, (void **)&d_out, err)) < 0) return fail(rc, "%s", err.c_str());
-        if ((rc = ctx->flow.get("lk_status", (size_t)npts, (void **)&d_st, err)) < 0) return fail(rc, "%s", err.c_str());
-        rc = flow_pyr_lk_dev(ctx->flow, prev, cur, h, w, pts, npts, win_w, win_h, max_level, max_count, epsilon, d_out, d_st, s, err);
+        if ((rc = fs.ws.get("lk_pts_out", sizeof(float) * 2 * (size_t)npts, (void **)&d_out, err)) < 0) return fail(rc, "%s", err.c_str());
+        if ((rc = fs.ws.get("lk_status", (size_t)npts, (void **)&d_st, err)) < 0) return fail(rc, "%s", err.c_str());
+        rc = flow_track_resident(fs, prev_side, cur_side, pts, npts, win_w, win_h, max_level, max_count, epsilon, d_out, d_st, s, err);
         if (rc < 0) return fail(rc, "%s", err.c_str());
-        HIP_TRY(hipHostGetDevicePointer((void **)&dev_res, ctx->fs_res, 0));
-        hipLaunchKernelGGL(k_flow_finish, dim3(1), dim3(1), 0, s, pts, d_out, d_st, npts, dev_res, pts_next);
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev_res, fs.res, 0));
+        if (npts <= FLOW_FINISH_MAX) hipLaunchKernelGGL(k_flow_finish, dim3(1), dim3(64), 2 * sizeof(float) * (size_t)npts, s, pts, d_out, d_st, npts, dev_res, pts_next);
+        else hipLaunchKernelGGL(k_flow_finish_seq, dim3(1), dim3(1), 0, s, pts, d_out, d_st, npts, dev_res, pts_next);
         LAUNCH_CHECK();
         HIP_TRY(stream_wait(s));
-        mean_xy_host[0] = ctx->fs_res[0]; mean_xy_host[1] = ctx->fs_res[1]; *n_good_host = (int)ctx->fs_res[2];
-        ctx->fs_npts = *n_good_host;
+        mean_xy_host[0] = fs.res[0]; mean_xy_host[1] = fs.res[1]; *n_good_host = (int)fs.res[2];
+        fs.npts = *n_good_host;
     }
-    ctx->fs_flip ^= 1;   // the crop just made is the next call's previous image, the packed points its input (base.py:381-382)
+    fs.flip ^= 1;   // the crop just made is the next call's previous image, the packed points its input (base.py:381-382)
     return RM_OK;
 }
 
-extern "C" int rm_flow_points(rm_ctx *ctx, float *pts_host, int cap, int *n_host, void *stream)
+extern "C" int rm_flow_points(rm_ctx *ctx, rm_flow_state *state, float *pts_host, int cap, int *n_host, void *stream)
 {
-    if (!ctx || !n_host || cap < 0 || (cap > 0 && !pts_host)) return fail(RM_E_BADARG, "rm_flow_points: bad argument");
-    *n_host = ctx->fs_npts;
-    if (ctx->fs_npts == 0 || cap == 0) return RM_OK;
+    if (!ctx || !state || !n_host || cap < 0 || (cap > 0 && !pts_host)) return fail(RM_E_BADARG, "rm_flow_points: bad argument");
+    FlowState &fs = state->fs;
+    *n_host = fs.npts;
+    if (fs.npts == 0 || cap == 0) return RM_OK;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
-    uint8_t *ca = nullptr, *cb = nullptr; float *pa = nullptr, *pb = nullptr;
-    RM_TRY(flow_state_bufs(ctx, ctx->fs_w, ctx->fs_h, ctx->fs_cap, &ca, &cb, &pa, &pb));
-    const int n = std::min(cap, ctx->fs_npts);
-    HIP_TRY(hipMemcpyAsync(pts_host, ctx->fs_flip ? pb : pa, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+    float *pa = nullptr, *pb = nullptr;
+    RM_TRY(flow_state_pts(fs, &pa, &pb));
+    const int n = std::min(cap, fs.npts);
+    HIP_TRY(hipMemcpyAsync(pts_host, fs.flip ? pb : pa, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
     HIP_TRY(stream_wait(s));
     return RM_OK;
 }

@@ -656,4 +656,166 @@ __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom 
     }
 }
 
+// The same sum with NW waves per tile when an image has fewer tiles than the chip has SIMDs (720p: 900 tiles on 1 024 SIMDs -- a
+// lone wave per tile is bound by the latency of its own dependency chain, and most of the VALU slots of its SIMD stay empty).
+// The time sum is a chain in t, but only its ADDITIONS are: round r takes frames t0 + r NW .. + NW - 1, wave w evaluates frame
+// t0 + r NW + w (the whole pyrUp chain of the tile, as in k_dense_sum_w) and parks its 16 masked values per lane in LDS; after a
+// barrier wave w adds the NW frames, in frame order, to ITS 16 / NW running sums per lane.  Same values, same order of additions:
+// bit-identical to k_dense_sum_w.
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, ChainGeom g, int t_first, int t_end, int T, CollapseState *st, double threshold,
+                                                          double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp)
+{
+    using G = DenseW<S>;
+    constexpr int R1 = G::R1, P1 = G::P1, R2 = G::R2, P2 = G::P2, PF = G::PF, PD = G::PD;
+    constexpr int QA = 16 / NW;   // running sums per lane and wave
+    HIP_DYNAMIC_SHARED(double, lds)
+    if (!sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse path took the sum)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // exchange: [NW frames][16 values][64 lanes]; a wave's footprint slice overlays ITS frame's part of the exchange (the slice is
+    // dead once the wave has its level-1 taps in registers, and DS operations of one wave execute in order): 8 KB per wave
+    static_assert(G::TOTAL <= 16 * 64, "the footprint slice must fit the wave's part of the exchange");
+    double *ex = lds;
+    double *sl = lds + (size_t)wave * 16 * 64;
+    const int tile = (int)blockIdx.x, ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    const int H0 = g.h[0], W0 = g.w[0], sh1 = g.h[1], sw1 = g.w[1];
+    const int yv1 = 8 * ty - 1, xv1 = 32 * tx - 1;
+    const int hS = g.h[S], wS = g.w[S];
+    const size_t fs = (size_t)hS * wS;
+    int off_g[PF], off_l[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int i = lane + 64 * p;
+        const int pitch = S == 2 ? P2 : P1;
+        const int r = i / pitch, c = i - r * pitch;
+        const int yv = (S == 2 ? 4 * ty - 1 : yv1) + r, xv = (S == 2 ? 16 * tx - 2 : xv1) + c;
+        const int ya = up_virtual_row(yv, hS), xa = min(max(xv, 0), wS - 1);
+        off_g[p] = ya * wS + xa;
+        off_l[p] = i < G::NST ? i : -1;
+    }
+    double hw_a = 0.0, hw_b = 0.0, hw_c = 0.0;
+    int h_base = 0;
+    if (S == 2) {
+        const int sw2 = g.w[2];
+        const int xv = xv1 + (lane < P1 ? lane : 0);
+        if (lane < P1 && xv >= 0 && xv < sw1) {
+            const int j = xv >> 1;
+            const bool left = j == 0, right = j == sw2 - 1;
+            if (xv & 1) { hw_b = right ? 8.0 : 4.0; hw_c = right ? 0.0 : 4.0; }
+            else { hw_a = left ? 0.0 : 1.0; hw_b = right ? 7.0 : 6.0; hw_c = left ? 2.0 : (right ? 0.0 : 1.0); }
+        }
+        h_base = ((xv >> 1) - 1) - (16 * tx - 2);
+        h_base = min(max(h_base, 0), P2 - 3);
+    }
+    const int cp = lane & 31, rh = lane >> 5;
+    const int X = 64 * tx + 2 * cp, Y0 = 16 * ty + 8 * rh;
+    double we_a, we_b, we_c, wo_b, wo_c;
+    {
+        const int j = X >> 1;
+        const bool left = j == 0, right = j >= sw1 - 1;
+        we_a = left ? 0.0 : 1.0; we_b = right ? 7.0 : 6.0; we_c = left ? 2.0 : (right ? 0.0 : 1.0);
+        wo_b = right ? 8.0 : 4.0; wo_c = right ? 0.0 : 4.0;
+    }
+    const int l0off = G::L1_OFF + (4 * rh) * P1 + cp;
+    double acc[QA];
+#pragma unroll
+    for (int j = 0; j < QA; ++j) acc[j] = 0.0;
+    double nxt[PD][PF];   // this wave's frames of the next PD rounds
+    auto fetch = [&](int d, int t) __attribute__((always_inline)) {
+        const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) nxt[d][p] = src[off_g[p]];
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch(d, t_first + d * NW + wave);
+    for (int tb = t_first; tb < t_end; tb += NW * PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int t0 = tb + d * NW;      // first frame of this round
+            if (t0 >= t_end) break;          // (uniform over the workgroup)
+#pragma unroll
+            for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) sl[off_l[p]] = nxt[d][p];
+            fetch(d, t0 + wave + NW * PD);
+            wave_sync();
+            if (S == 2) {
+                double *l1 = sl + G::L1_OFF;
+                double hq[R2];
+#pragma unroll
+                for (int q = 0; q < R2; ++q) {
+                    const double *row = sl + h_base + q * P2;
+                    hq[q] = dw_tap3(row[0], row[1], row[2], hw_a, hw_b, hw_c);
+                }
+                double prev = 0.0;
+#pragma unroll
+                for (int p = 0; p < R1; ++p) {
+                    const int q = p >> 1;
+                    double v = (p & 1) ? (hq[q] + hq[q + 1] * 6 + hq[q + 2]) * (1.0 / 64) : (hq[q] + hq[q + 1]) * (1.0 / 16);
+                    if (yv1 + p > sh1 - 1) v = prev;
+                    prev = v;
+                    if (lane < P1) l1[p * P1 + lane] = v;
+                }
+                wave_sync();
+            }
+            {
+                const double *l0src = sl + l0off;
+                double hve[6], hvo[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double *row = l0src + k * P1;
+                    const double a = row[0], b = row[1], c = row[2];
+                    hve[k] = dw_tap3(a, b, c, we_a, we_b, we_c);
+                    hvo[k] = __builtin_fma(c, wo_c, b * wo_b);
+                }
+                wave_sync();   // every lane has its taps: the slice may be overwritten (a no-op for the lockstep hardware wave)
+                double *exw = ex + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double e0 = (hve[m] + hve[m + 1] * 6 + hve[m + 2]) * (1.0 / 64), e1 = (hve[m + 1] + hve[m + 2]) * (1.0 / 16);
+                    const double o0 = (hvo[m] + hvo[m + 1] * 6 + hvo[m + 2]) * (1.0 / 64), o1 = (hvo[m + 1] + hvo[m + 2]) * (1.0 / 16);
+                    exw[(2 * m) * 64] = (e0 >= top) ? min_val : e0;
+                    exw[(2 * m + 1) * 64] = (e1 >= top) ? min_val : e1;
+                    exw[(8 + 2 * m) * 64] = (o0 >= top) ? min_val : o0;
+                    exw[(8 + 2 * m + 1) * 64] = (o1 >= top) ? min_val : o1;
+                }
+            }
+            __syncthreads();
+            const int nf = min(NW, t_end - t0);   // frames of this round that exist
+#pragma unroll
+            for (int f = 0; f < NW; ++f) {
+                if (f < nf) {
+                    const double *exf = ex + (size_t)f * 16 * 64 + (size_t)(wave * QA) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < QA; ++q) acc[q] = acc[q] + exf[q * 64];
+                }
+            }
+            __syncthreads();   // (the exchange and the slices are rewritten next round)
+        }
+    }
+    const double cnt = (double)avg_T;
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int j = wave * QA + q, o = j >> 3, r = j & 7;
+        const int y = Y0 + r;
+        if (y < H0 && X + o < W0) {
+            const double v = avg_T > 0 ? acc[q] / cnt : acc[q];
+            heat_sum[(size_t)y * W0 + X + o] = v;
+            hmn = (v < hmn) ? v : hmn; hmx = (v > hmx) ? v : hmx;
+        }
+    }
+    if (tile_nkept && threadIdx.x == 0) tile_nkept[tile] = t_end - t_first;
+    if (avg_T > 0) {
+        hmn = wave_min(hmn); hmx = wave_max(hmx);
+        if (lane == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp_ = (blockIdx.x * NW + wave) & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+        }
+    }
+}
+
 }  // namespace rm

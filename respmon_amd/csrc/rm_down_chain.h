@@ -74,20 +74,6 @@ template <int S, int SW, int V> struct DCLayout {
     static constexpr int total() { return rowbuf_off(S); }
 };
 
-// LDS hand-off between the lanes of ONE wave: the LDS executes a wave's DS instructions in order, so a
-// read issued after a write sees it; only the compiler must be kept from reordering them.  (The host
-// emulation models lanes as fibers and needs a real barrier.)
-__device__ __forceinline__ void wave_sync()
-{
-#ifdef RM_HIPEMU
-    __syncthreads();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
 // whole-wave shift by one lane (DPP wave_shr:1 / wave_shl:1): lane i receives lane i-1 / i+1;
 // the end lane keeps its own value (callers never use it)
 __device__ __forceinline__ double wave_from_prev(double v)

@@ -271,6 +271,31 @@ __device__ __forceinline__ int lk_dv(const short *d, int h, int w, int y, int x,
 }
 #define LK_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+// The raster-order float sums of the tracker (OpenCV's generic path adds the window's terms one after the other): every lane runs
+// the same chain.  The terms come from LDS sixteen bytes at a time (broadcast reads, requested well ahead of the additions that
+// use them): a loop of scalar reads paid one LDS round trip (~64 cycles) per term, 450 terms per iteration of the tracker.
+struct alignas(16) LkF4 { float x, y, z, w; };
+__device__ __forceinline__ void lk_seq_sum2(const float *a, const float *b, int n, float &sa, float &sb)
+{
+    const int n4 = n & ~3;
+#pragma unroll 4
+    for (int k = 0; k < n4; k += 4) {
+        const LkF4 va = *reinterpret_cast<const LkF4 *>(a + k), vb = *reinterpret_cast<const LkF4 *>(b + k);
+        sa += va.x; sb += vb.x; sa += va.y; sb += vb.y; sa += va.z; sb += vb.z; sa += va.w; sb += vb.w;
+    }
+    for (int k = n4; k < n; ++k) { sa += a[k]; sb += b[k]; }
+}
+__device__ __forceinline__ void lk_seq_sum3(const float *a, const float *b, const float *c, int n, float &sa, float &sb, float &sc)
+{
+    const int n4 = n & ~3;
+#pragma unroll 4
+    for (int k = 0; k < n4; k += 4) {
+        const LkF4 va = *reinterpret_cast<const LkF4 *>(a + k), vb = *reinterpret_cast<const LkF4 *>(b + k), vc = *reinterpret_cast<const LkF4 *>(c + k);
+        sa += va.x; sb += vb.x; sc += vc.x; sa += va.y; sb += vb.y; sc += vc.y; sa += va.z; sb += vb.z; sc += vc.z; sa += va.w; sb += vb.w; sc += vc.w;
+    }
+    for (int k = n4; k < n; ++k) { sa += a[k]; sb += b[k]; sc += c[k]; }
+}
+
 // One wavefront per point.  The 64 lanes compute the window's fixed-point terms in parallel; the float
 // accumulations run as one raster-order chain (replicated in every lane) to match OpenCV's generic path.
 __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in, int npts, int win_w, int win_h, int max_count,
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in
 {
     __shared__ short s_I[LK_MAX_WIN];
     __shared__ short s_dI[2 * LK_MAX_WIN];
-    __shared__ float s_t0[LK_MAX_WIN], s_t1[LK_MAX_WIN], s_t2[LK_MAX_WIN];
+    __shared__ __attribute__((aligned(16))) float s_t0[LK_MAX_WIN], s_t1[LK_MAX_WIN], s_t2[LK_MAX_WIN];
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= npts) return;
     const int ntap = win_w * win_h;
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in
         }
         __syncthreads();
         float iA11 = 0, iA12 = 0, iA22 = 0;
-        for (int k = 0; k < ntap; ++k) { iA11 += s_t0[k]; iA12 += s_t1[k]; iA22 += s_t2[k]; }
+        lk_seq_sum3(s_t0, s_t1, s_t2, ntap, iA11, iA12, iA22);
         const float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win_w * win_h);
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in
             }
             __syncthreads();
             float ib1 = 0, ib2 = 0;
-            for (int k = 0; k < ntap; ++k) { ib1 += s_t0[k]; ib2 += s_t1[k]; }
+            lk_seq_sum2(s_t0, s_t1, ntap, ib1, ib2);
             const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
             const float dx = (float)((A12 * b2 - A22 * b1) * D);
             const float dy = (float)((A12 * b1 - A11 * b2) * D);
@@ -447,7 +472,39 @@ inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *ne
 // One frame of extract_motion('flow') without a host round trip in the middle (base.py:377-388): the mean of old - new over
 // the points with status == 1 (float32, in point order: k_mean_flow's arithmetic) AND p1[st == 1] packed in order into the
 // buffer the next frame tracks from.  res (pinned host memory): {mean_x, mean_y, (float) n_good}.
-__global__ void k_flow_finish(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
+// One wave: the lanes pack the surviving points and their differences (ballot + prefix popcount, 64 points per trip), then
+// lane 0 adds the differences in point order from LDS.  (One THREAD walking global memory took 150 us for 1 000 points.)
+constexpr int FLOW_FINISH_MAX = 6000;   // points whose differences fit the LDS staging (2 floats each)
+__global__ __launch_bounds__(64) void k_flow_finish(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
+{
+    HIP_DYNAMIC_SHARED(float, s_d)     // [2 * n]: dx of the survivors, then dy
+    const int lane = threadIdx.x;
+    float *s_dx = s_d, *s_dy = s_d + n;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool good = i < n && st[i] == 1;
+        float ox = 0.f, oy = 0.f, nx = 0.f, ny = 0.f;
+        if (good) { ox = o[2 * i]; oy = o[2 * i + 1]; nx = nw[2 * i]; ny = nw[2 * i + 1]; }
+        const unsigned long long m = __ballot(good);
+        if (good) {
+            const int slot = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+            next_pts[2 * slot] = nx; next_pts[2 * slot + 1] = ny;
+            s_dx[slot] = ox - nx; s_dy[slot] = oy - ny;
+        }
+        base += (int)__popcll(m);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float sx = 0.f, sy = 0.f;
+        lk_seq_sum2(s_dx, s_dy, base, sx, sy);
+        res[0] = base ? sx / (float)base : 0.f;
+        res[1] = base ? sy / (float)base : 0.f;
+        res[2] = (float)base;
+    }
+}
+// (more points than the staging holds: one thread, global memory)
+__global__ void k_flow_finish_seq(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
 {
     float sx = 0.f, sy = 0.f;
     int m = 0;
@@ -460,6 +517,74 @@ __global__ void k_flow_finish(const float *o, const float *nw, const uint8_t *st
     res[0] = m ? sx / (float)m : 0.f;
     res[1] = m ? sy / (float)m : 0.f;
     res[2] = (float)m;
+}
+
+// Device-resident state of one extract_motion('flow') session (rm_flow_state): the two ROI crops a step works on -- the
+// previous one and its successor, alternating -- each with its LK pyramid (uint8 levels) and Scharr derivatives, the tracked
+// points, the pinned result words.  Every RespiratoryMonitor owns one, so two monitors on one GPU never see each other's
+// crops or points.  What a step builds for the NEW crop (pyramid) or for the crop it tracks FROM (derivatives) is kept: the crop
+// that was "next" in step i is "previous" in step i + 1 and arrives with its pyramid, so a step builds one pyramid and one set
+// of derivatives instead of two and two (base.py:381: `previous_cropped_image = cropped_image`).
+struct FlowState {
+    FlowWorkspace ws;
+    int w = 0, h = 0, npts = 0, cap = 0, flip = 0;
+    float *res = nullptr;            // pinned {mean_x, mean_y, n_good}
+    int pyr_levels[2] = {-1, -1};    // highest pyramid level that exists for side 0 / 1 (0: the crop only; -1: no crop)
+    int deriv_levels[2] = {-1, -1};  // highest level whose Scharr derivatives exist
+    bool begun = false;
+    ~FlowState() { if (res) (void)hipHostFree(res); }
+};
+
+inline int flow_side_buf(FlowState &fs, int side, const char *what, int level, size_t bytes, void **out, std::string &err)
+{
+    return fs.ws.get(std::string(what) + (side ? "_b" : "_a") + std::to_string(level), bytes, out, err);
+}
+
+// pyramids / derivatives of the two sides as far as this step needs them, then the tracking kernel (points stay on the device)
+inline int flow_track_resident(FlowState &fs, int prev_side, int cur_side, const float *d_in, int npts, int win_w, int win_h, int max_level,
+                               int max_count, double epsilon, float *d_out, uint8_t *d_st, hipStream_t s, std::string &err)
+{
+    const int h = fs.h, w = fs.w;
+    if (win_w * win_h > LK_MAX_WIN) { err = "winSize too large"; return RM_E_UNSUPPORTED; }
+    if (max_count < 0) max_count = 0;
+    if (max_count > 100) max_count = 100;
+    if (epsilon < 0) epsilon = 0;
+    if (epsilon > 10) epsilon = 10;
+    epsilon *= epsilon;
+    max_level = lk_max_level(h, w, win_w, win_h, max_level);
+    if (max_level + 1 > LK_MAX_LEVELS) { err = "too many pyramid levels"; return RM_E_UNSUPPORTED; }
+    LKLevels L;
+    L.n = max_level + 1;
+    int sh = h, sw = w;
+    for (int l = 0; l <= max_level; ++l) {
+        L.h[l] = sh; L.w[l] = sw;
+        const size_t n = (size_t)sh * sw;
+        uint8_t *pp = nullptr, *nn = nullptr;
+        short *dd = nullptr;
+        FLOW_TRY(flow_side_buf(fs, prev_side, "pyr", l, n, (void **)&pp, err));
+        FLOW_TRY(flow_side_buf(fs, cur_side, "pyr", l, n, (void **)&nn, err));
+        FLOW_TRY(flow_side_buf(fs, prev_side, "deriv", l, n * 2 * sizeof(short), (void **)&dd, err));
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (l > 0) {
+            if (fs.pyr_levels[prev_side] < l) {
+                hipLaunchKernelGGL(k_pyr_down_u8, dim3(grid), dim3(256), 0, s, L.prev[l - 1], L.h[l - 1], L.w[l - 1], pp, sh, sw);
+                fs.pyr_levels[prev_side] = l;
+            }
+            if (fs.pyr_levels[cur_side] < l) {
+                hipLaunchKernelGGL(k_pyr_down_u8, dim3(grid), dim3(256), 0, s, L.next[l - 1], L.h[l - 1], L.w[l - 1], nn, sh, sw);
+                fs.pyr_levels[cur_side] = l;
+            }
+        }
+        if (fs.deriv_levels[prev_side] < l) {
+            hipLaunchKernelGGL(k_scharr, dim3(grid), dim3(256), 0, s, pp, sh, sw, dd);
+            fs.deriv_levels[prev_side] = l;
+        }
+        L.prev[l] = pp; L.next[l] = nn; L.deriv[l] = dd;
+        sh = (sh + 1) / 2; sw = (sw + 1) / 2;
+    }
+    hipLaunchKernelGGL(k_lk_track, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
+    FLOW_HIP(hipGetLastError());
+    return max_level;
 }
 
 // ----------------------------------------------------------------------------------------

@@ -937,6 +937,20 @@ __device__ __forceinline__ void split_rc(int i, int nw, float inv_nw, int &r, in
     c = i - r * nw;
 }
 
+// LDS hand-off between the lanes of ONE wave: the LDS executes a wave's DS instructions in order, so a
+// read issued after a write sees it; only the compiler must be kept from reordering them.  (The host
+// emulation models lanes as fibers and needs a real barrier.)
+__device__ __forceinline__ void wave_sync()
+{
+#ifdef RM_HIPEMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // wave-uniform value into a scalar register (index math derived from it then runs on the scalar unit)
 __device__ __forceinline__ int uniform(int v)
 {
@@ -1156,6 +1170,138 @@ __global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeo
     if (threadIdx.x == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (blockIdx.x + blockIdx.y * 7) & (NSTRIPE - 1);
+        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        if (sm_mn <= sm_mx) {
+            const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
+            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
+            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+        }
+    }
+}
+
+// k_frame_bounds for wide levels (4K, skip 2), streaming: no row-extrema table, no workgroup barrier.  In k_frame_bounds a
+// thread per (row, tile column) reads its footprint straight from memory, lanes 64 >> S columns apart -- every load instruction
+// touches 64 cache lines -- and a band's table (100 KB at 4K) leaves one workgroup per CU.  Here a WAVE owns FB_TR consecutive tile
+// rows of a frame and walks down the level-S rows their footprints touch: lanes load consecutive columns (FB_MAXNL loads in flight,
+// the next row requested before this one is scanned), park the row in a skewed LDS buffer (index i + (i >> 4): the scans of
+// neighbouring tile columns hit different banks), lane tx takes the extrema of tile column tx's footprint columns from there and
+// folds them into the running extrema of the (at most two) tile rows whose footprint holds this row.  8 KB of LDS per wave.
+// Same bounds (min / max are exact in any order); the lattice samples are taken where a LANE met its extreme values, so the
+// sample set -- and with it how many pairs the selection keeps, never the result -- differs from k_frame_bounds'.
+constexpr int FB_MAXNL = 16;   // row length <= 64 * FB_MAXNL level-S columns
+#ifdef RM_HIPEMU
+#define RM_WAVES_PER_EU(n)
+#else
+#define RM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget of 512 / n per lane
+#endif
+// FB_TR (template): tile rows per wave -- 8 where that still gives every SIMD a few waves (halo rows: 12 %), 2 for small images
+__host__ __device__ __forceinline__ int fb_row_pitch(int wS) { return wS + (wS >> 4) + 2; }
+
+template <int FB_TR>
+__global__ __launch_bounds__(256) void k_frame_bounds_rows(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi,
+                                                           CollapseState *st, int *sel_cnt)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < ntiles; i += 256) sel_cnt[i] = 0;   // k_select_pairs counts into it
+    const double inf = __builtin_huge_val();
+    const int S = g.S, hS = g.h[S], wS = g.w[S], ntx = g.tiles_x;
+    const int t = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ty_first = (blockIdx.y * 4 + wave) * FB_TR;
+    const int ty_last = min(ty_first + FB_TR, g.tiles_y) - 1;
+    const bool have = ty_first <= ty_last;               // (wave-uniform; waves past the last tile row only keep the barriers company)
+    const int y_lo = have ? tile_region(g, ty_first * ntx, S).y0 : 0, y_hi = have ? tile_region(g, ty_last * ntx, S).y1 : -1;
+    const int nrows = y_hi - y_lo + 1;
+    int nrows_max = 0;                                   // trips every wave of the workgroup makes (host emulation: wave_sync() is a barrier)
+    for (int w = 0; w < 4; ++w) {
+        const int a = (blockIdx.y * 4 + w) * FB_TR, b = min(a + FB_TR, g.tiles_y) - 1;
+        if (a <= b) nrows_max = max(nrows_max, tile_region(g, b * ntx, S).y1 - tile_region(g, a * ntx, S).y0 + 1);
+    }
+    double *rowbuf = lds + (size_t)wave * fb_row_pitch(wS);
+    const double *p = cS + (size_t)t * hS * wS;
+    const int nl = (wS + 63) >> 6;
+    const int tx = min(lane, ntx - 1);
+    const Region Rx = tile_region(g, tx, S);             // column range of tile column tx (the same in every tile row)
+    double amn[FB_TR], amx[FB_TR];
+#pragma unroll
+    for (int k = 0; k < FB_TR; ++k) { amn[k] = inf; amx[k] = -inf; }
+    double t_mn = inf, t_mx = -inf;
+    int p_mn = -1, p_mx = -1;
+    double nxt[FB_MAXNL];
+    auto fetch = [&](int y) __attribute__((always_inline)) {
+        const double *row = p + (size_t)min(y_lo + max(min(y, nrows - 1), 0), hS - 1) * wS;
+#pragma unroll
+        for (int j = 0; j < FB_MAXNL; ++j)
+            if (j < nl) nxt[j] = row[min(lane + 64 * j, wS - 1)];
+    };
+    fetch(0);
+    for (int y = 0; y < nrows_max; ++y) {
+#pragma unroll
+        for (int j = 0; j < FB_MAXNL; ++j) {
+            const int x = lane + 64 * j;
+            if (j < nl && x < wS) rowbuf[x + (x >> 4)] = nxt[j];
+        }
+        fetch(y + 1);
+        wave_sync();
+        if (y < nrows) {
+            double mn = rowbuf[Rx.x0 + (Rx.x0 >> 4)], mx = mn;
+            for (int x = Rx.x0 + 1; x <= Rx.x1; ++x) {
+                const double v = rowbuf[x + (x >> 4)];
+                mn = (v < mn) ? v : mn; mx = (v > mx) ? v : mx;
+            }
+            const int ya = y_lo + y;
+#pragma unroll
+            for (int k = 0; k < FB_TR; ++k) {
+                const int ty = ty_first + k;
+                if (ty <= ty_last) {
+                    const Region R = tile_region(g, ty * ntx, S);
+                    if (ya >= R.y0 && ya <= R.y1) { amn[k] = (mn < amn[k]) ? mn : amn[k]; amx[k] = (mx > amx[k]) ? mx : amx[k]; }   // (uniform)
+                }
+            }
+            // the ROW in which this lane met its lowest / highest C_S so far; the column is looked up once, at the end
+            if (mn < t_mn) { t_mn = mn; p_mn = ya; }
+            if (mx > t_mx) { t_mx = mx; p_mx = ya; }
+        }
+        wave_sync();
+    }
+    if (have && lane < ntx) {   // first column of the extreme value inside its row's footprint
+        if (p_mn >= 0) { const double *row = p + (size_t)p_mn * wS; int x = Rx.x0; while (x < Rx.x1 && row[x] != t_mn) ++x; p_mn = p_mn * wS + x; }
+        if (p_mx >= 0) { const double *row = p + (size_t)p_mx * wS; int x = Rx.x0; while (x < Rx.x1 && row[x] != t_mx) ++x; p_mx = p_mx * wS + x; }
+    }
+    double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
+    if (have && lane < ntx) {
+#pragma unroll
+        for (int k = 0; k < FB_TR; ++k) {
+            const int ty = ty_first + k;
+            if (ty <= ty_last) {
+                const size_t o = (size_t)t * ntiles + (size_t)ty * ntx + lane;
+                lo[o] = amn[k]; hi[o] = amx[k];
+                lo_mn = (amn[k] < lo_mn) ? amn[k] : lo_mn; lo_mx = (amn[k] > lo_mx) ? amn[k] : lo_mx;
+                hi_mn = (amx[k] < hi_mn) ? amx[k] : hi_mn; hi_mx = (amx[k] > hi_mx) ? amx[k] : hi_mx;
+            }
+        }
+    }
+    double sm_mn = inf, sm_mx = -inf;
+    if (have && lane < ntx && hS >= 3 && wS >= 3) {
+        const int cand[2] = {p_mn, p_mx};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (cand[k] < 0) continue;
+            int y = cand[k] / wS, x = cand[k] - y * wS;
+            y = min(max(y, 1), hS - 2); x = min(max(x, 1), wS - 2);
+            const double *r1 = p + (size_t)y * wS;
+            const double v = lattice_sample(r1 - wS, r1, r1 + wS, x, g.lat_a, g.lat_b);
+            sm_mn = (v < sm_mn) ? v : sm_mn; sm_mx = (v > sm_mx) ? v : sm_mx;
+        }
+    }
+    lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
+    sm_mn = wave_min(sm_mn); sm_mx = wave_max(sm_mx);
+    if (lane == 0 && have) {
+        const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
+        const int sp = (blockIdx.x + (blockIdx.y * 4 + wave) * 7) & (NSTRIPE - 1);
         if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
         if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
         if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);

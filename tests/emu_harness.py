@@ -237,29 +237,36 @@ def _flow_methods():
         self.ck(self.lib.rm_roi_mean(self.ctx, ptr(f), DT[f.dtype], H, W, x, y, w, h, ctypes.byref(out), None), "roi_mean")
         return out.value
 
-    def flow_begin(self, frame_u8, x, y, w, h, maxCorners=100, qualityLevel=0.3, minDistance=7, blockSize=7):
+    def flow_state(self):
+        h = ctypes.c_void_p()
+        self.ck(self.lib.rm_flow_state_create(self.ctx, ctypes.byref(h)), "flow_state_create")
+        return h
+
+    def flow_begin(self, frame_u8, x, y, w, h, maxCorners=100, qualityLevel=0.3, minDistance=7, blockSize=7, state=None):
         f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
         H, W = f.shape
         pts = np.empty((max(int(maxCorners), 1), 2), np.float32)
         n = ctypes.c_int()
-        self.ck(self.lib.rm_flow_begin(self.ctx, ptr(f), DT[f.dtype], H, W, x, y, w, h, int(maxCorners), float(qualityLevel),
+        if getattr(self, "_fstate", None) is None:
+            self._fstate = self.flow_state()
+        self.ck(self.lib.rm_flow_begin(self.ctx, (state or self._fstate), ptr(f), DT[f.dtype], H, W, x, y, w, h, int(maxCorners), float(qualityLevel),
                                        float(minDistance), int(blockSize), ptr(pts), ctypes.byref(n), None), "flow_begin")
         return None if n.value == 0 else pts[:n.value].reshape(-1, 1, 2).copy()
 
-    def flow_step(self, frame_u8, x, y, w, h, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03)):
+    def flow_step(self, frame_u8, x, y, w, h, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03), state=None):
         f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
         H, W = f.shape
         m = np.empty(2, np.float32); ng = ctypes.c_int()
-        self.ck(self.lib.rm_flow_step(self.ctx, ptr(f), DT[f.dtype], H, W, x, y, w, h, winSize[0], winSize[1], maxLevel, criteria[1],
+        self.ck(self.lib.rm_flow_step(self.ctx, (state or self._fstate), ptr(f), DT[f.dtype], H, W, x, y, w, h, winSize[0], winSize[1], maxLevel, criteria[1],
                                       float(criteria[2]), ptr(m), ctypes.byref(ng), None), "flow_step")
         return m, ng.value
 
-    def flow_points(self, cap=1000):
+    def flow_points(self, cap=1000, state=None):
         pts = np.empty((cap, 2), np.float32); n = ctypes.c_int()
-        self.ck(self.lib.rm_flow_points(self.ctx, ptr(pts), cap, ctypes.byref(n), None), "flow_points")
+        self.ck(self.lib.rm_flow_points(self.ctx, (state or self._fstate), ptr(pts), cap, ctypes.byref(n), None), "flow_points")
         return pts[:min(n.value, cap)].reshape(-1, 1, 2).copy()
 
-    for f in (good_features, pyr_lk, mean_flow, pca_reduce, roi_mean, flow_begin, flow_step, flow_points):
+    for f in (good_features, pyr_lk, mean_flow, pca_reduce, roi_mean, flow_state, flow_begin, flow_step, flow_points):
         setattr(Emu, f.__name__, f)
 
 

@@ -400,6 +400,21 @@ def test_emu_banded_tile_bounds(emu, oracle):
             got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=64)
             assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (L, S, budget)
     emu.debug_set("bounds_table_bytes", 0)
+    # wide levels (>= 256 columns) take k_frame_bounds_rows -- a wave per level-S row, coalesced loads, skewed LDS row buffers --:
+    # same bounds as the thread-per-(row, tile column) kernel, in whole frames and in bands, ragged widths and heights
+    rng = np.random.default_rng(23)
+    for (T, H, W, L, S, budget) in [(3, 24, 1100, 4, 2, 0), (2, 37, 1100, 4, 2, 9000), (3, 21, 600, 3, 1, 0), (2, 50, 2100, 5, 3, 0)]:
+        v2 = rng.random((T, H, W))
+        emu.debug_set("bounds_table_bytes", budget)
+        emu.debug_set("bounds_scalar", 1)
+        ref, mm = emu.calibrate(v2, 10.0, levels=L, skip=S, flags=64)
+        emu.debug_set("bounds_scalar", 2)                    # (2: the streaming kernel whatever the image size)
+        got, mm2 = emu.calibrate(v2, 10.0, levels=L, skip=S, flags=64)
+        emu.debug_set("bounds_scalar", 0)
+        assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (T, H, W, L, S)
+        exhaustive, mm3 = emu.calibrate(v2, 10.0, levels=L, skip=S, flags=64 | 1)
+        assert np.array_equal(got, exhaustive) and tuple(mm) == tuple(mm3), (T, H, W, L, S, "no prune")
+    emu.debug_set("bounds_table_bytes", 0)
     emu.debug_set("no_fused_bounds", 0)
 
 
@@ -449,6 +464,11 @@ def test_emu_dense_sum_equals_sparse_path(emu):
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, fr, "wave-private tiles, ragged")
         emu.debug_set("dense_frames", 0)
+        for nw in (1, 2, 4):                                        # NW waves per tile, each evaluating every NW-th frame
+            emu.debug_set("dense_split", nw)
+            dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+            assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, nw, "frame-split tiles, ragged")
+        emu.debug_set("dense_split", 0)
     # rm_locate leaves the overflow rescue to the host: the sparse kernel stands down, the ROI stage's synchronisation finds the
     # pinned word set, the dense kernel is enqueued then and the ROI extracted again (skip 3: dense is never the automatic choice)
     v = synth.synth_breathing(10, 120, 160, seed=5).astype(np.float64) / 255

@@ -106,3 +106,28 @@ def test_emu_flow_step_resident_equals_four_calls(emu, oracle):
             assert ng == ng4 and np.array_equal(m, m4), (amp, t)
             q = p1[st.ravel() == 1].reshape(-1, 1, 2)
             assert np.array_equal(emu.flow_points(), q), (amp, t)
+
+
+def test_emu_two_flow_states_interleaved(emu):
+    """rm_flow_state: two sessions interleaved on one context give what each gives alone (index / buffer logic of the handle)."""
+    from respmon_amd import synth
+    ra, rb = synth.synth_texture(60, 72, seed=3), synth.synth_texture(60, 72, seed=4)
+    fa = [ra(0.5 * t, 0.2 * t) for t in range(4)]
+    fb = [rb(-0.4 * t, 0.3 * t) for t in range(4)]
+
+    def run(frames_list):
+        states = [emu.flow_state() for _ in frames_list]
+        out = [[emu.flow_begin(fr[0], 0, 0, 72, 60, 40, 0.3, 5, 7, state=st)] for fr, st in zip(frames_list, states)]
+        for t in range(1, 4):
+            for o, fr, st in zip(out, frames_list, states):
+                o.append(emu.flow_step(fr[t], 0, 0, 72, 60, state=st))
+        for o, st in zip(out, states):
+            o.append(emu.flow_points(100, state=st))
+        return out
+
+    (alone_a,), (alone_b,) = run([fa]), run([fb])
+    both_a, both_b = run([fa, fb])
+    for got, want in ((both_a, alone_a), (both_b, alone_b)):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[-1], want[-1])
+        for g, w in zip(got[1:-1], want[1:-1]):
+            assert np.array_equal(g[0], w[0]) and g[1] == w[1]

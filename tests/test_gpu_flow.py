@@ -198,3 +198,36 @@ def test_flow_step_resident_equals_four_calls(oracle):
         state = oracle.FlowState()
         ref = np.array([oracle.extract_motion_flow(state, oracle.uint8_to_float(frames[t])[y:y + h, x:x + w]) for t in range(T)])
         assert np.allclose(d1, ref, rtol=1e-9, atol=1e-12, equal_nan=True), amp
+
+
+def test_two_flow_sessions_interleaved_on_one_gpu(be):
+    """Two tracking sessions on one GPU and one library context (two RespiratoryMonitor objects in a process, or bench.py's
+    flow measurement beside a monitor): each owns an rm_flow_state, so interleaving their frames changes nothing -- the previous
+    crop, its pyramid and the tracked points of one session are never seen by the other."""
+    from respmon_amd import synth
+    ra, rb = synth.synth_texture(96, 128, seed=11), synth.synth_texture(96, 128, seed=12)     # same ROI size: the old shared state could not tell them apart
+    fa = [ra(0.8 * np.sin(0.3 * t), 0.4 * np.cos(0.2 * t)) for t in range(8)]
+    fb = [rb(-0.6 * np.sin(0.25 * t), 0.7 * np.sin(0.4 * t)) for t in range(8)]
+
+    def alone(frames):
+        st = be.flow_state()
+        pts = be.flow_begin(st, _dev(frames[0]), 0, 0, 128, 96, 100, 0.3, 7, 7)
+        out = [pts]
+        for f in frames[1:]:
+            out.append(be.flow_step(st, _dev(f), 0, 0, 128, 96, (15, 15), 2, (3, 10, 0.03)))
+        out.append(be.flow_points(st, 100))
+        return out
+
+    want_a, want_b = alone(fa), alone(fb)
+    sa, sb = be.flow_state(), be.flow_state()
+    got_a = [be.flow_begin(sa, _dev(fa[0]), 0, 0, 128, 96, 100, 0.3, 7, 7)]
+    got_b = [be.flow_begin(sb, _dev(fb[0]), 0, 0, 128, 96, 100, 0.3, 7, 7)]
+    for t in range(1, 8):
+        got_a.append(be.flow_step(sa, _dev(fa[t]), 0, 0, 128, 96, (15, 15), 2, (3, 10, 0.03)))
+        got_b.append(be.flow_step(sb, _dev(fb[t]), 0, 0, 128, 96, (15, 15), 2, (3, 10, 0.03)))
+    got_a.append(be.flow_points(sa, 100)); got_b.append(be.flow_points(sb, 100))
+    assert want_a[0] is not None and want_b[0] is not None and not np.array_equal(want_a[0], want_b[0])
+    for got, want in ((got_a, want_a), (got_b, want_b)):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[-1], want[-1])
+        for g, w in zip(got[1:-1], want[1:-1]):
+            assert np.array_equal(g[0], w[0]) and g[1] == w[1]

@@ -19,13 +19,14 @@ def main():
         render = synth.synth_texture(H, W, seed=4321)
         n = 120
         dev = [torch.from_numpy(render(1.5 * np.sin(2 * np.pi * 0.4 * t / 30), 0.5 * np.sin(2 * np.pi * 0.4 * t / 30 + np.pi / 3))).cuda() for t in range(n + 1)]
-        pts = be.flow_begin(dev[0], 0, 0, W, H, maxc, q, md, 7)
+        fs = be.flow_state()
+        pts = be.flow_begin(fs, dev[0], 0, 0, W, H, maxc, q, md, 7)
         for i in range(20):
-            be.flow_step(dev[i + 1], 0, 0, W, H, (15, 15), 2, (3, 10, 0.03))
+            be.flow_step(fs, dev[i + 1], 0, 0, W, H, (15, 15), 2, (3, 10, 0.03))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(20, n):
-            mean, ng = be.flow_step(dev[i + 1], 0, 0, W, H, (15, 15), 2, (3, 10, 0.03))
+            mean, ng = be.flow_step(fs, dev[i + 1], 0, 0, W, H, (15, 15), 2, (3, 10, 0.03))
         torch.cuda.synchronize()
         print("%s: %d corners, %.3f ms per rm_flow_step, %d points left" % (label, 0 if pts is None else len(pts), (time.perf_counter() - t0) / (n - 20) * 1e3, ng), flush=True)
 
