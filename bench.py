@@ -412,6 +412,11 @@ def main():
                  "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2],
                                     "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
                  "contour_components": cn.value, "contour_labelled": bool(cl.value)}
+            try:    # HBM bytes per launch of the frame-buffer kernel from the committed PMC passes of this configuration, if any
+                d["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(
+                    "%s_%dx%dx%d" % (cdt, cT, cH, cW), {}).get("bytes_per_launch")
+            except Exception:
+                d["traffic"] = None
             del cbuf
             torch.cuda.empty_cache()
             if check:

@@ -41,6 +41,9 @@ constexpr int U8_STRIP_PX = 16 * U8_VALID_LANES;  // 960 exact input columns per
 #ifndef RM_NARROW_FENCE
 #define RM_NARROW_FENCE 1
 #endif
+#ifndef RM_U8_LUT
+#define RM_U8_LUT 1
+#endif
 
 template <int S, int K> struct VStateU8 : VStateU8<S, K + 1> {
     double a[(16 >> K) / 2], b[(16 >> K) / 2], c[(16 >> K) / 2], t[(16 >> K) / 2];
@@ -246,10 +249,41 @@ struct RegChain {
         for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(rp + j * VPER);   // (plain: this kernel lives on cache hits for its strip halos -- non-temporal loads measured 0.43 -> 0.70 ms on the float32 buffer)
     }
 
+    // uint8 with RM_U8_LUT: uint8_to_float's 256 possible values k * (1./255) come from a 2 KB table in LDS -- one SDWA shift
+    // (byte k of the word, times 8) and one ds_read_b64 per pixel instead of bit-field extract + convert + multiply (three
+    // instructions on the units this kernel is bound by; the LDS reads run beside them)
+    const double *lut = nullptr;
+    template <int K> static __device__ __forceinline__ unsigned lut_offset(unsigned w)
+    {
+#ifdef RM_HIPEMU
+        return ((w >> (8 * K)) & 0xffu) << 3;
+#else
+        unsigned off;
+        const unsigned three = 3;
+        if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(three), "v"(w));
+        else if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(three), "v"(w));
+        else if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(three), "v"(w));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(three), "v"(w));
+        return off;
+#endif
+    }
+    template <int E> __device__ __forceinline__ void unpack_lut(const Raw16 &r, double (&v)[16]) const
+    {
+        if constexpr (E < 16) {
+            const unsigned w = (E >> 2) == 0 ? r.x : (E >> 2) == 1 ? r.y : (E >> 2) == 2 ? r.z : r.w;
+            v[E] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lut) + lut_offset<E & 3>(w));
+            unpack_lut<E + 1>(r, v);
+        }
+    }
+
     __device__ __forceinline__ void unpack_row(const Raw16 (&r)[NLD], double (&v)[16]) const
     {
+        if constexpr (sizeof(Tin) == 1 && RM_U8_LUT) {
+            unpack_lut<0>(r[0], v);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = unpack_px<Tin>(r[e / VPER], e % VPER);
+            for (int e = 0; e < 16; ++e) v[e] = unpack_px<Tin>(r[e / VPER], e % VPER);
+        }
     }
 
     template <int I> __device__ __forceinline__ void hot_rows(int base, Raw16 (&regs)[PF][NLD])
@@ -367,6 +401,12 @@ template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow
     const int inner = j % per_frame;
     const int seg = inner / g.strips, strip = inner - seg * g.strips;
     RegChain<S, Tin> rc(g);
+    if constexpr (sizeof(Tin) == 1 && RM_U8_LUT) {
+        __shared__ double s_lut[256];
+        for (int i = threadIdx.x; i < 256; i += 64) s_lut[i] = (double)i * (1.0 / 255);   // uint8_to_float, transforms.py:20-23
+        wave_sync();
+        rc.lut = s_lut;
+    }
     rc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }
 

@@ -298,6 +298,9 @@ __device__ __forceinline__ void lk_seq_sum3(const float *a, const float *b, cons
 
 // One wavefront per point.  The 64 lanes compute the window's fixed-point terms in parallel; the float
 // accumulations run as one raster-order chain (replicated in every lane) to match OpenCV's generic path.
+// ROUNDS: trips of the tap loops (lane k, k + 64, ...), unrolled so that the gathers of all of a window's taps are in flight
+// together: 4 covers winSize up to 16 x 16 (the reference's 15 x 15, base.py:96), 16 the 32 x 32 maximum.
+template <int ROUNDS>
 __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in, int npts, int win_w, int win_h, int max_count,
                                                  double epsilon, float *pts_out, uint8_t *status)
 {
@@ -312,6 +315,9 @@ __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in
     const int W_BITS = 14;
     const float min_eig_threshold = (float)1e-4;
     const float px_in = pts_in[2 * p], py_in = pts_in[2 * p + 1];
+    int tap_y[ROUNDS], tap_x[ROUNDS];     // window position of this lane's taps (one integer division each, once)
+#pragma unroll
+    for (int rnd = 0; rnd < ROUNDS; ++rnd) { const int k = lane + 64 * rnd; tap_y[rnd] = k / win_w; tap_x[rnd] = k - tap_y[rnd] * win_w; }
     float out_x = 0.f, out_y = 0.f;
     int st = 1;
     for (int level = L.n - 1; level >= 0; --level) {
@@ -336,9 +342,11 @@ __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in
         int iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         __syncthreads();
-        for (int k = lane; k < ntap; k += 64) {
-            const int y = k / win_w, x = k - y * win_w;
-            const int yy = ipy + y, xx = ipx + x;
+#pragma unroll
+        for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+            const int k = lane + 64 * rnd;
+            if (k >= ntap) continue;
+            const int yy = ipy + tap_y[rnd], xx = ipx + tap_x[rnd];
             int ival = LK_DESCALE(lk_px(I, h, w, yy, xx) * iw00 + lk_px(I, h, w, yy, xx + 1) * iw01 + lk_px(I, h, w, yy + 1, xx) * iw10 +
                                   lk_px(I, h, w, yy + 1, xx + 1) * iw11, W_BITS - 5);
             int ixval = LK_DESCALE(lk_dv(dI, h, w, yy, xx, 0) * iw00 + lk_dv(dI, h, w, yy, xx + 1, 0) * iw01 +
@@ -373,9 +381,11 @@ __global__ __launch_bounds__(64) void k_lk_track(LKLevels L, const float *pts_in
             iw10 = __float2int_rn((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             __syncthreads();
-            for (int k = lane; k < ntap; k += 64) {
-                const int y = k / win_w, x = k - y * win_w;
-                const int yy = iny + y, xx = inx + x;
+#pragma unroll
+            for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+                const int k = lane + 64 * rnd;
+                if (k >= ntap) continue;
+                const int yy = iny + tap_y[rnd], xx = inx + tap_x[rnd];
                 int diff = LK_DESCALE(lk_px(J, h, w, yy, xx) * iw00 + lk_px(J, h, w, yy, xx + 1) * iw01 + lk_px(J, h, w, yy + 1, xx) * iw10 +
                                       lk_px(J, h, w, yy + 1, xx + 1) * iw11, W_BITS - 5) - s_I[k];
                 s_t0[k] = (float)(diff * s_dI[2 * k]); s_t1[k] = (float)(diff * s_dI[2 * k + 1]);
@@ -445,7 +455,8 @@ inline int flow_pyr_lk_dev(FlowWorkspace &ws, const uint8_t *prev, const uint8_t
         L.prev[l] = pp; L.next[l] = nn; L.deriv[l] = dd;
         sh = (sh + 1) / 2; sw = (sw + 1) / 2;
     }
-    hipLaunchKernelGGL(k_lk_track, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
+    if (win_w * win_h <= 256) hipLaunchKernelGGL(k_lk_track<4>, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
+    else hipLaunchKernelGGL(k_lk_track<16>, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
     FLOW_HIP(hipGetLastError());
     return max_level;
 }
@@ -582,7 +593,8 @@ inline int flow_track_resident(FlowState &fs, int prev_side, int cur_side, const
         L.prev[l] = pp; L.next[l] = nn; L.deriv[l] = dd;
         sh = (sh + 1) / 2; sw = (sw + 1) / 2;
     }
-    hipLaunchKernelGGL(k_lk_track, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
+    if (win_w * win_h <= 256) hipLaunchKernelGGL(k_lk_track<4>, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
+    else hipLaunchKernelGGL(k_lk_track<16>, dim3(npts), dim3(64), 0, s, L, d_in, npts, win_w, win_h, max_count, epsilon, d_out, d_st);
     FLOW_HIP(hipGetLastError());
     return max_level;
 }

@@ -144,7 +144,7 @@ def test_emu_fused_down_chain_equals_per_level(emu):
     rng = np.random.default_rng(3)
     shapes = [(3, 64, 96, 4, 2), (2, 67, 131, 5, 3), (2, 48, 64, 3, 1), (2, 135, 240, 6, 4),
               (9, 32, 48, 4, 2), (2, 33, 47, 4, 2), (1, 200, 320, 7, 5), (1, 40, 800, 4, 2),
-              (1, 48, 704, 6, 4), (1, 36, 401, 5, 3), (2, 70, 1936, 6, 4)]
+              (1, 48, 704, 6, 4), (1, 36, 401, 5, 3), (1, 70, 1936, 6, 4)]
     # (the CPU suite has minutes, not hours: every dtype sees the geometries that differ per dtype -- vector width, strip
     #  count, odd sizes --, float64 sees them all; tests/test_gpu_calibration.py runs the full matrix on the device)
     ncase = 0
@@ -403,7 +403,7 @@ def test_emu_banded_tile_bounds(emu, oracle):
     # wide levels (>= 256 columns) take k_frame_bounds_rows -- a wave per level-S row, coalesced loads, skewed LDS row buffers --:
     # same bounds as the thread-per-(row, tile column) kernel, in whole frames and in bands, ragged widths and heights
     rng = np.random.default_rng(23)
-    for (T, H, W, L, S, budget) in [(3, 24, 1100, 4, 2, 0), (2, 37, 1100, 4, 2, 9000), (3, 21, 600, 3, 1, 0), (2, 50, 2100, 5, 3, 0)]:
+    for ci, (T, H, W, L, S, budget) in enumerate([(3, 24, 1100, 4, 2, 0), (2, 37, 1100, 4, 2, 9000), (3, 21, 600, 3, 1, 0), (1, 34, 2100, 5, 3, 0)]):
         v2 = rng.random((T, H, W))
         emu.debug_set("bounds_table_bytes", budget)
         emu.debug_set("bounds_scalar", 1)
@@ -412,8 +412,9 @@ def test_emu_banded_tile_bounds(emu, oracle):
         got, mm2 = emu.calibrate(v2, 10.0, levels=L, skip=S, flags=64)
         emu.debug_set("bounds_scalar", 0)
         assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (T, H, W, L, S)
-        exhaustive, mm3 = emu.calibrate(v2, 10.0, levels=L, skip=S, flags=64 | 1)
-        assert np.array_equal(got, exhaustive) and tuple(mm) == tuple(mm3), (T, H, W, L, S, "no prune")
+        if ci == 0:
+            exhaustive, mm3 = emu.calibrate(v2, 10.0, levels=L, skip=S, flags=64 | 1)
+            assert np.array_equal(got, exhaustive) and tuple(mm) == tuple(mm3), (T, H, W, L, S, "no prune")
     emu.debug_set("bounds_table_bytes", 0)
     emu.debug_set("no_fused_bounds", 0)
 
@@ -459,12 +460,13 @@ def test_emu_dense_sum_equals_sparse_path(emu):
                             (5, 50, 66, 5, 2), (2, 3, 3, 3, 1), (3, 47, 65, 3, 2)]:
         v = rng.random((T, H, W))
         sparse, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+        emu.debug_set("dense_split", 1)                             # (one wave per tile: k_dense_sum_w)
         for fr in (1, 2):                                           # one frame per trip / two interleaved
             emu.debug_set("dense_frames", fr)
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, fr, "wave-private tiles, ragged")
         emu.debug_set("dense_frames", 0)
-        for nw in (1, 2, 4):                                        # NW waves per tile, each evaluating every NW-th frame
+        for nw in ((2, 4) if (T, H, W) in ((3, 33, 70), (4, 17, 129), (5, 50, 66), (3, 47, 65)) else ()):   # NW waves per tile, each evaluating every NW-th frame
             emu.debug_set("dense_split", nw)
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, nw, "frame-split tiles, ragged")

@@ -1,6 +1,6 @@
 """gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) -> profiles/<tag>/ + profiles/hbm_traffic.json.
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r03 [P|Q|R|P32|P8]
 
 HBM traffic per launch of every kernel, from the two PMC passes, corrected as /opt/skills/guides/MI355X_MICROARCH.md
 (HBM section) prescribes for gfx950: FETCH_SIZE (KiB) reports half of the bytes of a wide coalesced streaming read, so
@@ -33,11 +33,17 @@ def counter_avg(path, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    src = os.path.join(ROOT, "gpurun_out", tag)
+    cfg_name = sys.argv[2] if len(sys.argv) > 2 else "P"
+    src = os.path.join(ROOT, "gpurun_out", tag) if cfg_name == "P" else os.path.join(ROOT, "gpurun_out", tag, cfg_name)
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
-    for a, b in [("bench_n1.json", "bench_n1.json"), ("bench_under_rocprof.json", "bench_n1_under_rocprof.json"),
-                 ("stats/k_kernel_stats.csv", "kernel_stats_bench_n1.csv")]:
+    sfx = "" if cfg_name == "P" else "_config_" + cfg_name
+    names = {"bench": "bench_n1.json" if cfg_name == "P" else "bench%s.json" % sfx,
+             "rocprof": "bench_n1_under_rocprof.json" if cfg_name == "P" else "bench%s_under_rocprof.json" % sfx,
+             "stats": "kernel_stats_bench_n1.csv" if cfg_name == "P" else "kernel_stats%s.csv" % sfx,
+             "pmc": "pmc_hbm_traffic_per_kernel.csv" if cfg_name == "P" else "pmc_hbm_traffic_per_kernel%s.csv" % sfx}
+    for a, b in [("bench_n1.json", names["bench"]), ("bench_under_rocprof.json", names["rocprof"]),
+                 ("stats/k_kernel_stats.csv", names["stats"])]:
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
     fetch = counter_avg(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
@@ -47,14 +53,14 @@ def main():
         fk, n = fetch[k]
         wk = write.get(k, (0.0, 0))[0]
         rows.append((k, n, fk, wk, 2 * fk * 1024 + wk * 1024))
-    with open(os.path.join(dst, "pmc_hbm_traffic_per_kernel.csv"), "w") as f:
+    with open(os.path.join(dst, names["pmc"]), "w") as f:
         f.write("kernel,launches_sampled,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch_corrected\n")
         for r in rows:
             f.write("%s,%d,%.1f,%.1f,%.0f\n" % r)
-    chain = [r for r in rows if r[0].startswith("rm::k_down_chain<double")]
+    chain = [r for r in rows if r[0].startswith("rm::k_down_chain")]   # the frame-buffer kernel: the largest fetch among the chains
     if chain:
         k, n, fk, wk, b = chain[0]
-        bench = json.load(open(os.path.join(dst, "bench_n1.json")))
+        bench = json.load(open(os.path.join(dst, names["bench"])))
         cfg = bench["config"]
         key = "%s_%dx%dx%d" % (cfg["frame_buffer_dtype"], cfg["frames"], cfg["height"], cfg["width"])
         path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -62,7 +68,7 @@ def main():
         table[key] = {"kernel": k, "bytes_per_launch": b, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
                       "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a wide "
                                     "coalesced stream, MI355X_MICROARCH.md HBM section); separate --pmc passes",
-                      "source": "profiles/%s/pmc_hbm_traffic_per_kernel.csv" % tag}
+                      "source": "profiles/%s/%s" % (tag, names["pmc"])}
         json.dump(table, open(path, "w"), indent=1)
         print(key, "traffic %.3f GB per launch = %.3fx algorithmic" % (b / 1e9, b / bench["roofline"]["algorithmic_bytes"]))
     for r in rows[:16]:
