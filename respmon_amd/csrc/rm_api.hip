@@ -825,11 +825,11 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
         if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny)) {
             const size_t fs = (size_t)h[0] * w[0];
             const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
-#define RM_REG_CASE(KK, SS, TT, ptr) case SS: hipLaunchKernelGGL((KK<SS, TT>), dim3(grid), dim3(64), 0, s, ptr, fs, g8, out); break;
+#define RM_REG_CASE(KK, SS, TT, ptr) case SS: hipLaunchKernelGGL((KK<SS, TT>), dim3(grid), dim3(64), narrow_ring_bytes<TT>(), s, ptr, fs, g8, out); break;
 #define RM_REG_SWITCH(KK, TT)                                                                               \
             {                                                                                               \
                 const TT *f = (const TT *)frames;                                                           \
-                switch (S) { RM_REG_CASE(KK, 1, TT, f) RM_REG_CASE(KK, 2, TT, f) RM_REG_CASE(KK, 3, TT, f) default: hipLaunchKernelGGL((KK<4, TT>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break; } \
+                switch (S) { RM_REG_CASE(KK, 1, TT, f) RM_REG_CASE(KK, 2, TT, f) RM_REG_CASE(KK, 3, TT, f) default: hipLaunchKernelGGL((KK<4, TT>), dim3(grid), dim3(64), narrow_ring_bytes<TT>(), s, f, fs, g8, out); break; } \
             }
             if (dtype == RM_U8) RM_REG_SWITCH(k_down_chain_u8, uint8_t)
             else if (dtype == RM_F16) RM_REG_SWITCH(k_down_chain_u8, __half)
@@ -1409,7 +1409,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
 #define RM_DENSE_WF(SS, NN)                                                                                                               \
             do {                                                                                                                          \
                 const size_t shf = sizeof(double) * (size_t)NN * 16 * 64;                                                                 \
-                hipLaunchKernelGGL((k_dense_sum_wf<SS, NN>), dim3((unsigned)cp.ntiles), dim3(64 * NN), shf, s, cp.cS, g, cp.t0, cp.t1, cp.T, st, thr,  \
+                hipLaunchKernelGGL((k_dense_sum_wf<SS, NN>), dim3(dense_tile_grid(cp.ntiles)), dim3(64 * NN), shf, s, cp.cS, g, cp.t0, cp.t1, cp.T, st, thr,  \
                                    heat_sum, avg_T, tile_nkept, sp);                                                                      \
             } while (0)
             if (cp.S == 2) { if (split == 4) RM_DENSE_WF(2, 4); else RM_DENSE_WF(2, 2); }
@@ -1418,7 +1418,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
             LAUNCH_CHECK();
         } else {
 #define RM_DENSE_W(SS, FF)                                                                                                                \
-        hipLaunchKernelGGL((k_dense_sum_w<SS, FF>), dim3((unsigned)cp.ntiles), dim3(64), sizeof(double) * DenseW<SS>::TOTAL * FF, s, cp.cS, g, cp.t0, \
+        hipLaunchKernelGGL((k_dense_sum_w<SS, FF>), dim3(dense_tile_grid(cp.ntiles)), dim3(64), sizeof(double) * DenseW<SS>::TOTAL * FF, s, cp.cS, g, cp.t0, \
                            cp.t1, cp.T, st, thr, heat_sum, avg_T, tile_nkept, sp)
         if (cp.S == 2) { if (fr == 2) RM_DENSE_W(2, 2); else RM_DENSE_W(2, 1); }
         else { if (fr == 2) RM_DENSE_W(1, 2); else RM_DENSE_W(1, 1); }

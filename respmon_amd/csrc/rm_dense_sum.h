@@ -485,6 +485,9 @@ __device__ __forceinline__ double dw_tap3(double a, double b, double c, double w
     return __builtin_fma(c, wc, __builtin_fma(a, wa, b * wb));
 }
 
+__host__ __device__ __forceinline__ int dense_tile_of_block(int block, int ntiles) { return (block & 7) * ((ntiles + 7) >> 3) + (block >> 3); }
+inline unsigned dense_tile_grid(int ntiles) { return (unsigned)(8 * ((ntiles + 7) >> 3)); }
+
 inline bool dense_wave_ok(const ChainGeom &g)
 {
     if (g.S < 1 || g.S > 2) return false;
@@ -505,7 +508,12 @@ __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom 
     HIP_DYNAMIC_SHARED(double, lds)
     if (!sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse path took the sum)
     const int lane = threadIdx.x;
-    const int tile = (int)blockIdx.x, ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    // workgroups are dealt to the 8 XCDs round robin (each with its own L2): XCD x takes the x-th EIGHTH of the tiles, so that the
+    // tiles a CU's neighbours work on -- whose footprints overlap this one's -- are cached in the same L2
+    const int ntiles_ = g.tiles_x * g.tiles_y;
+    const int tile = dense_tile_of_block((int)blockIdx.x, ntiles_);
+    if (tile >= ntiles_) return;   // (the grid is rounded up to a multiple of 8)
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
     if (blockIdx.x == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
@@ -677,7 +685,12 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
     static_assert(G::TOTAL <= 16 * 64, "the footprint slice must fit the wave's part of the exchange");
     double *ex = lds;
     double *sl = lds + (size_t)wave * 16 * 64;
-    const int tile = (int)blockIdx.x, ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    // workgroups are dealt to the 8 XCDs round robin (each with its own L2): XCD x takes the x-th EIGHTH of the tiles, so that the
+    // tiles a CU's neighbours work on -- whose footprints overlap this one's -- are cached in the same L2
+    const int ntiles_ = g.tiles_x * g.tiles_y;
+    const int tile = dense_tile_of_block((int)blockIdx.x, ntiles_);
+    if (tile >= ntiles_) return;   // (the grid is rounded up to a multiple of 8)
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
     const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }

@@ -54,12 +54,32 @@ template <typename Tin> struct RegTraits;   // NLD: 16-byte loads per lane and r
 // HOT: the static steady-state blocks of RegChain pay (measured, bench_micro/dc8_bench.hip, kernel ms old -> new): uint8 1080p x 256
 // 0.365 -> 0.30, float16 4K x 512 2.19 -> 2.03; the float32 chain is bound by bytes in flight, not by instruction issue, and
 // keeps the row-at-a-time form without a register cap (0.42 ms; 0.47 with hot blocks, 1.1 under a 256-register cap)
-template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8_PREFETCH; static constexpr bool HOT = RM_NARROW_HOT != 0; };
+// DMA: rows travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of RD rows per wave, RD - 1 of them in flight, and
+// cost no registers until they are unpacked.  The float16 / float32 chains spend half of their wave cycles waiting for memory with
+// 2 rows per wave in flight (profiles/r03/narrow_chain_sq_counters.txt: 55 % / 50 %); the uint8 chain is bound by instruction issue
+// and keeps its rows in registers.  (Host emulation: registers for all.)
+#ifndef RM_NARROW_DMA
+#define RM_NARROW_DMA 1
+#endif
+#ifdef RM_HIPEMU
+#define RM_NARROW_DMA_ON 0
+#else
+#define RM_NARROW_DMA_ON RM_NARROW_DMA
+#endif
+template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8_PREFETCH, RD = 8; static constexpr bool HOT = RM_NARROW_HOT != 0, DMA = false; };
 #ifndef RM_F16_PREFETCH
 #define RM_F16_PREFETCH 2
 #endif
-template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16_PREFETCH; static constexpr bool HOT = RM_NARROW_HOT != 0; };
-template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = 2; static constexpr bool HOT = false; };
+#ifndef RM_F16_RING
+#define RM_F16_RING 8
+#endif
+#ifndef RM_F32_RING
+#define RM_F32_RING 4
+#endif
+template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16_PREFETCH, RD = RM_F16_RING; static constexpr bool HOT = RM_NARROW_HOT != 0, DMA = RM_NARROW_DMA_ON != 0; };
+template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = 2, RD = RM_F32_RING; static constexpr bool HOT = false, DMA = RM_NARROW_DMA_ON != 0; };
+// LDS bytes per wave of the row ring (0: rows in registers)
+template <typename Tin> constexpr size_t narrow_ring_bytes() { return RegTraits<Tin>::DMA ? (size_t)RegTraits<Tin>::RD * RegTraits<Tin>::NLD * 1024 : 0; }
 
 template <int S, typename Tin = uint8_t>
 struct RegChain {
@@ -242,6 +262,61 @@ struct RegChain {
 #endif
     }
 
+    // ---- rows through LDS (RegTraits::DMA) -------------------------------------------------------------------------------
+    static constexpr bool DMA = RegTraits<Tin>::DMA;
+    static constexpr int RD = RegTraits<Tin>::RD;
+    static_assert((RD & (RD - 1)) == 0 && RD >= 4, "ring depth: a power of two");
+    unsigned ring_lds = 0;          // LDS byte address of this wave's ring (wave-uniform)
+    const char *ring_ptr = nullptr; // ... the same as a pointer, plus this lane's 16 bytes
+    int base0_ = 0;
+
+    __device__ __forceinline__ int slot_of(int row) const { return (row - base0_) & (RD - 1); }
+
+    // one row: NLD pieces of 1 KB (lane l's 16 bytes at + 16 l).  The statement sets M0 (the DMA's LDS base) itself and hides
+    // the load from the compiler, which would otherwise wait vmcnt(0) in front of every LDS read.
+    __device__ __forceinline__ void dma_issue(int row, int slot) const
+    {
+#if !defined(RM_HIPEMU)
+        const Tin *rp = src + (size_t)row * W;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            unsigned keep;
+            const unsigned dst = ring_lds + (unsigned)(slot * NLD + j) * 1024u;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(rp + j * VPER), "s"(dst) : "memory");
+        }
+#else
+        (void)row; (void)slot;
+#endif
+    }
+    // the row in `slot` has landed once at most (RD - 2) NLD younger DMA pieces are outstanding (loads retire in order; the
+    // chain's own stores only raise the count, i.e. make this wait longer)
+    __device__ __forceinline__ void dma_fetch(int slot, Raw16 (&r)[NLD]) const
+    {
+#if !defined(RM_HIPEMU)
+        constexpr int K = (RD - 2) * NLD;
+        __builtin_amdgcn_s_waitcnt((K & 0xF) | ((K >> 4) << 14) | 0x0F70);   // vmcnt(K) only
+        asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(ring_ptr + (size_t)(slot * NLD + j) * 1024);
+    }
+
+    template <int I> __device__ __forceinline__ void hot_rows_dma(int base)
+    {
+        if constexpr (I < B) {
+            double v[16], n[8];
+            Raw16 cur[NLD];
+            dma_fetch(slot_of(base + I), cur);
+            unpack_row(cur, v);
+            dma_issue(min(base + I + RD - 1, p_last), slot_of(base + I + RD - 1));   // (= the slot of row base + I - 1, read in the previous trip)
+            hfilter<0>(v, n);
+            hot_row<0, I>(n);
+            row_fence();
+            hot_rows_dma<I + 1>(base);
+        }
+    }
+
     __device__ __forceinline__ void issue(int row, Raw16 (&r)[NLD]) const
     {
         const Tin *rp = src + (size_t)row * W;
@@ -314,6 +389,38 @@ struct RegChain {
         col_S = c_first >> S;                                  // exact: P and 16*lane are multiples of 16 >= 2^S
         src = frame + min(max(c_first, 0), W - 16);
         p_first = next[0]; p_last = last[0];
+        if constexpr (DMA) {
+            base0_ = p_first - ((p_first + 2) & (B - 1));
+            for (int i = 0; i < RD - 1; ++i) dma_issue(min(p_first + i, p_last), slot_of(p_first + i));
+            int base = base0_;
+            while (base <= p_last) {
+                if constexpr (HOT) {
+                    if (hot_ok(base)) {
+                        do {
+                            hot_rows_dma<0>(base);
+#pragma unroll
+                            for (int k = 1; k < D; ++k) next[k] += B >> k;
+                            base += B;
+                        } while (hot_ok(base));
+                        continue;
+                    }
+                }
+                const int p_end = min(base + B - 1, p_last);
+#pragma nounroll
+                for (int p = max(base, p_first); p <= p_end; ++p) {
+                    Raw16 cur[NLD];
+                    double v[16], n[8];
+                    dma_fetch(slot_of(p), cur);
+                    unpack_row(cur, v);
+                    dma_issue(min(p + RD - 1, p_last), slot_of(p + RD - 1));
+                    hfilter<0>(v, n);
+                    feed<0>(p, n);
+                    row_fence();
+                }
+                base += B;
+            }
+            return;
+        }
         if constexpr (!HOT) {
             // row at a time, PF rows in flight in static register sets
             Raw16 regs[PF][NLD];
@@ -401,6 +508,13 @@ template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow
     const int inner = j % per_frame;
     const int seg = inner / g.strips, strip = inner - seg * g.strips;
     RegChain<S, Tin> rc(g);
+    if constexpr (RegTraits<Tin>::DMA) {
+        HIP_DYNAMIC_SHARED(char, ring)
+#if !defined(RM_HIPEMU)
+        rc.ring_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char *)ring);
+#endif
+        rc.ring_ptr = ring + 16 * threadIdx.x;
+    }
     if constexpr (sizeof(Tin) == 1 && RM_U8_LUT) {
         __shared__ double s_lut[256];
         for (int i = threadIdx.x; i < 256; i += 64) s_lut[i] = (double)i * (1.0 / 255);   // uint8_to_float, transforms.py:20-23

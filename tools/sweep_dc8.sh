@@ -7,7 +7,10 @@ CC="/opt/rocm/bin/hipcc -I../respmon_amd/csrc --offload-arch=gfx950 -O3 -std=c++
 build() { name=$1; shift; $CC "$@" -o dc_$name dc8_bench.hip 2> $OUT/build_$name.err || { echo "build $name failed"; tail -5 $OUT/build_$name.err; }; }
 cp old_rm_down_chain_u8.h.txt /tmp/old_dc8.h
 build old '-DRM_DC8_HEADER="/tmp/old_dc8.h"' &
-build w2pf2 -DRM_NARROW_WAVES=2 -DRM_U8_PREFETCH=2 -DRM_F16_PREFETCH=2 &
-build w2pf42 -DRM_NARROW_WAVES=2 -DRM_U8_PREFETCH=4 -DRM_F16_PREFETCH=2 &
+build nodma -DRM_NARROW_DMA=0 &
+build dma &
+build dma_r4 -DRM_F16_RING=4 &
+build dma_r16 -DRM_F16_RING=16 -DRM_F32_RING=8 &
+build dma_w3 -DRM_NARROW_WAVES=3 &
 wait
-for v in old w2pf2 w2pf42; do for segs in 0 2 3 6 8; do echo "== $v segs=$segs"; [ -x dc_$v ] && timeout 120 ./dc_$v $segs; done; done 2>&1 | tee $OUT/sweep.txt
+for v in old nodma dma dma_r4 dma_r16 dma_w3; do echo "== $v"; [ -x dc_$v ] && timeout 120 ./dc_$v "$@"; done 2>&1 | tee $OUT/sweep.txt
