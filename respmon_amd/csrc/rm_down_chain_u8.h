@@ -54,12 +54,14 @@ template <typename Tin> struct RegTraits;   // NLD: 16-byte loads per lane and r
 // HOT: the static steady-state blocks of RegChain pay (measured, bench_micro/dc8_bench.hip, kernel ms old -> new): uint8 1080p x 256
 // 0.365 -> 0.30, float16 4K x 512 2.19 -> 2.03; the float32 chain is bound by bytes in flight, not by instruction issue, and
 // keeps the row-at-a-time form without a register cap (0.42 ms; 0.47 with hot blocks, 1.1 under a 256-register cap)
-// DMA: rows travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of RD rows per wave, RD - 1 of them in flight, and
-// cost no registers until they are unpacked.  The float16 / float32 chains spend half of their wave cycles waiting for memory with
-// 2 rows per wave in flight (profiles/r03/narrow_chain_sq_counters.txt: 55 % / 50 %); the uint8 chain is bound by instruction issue
-// and keeps its rows in registers.  (Host emulation: registers for all.)
+// DMA (developer option, off): rows travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of RD rows per wave, RD - 1
+// of them in flight, and cost no registers until they are unpacked.  Written because the float16 / float32 chains spend half of
+// their wave cycles in s_waitcnt with 2 rows per wave in flight (profiles/r03/narrow_chain_sq_counters.txt: 55 % / 50 %) -- and
+// measured no faster (bench_micro/dc8_bench.hip, profiles/r03/narrow_chain_sweep.txt: float16 4K 2.13 -> 2.10 ms, float32 1080p
+// 0.45 -> 0.50 ms, bit-identical output): the reads of the chain's access pattern ALONE take 1.45 ms / 0.435 ms there, and the
+// float16 kernel also writes its 2.1 GB level-2 array -- both kernels already run at the bandwidth their traffic allows.
 #ifndef RM_NARROW_DMA
-#define RM_NARROW_DMA 1
+#define RM_NARROW_DMA 0
 #endif
 #ifdef RM_HIPEMU
 #define RM_NARROW_DMA_ON 0
