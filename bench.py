@@ -131,6 +131,19 @@ def cpu_baseline(vid_u8, n_frames, levels, skip, in_dtype, workers):
     return out
 
 
+def valu_roofline(dt, T, H, W, kernel_ms):
+    """Instruction-issue roofline of the frame-buffer kernel: VALU instructions per input pixel (SQ_INSTS_VALU of a committed PMC
+    pass) x ~4.8 cycles per wave64 instruction (bench_micro/valu_rate.hip) over 1024 SIMDs at 2.4 GHz; profiles/valu_issue.json."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
+        ipp = v["valu_instructions_per_pixel"]["%s_%dx%dx%d" % (dt, T, H, W)]
+    except Exception:
+        return None
+    bound_ms = T * H * W * ipp / 64.0 * v["cycles_per_wave_instruction"] / (v["simds"] * v["clock_ghz"] * 1e9) * 1e3
+    return {"bound": "valu_issue", "valu_instructions_per_pixel": ipp, "issue_bound_ms": bound_ms,
+            "frac": bound_ms / kernel_ms if kernel_ms > 0 else None, "source": "profiles/valu_issue.json (committed PMC figures, not measured in this run)"}
+
+
 def mode_b_exchange(rdist, need):
     """What respmon_amd.dist.ExchangePolicy does with a stream whose sparse packet needs `need` tiles: first step and steady state."""
     if need is None:
@@ -293,9 +306,15 @@ def main():
         buf8 = torch.from_numpy(vid_u8).cuda()
         for _ in range(a.warmup):
             locate1(buf8)
+        _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
         roi8, ms8 = timed(lambda: locate1(buf8), n_extra)
-        alt = {"frame_buffer_dtype": "u8", "value": T / ms8 * 1e3, "unit": "frames/s", "ms_per_step": ms8,
-               "roi": roi8, "roi_equals_headline": list(roi8 or []) == list(roi or [])}
+        _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
+        _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+        k8 = ms[0] / max(ncalls.value, 1)
+        alt = {"frame_buffer_dtype": "u8", "value": T / ms8 * 1e3, "unit": "frames/s", "ms_per_step": ms8, "kernel_ms": k8,
+               "roi": roi8, "roi_equals_headline": list(roi8 or []) == list(roi or []),
+               # this kernel is bound by instruction issue, not by bytes: its second roofline
+               "valu_roofline": valu_roofline("u8", T, H, W, k8)}
         del buf8
     # BASELINE config 4 is "calibration + ROI flow": the per-frame motion extraction (base.py:354-407, 'flow' method) on the
     # ROI just found -- Shi-Tomasi corners once, then pyramidal LK + mean flow + PCA per frame.  Latency bound
@@ -412,6 +431,7 @@ def main():
                  "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2],
                                     "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
                  "contour_components": cn.value, "contour_labelled": bool(cl.value)}
+            d["valu_roofline"] = valu_roofline(cdt, cT, cH, cW, ck_ms)
             try:    # HBM bytes per launch of the frame-buffer kernel from the committed PMC passes of this configuration, if any
                 d["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(
                     "%s_%dx%dx%d" % (cdt, cT, cH, cW), {}).get("bytes_per_launch")
@@ -526,7 +546,8 @@ def main():
                          "kernel": "frame-buffer pyrDown kernel (reads [T,H,W] once)", "kernel_ms": k_ms,
                          "algorithmic_bytes": b_alg,
                          # the contract figure of SURVEY 8(d): the WHOLE step (all kernels + host contour stage) against the peak
-                         "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS},
+                         "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS,
+                         "valu_roofline": valu_roofline(a.in_dtype, t_local, H, W, k_ms)},
             "phases_ms_per_step": phases,
             "roi": roi,
             "heatmap_exchange": (rdist.LAST_EXCHANGE and {"sparse": "one all-gather of sparse packets (%d-tile cap, %.2f MB per rank)"

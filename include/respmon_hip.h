@@ -70,7 +70,7 @@ size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
 /* developer / test switches, per context; the library never reads the process environment.  Every switch selects between
  * implementations with identical results or shrinks a tuning constant so that a test reaches a rare path:
  *   "temporal_valu" 0|1, "temporal_wide" -1|0|1, "dc_lds_front_end" 0|1, "no_fused_bounds" 0|1, "bounds_table_bytes" n, "dense_rows" 0|16|32|64,
- *   "dense_general" 0|1, "dense_wave" 1|0, "dense_frames" 0|1|2, "dense_split" 0|1|2|4, "bounds_scalar" 0|1|2, "dc_segs" n, "dc_wpg" n, "store_slots" n.  Unknown key -> RM_E_BADARG. */
+ *   "dense_general" 0|1, "dense_wave" 1|0, "dense_frames" 0|1|2, "dense_split" 0|1|2|4, "bounds_scalar" 0|1|2, "dc_segs" n, "dc_wpg" n, "dc_split" per mille, "store_slots" n.  Unknown key -> RM_E_BADARG. */
 int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
 
 /* ---- measurement hook for bench.py: mode 1 brackets only the frame-buffer kernel with hipEvents on the

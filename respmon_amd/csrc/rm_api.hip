@@ -84,6 +84,7 @@ struct DebugKnobs {
     int dense_split = 0;          // 1 / 2 / 4: waves per tile (k_dense_sum_wf for 2 and 4; 0: by the number of tiles)
     int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
+    int dc_split = 0;             // > 0: share (per mille) of the level-S rows the upper of exactly two segments takes (default 513)
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
 };
 
@@ -221,6 +222,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dense_split") d.dense_split = (int)value;
     else if (k == "dc_segs") d.dc_segs = (int)value;
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
+    else if (k == "dc_split") d.dc_split = (int)value;
     else if (k == "store_slots") d.store_slots = value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
     return RM_OK;
@@ -802,7 +804,7 @@ static int launch_down_chain_t(rm_ctx *ctx, const void *frames, int T, const std
 {
     const Tin *f = (const Tin *)frames;
     DownGeom g;
-    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny, ctx->dbg.dc_segs, ctx->dbg.dc_wpg)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+    if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny, ctx->dbg.dc_segs, ctx->dbg.dc_wpg, ctx->dbg.dc_split)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
     if (down_chain_hot_ok(S, h.data())) return launch_down_chain_g<Tin, false>(f, T, g, out, s);
     return launch_down_chain_g<Tin, true>(f, T, g, out, s);
 }

@@ -659,9 +659,9 @@ inline bool down_chain_hot_ok(int S, const int *h)
 }
 
 // geometry of one launch over level-S rows [y_begin, y_end)
-// force_segs / force_wpg > 0: developer overrides (rm_debug_set "dc_segs" / "dc_wpg")
+// force_segs / force_wpg / split_permille > 0: developer overrides (rm_debug_set "dc_segs" / "dc_wpg" / "dc_split")
 inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok, int y_begin, int y_end, DownGeom &g, bool tiny = false,
-                           int force_segs = 0, int force_wpg = 0)
+                           int force_segs = 0, int force_wpg = 0, int split_permille = 0)
 {
     if (S < 1 || S > 5 || y_end <= y_begin) return false;
     g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end;
@@ -690,7 +690,7 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
     // exactly two segments: split them 51.3 : 48.7 between an even XCD and its (slower) odd neighbour, see k_down_chain
     g.seg_split = 0;
     if (g.segs == 2 && !tiny && rows >= 8) {
-        int upper = (int)(rows * 0.513 + 0.5);
+        int upper = (int)(rows * (split_permille > 0 ? split_permille * 0.001 : 0.513) + 0.5);
         if (upper >= rows) upper = rows - 1;
         if (upper > g.seg_h) g.seg_split = y_begin + upper;
     }

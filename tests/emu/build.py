@@ -22,7 +22,7 @@ def build(force=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
            "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", "-Wno-unused-function", "-o", OUT]
     for u in units:
         cmd += ["-x", "c++", os.path.join(CSRC, u)]
