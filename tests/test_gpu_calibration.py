@@ -654,6 +654,14 @@ def test_dense_sum_equals_sparse_path(hip, oracle):
             device.debug_set("dense_rows", rows)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, rows)
             assert sum_path() == "dense"
+        if S <= 2:      # the wave-private kernels: one wave per tile (one frame per trip / two interleaved), two and four waves per tile
+            device.debug_set("dense_rows", 0)
+            for split, frames in ((1, 1), (1, 2), (2, 0), (4, 0)):
+                device.debug_set("dense_split", split)
+                device.debug_set("dense_frames", frames)
+                assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, "waves per tile", split, frames)
+            device.debug_set("dense_split", 0)
+            device.debug_set("dense_frames", 0)
         device.debug_set("dense_rows", 0)        # (rows 0 above: skip <= 2 takes the wave-private k_dense_sum_w; here the workgroup kernel)
         device.debug_set("dense_wave", 0)
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, "workgroup kernel")
@@ -767,3 +775,23 @@ def test_contour_stage_device_labelling(hip, oracle):
     r1 = dist.hip_heatmap_to_roi(noisy, 20); assert dist.contour_stats()[1] and r1 == r0
     assert dist.hip_heatmap_to_roi(clean, 20) == (200, 100, 300, 200) and dist.contour_stats()[1]
     assert dist.hip_heatmap_to_roi(clean, 20) == (200, 100, 300, 200) and not dist.contour_stats()[1]
+
+
+def test_streaming_tile_bounds_equal_table_form(hip):
+    """k_frame_bounds_rows (a wave per eight tile rows, rows parked in a skewed LDS buffer; the automatic choice for wide levels
+    with many frames: 4K x 512) against k_frame_bounds (row-extrema table) on wide, ragged levels: the same heatmap bit for bit,
+    pruned and exhaustive, and the same exact extrema."""
+    import torch
+    from respmon_amd import device, dist
+    rng = np.random.default_rng(31)
+    for (T, H, W, L, S) in [(6, 300, 1100, 4, 2), (4, 203, 2100, 5, 3), (5, 160, 1040, 3, 1), (3, 540, 3840, 6, 2)]:
+        buf = torch.from_numpy(rng.random((T, H, W))).cuda()
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S, flags=512)     # (per-level filter-first path: the bounds are a kernel of their own)
+        device.debug_set("bounds_scalar", 1)
+        ref, mm = dist.hip_calibrate(buf, 10, return_minmax=True, **kw)
+        device.debug_set("bounds_scalar", 2)
+        got, mm2 = dist.hip_calibrate(buf, 10, return_minmax=True, **kw)
+        device.debug_set("bounds_scalar", 0)
+        assert torch.equal(got, ref) and mm == mm2, (T, H, W, L, S)
+        exhaustive = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 1)
+        assert torch.equal(got, exhaustive), (T, H, W, L, S, "no prune")
