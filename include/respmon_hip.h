@@ -284,6 +284,7 @@ int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gr
  *      (rm_heatmap_to_roi, rm_locate, rm_shard_finish, rm_heat_sparse_merge_roi); rm_locate also takes it per call as
  *      RM_FLAG_CONTOUR_CLIP_FRAME. */
 int rm_set_contour_clip_frame(rm_ctx *ctx, int on);
+int rm_get_contour_clip_frame(rm_ctx *ctx, int *on);   /* so that a per-call override can put back what the context had */
 
 /* ---- base.py:568-575 on noisy thresholded images.  locate() keeps ONE contour (max contourArea -> boundingRect); when the
  *      image holds thousands of specks (BASELINE configs 2 / 5) the device labels the 8-connected components, reduces their
@@ -293,6 +294,7 @@ int rm_set_contour_clip_frame(rm_ctx *ctx, int on);
  *      0: never (every border is followed on the host); 1: always.  The ROI does not depend on the mode.
  *      rm_contour_stats: components / contours met by the last ROI extraction and whether it ran labelled (diagnostics). */
 int rm_set_contour_labelling(rm_ctx *ctx, int mode);
+int rm_get_contour_labelling(rm_ctx *ctx, int *mode);
 int rm_contour_stats(rm_ctx *ctx, int *n_components, int *labelled);
 
 #ifdef __cplusplus

@@ -36,6 +36,8 @@ SIGNATURES = {
     "rm_profile_enable": (_i, [_vp, _i]),
     "rm_set_contour_clip_frame": (_i, [_vp, _i]),
     "rm_set_contour_labelling": (_i, [_vp, _i]),
+    "rm_get_contour_clip_frame": (_i, [_vp, _c.POINTER(_i)]),
+    "rm_get_contour_labelling": (_i, [_vp, _c.POINTER(_i)]),
     "rm_contour_stats": (_i, [_vp, _vp, _vp]),
     "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_debug_counters": (_i, [_vp, _vp, _vp]),

@@ -11,8 +11,11 @@ Differences from the reference that are deliberate and documented in DESIGN.md:
   * the calibration buffer lives in HBM (`calibration_buffer` is a CUDA tensor);
   * `run_on_init=True` keeps the reference's "constructor blocks in run()" behaviour
     (base.py:164); pass False to drive the object step by step;
-  * `reset()` also forgets the flow state (`previous_cropped_image`, `motion_key_points`): the reference leaves them
-    (base.py:515-533) and overwrites them at the next corner initialisation, before anything reads them;
+  * `reset()` also forgets the flow state (`previous_cropped_image`, `motion_key_points`).  This DIFFERS from the reference:
+    its reset() (base.py:515-533) never sets `previous_cropped_image` back to None, so after a reset and a new calibration it
+    keeps tracking from the stale crop and the stale points (base.py:371) -- and `calcOpticalFlowPyrLK` fails outright if the
+    new ROI has another size.  Here the first frame after a recalibration initialises the corners again (a bug fix, listed
+    under "deliberate behavioural differences" in DESIGN.md);
   * after a calibration that finds no ROI the retry goes through `update_ui()` / `sync_to_fps()` like every other
     iteration; the reference `continue`s past them (base.py:451-454) -- no effect on the data path (the UI is a no-op here);
   * the default operation order of the calibration commutes two linear stages (`reference_operation_order`).

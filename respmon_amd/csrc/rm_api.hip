@@ -1862,6 +1862,20 @@ extern "C" int rm_set_contour_labelling(rm_ctx *ctx, int mode)
     return RM_OK;
 }
 
+extern "C" int rm_get_contour_labelling(rm_ctx *ctx, int *mode)
+{
+    if (!ctx || !mode) return fail(RM_E_BADARG, "rm_get_contour_labelling: bad argument");
+    *mode = ctx->label_mode;
+    return RM_OK;
+}
+
+extern "C" int rm_get_contour_clip_frame(rm_ctx *ctx, int *on)
+{
+    if (!ctx || !on) return fail(RM_E_BADARG, "rm_get_contour_clip_frame: bad argument");
+    *on = ctx->clip_frame ? 1 : 0;
+    return RM_OK;
+}
+
 extern "C" int rm_contour_stats(rm_ctx *ctx, int *n_components, int *labelled)
 {
     if (!ctx) return fail(RM_E_BADARG, "rm_contour_stats: ctx is NULL");
@@ -1888,6 +1902,7 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
                          void *stream)
 {
     if (!ctx || !xywh) return fail(RM_E_BADARG, "rm_locate: bad argument");
+    if (ctx->h_unserved) *ctx->h_unserved = 0;   // (a failed earlier call must not leave its "dense sum wanted" behind)
     double *heat = nullptr;
     RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
     CollapsePlan cp;
@@ -1895,10 +1910,13 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     const bool clip_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
     ctx->clip_frame_once = clip_once;
     int rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
-    if (rc >= 0 && cp.valid && ctx->h_unserved && *ctx->h_unserved) {
+    const bool unserved = ctx->h_unserved && *ctx->h_unserved;
+    if (ctx->h_unserved) *ctx->h_unserved = 0;
+    if (rc >= 0 && cp.valid && unserved) {
         // the selection kept more pairs than the value store holds and the sparse sum kernel stood down (the ROI stage above ran on
-        // a heatmap nobody wrote): take the sum with the dense kernel, now that the stream is idle, and extract the ROI again
-        *ctx->h_unserved = 0;
+        // a heatmap nobody wrote -- the price of not putting a host synchronisation in front of the ROI stage of EVERY call, which
+        // is what looking at the flag first would take): take the sum with the dense kernel, now that the stream is idle, and
+        // extract the ROI again
         hipStream_t s = (hipStream_t)stream;
         hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
         LAUNCH_CHECK();
@@ -2102,7 +2120,7 @@ extern "C" int rm_flow_step(rm_ctx *ctx, rm_flow_state *state, const void *frame
         rc = flow_track_resident(fs, prev_side, cur_side, pts, npts, win_w, win_h, max_level, max_count, epsilon, d_out, d_st, s, err);
         if (rc < 0) return fail(rc, "%s", err.c_str());
         HIP_TRY(hipHostGetDevicePointer((void **)&dev_res, fs.res, 0));
-        if (npts <= FLOW_FINISH_MAX) hipLaunchKernelGGL(k_flow_finish, dim3(1), dim3(64), 2 * sizeof(float) * (size_t)npts, s, pts, d_out, d_st, npts, dev_res, pts_next);
+        if (npts <= FLOW_FINISH_MAX) hipLaunchKernelGGL(k_flow_finish, dim3(1), dim3(64), 2 * sizeof(float) * (size_t)flow_finish_pitch(npts), s, pts, d_out, d_st, npts, dev_res, pts_next);
         else hipLaunchKernelGGL(k_flow_finish_seq, dim3(1), dim3(1), 0, s, pts, d_out, d_st, npts, dev_res, pts_next);
         LAUNCH_CHECK();
         HIP_TRY(stream_wait(s));

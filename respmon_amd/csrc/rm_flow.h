@@ -486,11 +486,12 @@ inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *ne
 // One wave: the lanes pack the surviving points and their differences (ballot + prefix popcount, 64 points per trip), then
 // lane 0 adds the differences in point order from LDS.  (One THREAD walking global memory took 150 us for 1 000 points.)
 constexpr int FLOW_FINISH_MAX = 6000;   // points whose differences fit the LDS staging (2 floats each)
+__host__ __device__ __forceinline__ int flow_finish_pitch(int n) { return (n + 3) & ~3; }   // floats per staged component
 __global__ __launch_bounds__(64) void k_flow_finish(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
 {
-    HIP_DYNAMIC_SHARED(float, s_d)     // [2 * n]: dx of the survivors, then dy
+    HIP_DYNAMIC_SHARED(float, s_d)     // [2 * flow_finish_pitch(n)]: dx of the survivors, then dy (both 16-byte aligned: lk_seq_sum2 reads float4)
     const int lane = threadIdx.x;
-    float *s_dx = s_d, *s_dy = s_d + n;
+    float *s_dx = s_d, *s_dy = s_d + flow_finish_pitch(n);
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;

@@ -97,19 +97,23 @@ def hip_heatmap_to_roi(heat, threshold=20, clip_frame=False, labelling=None):
     lib = _capi.load()
     H, W = heat.shape
     xywh = (ctypes.c_int32 * 4)()
-    # per-call overrides only: a context-wide rm_set_contour_clip_frame / rm_set_contour_labelling the caller made stays as it is
+    # per-call overrides: what the context had (rm_set_contour_clip_frame / rm_set_contour_labelling) is read first and put back
+    ctx = device.ctx()
+    had_clip, had_mode = ctypes.c_int(0), ctypes.c_int(-1)
     if clip_frame:
-        _capi.check(lib, lib.rm_set_contour_clip_frame(device.ctx(), 1), "rm_set_contour_clip_frame")
+        _capi.check(lib, lib.rm_get_contour_clip_frame(ctx, ctypes.byref(had_clip)), "rm_get_contour_clip_frame")
+        _capi.check(lib, lib.rm_set_contour_clip_frame(ctx, 1), "rm_set_contour_clip_frame")
     if labelling is not None:
-        _capi.check(lib, lib.rm_set_contour_labelling(device.ctx(), 1 if labelling else 0), "rm_set_contour_labelling")
+        _capi.check(lib, lib.rm_get_contour_labelling(ctx, ctypes.byref(had_mode)), "rm_get_contour_labelling")
+        _capi.check(lib, lib.rm_set_contour_labelling(ctx, 1 if labelling else 0), "rm_set_contour_labelling")
     try:
-        rc = _capi.check(lib, lib.rm_heatmap_to_roi(device.ctx(), device.ptr(heat), H, W, int(threshold), xywh, None, None,
+        rc = _capi.check(lib, lib.rm_heatmap_to_roi(ctx, device.ptr(heat), H, W, int(threshold), xywh, None, None,
                                                     device.stream_ptr()), "rm_heatmap_to_roi")
     finally:
         if clip_frame:
-            lib.rm_set_contour_clip_frame(device.ctx(), 0)
+            lib.rm_set_contour_clip_frame(ctx, had_clip.value)
         if labelling is not None:
-            lib.rm_set_contour_labelling(device.ctx(), -1)
+            lib.rm_set_contour_labelling(ctx, had_mode.value)
     return None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
 
 
