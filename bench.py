@@ -277,8 +277,13 @@ def main():
     tiles_needed = tn.value                       # largest per-rank tile count of the last sparse exchange (world > 1)
     dbg = (ctypes.c_longlong * 4)()
     _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
-    pairs = {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3],
-             "sum_path": "dense (every pair recomputed by the sum kernel, no value store)" if dbg[3] == 0 and dbg[0] else "sparse"}
+    def sum_path(d):
+        if d[3] == -1:
+            return "tile-major (rm_tile_eval.h: extrema from the C pairs, every kept pair evaluated where it is summed; no value store)"
+        return "dense (every pair recomputed by the sum kernel, no value store)" if d[3] == 0 and d[0] else "sparse (value store)"
+
+    pairs = {"total": dbg[0], "evaluated_for_extrema" if dbg[3] == -1 else "evaluated": dbg[1], "kept_for_sum": dbg[2],
+             "store_capacity": max(dbg[3], 0), "sum_path": sum_path(dbg)}
     cn, cl = ctypes.c_int(0), ctypes.c_int(0)
     _capi.check(lib, lib.rm_contour_stats(ctx, ctypes.byref(cn), ctypes.byref(cl)), "rm_contour_stats")
     contour_stage = {"components": cn.value,
@@ -387,8 +392,8 @@ def main():
         need = rdist.hip_sparse_tiles(heat_d)
         dense = {"video": "four blobs (A=0.2, 0.4 Hz, phases 0/90/180/270 deg) + noise sigma 0.06 (3x), seed 4321",
                  "ms_per_step": ms_d, "frames_per_s": T / ms_d * 1e3, "roi": roi_d,
-                 "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2], "store_capacity": dbg[3],
-                                    "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
+                 "collapse_pairs": {"total": dbg[0], "evaluated_for_extrema" if dbg[3] == -1 else "evaluated": dbg[1], "kept_for_sum": dbg[2],
+                                    "store_capacity": max(dbg[3], 0), "sum_path": sum_path(dbg)},
                  "mode_b_sparse_tiles_needed": need, "mode_b_sparse_tile_cap": rdist.SPARSE_CAP_TILES,
                  "mode_b_exchange": mode_b_exchange(rdist, need)}
         del dbuf, heat_d
@@ -428,8 +433,8 @@ def main():
                  "steps": n_steps, "ms_per_step": c_ms, "frames_per_s": cT / c_ms * 1e3, "kernel_ms": ck_ms,
                  "algorithmic_bytes": cb, "frac": cb / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ck_ms > 0 else None,
                  "step_frac": cb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "roi": c_roi,
-                 "collapse_pairs": {"total": dbg[0], "evaluated": dbg[1], "kept_for_sum": dbg[2],
-                                    "sum_path": "dense" if dbg[3] == 0 and dbg[0] else "sparse"},
+                 "collapse_pairs": {"total": dbg[0], "evaluated_for_extrema" if dbg[3] == -1 else "evaluated": dbg[1], "kept_for_sum": dbg[2],
+                                    "sum_path": sum_path(dbg)},
                  "contour_components": cn.value, "contour_labelled": bool(cl.value)}
             d["valu_roofline"] = valu_roofline(cdt, cT, cH, cW, ck_ms)
             try:    # HBM bytes per launch of the frame-buffer kernel from the committed PMC passes of this configuration, if any

@@ -21,6 +21,7 @@
 #include "rm_down_chain.h"
 #include "rm_down_chain_u8.h"
 #include "rm_dense_sum.h"
+#include "rm_tile_eval.h"
 #include "rm_ccl.h"
 #include "rm_flow.h"
 
@@ -65,6 +66,7 @@ struct CollapsePlan {
     int T = 0, t0 = 0, t1 = 0, H = 0, W = 0, S = 0;
     bool valid = false;
     bool no_prune = false;
+    bool fused = false;                    // k_eval_c + k_tile_sum (rm_tile_eval.h): no value store, no separate evaluation of the kept pairs
     SumPlan sp{0, 0, 0, 0};                // sparse or dense sum: decided on the device (rm_kernels.h sum_is_dense)
 };
 
@@ -85,6 +87,8 @@ struct DebugKnobs {
     int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
     int dc_split = 0;             // > 0: share (per mille) of the level-S rows the upper of exactly two segments takes (default 513)
+    int collapse_fused = -1;      // collapse passes without a value store (rm_tile_eval.h): -1 = where they apply by default (skip 3, 4), 0 = never, 1 = wherever TileEval can (skip 1 .. 4)
+    int tile_sum_half = -1;       // 0 / 1: k_tile_sum works on whole tiles / half tiles whatever the number of heavy tiles (-1: by that number)
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
 };
 
@@ -112,7 +116,7 @@ struct rm_ctx {
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     int *h_unserved = nullptr;      // pinned: set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
     // measurement hook (rm_profile_*)
-    long long dbg_pairs = 0, dbg_cap = 0, dbg_mine = 0; int dbg_mode = 0, dbg_auto_dense = 0;   // the SumPlan of the last collapse (host copy)
+    long long dbg_pairs = 0, dbg_cap = 0, dbg_mine = 0; int dbg_mode = 0, dbg_auto_dense = 0, dbg_fused = 0;   // the SumPlan of the last collapse (host copy)
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
     bool prof_on = false;
     int prof_calls = 0, prof_sampled = 0;
@@ -224,6 +228,8 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
     else if (k == "dc_split") d.dc_split = (int)value;
     else if (k == "store_slots") d.store_slots = value;
+    else if (k == "collapse_fused") d.collapse_fused = (int)value;
+    else if (k == "tile_sum_half") d.tile_sum_half = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
     return RM_OK;
 }
@@ -270,6 +276,7 @@ extern "C" int rm_debug_counters(rm_ctx *ctx, long long *out, void *stream)
                        (ctx->dbg_mode == 0 && ctx->dbg_auto_dense && (unsigned long long)h.n_slots * DENSE_ONE_IN > (unsigned long long)ctx->dbg_mine);
     out[0] = ctx->dbg_pairs; out[1] = (long long)h.n_list_a + (dense ? 0 : (long long)h.n_list_b); out[2] = h.n_slots;
     out[3] = dense ? 0 : ctx->dbg_cap;
+    if (ctx->dbg_fused) { out[1] = (long long)h.n_list_a; out[3] = -1; }   // store-less path: C pairs evaluated for the extrema; the kept pairs where they are summed
     return RM_OK;
 }
 
@@ -1270,6 +1277,11 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     if (sp.mode == 1) cap = 0;
     sp.cap_slots = (unsigned)cap;
     cp.store = nullptr;
+    // skip 3 / 4 (locate()'s default): the kept pairs are evaluated where they are summed, tile by tile, and nothing is stored
+    // (rm_tile_eval.h); the flags that name a sum kernel of the store-based path keep that path (tests compare the two bit for bit)
+    cp.fused = tile_eval_ok(g) && !(flags & (RM_FLAG_DENSE_SUM | RM_FLAG_SPARSE_SUM | RM_FLAG_TINY_STORE)) && ctx->dbg.store_slots <= 0 &&
+               (ctx->dbg.collapse_fused > 0 || (ctx->dbg.collapse_fused < 0 && sl.S >= 3));
+    if (cp.fused) { cap = 0; sp.cap_slots = 0; sp.mode = 0; }
     if (cap > 0) RM_TRY(ws(ctx, "value_store", (size_t)cap * CT_H * CT_W, &cp.store));
     ctx->dbg_pairs = npairs; ctx->dbg_cap = cap; ctx->dbg_mine = npairs_mine; ctx->dbg_mode = sp.mode; ctx->dbg_auto_dense = sp.auto_dense_ok;
     RM_TRY(ws(ctx, "sel_cnt", (size_t)ntiles, &cp.sel_cnt));
@@ -1315,6 +1327,23 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     hipLaunchKernelGGL(k_select_pairs, dim3((ntiles + SEL_TILES - 1) / SEL_TILES, (Th + SEL_PH * SEL_U - 1) / (SEL_PH * SEL_U)), dim3(256), 0, s,
                        cp.lo, cp.hi, ntiles, Th, T, t0, t1, st, cp.list_a, cp.list_b, cp.slot_of, prune_ok ? 0 : 1, thr, cp.sel_cnt, cp.heavy);
     LAUNCH_CHECK();
+    if (cp.fused) {
+        // exact extrema from the C pairs: one wave per pair, a grid that covers the few pairs of a pruned selection at once and loops
+        // over an exhaustive one
+        const unsigned cgrid = (unsigned)std::min<long long>(npairs, 8192);
+        ctx->dbg_fused = 1;
+#define RM_EVAL_C(SS)                                                                                            \
+        do {                                                                                                     \
+            using FootC = TileFoot<SS, false>;                                                                   \
+            hipLaunchKernelGGL((k_eval_c<SS>), dim3(cgrid), dim3(64), sizeof(double) * FootC::TOTAL, s, sl.cS, g, ntiles, cp.list_a, st); \
+        } while (0)
+        switch (sl.S) { case 1: RM_EVAL_C(1); break; case 2: RM_EVAL_C(2); break; case 3: RM_EVAL_C(3); break; default: RM_EVAL_C(4); break; }
+#undef RM_EVAL_C
+        LAUNCH_CHECK();
+        cp.valid = true;
+        return RM_OK;
+    }
+    ctx->dbg_fused = 0;
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
     // one resident round of single-wave workgroups that loop over the lists: their lengths live on the device, and
     // dispatching thousands of workgroups that find nothing to do costs more than the loop.  "Resident" is what the
@@ -1369,6 +1398,30 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
+    if (cp.fused) {
+        // one workgroup of TS_NW waves per CU (the exchange takes most of a CU's LDS): the heavy tiles' items first, the workgroups
+        // left without one fill the constant tiles
+        int cus = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+#else
+        cus = 6;   // (host emulation: few, looping workgroups compute the same thing)
+#endif
+        const int nworkers = std::max(1, std::min(2 * cp.ntiles, cus));
+#define RM_TILE_SUM(SS)                                                                                                                  \
+        do {                                                                                                                             \
+            constexpr int exd = tile_sum_exchange_doubles<SS, false>();                                                                  \
+            const size_t shb = sizeof(double) * (size_t)exd + sizeof(int) * (size_t)cp.T;                                                \
+            if (shb > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tile_sum<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb)); \
+            hipLaunchKernelGGL((k_tile_sum<SS>), dim3(nworkers), dim3(64 * TS_NW), shb, s, cp.cS, cp.g, cp.t0, cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr,  \
+                               heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, ctx->dbg.tile_sum_half);                     \
+        } while (0)
+        switch (cp.S) { case 1: RM_TILE_SUM(1); break; case 2: RM_TILE_SUM(2); break; case 3: RM_TILE_SUM(3); break; default: RM_TILE_SUM(4); break; }
+#undef RM_TILE_SUM
+        LAUNCH_CHECK();
+        ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;
+        return RM_OK;
+    }
     const SumPlan &sp = cp.sp;
     // Both sum kernels are enqueued and the one whose turn it is not returns at once (sum_is_dense, decided from this call's own
     // selection); a launch that can never be chosen is left out: the sparse one when the dense kernel is forced, the dense one when

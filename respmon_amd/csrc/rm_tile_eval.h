@@ -1,0 +1,429 @@
+// respmon_amd/csrc/rm_tile_eval.h -- the collapse passes of skip_levels_at_top = 3, 4 without a value store (round 4)
+//
+//   raw[t] = pyrUp^S(C_S[t])                        (pyramid.py:51-57 below `skip`: transforms.py:150-160 leaves those levels zero)
+//   heat   = (1 / T) sum_t (raw[t] >= top ? min : raw[t])      (transforms.py:184-192, base.py:562), sequentially in t
+//
+// Rounds 1-3 evaluated every kept (tile, frame) pair in one flat pass (k_eval_pairs: a single-wave workgroup runs the generic pyrUp
+// chain in LDS, ~2 800 instructions per pair, 20+ us of latency), parked the 8 KB of values of each pair in a value store and summed
+// them in a second pass (k_masked_sum_tiles): 28 + 21 us per step at 1080p x 256 for 2 600 pairs, 21 MB written and read back.
+// Here:
+//   * TileEval<S, HALF>: ONE wave evaluates a 64 x 16 tile (or its upper / lower 8 rows) of a frame from the tile's level-S footprint
+//     with everything frame-invariant settled before the frame loop, as rm_dense_sum.h's DenseW does for S <= 2: the footprint of the
+//     tile at level k is the fixed VIRTUAL rectangle rows (16 ty >> k) - 1 ..  by columns (64 tx >> k) - 1 .. (10 x 34, 7 x 19,
+//     5 x 11, 4 x 7 at k = 1 .. 4); virtual rows outside the image are materialised as the rows OpenCV's border rules substitute
+//     (row -1 := row 1 falls out of the arithmetic, rows past the bottom repeat the last one), columns outside the image only ever
+//     meet a zero weight; lane = destination column, the horizontal values of a step stay in registers and the row structure (which
+//     rows are even, which three values meet) is compile time.  ~300 instructions per (tile, frame) instead of ~2 800.
+//     Same expressions per value as up_at() / chain_step() / level0_rows() (commuted additions and merged power-of-two scalings at
+//     most): bit-identical to the generic chain.
+//   * k_eval_c<S>: the exact raw.min() / raw.max() from the C pairs alone (k_select_pairs' list_a), one wave per pair.
+//   * k_tile_sum<S>: one workgroup of 16 waves per heavy tile (or half tile): round r evaluates the tile's next 16 kept frames
+//     -- in TIME order; wave w takes frame r * 16 + w -- masks them with the exact `top` and parks them in LDS; after a barrier the
+//     waves add the 16 frames, in frame order and with the pruned frames' `min` in between, to the running sums they own.  Same values,
+//     same order of additions as k_masked_sum_tiles / k_dense_sum: bit-identical.  Nothing but C_S is read, nothing but the heatmap
+//     written, and the cost of a tile grows with ITS kept frames only -- from the sparse synthetic stream (86 heavy tiles) to a stream
+//     that keeps every pair.
+#pragma once
+
+namespace rm {
+
+// geometry of the virtual footprints; HALF: the upper or lower 8 rows of the tile only
+template <int S, bool HALF> struct TileFoot {
+    static_assert(S >= 1 && S <= 4, "TileEval covers skip_levels_at_top 1 .. 4");
+    static constexpr int nc(int k) { return k == 1 ? 34 : k == 2 ? 19 : k == 3 ? 11 : 7; }
+    // rows of level k the evaluation holds in its buffer
+    static constexpr int nr(int k)
+    {
+        if (!HALF) return k == 1 ? 10 : k == 2 ? 7 : k == 3 ? 5 : 4;
+        return k == 1 ? 6 : k == 2 ? 5 : k == 3 ? (S == 4 ? 5 : 4) : 4;   // (S = 4: level 3 is computed whole, its needed rows start at an odd index)
+    }
+    // rows of level k a step k -> k - 1 reads
+    static constexpr int nr_src(int k)
+    {
+        if (!HALF) return nr(k);
+        return k == 2 ? 5 : 4;
+    }
+    static constexpr int size(int k) { return nr(k) * nc(k); }
+    static constexpr int off(int k) { int o = 0; for (int i = 1; i < k; ++i) o += size(i); return o; }   // level 1 first
+    static constexpr int TOTAL = off(S) + size(S);    // doubles of LDS per wave
+    static constexpr int NST = size(S);               // staged elements
+    static constexpr int PF = (NST + 63) / 64;        // ... per lane
+    static constexpr int NV = HALF ? 8 : 16;          // level-0 values per lane
+};
+
+// first row index (inside the FULL virtual footprint of level k) of the rows a half-tile evaluation holds of level k
+template <int S, bool HALF> __host__ __device__ __forceinline__ int te_row_start(int k, int hsel)
+{
+    if (!HALF) return 0;
+    return k == 1 ? 4 * hsel : k == 2 ? 2 * hsel : (k == 3 && S == 3) ? hsel : 0;
+}
+
+inline bool tile_eval_ok(const ChainGeom &g)
+{
+    if (g.S < 1 || g.S > 4) return false;
+    for (int k = 1; k <= g.S; ++k) if (g.h[k] < 2 || g.w[k] < 2) return false;
+    return true;
+}
+
+// everything about a tile that does not depend on the frame
+template <int S, bool HALF> struct TileSetup {
+    using F = TileFoot<S, HALF>;
+    int off_g[F::PF];             // staged element lane + 64 p: offset inside a frame of C_S (virtual rows / columns resolved)
+    int ha[S + 1], hb[S + 1], hc[S + 1];   // step k -> k - 1 (k = 2 .. S), lane < nc(k - 1): element offsets of the three column taps in a source row
+    double wa[S + 1], wb[S + 1], wc[S + 1];
+    int lastrow[S + 1];           // level k (k = 1 .. S - 1): last buffer row that lies inside the image; later rows repeat it
+    int src_row0[S + 1];          // step k -> k - 1: first buffer row of level k the step reads
+    double we_a, we_b, we_c, wo_b, wo_c;   // level 1 -> 0, this lane's column pair
+    int l0off;                    // ... its taps of source row k: slice[l0off + k * nc(1) + {0, 1, 2}]
+    int X, Y0;                    // ... its pixels: columns X, X + 1, rows Y0 .. Y0 + NV / 2 - 1
+};
+
+template <int S, bool HALF>
+__device__ __forceinline__ void tile_setup(const ChainGeom &g, int tx, int ty, int hsel, int lane, TileSetup<S, HALF> &ts)
+{
+    using F = TileFoot<S, HALF>;
+    const int hS = g.h[S], wS = g.w[S];
+    {   // staging: virtual rows / columns of the level-S footprint resolved to addresses
+        const int fy = ((16 * ty) >> S) - 1 + te_row_start<S, HALF>(S, hsel), fx = ((64 * tx) >> S) - 1;
+#pragma unroll
+        for (int p = 0; p < F::PF; ++p) {
+            const int i = min(lane + 64 * p, F::NST - 1);
+            const int r = i / F::nc(S), c = i - r * F::nc(S);
+            const int yv = fy + r, xv = fx + c;
+            const int ya = yv < 0 ? 1 : (yv > hS - 1 ? hS - 1 : yv), xa = min(max(xv, 0), wS - 1);
+            ts.off_g[p] = ya * wS + xa;
+        }
+    }
+#pragma unroll
+    for (int k = 2; k <= S; ++k) {
+        // lane c owns destination column xv of level k - 1; its taps j - 1, j, j + 1 of level k (make_htap's five shapes)
+        const int fxd = ((64 * tx) >> (k - 1)) - 1, fxs = ((64 * tx) >> k) - 1;
+        const int xv = fxd + lane;
+        const int sw = g.w[k], dw = g.w[k - 1];
+        ts.ha[k] = ts.hb[k] = ts.hc[k] = 0; ts.wa[k] = ts.wb[k] = ts.wc[k] = 0.0;   // (outside the image / beyond the footprint: a finite value nobody reads with a non-zero weight)
+        if (lane < F::nc(k - 1) && xv >= 0 && xv < dw) {
+            const HTap t = make_htap(xv, sw);
+            ts.ha[k] = t.ia - fxs; ts.hb[k] = t.ib - fxs; ts.hc[k] = t.ic - fxs;
+            ts.wa[k] = t.wa; ts.wb[k] = t.wb; ts.wc[k] = t.wc;
+        }
+        ts.src_row0[k] = (te_row_start<S, HALF>(k - 1, hsel) >> 1) - te_row_start<S, HALF>(k, hsel);
+    }
+#pragma unroll
+    for (int k = 1; k < S; ++k) ts.lastrow[k] = (g.h[k] - 1) - (((16 * ty) >> k) - 1 + te_row_start<S, HALF>(k, hsel));
+    // level 1 -> 0: lane = (column pair cp, row group rg): columns X, X + 1; full tile: rows 16 ty + 8 rg .. + 7, half: 16 ty + 8 hsel + 4 rg .. + 3
+    const int cp = lane & 31, rg = lane >> 5;
+    const int sw1 = g.w[1];
+    ts.X = 64 * tx + 2 * cp;
+    ts.Y0 = 16 * ty + (HALF ? 8 * hsel + 4 * rg : 8 * rg);
+    {
+        const int j = ts.X >> 1;
+        const bool left = j == 0, right = j >= sw1 - 1;
+        ts.we_a = left ? 0.0 : 1.0; ts.we_b = right ? 7.0 : 6.0; ts.we_c = left ? 2.0 : (right ? 0.0 : 1.0);
+        ts.wo_b = right ? 8.0 : 4.0; ts.wo_c = right ? 0.0 : 4.0;
+    }
+    // source rows (Y0 >> 1) - 1 .. of level 1; the buffer's first row is virtual row 8 ty - 1 + te_row_start(1)
+    ts.l0off = F::off(1) + ((HALF ? 2 * rg : 4 * rg)) * F::nc(1) + cp;
+}
+
+// one pyrUp step inside the wave's slice, level K -> K - 1 (K >= 2)
+template <int S, bool HALF, int K>
+__device__ __forceinline__ void te_step(const TileSetup<S, HALF> &ts, double *sl, int lane)
+{
+    using F = TileFoot<S, HALF>;
+    constexpr int NRS = F::nr_src(K), PS = F::nc(K), NRD = F::nr(K - 1), PD = F::nc(K - 1);
+    static_assert(((NRD - 1) >> 1) + ((NRD - 1) & 1 ? 2 : 1) <= NRS - 1, "source rows of the last destination row");
+    const double *src = sl + F::off(K) + ts.src_row0[K] * PS;
+    double *dst = sl + F::off(K - 1);
+    const int oa = ts.ha[K], ob = ts.hb[K], oc = ts.hc[K];
+    const double wa = ts.wa[K], wb = ts.wb[K], wc = ts.wc[K];
+    double hq[NRS];
+#pragma unroll
+    for (int q = 0; q < NRS; ++q) hq[q] = dw_tap3(src[q * PS + oa], src[q * PS + ob], src[q * PS + oc], wa, wb, wc);
+    // buffer row p of level K - 1 <-> an odd virtual row for even p (the values of rows q, q + 1 of level K), an even one for odd p
+    // (rows q, q + 1, q + 2): up_at() with the exact power-of-two scalings merged
+    const int last = ts.lastrow[K - 1];
+    double prev = 0.0;
+#pragma unroll
+    for (int p = 0; p < NRD; ++p) {
+        const int q = p >> 1;
+        double v = (p & 1) ? (hq[q] + hq[q + 1] * 6 + hq[q + 2]) * (1.0 / 64) : (hq[q] + hq[q + 1]) * (1.0 / 16);
+        if (p > last) v = prev;   // (uniform) virtual row past the bottom of the image: the last row again (up_at()'s r2)
+        prev = v;
+        if (lane < PD) dst[p * PD + lane] = v;
+    }
+}
+
+template <int S, bool HALF, int K> struct TeChain {
+    static __device__ __forceinline__ void run(const TileSetup<S, HALF> &ts, double *sl, int lane)
+    {
+        te_step<S, HALF, K>(ts, sl, lane);
+        wave_sync();
+        TeChain<S, HALF, K - 1>::run(ts, sl, lane);
+    }
+};
+template <int S, bool HALF> struct TeChain<S, HALF, 1> {
+    static __device__ __forceinline__ void run(const TileSetup<S, HALF> &, double *, int) {}
+};
+
+// the staged level S of the frame is in the slice (and visible): run the chain; out[8 o + r] (full tile) / out[4 o + r] (half) =
+// raw[t, Y0 + r, X + o]
+template <int S, bool HALF>
+__device__ __forceinline__ void tile_eval(const TileSetup<S, HALF> &ts, double *sl, int lane, double (&out)[TileFoot<S, HALF>::NV])
+{
+    using F = TileFoot<S, HALF>;
+    TeChain<S, HALF, S>::run(ts, sl, lane);
+    constexpr int P1 = F::nc(1), NM = F::NV / 4, NK = NM + 2;   // NM source rows own an (even, odd) output row pair
+    const double *l0src = sl + ts.l0off;
+    double hve[NK], hvo[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const double *row = l0src + k * P1;
+        const double a = row[0], b = row[1], c = row[2];
+        hve[k] = dw_tap3(a, b, c, ts.we_a, ts.we_b, ts.we_c);
+        hvo[k] = __builtin_fma(c, ts.wo_c, b * ts.wo_b);   // b * 4 + c * 4 (or b * 8 + c * 0): both products exact
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        out[2 * m] = (hve[m] + hve[m + 1] * 6 + hve[m + 2]) * (1.0 / 64);
+        out[2 * m + 1] = (hve[m + 1] + hve[m + 2]) * (1.0 / 16);
+        out[F::NV / 2 + 2 * m] = (hvo[m] + hvo[m + 1] * 6 + hvo[m + 2]) * (1.0 / 64);
+        out[F::NV / 2 + 2 * m + 1] = (hvo[m + 1] + hvo[m + 2]) * (1.0 / 16);
+    }
+}
+
+// ---- exact raw.min() / raw.max() (transforms.py:185, 187) from the C pairs: one wave per listed pair -------------------------------
+template <int S>
+__global__ __launch_bounds__(64) void k_eval_c(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, CollapseState *st)
+{
+    using F = TileFoot<S, false>;
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int lane = threadIdx.x;
+    // the first list entry is requested together with the list length (the list buffer is valid memory whatever it turns out to be)
+    const unsigned first_idx = list_a[blockIdx.x];
+    const unsigned nA = st->n_list_a;
+    const double inf = __builtin_huge_val();
+    const size_t fs = (size_t)g.h[S] * g.w[S];
+    const int H0 = g.h[0], W0 = g.w[0];
+    double mn = inf, mx = -inf;
+    for (unsigned c = blockIdx.x; c < nA; c += gridDim.x) {
+        const unsigned idx = (unsigned)uniform((int)(c == blockIdx.x ? first_idx : list_a[c]));
+        const int u = idx / ntiles, tile = idx - u * ntiles;
+        const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+        TileSetup<S, false> ts;
+        tile_setup<S, false>(g, tx, ty, 0, lane, ts);
+        const double *src = cS + (size_t)u * fs;
+        double stg[F::PF];
+#pragma unroll
+        for (int p = 0; p < F::PF; ++p) stg[p] = src[ts.off_g[p]];
+        wave_sync();   // the previous pair's reads of the slice are behind us
+#pragma unroll
+        for (int p = 0; p < F::PF; ++p) if (lane + 64 * p < F::NST) lds[F::off(S) + lane + 64 * p] = stg[p];
+        wave_sync();
+        double v[16];
+        tile_eval<S, false>(ts, lds, lane, v);
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (ts.Y0 + r < H0 && ts.X + o < W0) { const double x = v[8 * o + r]; mn = (x < mn) ? x : mn; mx = (x > mx) ? x : mx; }
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if (lane == 0 && blockIdx.x < nA) {
+        const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
+        const int sp_ = blockIdx.x & (NSTRIPE - 1);
+        if (kmn < *(volatile unsigned long long *)&st->min_keys[sp_]) atomicMin(&st->min_keys[sp_], kmn);
+        if (kmx > *(volatile unsigned long long *)&st->max_keys[sp_]) atomicMax(&st->max_keys[sp_], kmx);
+    }
+}
+
+// ---- masked time sum, tile by tile ----------------------------------------------------------------------------------------------------
+// Work item i = (heavy tile, half) [HALF] or one heavy tile; a workgroup of TS_NW waves takes the items i = blockIdx.x, + nworkers, ...
+// The workgroups left without an item fill the tiles without kept pairs with their constant (as k_masked_sum_tiles did).
+// LDS: the exchange [TS_NW frames][NV values][64 lanes] -- a wave's footprint slice overlays ITS frame's part of it (the slice is dead
+// once the wave holds its level-0 values in registers) -- then the tile's kept frames s_kt[T].
+constexpr int TS_NW = 16;
+
+template <int S, bool HALF> __host__ __device__ constexpr int tile_sum_exchange_doubles()
+{
+    return TS_NW * (TileFoot<S, HALF>::NV * 64 > TileFoot<S, HALF>::TOTAL ? TileFoot<S, HALF>::NV * 64 : TileFoot<S, HALF>::TOTAL);
+}
+
+template <int S, bool HALF>
+__device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom &g, int t_first, int t_end, int T, int ntiles, const int *slot_of,
+                                              CollapseState *st, double threshold, double *heat_sum, int avg_T, int *tile_nkept,
+                                              const int *sel_cnt, const unsigned int *heavy, int nworkers, double *lds, int *s_wcnt, int tile0, int slot0,
+                                              int nheavy)
+{
+    using F = TileFoot<S, HALF>;
+    constexpr int NV = F::NV, NW = TS_NW;
+    constexpr int WSTRIDE = tile_sum_exchange_doubles<S, HALF>() / NW;   // doubles per wave of the exchange (>= NV * 64 and >= the slice)
+    constexpr int NSUB = HALF ? 2 : 1;
+    static_assert(NV * 64 % (64 * NW) == 0 || NV * 64 < 64 * NW, "values per thread of the accumulation");
+    int *s_kt = reinterpret_cast<int *>(lds + tile_sum_exchange_doubles<S, false>());   // behind the (full-tile sized) exchange
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int H0 = g.h[0], W0 = g.w[0];
+    const int nitems = nheavy * NSUB;
+    // transforms.py:184-189: min, max, top = max - (max - min) * threshold
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;
+    if (blockIdx.x == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    const double cnt = (double)avg_T;
+    const size_t fs = (size_t)g.h[S] * g.w[S];
+    double *sl = lds + (size_t)wave * WSTRIDE;       // this wave's footprint slice == its part of the exchange
+    // accumulation: value v (0 .. NV - 1) of lane l sits at ex[frame][v * 64 + l]; thread (wave, lane) owns the values v = wave + NW * j
+    constexpr int QA = (NV + NW - 1) / NW;            // running sums per thread (NV = 16: 1; NV = 8: waves 0 .. 7 own one, the others none)
+    for (int item = (int)blockIdx.x; item < nitems; item += nworkers) {
+        const bool first = item == (int)blockIdx.x;
+        const int tile = first ? tile0 : (int)heavy[item / NSUB], hsel = HALF ? item % NSUB : 0;
+        const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+        // the tile's kept frames in time order (ballot + prefix popcount, 64 * NW frames per round)
+        int nkept = 0;
+        for (int c0 = t_first; c0 < t_end; c0 += 64 * NW) {
+            const int t = c0 + tid;
+            int slot = SLOT_PRUNED;
+            if (first && c0 == t_first) slot = slot0;
+            else if (t < t_end) slot = slot_of[(size_t)sym_frame(t, T) * ntiles + tile];
+            const bool kept = slot != SLOT_PRUNED;
+            const unsigned long long m = __ballot(kept);
+            if (lane == 0) s_wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = nkept, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
+            if (kept) s_kt[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
+            nkept += tot;
+            __syncthreads();
+        }
+        if (tid == 0 && hsel == 0 && tile_nkept) tile_nkept[tile] = nkept;
+        TileSetup<S, HALF> ts;
+        tile_setup<S, HALF>(g, tx, ty, hsel, lane, ts);
+        double acc[QA];
+#pragma unroll
+        for (int j = 0; j < QA; ++j) acc[j] = 0.0;
+        int t_done = t_first;
+        // this wave's frame of the first round is requested now; inside the loop the next round's travels while this one is evaluated
+        double stg[F::PF];
+        auto fetch = [&](int fi) __attribute__((always_inline)) {
+            const int t = s_kt[min(fi, nkept - 1)];
+            const double *src = cS + (size_t)sym_frame(t, T) * fs;
+#pragma unroll
+            for (int p = 0; p < F::PF; ++p) stg[p] = src[ts.off_g[p]];
+        };
+        if (nkept > 0) fetch(wave);
+        for (int r0 = 0; r0 < nkept; r0 += NW) {
+#pragma unroll
+            for (int p = 0; p < F::PF; ++p) if (lane + 64 * p < F::NST) sl[F::off(S) + lane + 64 * p] = stg[p];
+            fetch(r0 + NW + wave);
+            wave_sync();
+            double v[NV];
+            tile_eval<S, HALF>(ts, sl, lane, v);
+            wave_sync();   // every lane has its values: the slice may be overwritten
+#pragma unroll
+            for (int j = 0; j < NV; ++j) sl[j * 64 + lane] = (v[j] >= top) ? min_val : v[j];
+            __syncthreads();
+            const int nf = min(NW, nkept - r0);
+            if (wave < NV) {
+                for (int f = 0; f < nf; ++f) {
+                    const int t_stop = uniform(s_kt[r0 + f]);              // frames [t_done, t_stop) are pruned
+                    for (int t = t_done; t < t_stop; ++t) {
+#pragma unroll
+                        for (int j = 0; j < QA; ++j) acc[j] = acc[j] + min_val;
+                    }
+                    const double *exf = lds + (size_t)f * WSTRIDE + lane;
+#pragma unroll
+                    for (int j = 0; j < QA; ++j) if (wave + NW * j < NV) acc[j] = acc[j] + exf[(wave + NW * j) * 64];
+                    t_done = t_stop + 1;
+                }
+            }
+            __syncthreads();   // (the exchange and the slices are rewritten next round)
+        }
+        for (int t = t_done; t < t_end; ++t) {
+#pragma unroll
+            for (int j = 0; j < QA; ++j) acc[j] = acc[j] + min_val;
+        }
+        // base.py:562: np.average = sum / T when the whole buffer was summed here; the heatmap's extrema for base.py:563
+        double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+#pragma unroll
+        for (int j = 0; j < QA; ++j) {
+            const int vi = wave + NW * j;
+            if (vi < NV) {
+                const int o = vi / (NV / 2), r = vi - o * (NV / 2);
+                const int y = ts.Y0 + r, x = ts.X + o;
+                if (y < H0 && x < W0) {
+                    const double a = avg_T > 0 ? acc[j] / cnt : acc[j];
+                    heat_sum[(size_t)y * W0 + x] = a;
+                    hmn = (a < hmn) ? a : hmn; hmx = (a > hmx) ? a : hmx;
+                }
+            }
+        }
+        if (avg_T > 0) {
+            hmn = wave_min(hmn); hmx = wave_max(hmx);
+            if (lane == 0 && wave < NV) {
+                const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+                const int sp_ = (blockIdx.x * NW + wave) & (NSTRIPE - 1);
+                if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
+                if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+            }
+        }
+        __syncthreads();   // s_kt is rewritten by the next item
+    }
+    // FILL: by the workgroups without items when there are any, by every workgroup otherwise
+    const int idle = nworkers - min(nitems, nworkers);
+    const int nfill = idle > 0 ? idle : nworkers;
+    const int fid = idle > 0 ? (int)blockIdx.x - nitems : (int)blockIdx.x;
+    if (fid < 0) return;
+    double lead = 0.0;
+    for (int t = t_first; t < t_end; ++t) lead = lead + min_val;
+    const double fv = avg_T > 0 ? lead / cnt : lead;
+    bool any = false;
+    const int tiles_x = g.tiles_x;
+    // a tile = 16 rows x 64 columns = 1024 values: one per thread (wave = row)
+    constexpr int FU = 4;    // tiles whose kept-pair counts are requested together
+    for (int base = fid; base < ntiles; base += FU * nfill) {
+        int cntk[FU];
+#pragma unroll
+        for (int k = 0; k < FU; ++k) { const int tile = base + k * nfill; cntk[k] = tile < ntiles ? sel_cnt[tile] : 1; }
+#pragma unroll
+        for (int k = 0; k < FU; ++k) {
+            const int tile = base + k * nfill;
+            if (cntk[k] != 0) continue;               // past the end, or a worker sums this tile
+            any = true;
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int x = tx * CT_W + lane, y = ty * CT_H + wave;
+            if (x < W0 && y < H0) heat_sum[(size_t)y * W0 + x] = fv;
+            if (tid == 0 && tile_nkept) tile_nkept[tile] = 0;     // 0: every pixel of the tile is the same constant
+        }
+    }
+    if (any && tid == 0 && avg_T > 0) {
+        const unsigned long long kv = f64_key(fv);
+        const int sp_ = blockIdx.x & (NSTRIPE - 1);
+        if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kv);
+        if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kv);
+    }
+}
+
+// one launch serves both granularities: half tiles when that still leaves every work item a workgroup of its own (the sparse case: few
+// heavy tiles, the longest chain of rounds decides), whole tiles otherwise (no part of the chain is evaluated twice)
+template <int S>
+__global__ __launch_bounds__(64 * TS_NW) void k_tile_sum(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles, const int *slot_of,
+                                                          CollapseState *st, double threshold, double *heat_sum, int avg_T, int *tile_nkept,
+                                                          const int *sel_cnt, const unsigned int *heavy, int nworkers, int force_half)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    __shared__ int s_wcnt[TS_NW];
+    const int tid = threadIdx.x;
+    // requested before the state: the tile of this workgroup's first item under either granularity (heavy[] is valid memory whatever
+    // n_heavy turns out to be) and its first slot_of column
+    const int tile_a = (int)(heavy[blockIdx.x] % (unsigned)ntiles), tile_b = (int)(heavy[blockIdx.x >> 1] % (unsigned)ntiles);
+    int slot_a = SLOT_PRUNED, slot_b = SLOT_PRUNED;
+    if (t_first + tid < t_end) {
+        const size_t row = (size_t)sym_frame(t_first + tid, T) * ntiles;
+        slot_a = slot_of[row + tile_a]; slot_b = slot_of[row + tile_b];
+    }
+    const int nheavy = (int)st->n_heavy;
+    const bool half = force_half >= 0 ? force_half != 0 : 2 * nheavy <= nworkers;   // (uniform over the grid; force_half: test hook)
+    if (half) tile_sum_body<S, true>(cS, g, t_first, t_end, T, ntiles, slot_of, st, threshold, heat_sum, avg_T, tile_nkept, sel_cnt, heavy, nworkers, lds, s_wcnt, tile_b, slot_b, nheavy);
+    else tile_sum_body<S, false>(cS, g, t_first, t_end, T, ntiles, slot_of, st, threshold, heat_sum, avg_T, tile_nkept, sel_cnt, heavy, nworkers, lds, s_wcnt, tile_a, slot_a, nheavy);
+}
+
+}  // namespace rm

@@ -555,3 +555,54 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
     r2 = emu.heatmap_to_roi(noisy, threshold=20)[0]
     assert emu.contour_stats()[1] == 1
     assert r2 == emu.heatmap_to_roi(noisy, threshold=20, labelling=0)[0]
+
+
+def test_emu_fused_collapse_equals_store_path(emu, oracle):
+    """rm_tile_eval.h (round 4): the store-less collapse passes -- k_eval_c (exact extrema from the C pairs) + k_tile_sum (every kept
+    pair evaluated where it is summed, tile by tile, whole tiles or half tiles) -- against the selection / value-store path
+    (flags=256), bit for bit: skip 1..4, ragged geometries whose virtual footprints meet every border rule (top row, rows past the
+    bottom, left / right columns, 2-row / 2-column levels), exhaustive evaluation, frame shards, and the oracle's ROI."""
+    rng = np.random.default_rng(11)
+    cases = [(5, 64, 96, 6, 4), (3, 67, 131, 5, 3), (3, 135, 130, 6, 4), (4, 48, 64, 3, 1), (3, 70, 300, 4, 2), (3, 33, 70, 6, 4),
+             (4, 17, 129, 5, 3), (2, 31, 193, 7, 4), (3, 47, 65, 5, 4), (2, 32, 32, 6, 4), (6, 100, 200, 9, 4), (3, 16, 16, 5, 3),
+             (3, 50, 66, 5, 2), (2, 24, 40, 5, 3)]
+    try:
+        for (T, H, W, L, S) in cases:
+            v = rng.random((T, H, W))
+            emu.debug_set("collapse_fused", 0)
+            store, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            emu.debug_set("collapse_fused", 1)
+            for half in (0, 1):     # whole-tile / half-tile work items (chosen by the number of heavy tiles otherwise)
+                emu.debug_set("tile_sum_half", half)
+                fused, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+                assert np.array_equal(fused, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "fused", half)
+            emu.debug_set("tile_sum_half", -1)
+            fused, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=1)
+            assert np.array_equal(fused, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "fused, no_prune")
+            emu.debug_set("collapse_fused", -1)
+            auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+            assert np.array_equal(auto, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "default")
+        # a breathing video: few heavy tiles (half-tile work items), pruned pairs in between, and the oracle's ROI
+        from respmon_amd import synth
+        v8 = synth.synth_breathing(24, 96, 160, seed=3)
+        fr = oracle.uint8_to_float(v8)
+        for (L, S) in [(6, 4), (5, 3)]:
+            emu.debug_set("collapse_fused", 0)
+            store, mm = emu.calibrate(fr, 10.0, levels=L, skip=S, flags=256)
+            emu.debug_set("collapse_fused", 1)
+            for half in (0, 1):
+                emu.debug_set("tile_sum_half", half)
+                fused, mm2 = emu.calibrate(fr, 10.0, levels=L, skip=S)
+                assert np.array_equal(fused, store) and tuple(mm) == tuple(mm2), (L, S, "breathing video", half)
+            emu.debug_set("tile_sum_half", -1)
+            assert emu.locate(fr, 10.0, levels=L, skip=S) == oracle.locate(fr, 10, pyramid_levels=L, skip_levels_at_top=S)
+            # frame shards: partial time sums of the store-less path equal the store path's
+            for world in (2, 3):
+                emu.debug_set("collapse_fused", 0)
+                r0, h0, m0 = emu.locate_sharded(fr, world, levels=L, skip=S, flags=256)
+                emu.debug_set("collapse_fused", 1)
+                r1, h1, m1 = emu.locate_sharded(fr, world, levels=L, skip=S)
+                assert r0 == r1 and np.array_equal(h0, h1) and tuple(m0) == tuple(m1), (L, S, world, "sharded")
+    finally:
+        emu.debug_set("collapse_fused", -1)
+        emu.debug_set("tile_sum_half", -1)
