@@ -87,7 +87,9 @@ struct DebugKnobs {
     int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
     int dc_split = 0;             // > 0: share (per mille) of the level-S rows the upper of exactly two segments takes (default 513)
-    int collapse_fused = -1;      // collapse passes without a value store (rm_tile_eval.h): -1 = where they apply by default (skip 3, 4), 0 = never, 1 = wherever TileEval can (skip 1 .. 4)
+    int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
+    int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
+    int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
     int tile_sum_half = -1;       // 0 / 1: k_tile_sum works on whole tiles / half tiles whatever the number of heavy tiles (-1: by that number)
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
 };
@@ -230,6 +232,8 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "store_slots") d.store_slots = value;
     else if (k == "collapse_fused") d.collapse_fused = (int)value;
     else if (k == "tile_sum_half") d.tile_sum_half = (int)value;
+    else if (k == "eval_fast") d.eval_fast = (int)value;
+    else if (k == "sum_sym") d.sum_sym = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
     return RM_OK;
 }
@@ -1280,7 +1284,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     // skip 3 / 4 (locate()'s default): the kept pairs are evaluated where they are summed, tile by tile, and nothing is stored
     // (rm_tile_eval.h); the flags that name a sum kernel of the store-based path keep that path (tests compare the two bit for bit)
     cp.fused = tile_eval_ok(g) && !(flags & (RM_FLAG_DENSE_SUM | RM_FLAG_SPARSE_SUM | RM_FLAG_TINY_STORE)) && ctx->dbg.store_slots <= 0 &&
-               (ctx->dbg.collapse_fused > 0 || (ctx->dbg.collapse_fused < 0 && sl.S >= 3));
+               ctx->dbg.collapse_fused > 0;
     if (cp.fused) { cap = 0; sp.cap_slots = 0; sp.mode = 0; }
     if (cap > 0) RM_TRY(ws(ctx, "value_store", (size_t)cap * CT_H * CT_W, &cp.store));
     ctx->dbg_pairs = npairs; ctx->dbg_cap = cap; ctx->dbg_mine = npairs_mine; ctx->dbg_mode = sp.mode; ctx->dbg_auto_dense = sp.auto_dense_ok;
@@ -1369,7 +1373,27 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
 #else
     if ((long long)egrid > npairs) egrid = (unsigned)npairs;
 #endif
-    hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp);
+    if (tile_eval_ok(g) && ctx->dbg.eval_fast) {
+        // the wave-private evaluator (rm_tile_eval.h): ~70 VGPRs and < 5 KB of LDS per single-wave workgroup -- 24 per CU stay resident
+        int cus = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        const unsigned fgrid = (unsigned)std::min<long long>(npairs, 24ll * cus);
+#else
+        const unsigned fgrid = egrid;
+#endif
+#define RM_EVAL_FAST(SS)                                                                                                              \
+        do {                                                                                                                          \
+            using FootE = TileFoot<SS, false>;                                                                                        \
+            hipLaunchKernelGGL((k_eval_pairs_fast<SS>), dim3(fgrid), dim3(64), sizeof(double) * FootE::TOTAL, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, \
+                               cp.slot_of, st, cp.store, sp);                                                                         \
+        } while (0)
+        switch (sl.S) { case 1: RM_EVAL_FAST(1); break; case 2: RM_EVAL_FAST(2); break; case 3: RM_EVAL_FAST(3); break; default: RM_EVAL_FAST(4); break; }
+#undef RM_EVAL_FAST
+        (void)cus;
+    } else {
+        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp);
+    }
     LAUNCH_CHECK();
     cp.valid = true;
     return RM_OK;
@@ -1398,7 +1422,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
-    if (cp.fused) {
+    auto launch_tile_sum = [&](int only_if_dense) -> int {
         // one workgroup of TS_NW waves per CU (the exchange takes most of a CU's LDS): the heavy tiles' items first, the workgroups
         // left without one fill the constant tiles
         int cus = 256;
@@ -1414,11 +1438,15 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
             const size_t shb = sizeof(double) * (size_t)exd + sizeof(int) * (size_t)cp.T;                                                \
             if (shb > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_tile_sum<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb)); \
             hipLaunchKernelGGL((k_tile_sum<SS>), dim3(nworkers), dim3(64 * TS_NW), shb, s, cp.cS, cp.g, cp.t0, cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr,  \
-                               heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, ctx->dbg.tile_sum_half);                     \
+                               heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, ctx->dbg.tile_sum_half, cp.sp, only_if_dense);          \
         } while (0)
         switch (cp.S) { case 1: RM_TILE_SUM(1); break; case 2: RM_TILE_SUM(2); break; case 3: RM_TILE_SUM(3); break; default: RM_TILE_SUM(4); break; }
 #undef RM_TILE_SUM
         LAUNCH_CHECK();
+        return RM_OK;
+    };
+    if (cp.fused) {
+        RM_TRY(launch_tile_sum(0));
         ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;
         return RM_OK;
     }
@@ -1443,8 +1471,15 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
 #else
         const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
 #endif
-        hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), 2 * sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
-                           cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, sp, unserved_dev);
+        if (cp.t0 == 0 && cp.t1 == cp.T && avg_T == cp.T && ctx->dbg.sum_sym) {
+            // the whole buffer: every unique frame loaded once and added on the way up and on the way down (rm_tile_eval.h)
+            const int nw2 = std::min(nworkers, 512);   // 220 VGPRs: two workgroups per CU stay resident
+            hipLaunchKernelGGL(k_masked_sum_sym, dim3(nw2), dim3(64 * MS_RQ), 2 * sizeof(int) * (size_t)sym_frames(cp.T), s, cp.T, cp.ntiles, cp.W, cp.H,
+                               cp.slot_of, cp.store, st, thr, heat_sum, tile_nkept, cp.sel_cnt, cp.heavy, nw2, sp, unserved_dev);
+        } else {
+            hipLaunchKernelGGL(k_masked_sum_tiles, dim3(nworkers), dim3(64 * MS_RQ), 2 * sizeof(int) * (size_t)cp.T, s, cp.t0, cp.t1, cp.T, cp.ntiles,
+                               cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum, avg_T, tile_nkept, cp.sel_cnt, cp.heavy, nworkers, sp, unserved_dev);
+        }
         LAUNCH_CHECK();
     }
     if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
@@ -1480,6 +1515,10 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
 #undef RM_DENSE_W
         LAUNCH_CHECK();
         }
+    } else if (may_dense && cp.S >= 3 && tile_eval_ok(cp.g) && !ctx->dbg.dense_rows && !ctx->dbg.dense_general) {
+        // deeper chains: every kept pair evaluated where it is summed, tile by tile (rm_tile_eval.h k_tile_sum); it looks at the
+        // selection itself when the sparse kernel was enqueued in front of it
+        RM_TRY(launch_tile_sum(sp.mode == 1 ? 0 : 1));
     } else if (may_dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
         // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts

@@ -142,6 +142,15 @@ __device__ __forceinline__ void te_step(const TileSetup<S, HALF> &ts, double *sl
     // buffer row p of level K - 1 <-> an odd virtual row for even p (the values of rows q, q + 1 of level K), an even one for odd p
     // (rows q, q + 1, q + 2): up_at() with the exact power-of-two scalings merged
     const int last = ts.lastrow[K - 1];
+    if (last >= NRD - 1) {   // (uniform) every buffer row lies inside the image: the common case, no selects
+#pragma unroll
+        for (int p = 0; p < NRD; ++p) {
+            const int q = p >> 1;
+            const double v = (p & 1) ? (hq[q] + hq[q + 1] * 6 + hq[q + 2]) * (1.0 / 64) : (hq[q] + hq[q + 1]) * (1.0 / 16);
+            if (lane < PD) dst[p * PD + lane] = v;
+        }
+        return;
+    }
     double prev = 0.0;
 #pragma unroll
     for (int p = 0; p < NRD; ++p) {
@@ -195,6 +204,7 @@ __device__ __forceinline__ void tile_eval(const TileSetup<S, HALF> &ts, double *
 template <int S>
 __global__ __launch_bounds__(64) void k_eval_c(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, CollapseState *st)
 {
+    RM_TRACE_SCOPE(5);
     using F = TileFoot<S, false>;
     HIP_DYNAMIC_SHARED(double, lds)
     const int lane = threadIdx.x;
@@ -236,6 +246,268 @@ __global__ __launch_bounds__(64) void k_eval_c(const double *cS, ChainGeom g, in
     }
 }
 
+// ---- the flat evaluation pass of the sparse path with the wave-private evaluator (k_eval_pairs' job, rm_kernels.h) ---------------------
+// One wave per listed pair, every SIMD of the chip busy whatever tile the pairs belong to: exact min / max from all evaluated pairs,
+// the values of the kept ones parked in their slot of the value store ([slot][row][column], 16 bytes per lane and row) for
+// k_masked_sum_tiles.  ~500 instructions per pair instead of ~2 800.
+template <int S>
+__global__ __launch_bounds__(64) void k_eval_pairs_fast(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, const unsigned int *list_b,
+                                                        int *slot_of, CollapseState *st, double *store, SumPlan sp)
+{
+    RM_TRACE_SCOPE(5);
+    using F = TileFoot<S, false>;
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int lane = threadIdx.x;
+    const unsigned first_idx = list_a[blockIdx.x];
+    const unsigned nA = st->n_list_a, nB = st->n_list_b;
+    const bool dense = sum_is_dense(st, sp);
+    const unsigned n = nA + (dense ? 0u : nB);
+    const double inf = __builtin_huge_val();
+    const double top_ub = st->top_ub;   // upper bound of `top` from the tile bounds (k_select_pairs)
+    const size_t fs = (size_t)g.h[S] * g.w[S];
+    const int H0 = g.h[0], W0 = g.w[0];
+    double mn = inf, mx = -inf;
+    for (unsigned c = blockIdx.x; c < n; c += gridDim.x) {
+        RM_TRACE_MARK(5, 0);
+        const unsigned raw_idx = c < nA ? (c == blockIdx.x ? first_idx : list_a[c]) : list_b[c - nA];
+        const unsigned idx = (unsigned)uniform((int)raw_idx);
+        const int slot = dense ? SLOT_PRUNED : uniform(slot_of[idx]);   // (needed after the chain: requested now)
+        const int u = idx / ntiles, tile = idx - u * ntiles;
+        const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+        RM_TRACE_MARK(5, 1);
+        TileSetup<S, false> ts;
+        tile_setup<S, false>(g, tx, ty, 0, lane, ts);
+        const double *src = cS + (size_t)u * fs;
+        double stg[F::PF];
+#pragma unroll
+        for (int p = 0; p < F::PF; ++p) stg[p] = src[ts.off_g[p]];
+        RM_TRACE_MARK(5, 2);
+        wave_sync();   // the previous pair's reads of the slice are behind us
+#pragma unroll
+        for (int p = 0; p < F::PF; ++p) if (lane + 64 * p < F::NST) lds[F::off(S) + lane + 64 * p] = stg[p];
+        wave_sync();
+        RM_TRACE_MARK(5, 3);
+        double v[16];
+        tile_eval<S, false>(ts, lds, lane, v);
+        RM_TRACE_MARK(5, 4);
+        double pmn = inf;   // minimum of this pair's tile
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (ts.Y0 + r < H0 && ts.X + o < W0) { const double x = v[8 * o + r]; pmn = (x < pmn) ? x : pmn; mx = (x > mx) ? x : mx; }
+        mn = (pmn < mn) ? pmn : mn;
+        if (slot != SLOT_PRUNED) {   // wave-uniform
+            pmn = wave_min(pmn);
+            // nothing of this tile can fall below top (top <= top_ub): every pixel adds `min`, exactly like a pruned pair --
+            // no values to park, and the sum pass never sees the frame
+            if (pmn >= top_ub) {
+                if (lane == 0) slot_of[idx] = SLOT_PRUNED;
+            } else {
+                // lane (column pair cp, row half rg): rows 8 rg .. 8 rg + 7 of the tile, columns 2 cp, 2 cp + 1: 16 bytes per row
+                F64Pair *d = reinterpret_cast<F64Pair *>(store + (size_t)slot * (CT_H * CT_W) + (size_t)(8 * (lane >> 5)) * CT_W + 2 * (lane & 31));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) d[r * (CT_W / 2)] = F64Pair{v[r], v[8 + r]};
+            }
+        }
+        RM_TRACE_MARK(5, 5);
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    RM_TRACE_MARK(5, 6);
+    if (lane == 0 && blockIdx.x < n) {
+        // non-returning atomics and NO load in front of them: a load here would wait (vmcnt) for the acknowledgement of the value
+        // stores above, 4-15 us at 1080p x 256 (workgroup timelines, profiles/r04) -- the wave may end while its stores are in flight
+        const int sp_ = blockIdx.x & (NSTRIPE - 1);
+        atomicMin(&st->min_keys[sp_], f64_key(mn));
+        atomicMax(&st->max_keys[sp_], f64_key(mx));
+    }
+}
+
+// ---- the masked time sum of the sparse path over the WHOLE buffer, unique frames loaded once (k_masked_sum_tiles' job) ------------------
+//   heat[y, x] = (1 / T) sum_t (raw[t] >= top ? min : raw[t]),  t = 0 .. T - 1 in order            (transforms.py:184-192, base.py:562)
+// The band-passed signal is even in time (rm_kernels.h sym_frame): frame t > T / 2 is frame T - t again, so the time-ordered walk of a
+// pixel visits the tile's kept UNIQUE frames twice -- ascending, then descending.  k_masked_sum_tiles fetched every visit (16 loads per
+// batch, one memory round trip per batch: 4-7 dependent round trips for the heaviest tile of the synthetic stream = 21 us).  Here a
+// thread requests the values of up to MS2_B unique frames of its pixel TOGETHER (one round trip), adds them on the way up and again,
+// from the same registers, on the way down; frame numbers and slots travel as one value per LANE and are read with v_readlane at
+// compile-time positions.  More than MS2_B kept unique frames: batches (the last batch of the way up is the first of the way down).
+// Same additions in the same order as k_masked_sum_tiles: bit-identical.  Work items, the constant fill and the heatmap's extrema as
+// there.  Dynamic LDS: s_ku[Th], s_ks[Th].
+constexpr int MS2_B = 48;
+
+__device__ __forceinline__ int lane_value(int v, int b)   // v of lane b (b: compile-time after unrolling), wave-uniform
+{
+#ifdef RM_HIPEMU
+    return __shfl(v, b);
+#else
+    return __builtin_amdgcn_readlane(v, b);
+#endif
+}
+
+__global__ __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
+                                                               double threshold, double *heat, int *tile_nkept, const int *sel_cnt,
+                                                               const unsigned int *heavy, int nworkers, SumPlan sp, int *unserved_host)
+{
+    RM_TRACE_SCOPE(6);
+    HIP_DYNAMIC_SHARED(int, s_ku)     // kept unique frames of the tile, ascending; then their slots
+    const int Th = sym_frames(T);
+    int *s_ks = s_ku + Th;
+    __shared__ int s_wcnt[MS_RQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int tiles_x = (W0 + CT_W - 1) / CT_W;
+    // requested before the state: the tile of this workgroup's first item and its first slot_of column
+    const int tile0 = (int)(heavy[blockIdx.x / MS_Q] % (unsigned)ntiles);
+    int slot0 = SLOT_PRUNED;
+    if (tid < Th) slot0 = slot_of[(size_t)tid * ntiles + tile0];
+    const int nitems = (int)st->n_heavy * MS_Q;
+    if (sum_is_dense(st, sp)) {   // (uniform over the grid) the value store overflowed: the caller takes the sum another way
+        if (unserved_host && blockIdx.x == 0 && tid == 0) *unserved_host = 1;
+        return;
+    }
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
+    if (blockIdx.x == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    const double cnt = (double)T;
+    const int t_up_end = T / 2 + 1;              // the way up: t = u = 0 .. T / 2
+    const int u_down = (T + 1) / 2 - 1;          // the way down starts at t = T / 2 + 1, i.e. u = T - t = u_down, and ends at u = 1
+    RM_TRACE_MARK(6, 0);
+    for (int item = (int)blockIdx.x; item < nitems; item += nworkers) {
+        const bool first = item == (int)blockIdx.x;
+        const int tile = first ? tile0 : (int)heavy[item / MS_Q], q = item % MS_Q;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        // the tile's kept unique frames, ascending (ballot + prefix popcount, 256 frames per round)
+        int m = 0;
+        for (int c0 = 0; c0 < Th; c0 += 64 * MS_RQ) {
+            const int u = c0 + tid;
+            int slot = SLOT_PRUNED;
+            if (first && c0 == 0) slot = slot0;
+            else if (u < Th) slot = slot_of[(size_t)u * ntiles + tile];
+            const bool kept = slot != SLOT_PRUNED;
+            const unsigned long long mk = __ballot(kept);
+            if (lane == 0) s_wcnt[wave] = __popcll(mk);
+            __syncthreads();
+            int off = m, tot = 0;
+#pragma unroll
+            for (int w = 0; w < MS_RQ; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
+            if (kept) { const int pos = off + __popcll(mk & ((1ull << lane) - 1ull)); s_ku[pos] = u; s_ks[pos] = slot; }
+            m += tot;
+            __syncthreads();
+        }
+        RM_TRACE_MARK(6, 1);
+        if (tid == 0 && q == 0 && tile_nkept) {   // kept frames in time order (0: every pixel of the tile ends up as the same constant)
+            int n_t = 0;
+            for (int i = 0; i < m; ++i) { const int u = s_ku[i]; n_t += 1 + ((u >= 1 && u <= u_down) ? 1 : 0); }
+            tile_nkept[tile] = n_t;
+        }
+        const int x = tx * CT_W + lane;
+        const int row = q * MS_RQ + wave, y = ty * CT_H + row;
+        const bool active = x < W0 && y < H0;
+        const double *mine = store + (size_t)row * CT_W + lane;   // + slot * 1024: this pixel in the pair parked in `slot`
+        const int nb = (m + MS2_B - 1) / MS2_B;
+        double acc = 0.0;
+        int t_done = 0;
+        double v[MS2_B];
+        int ku = 0x7fffffff, ks = 0;     // lane l: frame number and slot of the batch's l-th kept frame
+        auto load_batch = [&](int bi) __attribute__((always_inline)) {
+            const int i = bi * MS2_B + lane;
+            ku = i < m ? s_ku[i] : 0x7fffffff;
+            ks = i < m ? s_ks[i] : 0;
+#pragma unroll
+            for (int b = 0; b < MS2_B; ++b) {
+                const int slot = lane_value(ks, b);
+                v[b] = (bi * MS2_B + b < m && active) ? mine[(size_t)slot * (CT_H * CT_W)] : 0.0;
+            }
+        };
+        // the way up: t = u
+        for (int bi = 0; bi < nb; ++bi) {
+            load_batch(bi);
+            RM_TRACE_MARK(6, 2);
+#pragma unroll
+            for (int b = 0; b < MS2_B; ++b) {
+                if (bi * MS2_B + b < m) {   // (uniform)
+                    const int t_stop = lane_value(ku, b);               // frames [t_done, t_stop) are pruned
+                    for (int t = t_done; t < t_stop; ++t) acc = acc + min_val;
+                    acc = acc + ((v[b] >= top) ? min_val : v[b]);
+                    t_done = t_stop + 1;
+                }
+            }
+        }
+        for (int t = t_done; t < t_up_end; ++t) acc = acc + min_val;
+        t_done = t_up_end;
+        RM_TRACE_MARK(6, 3);
+        // the way down: t = T - u for the kept u in [1, u_down], largest first (the batch in registers is the last one of the way up)
+        for (int bi = nb - 1; bi >= 0; --bi) {
+            if (bi != nb - 1) load_batch(bi);
+#pragma unroll
+            for (int b = MS2_B - 1; b >= 0; --b) {
+                if (bi * MS2_B + b < m) {   // (uniform)
+                    const int u = lane_value(ku, b);
+                    if (u >= 1 && u <= u_down) {
+                        const int t_stop = T - u;
+                        for (int t = t_done; t < t_stop; ++t) acc = acc + min_val;
+                        acc = acc + ((v[b] >= top) ? min_val : v[b]);
+                        t_done = t_stop + 1;
+                    }
+                }
+            }
+        }
+        for (int t = t_done; t < T; ++t) acc = acc + min_val;
+        RM_TRACE_MARK(6, 12);
+        double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+        if (active) {
+            const double a = acc / cnt;          // base.py:562: np.average = sum / T
+            heat[(size_t)y * W0 + x] = a;
+            hmn = a; hmx = a;
+        }
+        block_minmax(hmn, hmx);                  // the heatmap's extrema for base.py:563
+        if (tid == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp_ = blockIdx.x & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+        }
+        RM_TRACE_MARK(6, 13);
+        __syncthreads();   // s_ku is rewritten by the next item
+    }
+    // FILL: by the workgroups without items when there are any, by every workgroup otherwise (as in k_masked_sum_tiles)
+    const int idle = nworkers - min(nitems, nworkers);
+    const int nfill = idle > 0 ? idle : nworkers;
+    const int fid = idle > 0 ? (int)blockIdx.x - nitems : (int)blockIdx.x;
+    if (fid < 0) return;
+    double lead = 0.0;
+    for (int t = 0; t < T; ++t) lead = lead + min_val;
+    const double fv = lead / cnt;
+    bool any = false;
+    constexpr int FU = 4;    // tiles whose kept-pair counts are requested together
+    for (int base = fid; base < ntiles; base += FU * nfill) {
+        int cntk[FU];
+#pragma unroll
+        for (int k = 0; k < FU; ++k) { const int tile = base + k * nfill; cntk[k] = tile < ntiles ? sel_cnt[tile] : 1; }
+#pragma unroll
+        for (int k = 0; k < FU; ++k) {
+            const int tile = base + k * nfill;
+            if (cntk[k] != 0) continue;               // past the end, or a worker sums this tile
+            any = true;
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int x = tx * CT_W + lane, y0 = ty * CT_H;
+            if (x < W0) {
+#pragma unroll
+                for (int j = 0; j < CT_H / MS_RQ; ++j) {
+                    const int y = y0 + wave * (CT_H / MS_RQ) + j;
+                    if (y < H0) heat[(size_t)y * W0 + x] = fv;
+                }
+            }
+            if (tid == 0 && tile_nkept) tile_nkept[tile] = 0;     // 0: every pixel of the tile is the same constant
+        }
+    }
+    if (any && tid == 0) {
+        const unsigned long long kv = f64_key(fv);
+        const int sp_ = blockIdx.x & (NSTRIPE - 1);
+        if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kv);
+        if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kv);
+    }
+}
+
 // ---- masked time sum, tile by tile ----------------------------------------------------------------------------------------------------
 // Work item i = (heavy tile, half) [HALF] or one heavy tile; a workgroup of TS_NW waves takes the items i = blockIdx.x, + nworkers, ...
 // The workgroups left without an item fill the tiles without kept pairs with their constant (as k_masked_sum_tiles did).
@@ -258,7 +530,6 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
     constexpr int NV = F::NV, NW = TS_NW;
     constexpr int WSTRIDE = tile_sum_exchange_doubles<S, HALF>() / NW;   // doubles per wave of the exchange (>= NV * 64 and >= the slice)
     constexpr int NSUB = HALF ? 2 : 1;
-    static_assert(NV * 64 % (64 * NW) == 0 || NV * 64 < 64 * NW, "values per thread of the accumulation");
     int *s_kt = reinterpret_cast<int *>(lds + tile_sum_exchange_doubles<S, false>());   // behind the (full-tile sized) exchange
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int H0 = g.h[0], W0 = g.w[0];
@@ -269,9 +540,9 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
     if (blockIdx.x == 0 && tid == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
     const double cnt = (double)avg_T;
     const size_t fs = (size_t)g.h[S] * g.w[S];
-    double *sl = lds + (size_t)wave * WSTRIDE;       // this wave's footprint slice == its part of the exchange
-    // accumulation: value v (0 .. NV - 1) of lane l sits at ex[frame][v * 64 + l]; thread (wave, lane) owns the values v = wave + NW * j
-    constexpr int QA = (NV + NW - 1) / NW;            // running sums per thread (NV = 16: 1; NV = 8: waves 0 .. 7 own one, the others none)
+    constexpr int NBUF = HALF ? 2 : 1;               // exchange buffers (both granularities fill the same LDS)
+    static_assert(NV <= NW, "one running sum per thread: value v of lane l is owned by thread (wave v, lane l)");
+    RM_TRACE_MARK(6, 0);
     for (int item = (int)blockIdx.x; item < nitems; item += nworkers) {
         const bool first = item == (int)blockIdx.x;
         const int tile = first ? tile0 : (int)heavy[item / NSUB], hsel = HALF ? item % NSUB : 0;
@@ -295,11 +566,11 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
             __syncthreads();
         }
         if (tid == 0 && hsel == 0 && tile_nkept) tile_nkept[tile] = nkept;
+        RM_TRACE_MARK(6, 1);
         TileSetup<S, HALF> ts;
         tile_setup<S, HALF>(g, tx, ty, hsel, lane, ts);
-        double acc[QA];
-#pragma unroll
-        for (int j = 0; j < QA; ++j) acc[j] = 0.0;
+        RM_TRACE_MARK(6, 2);
+        double acc = 0.0;                             // this thread's running sum: value `wave` of lane `lane` (waves >= NV own none)
         int t_done = t_first;
         // this wave's frame of the first round is requested now; inside the loop the next round's travels while this one is evaluated
         double stg[F::PF];
@@ -310,7 +581,12 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
             for (int p = 0; p < F::PF; ++p) stg[p] = src[ts.off_g[p]];
         };
         if (nkept > 0) fetch(wave);
-        for (int r0 = 0; r0 < nkept; r0 += NW) {
+        int round = 0;
+        for (int r0 = 0; r0 < nkept; r0 += NW, ++round) {
+            // half tiles: TWO exchange buffers, so that the additions of round r overlap the evaluation of round r + 1 and one
+            // barrier per round is enough (a buffer is rewritten two rounds later, behind the next round's barrier)
+            double *exb = lds + (size_t)(NBUF == 2 ? (round & 1) : 0) * NW * WSTRIDE;
+            double *sl = exb + (size_t)wave * WSTRIDE;   // this wave's footprint slice == its part of the exchange
 #pragma unroll
             for (int p = 0; p < F::PF; ++p) if (lane + 64 * p < F::NST) sl[F::off(S) + lane + 64 * p] = stg[p];
             fetch(r0 + NW + wave);
@@ -323,37 +599,35 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
             __syncthreads();
             const int nf = min(NW, nkept - r0);
             if (wave < NV) {
-                for (int f = 0; f < nf; ++f) {
-                    const int t_stop = uniform(s_kt[r0 + f]);              // frames [t_done, t_stop) are pruned
-                    for (int t = t_done; t < t_stop; ++t) {
+                // the round's values of this thread's pixel and the frames they belong to, requested together; then the chain of additions
+                double ev[NW];
+                int tk[NW];
 #pragma unroll
-                        for (int j = 0; j < QA; ++j) acc[j] = acc[j] + min_val;
+                for (int f = 0; f < NW; ++f) { tk[f] = s_kt[min(r0 + f, nkept - 1)]; ev[f] = exb[(size_t)f * WSTRIDE + wave * 64 + lane]; }
+#pragma unroll
+                for (int f = 0; f < NW; ++f) {
+                    if (f < nf) {   // (uniform)
+                        const int t_stop = uniform(tk[f]);              // frames [t_done, t_stop) are pruned
+                        for (int t = t_done; t < t_stop; ++t) acc = acc + min_val;
+                        acc = acc + ev[f];
+                        t_done = t_stop + 1;
                     }
-                    const double *exf = lds + (size_t)f * WSTRIDE + lane;
-#pragma unroll
-                    for (int j = 0; j < QA; ++j) if (wave + NW * j < NV) acc[j] = acc[j] + exf[(wave + NW * j) * 64];
-                    t_done = t_stop + 1;
                 }
             }
-            __syncthreads();   // (the exchange and the slices are rewritten next round)
+            if (NBUF == 1) __syncthreads();   // (one buffer: the exchange and the slices are rewritten next round)
+            RM_TRACE_MARK(6, 3 + (round < 9 ? round : 9));
         }
-        for (int t = t_done; t < t_end; ++t) {
-#pragma unroll
-            for (int j = 0; j < QA; ++j) acc[j] = acc[j] + min_val;
-        }
+        for (int t = t_done; t < t_end; ++t) acc = acc + min_val;
+        RM_TRACE_MARK(6, 13);
         // base.py:562: np.average = sum / T when the whole buffer was summed here; the heatmap's extrema for base.py:563
         double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
-#pragma unroll
-        for (int j = 0; j < QA; ++j) {
-            const int vi = wave + NW * j;
-            if (vi < NV) {
-                const int o = vi / (NV / 2), r = vi - o * (NV / 2);
-                const int y = ts.Y0 + r, x = ts.X + o;
-                if (y < H0 && x < W0) {
-                    const double a = avg_T > 0 ? acc[j] / cnt : acc[j];
-                    heat_sum[(size_t)y * W0 + x] = a;
-                    hmn = (a < hmn) ? a : hmn; hmx = (a > hmx) ? a : hmx;
-                }
+        if (wave < NV) {
+            const int o = wave / (NV / 2), r = wave - o * (NV / 2);
+            const int y = ts.Y0 + r, x = ts.X + o;
+            if (y < H0 && x < W0) {
+                const double a = avg_T > 0 ? acc / cnt : acc;
+                heat_sum[(size_t)y * W0 + x] = a;
+                hmn = a; hmx = a;
             }
         }
         if (avg_T > 0) {
@@ -365,6 +639,7 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
                 if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
             }
         }
+        RM_TRACE_MARK(6, 14);
         __syncthreads();   // s_kt is rewritten by the next item
     }
     // FILL: by the workgroups without items when there are any, by every workgroup otherwise
@@ -407,11 +682,15 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
 template <int S>
 __global__ __launch_bounds__(64 * TS_NW) void k_tile_sum(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles, const int *slot_of,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T, int *tile_nkept,
-                                                          const int *sel_cnt, const unsigned int *heavy, int nworkers, int force_half)
+                                                          const int *sel_cnt, const unsigned int *heavy, int nworkers, int force_half, SumPlan sp,
+                                                          int only_if_dense)
 {
+    RM_TRACE_SCOPE(6);
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ int s_wcnt[TS_NW];
     const int tid = threadIdx.x;
+    // enqueued behind the sparse sum kernel as its stand-in for a selection the value store cannot hold: that kernel took the sum
+    if (only_if_dense && !sum_is_dense(st, sp)) return;   // (uniform over the grid)
     // requested before the state: the tile of this workgroup's first item under either granularity (heavy[] is valid memory whatever
     // n_heavy turns out to be) and its first slot_of column
     const int tile_a = (int)(heavy[blockIdx.x] % (unsigned)ntiles), tile_b = (int)(heavy[blockIdx.x >> 1] % (unsigned)ntiles);

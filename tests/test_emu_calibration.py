@@ -570,7 +570,20 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
         for (T, H, W, L, S) in cases:
             v = rng.random((T, H, W))
             emu.debug_set("collapse_fused", 0)
+            emu.debug_set("eval_fast", 0)            # the generic chain in LDS (k_eval_pairs): the reference of both newer forms
+            emu.debug_set("sum_sym", 0)              # ... and the sum that fetches every visit of a frame (k_masked_sum_tiles)
             store, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            emu.debug_set("sum_sym", 1)              # unique frames loaded once, added on the way up and down (k_masked_sum_sym)
+            sym, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            assert np.array_equal(sym, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_sym")
+            emu.debug_set("sum_sym", 0)
+            tiny, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=4)   # an 8-slot store overflows: k_tile_sum stands in at skip >= 3
+            assert np.array_equal(tiny, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "store overflow")
+            emu.debug_set("eval_fast", 1)            # the same flat pass with the wave-private evaluator (k_eval_pairs_fast)
+            fast, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            assert np.array_equal(fast, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_eval_pairs_fast")
+            fast, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256 | 1)
+            assert np.array_equal(fast, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_eval_pairs_fast, no_prune")
             emu.debug_set("collapse_fused", 1)
             for half in (0, 1):     # whole-tile / half-tile work items (chosen by the number of heavy tiles otherwise)
                 emu.debug_set("tile_sum_half", half)
@@ -579,9 +592,19 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             emu.debug_set("tile_sum_half", -1)
             fused, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=1)
             assert np.array_equal(fused, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "fused, no_prune")
-            emu.debug_set("collapse_fused", -1)
+            emu.debug_set("collapse_fused", 0)
             auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
             assert np.array_equal(auto, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "default")
+        # more kept unique frames than one batch of k_masked_sum_sym holds (48): several batches up, the same ones down again
+        for (T, H, W, L, S) in [(130, 20, 70, 4, 2), (101, 33, 40, 5, 3)]:
+            v = rng.random((T, H, W))
+            emu.debug_set("collapse_fused", 0)
+            emu.debug_set("sum_sym", 0)
+            store, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            emu.debug_set("sum_sym", 1)
+            sym, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            emu.debug_set("sum_sym", 0)
+            assert np.array_equal(sym, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_sym, batches")
         # a breathing video: few heavy tiles (half-tile work items), pruned pairs in between, and the oracle's ROI
         from respmon_amd import synth
         v8 = synth.synth_breathing(24, 96, 160, seed=3)
@@ -604,5 +627,7 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
                 r1, h1, m1 = emu.locate_sharded(fr, world, levels=L, skip=S)
                 assert r0 == r1 and np.array_equal(h0, h1) and tuple(m0) == tuple(m1), (L, S, world, "sharded")
     finally:
-        emu.debug_set("collapse_fused", -1)
+        emu.debug_set("collapse_fused", 0)
         emu.debug_set("tile_sum_half", -1)
+        emu.debug_set("eval_fast", 1)
+        emu.debug_set("sum_sym", 0)

@@ -700,7 +700,6 @@ def test_dense_sum_equals_sparse_path(hip, oracle):
     # config P's video: sparse stays sparse, and the forced dense kernel agrees
     T, H, W = 256, 1080, 1920
     buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=1234)).cuda()
-    device.debug_set("collapse_fused", 0)       # (the store-based path; skip 4 takes the store-less one by default, rm_tile_eval.h)
     a = dist.hip_calibrate(buf, 10)
     torch.cuda.synchronize()
     b = dist.hip_calibrate(buf, 10)
@@ -711,13 +710,18 @@ def test_dense_sum_equals_sparse_path(hip, oracle):
     assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "dense"
     device.debug_set("store_slots", 0)
     assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "sparse"
-    device.debug_set("collapse_fused", -1)
-    # the default at skip 4: no value store, kept pairs evaluated where they are summed -- whole tiles or half tiles, same bits
+    # the store-less passes (rm_tile_eval.h): kept pairs evaluated where they are summed -- whole tiles or half tiles, same bits
+    device.debug_set("collapse_fused", 1)
     for half in (-1, 0, 1):
         device.debug_set("tile_sum_half", half)
         assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "fused", half
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=1), a), ("no_prune", half)
     device.debug_set("tile_sum_half", -1)
+    device.debug_set("collapse_fused", 0)
+    # ... which are also what stands in for an overflowing value store at skip >= 3 (k_tile_sum behind the sparse kernel)
+    device.debug_set("store_slots", 1000)
+    assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "dense"
+    device.debug_set("store_slots", 0)
 
 
 def test_fused_collapse_equals_store_path(hip, oracle):
@@ -729,19 +733,28 @@ def test_fused_collapse_equals_store_path(hip, oracle):
     try:
         for n, (T, H, W, L, S) in enumerate([(5, 64, 96, 6, 4), (3, 67, 131, 5, 3), (4, 135, 240, 6, 4), (6, 48, 64, 3, 1), (8, 360, 640, 4, 2),
                                              (16, 270, 480, 9, 4), (4, 540, 1936, 8, 4), (3, 300, 2000, 6, 3), (7, 700, 1300, 5, 3),
-                                             (2, 33, 70, 6, 4), (3, 17, 129, 5, 3), (5, 1080, 1920, 9, 4), (3, 31, 193, 7, 4)]):
+                                             (2, 33, 70, 6, 4), (3, 17, 129, 5, 3), (5, 1080, 1920, 9, 4), (3, 31, 193, 7, 4),
+                                             (130, 40, 70, 4, 2), (101, 33, 140, 5, 3), (256, 64, 128, 6, 4)]):
             dt = (np.float64, np.uint8, np.float32, np.float16)[n % 4]
             v = (rng.random((T, H, W)) * 255).astype(np.uint8) if dt == np.uint8 else rng.random((T, H, W)).astype(dt)
             buf = torch.from_numpy(v).cuda()
             kw = dict(pyramid_levels=L, skip_levels_at_top=S)
             device.debug_set("collapse_fused", 0)
+            device.debug_set("eval_fast", 0)         # the generic chain in LDS (k_eval_pairs): the reference of both newer forms
+            device.debug_set("sum_sym", 0)           # ... and the sum that fetches every visit of a frame (k_masked_sum_tiles)
             store = dist.hip_calibrate(buf, 10, flags=256, **kw)
+            device.debug_set("sum_sym", 1)           # unique frames loaded once, added on the way up and down (k_masked_sum_sym)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=256, **kw), store), (dt, T, H, W, L, S, "k_masked_sum_sym")
+            device.debug_set("sum_sym", 0)
+            device.debug_set("eval_fast", 1)         # the same flat pass with the wave-private evaluator (k_eval_pairs_fast)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=256, **kw), store), (dt, T, H, W, L, S, "k_eval_pairs_fast")
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=256 | 1, **kw), store), (dt, T, H, W, L, S, "k_eval_pairs_fast, no_prune")
             device.debug_set("collapse_fused", 1)
             for half in (0, 1, -1):
                 device.debug_set("tile_sum_half", half)
                 assert torch.equal(dist.hip_calibrate(buf, 10, **kw), store), (dt, T, H, W, L, S, half)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=1, **kw), store), (dt, T, H, W, L, S, "no_prune")
-        device.debug_set("collapse_fused", -1)
+        device.debug_set("collapse_fused", 1)
         v8 = synth.synth_breathing(64, 270, 480, seed=5)
         fr = oracle.uint8_to_float(v8)
         buf = torch.from_numpy(fr).cuda()
@@ -749,12 +762,14 @@ def test_fused_collapse_equals_store_path(hip, oracle):
             heat = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
             device.debug_set("collapse_fused", 0)
             store = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)
-            device.debug_set("collapse_fused", -1)
+            device.debug_set("collapse_fused", 1)
             assert torch.equal(heat, store)
             assert dist.hip_heatmap_to_roi(heat, 20) == oracle.locate(fr, 10, pyramid_levels=L, skip_levels_at_top=S)
     finally:
-        device.debug_set("collapse_fused", -1)
+        device.debug_set("collapse_fused", 0)
         device.debug_set("tile_sum_half", -1)
+        device.debug_set("eval_fast", 1)
+        device.debug_set("sum_sym", 0)
 
 
 def test_filter_first_per_level_equals_fused(hip):

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 NAMES = {0: "k_down_chain", 1: "k_small_pyramid", 2: "k_temporal_mfma", 3: "k_small_filter_first (or k_small_collapse_bounds)", 4: "k_select_pairs",
-         5: "k_eval_pairs", 6: "k_masked_sum_tiles", 7: "k_heat_to_u8", 8: "k_extra8", 9: "k_extra9"}
+         5: "k_eval_pairs | k_eval_c", 6: "k_masked_sum_tiles | k_tile_sum", 7: "k_heat_to_u8", 8: "k_extra8", 9: "k_extra9"}
 KERNELS, BLOCKS = 16, 20480
 
 
@@ -27,10 +27,11 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "trace"))
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="rm_debug_set switches of the traced context")
     a = ap.parse_args()
     import torch
     from respmon_amd import _capi, synth
-    _capi.LIB_PATH = os.path.join(ROOT, "respmon_amd", "csrc", "librespmon_hip_trace.so")
+    _capi.LIB_PATH = os.path.join(ROOT, "respmon_amd", "csrc", os.environ.get("RM_TRACE_LIB", "librespmon_hip_trace.so"))
     lib = _capi.load()
     lib.rm_trace_start.restype = ctypes.c_int
     lib.rm_trace_read.restype = ctypes.c_int
@@ -45,6 +46,10 @@ def main():
         buf[t0:t0 + 16] = (torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)).to(tdt)
     from respmon_amd.base import _Backend
     be = _Backend()
+    from respmon_amd import device
+    for kv in a.debug_set:
+        k, v = kv.split("=", 1)
+        lib.rm_debug_set(device.ctx(), k.encode(), int(v))
 
     def step():
         return be.locate(buf, 10, 0.1, 1.0, 500, L, S, 0.7, 20, 0)
