@@ -88,6 +88,7 @@ struct DebugKnobs {
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
     int dc_split = 0;             // > 0: share (per mille) of the level-S rows the upper of exactly two segments takes (default 513)
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
+    int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
     int tile_sum_half = -1;       // 0 / 1: k_tile_sum works on whole tiles / half tiles whatever the number of heavy tiles (-1: by that number)
@@ -234,6 +235,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "tile_sum_half") d.tile_sum_half = (int)value;
     else if (k == "eval_fast") d.eval_fast = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
+    else if (k == "sum_rows") d.sum_rows = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
     return RM_OK;
 }
@@ -1386,13 +1388,13 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
         do {                                                                                                                          \
             using FootE = TileFoot<SS, false>;                                                                                        \
             hipLaunchKernelGGL((k_eval_pairs_fast<SS>), dim3(fgrid), dim3(64), sizeof(double) * FootE::TOTAL, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, \
-                               cp.slot_of, st, cp.store, sp);                                                                         \
+                               cp.slot_of, st, cp.store, sp, Th);                                                                     \
         } while (0)
         switch (sl.S) { case 1: RM_EVAL_FAST(1); break; case 2: RM_EVAL_FAST(2); break; case 3: RM_EVAL_FAST(3); break; default: RM_EVAL_FAST(4); break; }
 #undef RM_EVAL_FAST
         (void)cus;
     } else {
-        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp);
+        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp, Th);
     }
     LAUNCH_CHECK();
     cp.valid = true;
@@ -1471,7 +1473,21 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
 #else
         const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
 #endif
-        if (cp.t0 == 0 && cp.t1 == cp.T && avg_T == cp.T && ctx->dbg.sum_sym) {
+        if (cp.t0 == 0 && cp.t1 == cp.T && avg_T == cp.T && ctx->dbg.sum_rows) {
+            // the whole buffer: one wave per (heavy tile, row), the kept unique frames' values staged by LDS-DMA (rm_tile_eval.h)
+            const size_t shr = sizeof(double) * MSR_CHUNK * 64 + 2 * sizeof(int) * (size_t)sym_frames(cp.T);
+#ifdef RM_HIPEMU
+            const int nw3 = std::min(cp.ntiles * CT_H, 40);
+#else
+            // one resident round: what the LDS footprint lets a CU hold (a queued wave starts its chain of round trips late)
+            int cus3 = 256;
+            HIP_TRY(hipDeviceGetAttribute(&cus3, hipDeviceAttributeMultiprocessorCount, ctx->device));
+            const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)160 * 1024) / (shr + 512)));
+            const int nw3 = std::min(cp.ntiles * CT_H, per_cu3 * cus3);
+#endif
+            hipLaunchKernelGGL(k_masked_sum_rows, dim3(nw3), dim3(64), shr, s, cp.T, cp.ntiles, cp.W, cp.H, cp.slot_of, cp.store, st, thr, heat_sum,
+                               tile_nkept, cp.sel_cnt, cp.heavy, nw3, sp, unserved_dev);
+        } else if (cp.t0 == 0 && cp.t1 == cp.T && avg_T == cp.T && ctx->dbg.sum_sym) {
             // the whole buffer: every unique frame loaded once and added on the way up and on the way down (rm_tile_eval.h)
             const int nw2 = std::min(nworkers, 512);   // 220 VGPRs: two workgroups per CU stay resident
             hipLaunchKernelGGL(k_masked_sum_sym, dim3(nw2), dim3(64 * MS_RQ), 2 * sizeof(int) * (size_t)sym_frames(cp.T), s, cp.T, cp.ntiles, cp.W, cp.H,

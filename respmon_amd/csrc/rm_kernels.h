@@ -95,6 +95,11 @@ __host__ __device__ __forceinline__ bool sym_in_range(int u, int T, int t0, int 
     return (u >= t0 && u < t1) || (u > 0 && T - u >= t0 && T - u < t1);
 }
 
+// slot_of[] (which pairs the masked time sum keeps, k_select_pairs) is TILE-major -- [tile][unique frame] -- so that the sum kernels,
+// which walk the frames of one tile, find them in a few cache lines (frame-major: one line per frame, 129 scattered lines per tile
+// and reader at 1080p x 256); the pair index of the lists and bounds stays u * ntiles + tile
+__host__ __device__ __forceinline__ size_t slot_index(int u, int tile, int Th) { return (size_t)tile * Th + u; }
+
 // widening loads; uint8 applies uint8_to_float's  k * (1./255)  (transforms.py:20-23)
 __device__ __forceinline__ double load_px(const uint8_t *p, size_t i) { return (double)p[i] * (1.0 / 255); }
 __device__ __forceinline__ double load_px(const __half *p, size_t i) { return (double)__half2float(p[i]); }
@@ -1640,7 +1645,7 @@ __global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const do
         const int u = u0 + SEL_PH * k;
         const unsigned int i = (unsigned)u * (unsigned)ntiles + (unsigned)tile;
         const bool isC = (fC >> k) & 1u, isD = (fD >> k) & 1u;
-        slot_of[i] = isD ? (int)oD : SLOT_PRUNED;
+        slot_of[slot_index(u, tile, Th)] = isD ? (int)oD : SLOT_PRUNED;
         if (isD) ++oD;
         if (isC) list_a[oA++] = i;
         else if (isD) list_b[oB++] = i;
@@ -1777,7 +1782,7 @@ __global__ __launch_bounds__(64) void k_ff_collapse(const double *xS, const doub
 // fall below `top` (list_a's kept pairs and all of list_b) are parked in their slot of `store` ([slot][row][lane], coalesced) for
 // the masked time sum.  On the dense path (sum_is_dense) list_b is not touched and nothing is stored.
 __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, const unsigned int *list_b,
-                                                   int *slot_of, CollapseState *st, double *store, SumPlan sp)
+                                                   int *slot_of, CollapseState *st, double *store, SumPlan sp, int Th)
 {
     RM_TRACE_SCOPE(5);
     HIP_DYNAMIC_SHARED(double, lds)
@@ -1795,8 +1800,8 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
         RM_TRACE_MARK(5, 0);
         const unsigned raw_idx = c < nA ? (c == blockIdx.x ? first_idx : list_a[c]) : list_b[c - nA];
         const unsigned idx = (unsigned)uniform((int)raw_idx);   // wave-uniform: the tile geometry stays in scalar registers
-        const int slot = dense ? SLOT_PRUNED : uniform(slot_of[idx]);   // (needed after the chain: requested now)
         const int u = idx / ntiles, tile = idx - u * ntiles;
+        const int slot = dense ? SLOT_PRUNED : uniform(slot_of[slot_index(u, tile, Th)]);   // (needed after the chain: requested now)
         const Region R0 = tile_region(g, tile, 0), R1 = tile_region(g, tile, 1);
         RM_TRACE_MARK(5, 1);
         chain_to_level1(g, tile, cS + (size_t)u * g.h[g.S] * g.w[g.S], lds);
@@ -1818,7 +1823,7 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
             // nothing of this tile can fall below top (top <= top_ub): every pixel adds `min`, exactly like a pruned pair --
             // no values to park, and the sum pass never sees the frame
             if (pmn >= top_ub) {
-                if (lane == 0) slot_of[idx] = SLOT_PRUNED;
+                if (lane == 0) slot_of[slot_index(u, tile, Th)] = SLOT_PRUNED;
             } else if (x <= R0.x1) {
                 double *d = store + (size_t)slot * (CT_H * CT_W) + lane;
 #pragma unroll
@@ -1906,7 +1911,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
     // first slot_of column (speculatively: heavy[] and slot_of[] are valid memory whatever n_heavy turns out to be)
     const int tile0 = (int)(heavy[blockIdx.x / MS_Q] % (unsigned)ntiles);
     int slot0 = SLOT_PRUNED;
-    if (t_first + tid < t_end) slot0 = slot_of[(size_t)sym_frame(t_first + tid, T) * ntiles + tile0];
+    if (t_first + tid < t_end) slot0 = slot_of[slot_index(sym_frame(t_first + tid, T), tile0, sym_frames(T))];
     const int nitems = (int)st->n_heavy * MS_Q;
     if (sum_is_dense(st, sp)) {   // (uniform over the grid: k_dense_sum takes the sum)
         // unserved_host (pinned, nullable): no dense kernel follows on the stream -- the caller synchronises anyway and enqueues it
@@ -1936,7 +1941,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
             const int t = c0 + tid;
             int slot = SLOT_PRUNED;
             if (first && c0 == t_first) slot = slot0;
-            else if (t < t_end) slot = slot_of[(size_t)sym_frame(t, T) * ntiles + tile];
+            else if (t < t_end) slot = slot_of[slot_index(sym_frame(t, T), tile, sym_frames(T))];
             const bool kept = slot != SLOT_PRUNED;
             const unsigned long long m = __ballot(kept);
             if (lane == 0) s_wcnt[wave] = __popcll(m);

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void k_eval_c(const double *cS, ChainGeom g, in
 // k_masked_sum_tiles.  ~500 instructions per pair instead of ~2 800.
 template <int S>
 __global__ __launch_bounds__(64) void k_eval_pairs_fast(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, const unsigned int *list_b,
-                                                        int *slot_of, CollapseState *st, double *store, SumPlan sp)
+                                                        int *slot_of, CollapseState *st, double *store, SumPlan sp, int Th)
 {
     RM_TRACE_SCOPE(5);
     using F = TileFoot<S, false>;
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(64) void k_eval_pairs_fast(const double *cS, ChainG
         RM_TRACE_MARK(5, 0);
         const unsigned raw_idx = c < nA ? (c == blockIdx.x ? first_idx : list_a[c]) : list_b[c - nA];
         const unsigned idx = (unsigned)uniform((int)raw_idx);
-        const int slot = dense ? SLOT_PRUNED : uniform(slot_of[idx]);   // (needed after the chain: requested now)
         const int u = idx / ntiles, tile = idx - u * ntiles;
+        const int slot = dense ? SLOT_PRUNED : uniform(slot_of[slot_index(u, tile, Th)]);   // (needed after the chain: requested now)
         const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
         RM_TRACE_MARK(5, 1);
         TileSetup<S, false> ts;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void k_eval_pairs_fast(const double *cS, ChainG
             // nothing of this tile can fall below top (top <= top_ub): every pixel adds `min`, exactly like a pruned pair --
             // no values to park, and the sum pass never sees the frame
             if (pmn >= top_ub) {
-                if (lane == 0) slot_of[idx] = SLOT_PRUNED;
+                if (lane == 0) slot_of[slot_index(u, tile, Th)] = SLOT_PRUNED;
             } else {
                 // lane (column pair cp, row half rg): rows 8 rg .. 8 rg + 7 of the tile, columns 2 cp, 2 cp + 1: 16 bytes per row
                 F64Pair *d = reinterpret_cast<F64Pair *>(store + (size_t)slot * (CT_H * CT_W) + (size_t)(8 * (lane >> 5)) * CT_W + 2 * (lane & 31));
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int nti
     // requested before the state: the tile of this workgroup's first item and its first slot_of column
     const int tile0 = (int)(heavy[blockIdx.x / MS_Q] % (unsigned)ntiles);
     int slot0 = SLOT_PRUNED;
-    if (tid < Th) slot0 = slot_of[(size_t)tid * ntiles + tile0];
+    if (tid < Th) slot0 = slot_of[slot_index(tid, tile0, Th)];
     const int nitems = (int)st->n_heavy * MS_Q;
     if (sum_is_dense(st, sp)) {   // (uniform over the grid) the value store overflowed: the caller takes the sum another way
         if (unserved_host && blockIdx.x == 0 && tid == 0) *unserved_host = 1;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int nti
             const int u = c0 + tid;
             int slot = SLOT_PRUNED;
             if (first && c0 == 0) slot = slot0;
-            else if (u < Th) slot = slot_of[(size_t)u * ntiles + tile];
+            else if (u < Th) slot = slot_of[slot_index(u, tile, Th)];
             const bool kept = slot != SLOT_PRUNED;
             const unsigned long long mk = __ballot(kept);
             if (lane == 0) s_wcnt[wave] = __popcll(mk);
@@ -508,6 +508,232 @@ __global__ __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int nti
     }
 }
 
+// ---- the masked time sum of the sparse path, one wave per (heavy tile, row), values staged by LDS-DMA ---------------------------------
+// k_masked_sum_tiles walks a pixel's kept frames in batches of 16 register loads, one memory round trip per batch: 4-7 dependent round
+// trips for the heaviest tiles of the synthetic stream (21 us).  Here ONE wave owns one row of a heavy tile (lane = column):
+//   1. the tile's kept UNIQUE frames (the band-passed signal is even in time: rm_kernels.h sym_frame), compacted by ballot;
+//   2. their values of this row travel store -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, two rows of 512 bytes per
+//      instruction, no registers, ALL requests in flight together: one round trip however many frames);
+//   3. the additions run from LDS: on the way up (t = u) and, from the same LDS copy, on the way down (t = T - u) -- every stored value
+//      is fetched once.
+// More kept unique frames than MSR_CHUNK: chunks (the last chunk of the way up is the first of the way down).  Same additions in the
+// same order as k_masked_sum_tiles: bit-identical.  Whole-buffer sums only (frame shards keep k_masked_sum_tiles).
+// Dynamic LDS: val[MSR_CHUNK][64] doubles, then s_ku[Th], s_ks[Th].
+constexpr int MSR_CHUNK = 40;
+constexpr int MSR_PRE = 3;     // trips of the frame compaction whose slot_of entries the first item requests up front (T <= 382)
+
+__device__ __forceinline__ double masked_gap(double acc, int n, double min_val)   // n sequential additions of `min`
+{
+    for (; n >= 8; n -= 8) {
+        acc = acc + min_val; acc = acc + min_val; acc = acc + min_val; acc = acc + min_val;
+        acc = acc + min_val; acc = acc + min_val; acc = acc + min_val; acc = acc + min_val;
+    }
+    switch (n) {   // (one jump instead of a loop of taken branches)
+    case 7: acc = acc + min_val; [[fallthrough]];
+    case 6: acc = acc + min_val; [[fallthrough]];
+    case 5: acc = acc + min_val; [[fallthrough]];
+    case 4: acc = acc + min_val; [[fallthrough]];
+    case 3: acc = acc + min_val; [[fallthrough]];
+    case 2: acc = acc + min_val; [[fallthrough]];
+    case 1: acc = acc + min_val; [[fallthrough]];
+    default: break;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ int lane_value_dyn(int v, int b)   // v of lane b (b wave-uniform, not compile-time)
+{
+#ifdef RM_HIPEMU
+    return __shfl(v, b);
+#else
+    return __builtin_amdgcn_readlane(v, b);
+#endif
+}
+
+__global__ __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
+                                                        double threshold, double *heat, int *tile_nkept, const int *sel_cnt,
+                                                        const unsigned int *heavy, int nworkers, SumPlan sp, int *unserved_host)
+{
+    RM_TRACE_SCOPE(6);
+    HIP_DYNAMIC_SHARED(double, val)    // [MSR_CHUNK][64]
+    const int Th = sym_frames(T);
+    int *s_ku = reinterpret_cast<int *>(val + MSR_CHUNK * 64);   // kept unique frames of the tile, ascending; then their slots
+    int *s_ks = s_ku + Th;
+    const int lane = threadIdx.x;
+    const int tiles_x = (W0 + CT_W - 1) / CT_W;
+    // requested before the state: the tile of this wave's first item and its first slot_of entries
+    const int tile0 = (int)(heavy[blockIdx.x / CT_H] % (unsigned)ntiles);
+    int slot0[MSR_PRE];
+#pragma unroll
+    for (int k = 0; k < MSR_PRE; ++k) slot0[k] = (lane + 64 * k < Th) ? slot_of[slot_index(lane + 64 * k, tile0, Th)] : SLOT_PRUNED;
+    const int nitems = (int)st->n_heavy * CT_H;
+    if (sum_is_dense(st, sp)) {   // (uniform over the grid) the value store overflowed: the sum is taken another way
+        if (unserved_host && blockIdx.x == 0 && lane == 0) *unserved_host = 1;
+        return;
+    }
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
+    if (blockIdx.x == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    const double cnt = (double)T;
+    const int t_up_end = T / 2 + 1;              // the way up: t = u = 0 .. T / 2
+    const int u_down = (T + 1) / 2 - 1;          // the way down starts at t = T / 2 + 1, i.e. u = T - t = u_down, and ends at u = 1
+#ifndef RM_HIPEMU
+    const unsigned val_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char *)val);
+#endif
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+    RM_TRACE_MARK(6, 0);
+    for (int item = (int)blockIdx.x; item < nitems; item += nworkers) {
+        const bool first = item == (int)blockIdx.x;
+        const int tile = first ? tile0 : (int)heavy[item / CT_H], row = item % CT_H;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        // the tile's kept unique frames, ascending (ballot + prefix popcount, 64 frames per trip)
+        wave_sync();   // (the previous item's reads of the lists are behind us)
+        int m = 0;
+        for (int c0 = 0; c0 < Th; c0 += 64) {
+            const int u = c0 + lane;
+            int slot = SLOT_PRUNED;
+            if (first && c0 < 64 * MSR_PRE) {
+#pragma unroll
+                for (int k = 0; k < MSR_PRE; ++k) if (c0 == 64 * k) slot = slot0[k];
+            } else if (u < Th) slot = slot_of[slot_index(u, tile, Th)];
+            const bool kept = slot != SLOT_PRUNED;
+            const unsigned long long mk = __ballot(kept);
+            if (kept) { const int pos = m + __popcll(mk & ((1ull << lane) - 1ull)); s_ku[pos] = u; s_ks[pos] = slot; }
+            m += __popcll(mk);
+        }
+        wave_sync();
+        RM_TRACE_MARK(6, 1);
+        if (row == 0 && tile_nkept) {   // kept frames in time order (0: every pixel of the tile ends up as the same constant)
+            int n_t = 0;
+            for (int i = lane; i < m; i += 64) { const int u = s_ku[i]; n_t += 1 + ((u >= 1 && u <= u_down) ? 1 : 0); }
+            for (int d = 32; d >= 1; d >>= 1) n_t += __shfl_xor(n_t, d);
+            if (lane == 0) tile_nkept[tile] = n_t;
+        }
+        const int x = tx * CT_W + lane, y = ty * CT_H + row;
+        const bool active = x < W0 && y < H0;
+        // chunk ci of the kept frames -> val[j][*]: lanes 0 .. 31 fetch frame 2 i, lanes 32 .. 63 frame 2 i + 1 of the pair i
+        auto stage = [&](int ci) __attribute__((always_inline)) {
+            const int i0 = ci * MSR_CHUNK, n = min(m - i0, MSR_CHUNK);
+            wave_sync();   // the previous chunk's reads of val are behind us
+#ifndef RM_HIPEMU
+            const int half = lane >> 5, l32 = lane & 31;
+            for (int j = 0; j < n; j += 2) {
+                const int jj = min(j + half, n - 1);     // (an odd count: the upper half repeats the last frame into a row nobody reads)
+                const int slot = s_ks[i0 + jj];
+                const double *gp = store + (size_t)slot * (CT_H * CT_W) + (size_t)row * CT_W + 2 * l32;
+                unsigned keep;
+                const unsigned dst = val_lds + (unsigned)j * 512u;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only: every piece has landed
+            asm volatile("" ::: "memory");
+#else
+            for (int j = 0; j < n; ++j) val[j * 64 + lane] = store[(size_t)s_ks[i0 + j] * (CT_H * CT_W) + (size_t)row * CT_W + lane];
+#endif
+            wave_sync();
+            return n;
+        };
+        const int nc = (m + MSR_CHUNK - 1) / MSR_CHUNK;
+        double acc = 0.0;
+        int t_done = 0;
+        int n_last = 0;
+        // the way up: t = u.  The chunk's frame numbers travel as one value per lane (read with v_readlane), its values come from
+        // LDS four at a time: the chain of additions never waits for a look-up of its own
+        int kuv = 0;
+        for (int ci = 0; ci < nc; ++ci) {
+            const int n = stage(ci);
+            n_last = n;
+            RM_TRACE_MARK(6, 2);
+            const int i0 = ci * MSR_CHUNK;
+            kuv = lane < n ? s_ku[i0 + lane] : 0;
+            for (int j0 = 0; j0 < n; j0 += 4) {
+                double v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v4[k] = val[min(j0 + k, n - 1) * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 + k < n) {   // (uniform)
+                        const int t_stop = lane_value_dyn(kuv, j0 + k);     // frames [t_done, t_stop) are pruned
+                        acc = masked_gap(acc, t_stop - t_done, min_val);
+                        acc = acc + ((v4[k] >= top) ? min_val : v4[k]);
+                        t_done = t_stop + 1;
+                    }
+                }
+            }
+        }
+        acc = masked_gap(acc, t_up_end - t_done, min_val);
+        t_done = t_up_end;
+        RM_TRACE_MARK(6, 3);
+        // the way down: t = T - u for the kept u in [1, u_down], largest first (the chunk in LDS is the last one of the way up)
+        for (int ci = nc - 1; ci >= 0; --ci) {
+            const int n = ci == nc - 1 ? n_last : stage(ci);
+            const int i0 = ci * MSR_CHUNK;
+            if (ci != nc - 1) kuv = lane < n ? s_ku[i0 + lane] : 0;
+            for (int j0 = n - 1; j0 >= 0; j0 -= 4) {
+                double v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v4[k] = val[max(j0 - k, 0) * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 - k >= 0) {   // (uniform)
+                        const int u = lane_value_dyn(kuv, j0 - k);
+                        if (u >= 1 && u <= u_down) {
+                            const int t_stop = T - u;
+                            acc = masked_gap(acc, t_stop - t_done, min_val);
+                            acc = acc + ((v4[k] >= top) ? min_val : v4[k]);
+                            t_done = t_stop + 1;
+                        }
+                    }
+                }
+            }
+        }
+        acc = masked_gap(acc, T - t_done, min_val);
+        RM_TRACE_MARK(6, 12);
+        if (active) {
+            const double a = acc / cnt;          // base.py:562: np.average = sum / T
+            heat[(size_t)y * W0 + x] = a;
+            hmn = (a < hmn) ? a : hmn; hmx = (a > hmx) ? a : hmx;
+        }
+    }
+    // FILL: by the waves without items when there are any, by every wave otherwise
+    const int idle = nworkers - min(nitems, nworkers);
+    const int nfill = idle > 0 ? idle : nworkers;
+    const int fid = idle > 0 ? (int)blockIdx.x - nitems : (int)blockIdx.x;
+    if (fid >= 0) {
+        const double fv = masked_gap(0.0, T, min_val) / cnt;
+        constexpr int FU = 4;    // tiles whose kept-pair counts are requested together
+        bool any = false;
+        for (int base = fid; base < ntiles; base += FU * nfill) {
+            int cntk[FU];
+#pragma unroll
+            for (int k = 0; k < FU; ++k) { const int tile = base + k * nfill; cntk[k] = tile < ntiles ? sel_cnt[tile] : 1; }
+#pragma unroll
+            for (int k = 0; k < FU; ++k) {
+                const int tile = base + k * nfill;
+                if (cntk[k] != 0) continue;               // past the end, or workers sum this tile
+                any = true;
+                const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const int x = tx * CT_W + lane, y0 = ty * CT_H;
+                if (x < W0) {
+#pragma unroll
+                    for (int j = 0; j < CT_H; ++j) if (y0 + j < H0) heat[(size_t)(y0 + j) * W0 + x] = fv;
+                }
+                if (lane == 0 && tile_nkept) tile_nkept[tile] = 0;     // 0: every pixel of the tile is the same constant
+            }
+        }
+        if (any) { hmn = (fv < hmn) ? fv : hmn; hmx = (fv > hmx) ? fv : hmx; }
+    }
+    // the heatmap's extrema for base.py:563
+    hmn = wave_min(hmn); hmx = wave_max(hmx);
+    if (lane == 0 && hmn <= hmx) {
+        const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+        const int sp_ = blockIdx.x & (NSTRIPE - 1);
+        if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
+        if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+    }
+}
+
 // ---- masked time sum, tile by tile ----------------------------------------------------------------------------------------------------
 // Work item i = (heavy tile, half) [HALF] or one heavy tile; a workgroup of TS_NW waves takes the items i = blockIdx.x, + nworkers, ...
 // The workgroups left without an item fill the tiles without kept pairs with their constant (as k_masked_sum_tiles did).
@@ -553,7 +779,7 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
             const int t = c0 + tid;
             int slot = SLOT_PRUNED;
             if (first && c0 == t_first) slot = slot0;
-            else if (t < t_end) slot = slot_of[(size_t)sym_frame(t, T) * ntiles + tile];
+            else if (t < t_end) slot = slot_of[slot_index(sym_frame(t, T), tile, sym_frames(T))];
             const bool kept = slot != SLOT_PRUNED;
             const unsigned long long m = __ballot(kept);
             if (lane == 0) s_wcnt[wave] = __popcll(m);
@@ -696,8 +922,8 @@ __global__ __launch_bounds__(64 * TS_NW) void k_tile_sum(const double *cS, Chain
     const int tile_a = (int)(heavy[blockIdx.x] % (unsigned)ntiles), tile_b = (int)(heavy[blockIdx.x >> 1] % (unsigned)ntiles);
     int slot_a = SLOT_PRUNED, slot_b = SLOT_PRUNED;
     if (t_first + tid < t_end) {
-        const size_t row = (size_t)sym_frame(t_first + tid, T) * ntiles;
-        slot_a = slot_of[row + tile_a]; slot_b = slot_of[row + tile_b];
+        const int u0 = sym_frame(t_first + tid, T), Th_ = sym_frames(T);
+        slot_a = slot_of[slot_index(u0, tile_a, Th_)]; slot_b = slot_of[slot_index(u0, tile_b, Th_)];
     }
     const int nheavy = (int)st->n_heavy;
     const bool half = force_half >= 0 ? force_half != 0 : 2 * nheavy <= nworkers;   // (uniform over the grid; force_half: test hook)

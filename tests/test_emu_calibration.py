@@ -572,7 +572,12 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             emu.debug_set("collapse_fused", 0)
             emu.debug_set("eval_fast", 0)            # the generic chain in LDS (k_eval_pairs): the reference of both newer forms
             emu.debug_set("sum_sym", 0)              # ... and the sum that fetches every visit of a frame (k_masked_sum_tiles)
+            emu.debug_set("sum_rows", 0)
             store, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            emu.debug_set("sum_rows", 1)             # one wave per (tile, row), unique frames staged through LDS (k_masked_sum_rows)
+            rows, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            assert np.array_equal(rows, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_rows")
+            emu.debug_set("sum_rows", 0)
             emu.debug_set("sum_sym", 1)              # unique frames loaded once, added on the way up and down (k_masked_sum_sym)
             sym, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
             assert np.array_equal(sym, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_sym")
@@ -600,11 +605,16 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             v = rng.random((T, H, W))
             emu.debug_set("collapse_fused", 0)
             emu.debug_set("sum_sym", 0)
+            emu.debug_set("sum_rows", 0)
             store, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
             emu.debug_set("sum_sym", 1)
             sym, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
             emu.debug_set("sum_sym", 0)
             assert np.array_equal(sym, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_sym, batches")
+            emu.debug_set("sum_rows", 1)
+            rows, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
+            assert np.array_equal(rows, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_rows, chunks")
+        emu.debug_set("sum_rows", 1)
         # a breathing video: few heavy tiles (half-tile work items), pruned pairs in between, and the oracle's ROI
         from respmon_amd import synth
         v8 = synth.synth_breathing(24, 96, 160, seed=3)
@@ -631,3 +641,4 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
         emu.debug_set("tile_sum_half", -1)
         emu.debug_set("eval_fast", 1)
         emu.debug_set("sum_sym", 0)
+        emu.debug_set("sum_rows", 1)

@@ -742,7 +742,11 @@ def test_fused_collapse_equals_store_path(hip, oracle):
             device.debug_set("collapse_fused", 0)
             device.debug_set("eval_fast", 0)         # the generic chain in LDS (k_eval_pairs): the reference of both newer forms
             device.debug_set("sum_sym", 0)           # ... and the sum that fetches every visit of a frame (k_masked_sum_tiles)
+            device.debug_set("sum_rows", 0)
             store = dist.hip_calibrate(buf, 10, flags=256, **kw)
+            device.debug_set("sum_rows", 1)          # one wave per (tile, row), unique frames staged by LDS-DMA (k_masked_sum_rows)
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=256, **kw), store), (dt, T, H, W, L, S, "k_masked_sum_rows")
+            device.debug_set("sum_rows", 0)
             device.debug_set("sum_sym", 1)           # unique frames loaded once, added on the way up and down (k_masked_sum_sym)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=256, **kw), store), (dt, T, H, W, L, S, "k_masked_sum_sym")
             device.debug_set("sum_sym", 0)
@@ -755,6 +759,7 @@ def test_fused_collapse_equals_store_path(hip, oracle):
                 assert torch.equal(dist.hip_calibrate(buf, 10, **kw), store), (dt, T, H, W, L, S, half)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=1, **kw), store), (dt, T, H, W, L, S, "no_prune")
         device.debug_set("collapse_fused", 1)
+        device.debug_set("sum_rows", 1)
         v8 = synth.synth_breathing(64, 270, 480, seed=5)
         fr = oracle.uint8_to_float(v8)
         buf = torch.from_numpy(fr).cuda()
@@ -770,6 +775,7 @@ def test_fused_collapse_equals_store_path(hip, oracle):
         device.debug_set("tile_sum_half", -1)
         device.debug_set("eval_fast", 1)
         device.debug_set("sum_sym", 0)
+        device.debug_set("sum_rows", 1)
 
 
 def test_filter_first_per_level_equals_fused(hip):
