@@ -1380,7 +1380,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
         int cus = 256;
 #ifndef RM_HIPEMU
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        const unsigned fgrid = (unsigned)std::min<long long>(npairs, 24ll * cus);
+        const unsigned fgrid = (unsigned)std::min<long long>(npairs, 12ll * cus);   // (launching more single-wave workgroups than pairs costs ~0.5 us of ramp per thousand)
 #else
         const unsigned fgrid = egrid;
 #endif
@@ -1471,7 +1471,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
 #ifdef RM_HIPEMU
         const int nworkers = std::min(cp.ntiles * MS_Q, 24);    // (host emulation: fewer, looping workgroups compute the same thing)
 #else
-        const int nworkers = std::min(cp.ntiles * MS_Q, 768);   // 3 workgroups per CU (registers): one resident round
+        const int nworkers = std::min(cp.ntiles * MS_Q, MS_B > 16 ? 512 : 768);   // 2-3 workgroups per CU (registers): one resident round
 #endif
         if (cp.t0 == 0 && cp.t1 == cp.T && avg_T == cp.T && ctx->dbg.sum_rows) {
             // the whole buffer: one wave per (heavy tile, row), the kept unique frames' values staged by LDS-DMA (rm_tile_eval.h)

@@ -1893,7 +1893,10 @@ __global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, co
 constexpr int MAX_T = 4096;
 constexpr int MS_Q = 4;              // row groups (worker items) per heavy tile
 constexpr int MS_RQ = CT_H / MS_Q;   // rows per worker == waves per workgroup
-constexpr int MS_B = 16;             // kept frames per batch
+#ifndef RM_MS_B
+#define RM_MS_B 16
+#endif
+constexpr int MS_B = RM_MS_B;        // kept frames per batch (32: 220 VGPRs, two waves per SIMD -- measured 32 us against 20)
 
 __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int t_end, int T, int ntiles, int W0, int H0,
                                                           const int *slot_of, const double *store,
