@@ -61,6 +61,8 @@ def parse():
                     "independent [T,H,W] stream per GPU + one heatmap exchange, weak scaling.  sharded: ONE [T,H,W] buffer split by frame "
                     "index over the GPUs (respmon_amd.dist.locate_sharded), strong scaling")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--video", default="breathing", choices=["breathing", "dense", "noise", "blobs16"], help="synthetic stream of the timed steps "
+                    "(developer option: breathing is the metric's video; the others are the data-dependence / worst-case streams)")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="developer switch of the library context "
                     "(include/respmon_hip.h rm_debug_set), e.g. temporal_wide=0; listed in the JSON line as debug_set")
     ap.add_argument("--no-extras", action="store_true", help="skip everything outside the contract line: uint8-buffer variant, ROI "
@@ -68,6 +70,8 @@ def parse():
     ap.add_argument("--no-u8-alt", action="store_true", help="skip the extra measurement with a uint8 frame buffer")
     ap.add_argument("--no-roi-flow", action="store_true", help="skip the per-frame ROI optical-flow measurement")
     ap.add_argument("--no-data-dependence", action="store_true", help="skip the no-prune and dense-stream measurements")
+    ap.add_argument("--no-batches", action="store_true", help="skip the four extra batches of --steps behind the timed one (ms_per_step_batches)")
+    ap.add_argument("--no-worst-case", action="store_true", help="skip the worst-case streams (full-frame noise, sixteen blobs) of `worst_case`")
     ap.add_argument("--no-configs", action="store_true", help="skip the summaries of the other BASELINE configs (Q, R, F, and P with a "
                     "float32 frame buffer) that the default single-GPU P line carries under `configs`")
     ap.add_argument("--configs", default="Q,R,F,P32", help="which of those summaries to run (comma separated)")
@@ -192,7 +196,11 @@ def main():
     big = T * H * W > 1 << 30
     gen = synth.synth_breathing_blocks if big else synth.synth_breathing
     # config 4: an independent stream per GPU; sharded mode: the same buffer everywhere, each rank keeps its frame shard
-    vid_u8 = gen(T, H, W, seed=1234 + (0 if sharded else rank))
+    if a.video != "breathing":
+        gen = {"dense": synth.synth_breathing_dense, "noise": synth.synth_noise_only, "blobs16": synth.synth_breathing_16}[a.video]
+        vid_u8 = gen(T, H, W)
+    else:
+        vid_u8 = gen(T, H, W, seed=1234 + (0 if sharded else rank))
     if sharded:
         t_lo, t_hi = rdist.shard_frames(T, rank, world)
         vid_u8 = vid_u8[t_lo:t_hi]
@@ -272,6 +280,17 @@ def main():
     ncalls = ctypes.c_int()
     _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
     k_ms_total, k_calls = ms[0], ncalls.value     # frame-buffer kernel, HIP events inside the timed region
+    # box noise made visible in one run: four more batches of --steps (`value` stays the first batch above)
+    batch_ms = [elapsed / a.steps * 1e3]
+    if world == 1 and not a.no_batches:
+        for _ in range(4):
+            barrier()
+            tb = time.perf_counter()
+            for _ in range(a.steps):
+                roi = step()
+            barrier()
+            batch_ms.append((time.perf_counter() - tb) / a.steps * 1e3)
+        _capi.check(lib, lib.rm_profile_read(ctx, (ctypes.c_double * 4)(), None), "rm_profile_read")
     tn = ctypes.c_int(0)
     _capi.check(lib, lib.rm_heat_sparse_tiles_needed(ctx, ctypes.byref(tn)), "rm_heat_sparse_tiles_needed")
     tiles_needed = tn.value                       # largest per-rank tile count of the last sparse exchange (world > 1)
@@ -399,6 +418,40 @@ def main():
         del dbuf, heat_d
         torch.cuda.empty_cache()
 
+    # Worst case under DEFAULT flags: streams on which the pruning of the collapse passes finds little to prune --
+    # sensor noise of sigma 0.1 in every pixel and no breathing region; sixteen small blobs a sixteenth of a period apart -- with
+    # their pair counts, against the headline's step time, and the oracle's ROI on the same video.
+    worst = None
+    if extras and not a.no_data_dependence and not a.no_worst_case and not a.no_prune and a.config == "P":
+        from oracle import respmon_oracle as oracle
+        oracle.build()
+        worst = {"headline_ms_per_step": elapsed / a.steps * 1e3}
+        for name, gen_w, desc in (("noise", synth.synth_noise_only, "static texture + noise sigma 0.1 in every pixel, no breathing region, seed 777"),
+                                  ("blobs16", synth.synth_breathing_16, "sixteen blobs (A=0.2, 0.4 Hz, sigma 0.05H x 0.04W, phases 22.5 deg apart) + noise sigma 0.04, seed 888")):
+            try:
+                del buf
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            v8w = gen_w(T, H, W, workers=None if big else 8)
+            wbuf = to_device(v8w)
+            for _ in range(a.warmup + 5):
+                locate1(wbuf)
+            roi_w, ms_w = timed(lambda: locate1(wbuf), n_extra)
+            _capi.check(lib, lib.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
+            del wbuf
+            torch.cuda.empty_cache()
+            fr = oracle.uint8_to_float(v8w)
+            if a.in_dtype in ("f32", "f16"):
+                fr = fr.astype({"f32": np.float32, "f16": np.float16}[a.in_dtype]).astype(np.float64)
+            r_or = oracle.locate_parallel(fr, 10, pyramid_levels=a.levels, skip_levels_at_top=a.skip, workers=min(64, os.cpu_count() or 1))
+            del fr, v8w
+            worst[name] = {"video": desc, "ms_per_step": ms_w, "frames_per_s": T / ms_w * 1e3, "vs_headline": ms_w / worst["headline_ms_per_step"],
+                           "roi": roi_w, "oracle_roi": r_or, "roi_equals_oracle": list(r_or or []) == list(roi_w or []),
+                           "collapse_pairs": {"total": dbg[0], "evaluated_for_extrema" if dbg[3] == -1 else "evaluated": dbg[1],
+                                              "kept_for_sum": dbg[2], "store_capacity": max(dbg[3], 0), "sum_path": sum_path(dbg)}}
+        worst["slowest_vs_headline"] = max(worst[k]["vs_headline"] for k in ("noise", "blobs16"))
+
     # The other BASELINE configs as driver-verifiable summaries inside the default P line (config 2 = Q, config 5 = R,
     # config 3 = F; P32 = the headline workload with the float32 frame buffer BASELINE.md quotes its time on).  Each one is
     # measured like the headline (resident buffer, HIP events around the frame-buffer kernel inside the timed loop) and its ROI
@@ -431,7 +484,8 @@ def main():
             cb = cT * cH * cW * DT_BYTES[cdt] + cH * cW * 8
             d = {"workload": "%dx%dx%d %s frame buffer, %d-level pyramid, skip %d" % (cT, cH, cW, cdt, cL, cS),
                  "steps": n_steps, "ms_per_step": c_ms, "frames_per_s": cT / c_ms * 1e3, "kernel_ms": ck_ms,
-                 "algorithmic_bytes": cb, "frac": cb / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ck_ms > 0 else None,
+                 "algorithmic_bytes": cb, "frac": cb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,      # whole step, as `roofline.frac`
+                 "kernel_frac": cb / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ck_ms > 0 else None,
                  "step_frac": cb / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "roi": c_roi,
                  "collapse_pairs": {"total": dbg[0], "evaluated_for_extrema" if dbg[3] == -1 else "evaluated": dbg[1], "kept_for_sum": dbg[2],
                                     "sum_path": sum_path(dbg)},
@@ -532,7 +586,9 @@ def main():
         out = {
             "metric": metric,
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": step_ms, "pre_warm_steps": pre_steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "ms_per_step": step_ms, "ms_per_step_batches": {"batches": batch_ms, "min": min(batch_ms), "median": float(np.median(batch_ms)),
+                                                            "note": "batch 0 is the timed region `value` comes from; the others follow it"},
+            "pre_warm_steps": pre_steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64", "frame_buffer_dtype": a.in_dtype, "data": "synthetic",
             "config": {"workload": "%s: Eulerian calibration + ROI (locate) on a %dx%dx%d %s frame buffer, %d-level Laplacian pyramid, "
@@ -542,10 +598,13 @@ def main():
                                        "one RCCL heatmap exchange" if sharded else "one independent stream per GPU + one RCCL exchange of the heatmaps"),
                        "preset": a.config, "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "levels": a.levels,
                        "skip": a.skip, "prune": not a.no_prune, "mode": a.mode if world > 1 else "single"},
-            "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
+            "video": a.video, "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
             "debug_set": a.debug_set,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+            # `achieved` / `frac` are the contract figure -- algorithmic bytes over the WHOLE step (all kernels + the host
+            # contour stage) against the peak; the frame-buffer kernel alone is `kernel_achieved` / `kernel_frac`
+            "roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": step_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_achieved": achieved, "kernel_frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
                                            if traffic else None,
                          "kernel": "frame-buffer pyrDown kernel (reads [T,H,W] once)", "kernel_ms": k_ms,
@@ -566,6 +625,7 @@ def main():
             "contour_stage": contour_stage,
             "no_prune": no_prune,
             "dense_stream": dense,
+            "worst_case": worst,
             "configs": other,
         }
         if world == 1 and a.cpu_frames != 0:

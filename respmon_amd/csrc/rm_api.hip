@@ -53,6 +53,7 @@ static int fail(int code, const char *fmt, ...)
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
+constexpr long long STORE_MAX_SLOTS = 524288;   // value store: at most 4 GiB (8 KB per kept (tile, frame) pair)
 
 // what the collapse passes share (see collapse_eval / collapse_sum below)
 struct CollapsePlan {
@@ -91,7 +92,9 @@ struct DebugKnobs {
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
+    int dense_tiles = 1;          // 0: k_tile_sum (rounds of sixteen waves per tile) instead of k_dense_sum_t (one wave per tile) where a store-less sum at skip >= 3 is due
     int tile_sum_half = -1;       // 0 / 1: k_tile_sum works on whole tiles / half tiles whatever the number of heavy tiles (-1: by that number)
+    long long store_default_slots = 0;   // > 0: slots the value store starts with before any selection has made it grow (default 16 384)
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
 };
 
@@ -117,6 +120,8 @@ struct rm_ctx {
     size_t eval_shmem = ~(size_t)0; int eval_per_cu = 0, eval_cus = 0;   // k_eval_pairs: resident workgroups per CU at this LDS footprint
     int nkept_H = 0, nkept_W = 0;   // geometry the "tile_nkept" workspace buffer (last rm_calibrate) belongs to; 0 = none
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
+    int dense_hint = 0;             // the last rm_locate of this context met a dense selection (more than a quarter of the pairs kept)
+    long long store_hint_slots = 0; // slots a selection of this context needed when it overflowed the value store (rm_locate grows the store to it)
     int *h_unserved = nullptr;      // pinned: set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0, dbg_mine = 0; int dbg_mode = 0, dbg_auto_dense = 0, dbg_fused = 0;   // the SumPlan of the last collapse (host copy)
@@ -231,8 +236,10 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
     else if (k == "dc_split") d.dc_split = (int)value;
     else if (k == "store_slots") d.store_slots = value;
+    else if (k == "store_default_slots") d.store_default_slots = value;
     else if (k == "collapse_fused") d.collapse_fused = (int)value;
     else if (k == "tile_sum_half") d.tile_sum_half = (int)value;
+    else if (k == "dense_tiles") d.dense_tiles = (int)value;
     else if (k == "eval_fast") d.eval_fast = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
@@ -1226,6 +1233,63 @@ static int zero_result(rm_ctx *ctx, size_t npix, double *heat, double *minmax_ho
     return RM_OK;
 }
 
+// the flat evaluation pass over the listed pairs (exact extrema; values of the kept pairs into the value store)
+static int launch_eval_pairs(rm_ctx *ctx, const CollapsePlan &cp, hipStream_t s)
+{
+    CollapseState *st = ctx->d_state;
+    const ChainGeom &g = cp.g;
+    const int ntiles = cp.ntiles, npairs = cp.npairs, Th = sym_frames(cp.T);
+    const SumPlan &sp = cp.sp;
+    struct { const double *cS; int S; } sl{cp.cS, cp.S};
+    // one resident round of single-wave workgroups that loop over the lists: their lengths live on the device, and
+    // dispatching thousands of workgroups that find nothing to do costs more than the loop.  "Resident" is what the
+    // kernel's registers and this geometry's LDS footprint allow per CU (asked of the runtime once per footprint).
+    unsigned egrid = 64;   // (host emulation: a fiber per lane -- few, looping workgroups compute the same thing)
+#ifndef RM_HIPEMU
+    {
+        size_t &cached_shmem = ctx->eval_shmem;
+        int &cached_per_cu = ctx->eval_per_cu, &cached_cus = ctx->eval_cus;
+        if (cached_shmem != cp.shmem) {
+            int per_cu = 0, cus = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_eval_pairs, 64, cp.shmem));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+            per_cu -= 1;   // (measured: the runtime's figure ignores the LDS allocation granule -- its last workgroup queues)
+#ifdef RM_EVAL_PER_CU
+            per_cu = RM_EVAL_PER_CU;
+#endif
+            cached_per_cu = per_cu < 1 ? 1 : per_cu; cached_cus = cus < 1 ? 1 : cus; cached_shmem = cp.shmem;
+        }
+        const long long capw = (long long)cached_per_cu * cached_cus;
+        egrid = (unsigned)(npairs < capw ? npairs : capw);
+    }
+#else
+    if ((long long)egrid > npairs) egrid = (unsigned)npairs;
+#endif
+    if (tile_eval_ok(g) && ctx->dbg.eval_fast) {
+        // the wave-private evaluator (rm_tile_eval.h): ~70 VGPRs and < 5 KB of LDS per single-wave workgroup -- 24 per CU stay resident
+        int cus = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        const unsigned fgrid = (unsigned)std::min<long long>(npairs, 12ll * cus);   // (launching more single-wave workgroups than pairs costs ~0.5 us of ramp per thousand)
+#else
+        const unsigned fgrid = egrid;
+#endif
+#define RM_EVAL_FAST(SS)                                                                                                              \
+        do {                                                                                                                          \
+            using FootE = TileFoot<SS, false>;                                                                                        \
+            hipLaunchKernelGGL((k_eval_pairs_fast<SS>), dim3(fgrid), dim3(64), sizeof(double) * FootE::TOTAL, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, \
+                               cp.slot_of, st, cp.store, sp, Th);                                                                     \
+        } while (0)
+        switch (sl.S) { case 1: RM_EVAL_FAST(1); break; case 2: RM_EVAL_FAST(2); break; case 3: RM_EVAL_FAST(3); break; default: RM_EVAL_FAST(4); break; }
+#undef RM_EVAL_FAST
+        (void)cus;
+    } else {
+        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp, Th);
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // back half: C_S -> exact raw.min()/raw.max() -> masked time sum, for the frames [t0, t1) of the buffer.
 // The bounds and the pruning decisions always cover all T frames (they are cheap and every rank of a
@@ -1271,7 +1335,11 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     // Capped at STORE_BUDGET_SLOTS (1 GiB): a selection that keeps more takes the dense sum kernel, which needs no store --
     // decided on the device, in this same call (sum_is_dense).  The exhaustive-evaluation baseline (RM_FLAG_NO_PRUNE) and a
     // forced sparse path park every pair they are told to, so they get a slot per pair.
-    constexpr long long STORE_BUDGET_SLOTS = 131072;
+    // (round 4) The store starts at STORE_DEFAULT_SLOTS (128 MiB) and GROWS when a selection of this context has overflowed it
+    // (rm_locate reads the kept count after its host synchronisation and runs the evaluation and the sum again with a store that
+    // holds it: memory is committed for the streams that need it, up to STORE_MAX_SLOTS = 4 GiB; ctx->store_hint_slots).
+    const long long STORE_DEFAULT_SLOTS = ctx->dbg.store_default_slots > 0 ? ctx->dbg.store_default_slots : 16384;   // (knob: test hook)
+    const long long STORE_BUDGET_SLOTS = std::min(STORE_MAX_SLOTS, std::max(STORE_DEFAULT_SLOTS, ctx->store_hint_slots));
     cp.no_prune = no_prune != 0;
     SumPlan &sp = cp.sp;
     sp.mode = (flags & RM_FLAG_DENSE_SUM) ? 1 : ((flags & RM_FLAG_SPARSE_SUM) || no_prune) ? 2 : 0;
@@ -1351,52 +1419,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
     }
     ctx->dbg_fused = 0;
     cp.shmem = sizeof(double) * (size_t)g.lds_total;
-    // one resident round of single-wave workgroups that loop over the lists: their lengths live on the device, and
-    // dispatching thousands of workgroups that find nothing to do costs more than the loop.  "Resident" is what the
-    // kernel's registers and this geometry's LDS footprint allow per CU (asked of the runtime once per footprint).
-    unsigned egrid = 64;   // (host emulation: a fiber per lane -- few, looping workgroups compute the same thing)
-#ifndef RM_HIPEMU
-    {
-        size_t &cached_shmem = ctx->eval_shmem;
-        int &cached_per_cu = ctx->eval_per_cu, &cached_cus = ctx->eval_cus;
-        if (cached_shmem != cp.shmem) {
-            int per_cu = 0, cus = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_eval_pairs, 64, cp.shmem));
-            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-            per_cu -= 1;   // (measured: the runtime's figure ignores the LDS allocation granule -- its last workgroup queues)
-#ifdef RM_EVAL_PER_CU
-            per_cu = RM_EVAL_PER_CU;
-#endif
-            cached_per_cu = per_cu < 1 ? 1 : per_cu; cached_cus = cus < 1 ? 1 : cus; cached_shmem = cp.shmem;
-        }
-        const long long capw = (long long)cached_per_cu * cached_cus;
-        egrid = (unsigned)(npairs < capw ? npairs : capw);
-    }
-#else
-    if ((long long)egrid > npairs) egrid = (unsigned)npairs;
-#endif
-    if (tile_eval_ok(g) && ctx->dbg.eval_fast) {
-        // the wave-private evaluator (rm_tile_eval.h): ~70 VGPRs and < 5 KB of LDS per single-wave workgroup -- 24 per CU stay resident
-        int cus = 256;
-#ifndef RM_HIPEMU
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        const unsigned fgrid = (unsigned)std::min<long long>(npairs, 12ll * cus);   // (launching more single-wave workgroups than pairs costs ~0.5 us of ramp per thousand)
-#else
-        const unsigned fgrid = egrid;
-#endif
-#define RM_EVAL_FAST(SS)                                                                                                              \
-        do {                                                                                                                          \
-            using FootE = TileFoot<SS, false>;                                                                                        \
-            hipLaunchKernelGGL((k_eval_pairs_fast<SS>), dim3(fgrid), dim3(64), sizeof(double) * FootE::TOTAL, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, \
-                               cp.slot_of, st, cp.store, sp, Th);                                                                     \
-        } while (0)
-        switch (sl.S) { case 1: RM_EVAL_FAST(1); break; case 2: RM_EVAL_FAST(2); break; case 3: RM_EVAL_FAST(3); break; default: RM_EVAL_FAST(4); break; }
-#undef RM_EVAL_FAST
-        (void)cus;
-    } else {
-        hipLaunchKernelGGL(k_eval_pairs, dim3(egrid), dim3(64), cp.shmem, s, sl.cS, g, ntiles, cp.list_a, cp.list_b, cp.slot_of, st, cp.store, sp, Th);
-    }
-    LAUNCH_CHECK();
+    RM_TRY(launch_eval_pairs(ctx, cp, s));
     cp.valid = true;
     return RM_OK;
 }
@@ -1424,6 +1447,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     }
     int *tile_nkept = nullptr;
     RM_TRY(ws(ctx, "tile_nkept", (size_t)cp.ntiles, &tile_nkept));
+    int *unserved_dev = nullptr;
     auto launch_tile_sum = [&](int only_if_dense) -> int {
         // one workgroup of TS_NW waves per CU (the exchange takes most of a CU's LDS): the heavy tiles' items first, the workgroups
         // left without one fill the constant tiles
@@ -1447,7 +1471,21 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         LAUNCH_CHECK();
         return RM_OK;
     };
+    auto launch_dense_t = [&](int only_if_dense) -> int {
+        // one wave per tile, frame after frame (rm_tile_eval.h k_dense_sum_t)
+#define RM_DENSE_T(SS)                                                                                                                   \
+        do {                                                                                                                             \
+            using FootD = TileFoot<SS, false>;                                                                                           \
+            hipLaunchKernelGGL((k_dense_sum_t<SS>), dim3(dense_tile_grid(cp.ntiles)), dim3(64), sizeof(double) * (FootD::TOTAL + DST_MAXW), s, cp.cS, cp.g, cp.t0, \
+                               cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr, heat_sum, avg_T, tile_nkept, cp.sp, only_if_dense, unserved_dev); \
+        } while (0)
+        switch (cp.S) { case 1: RM_DENSE_T(1); break; case 2: RM_DENSE_T(2); break; case 3: RM_DENSE_T(3); break; default: RM_DENSE_T(4); break; }
+#undef RM_DENSE_T
+        LAUNCH_CHECK();
+        return RM_OK;
+    };
     if (cp.fused) {
+        if (ctx->dbg.dense_tiles) RM_TRY(launch_dense_t(0)); else
         RM_TRY(launch_tile_sum(0));
         ctx->nkept_H = cp.H; ctx->nkept_W = cp.W;
         return RM_OK;
@@ -1459,8 +1497,9 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     const bool may_sparse = sp.mode != 1;
     const bool auto_dense = sp.mode == 0 && sp.auto_dense_ok;
     const bool overflow_only = !auto_dense && sp.mode != 1 && sp.cap_slots < sp.npairs_mine;
-    const bool may_dense = sp.mode == 1 || auto_dense || (overflow_only && !host_rescue);
-    int *unserved_dev = nullptr;
+    // (a context whose last selection was dense enqueues the stand-in behind the sparse kernel instead of waiting for the host to
+    //  find the store overflowed: ctx->dense_hint, set and cleared by rm_locate)
+    const bool may_dense = sp.mode == 1 || auto_dense || (overflow_only && (!host_rescue || ctx->dense_hint));
     if (overflow_only && host_rescue) {
         if (!ctx->h_unserved) HIP_TRY(hipHostMalloc((void **)&ctx->h_unserved, sizeof(int), hipHostMallocDefault));
         *ctx->h_unserved = 0;
@@ -1534,7 +1573,8 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     } else if (may_dense && cp.S >= 3 && tile_eval_ok(cp.g) && !ctx->dbg.dense_rows && !ctx->dbg.dense_general) {
         // deeper chains: every kept pair evaluated where it is summed, tile by tile (rm_tile_eval.h k_tile_sum); it looks at the
         // selection itself when the sparse kernel was enqueued in front of it
-        RM_TRY(launch_tile_sum(sp.mode == 1 ? 0 : 1));
+        if (ctx->dbg.dense_tiles) RM_TRY(launch_dense_t(sp.mode == 1 ? 0 : 1));
+        else RM_TRY(launch_tile_sum(sp.mode == 1 ? 0 : 1));
     } else if (may_dense) {
         // super-tiles of 64 x 64 pixels (four waves, 16 rows each) when that still gives every CU two workgroups, 64 x 32 (two
         // waves) next; with fewer tiles than that, one 64 x 16 tile per workgroup and four rows per wave: the per-frame latency counts
@@ -2018,8 +2058,10 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     const bool clip_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
     ctx->clip_frame_once = clip_once;
     int rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
-    const bool unserved = ctx->h_unserved && *ctx->h_unserved;
+    const int unserved_word = ctx->h_unserved ? *ctx->h_unserved : 0;   // 1: the sparse kernel stood down and nothing took the sum; 2: the stand-in did
+    const bool unserved = unserved_word == 1;
     if (ctx->h_unserved) *ctx->h_unserved = 0;
+    if (ctx->dense_hint && unserved_word != 2) ctx->dense_hint = 0;   // (the stand-in enqueued on the hint was not needed: back to the plain path)
     if (rc >= 0 && cp.valid && unserved) {
         // the selection kept more pairs than the value store holds and the sparse sum kernel stood down (the ROI stage above ran on
         // a heatmap nobody wrote -- the price of not putting a host synchronisation in front of the ROI stage of EVERY call, which
@@ -2028,9 +2070,26 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
         hipStream_t s = (hipStream_t)stream;
         hipLaunchKernelGGL(k_heat_state_init, dim3(1), dim3(NSTRIPE), 0, s, ctx->d_state);
         LAUNCH_CHECK();
-        CollapsePlan dense = cp;
-        dense.sp.mode = 1;
-        RM_TRY(collapse_sum(ctx, dense, temporal_thr, heat, s, T));
+        // how many pairs did the selection keep?  A store that holds them (up to STORE_MAX_SLOTS) is allocated -- for this call and the
+        // later ones of the context -- and the evaluation + sum run again through it; beyond that the store-less sum takes over
+        HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(CollapseState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(stream_wait(s));
+        const long long kept = (long long)ctx->h_state->n_slots;
+        CollapsePlan again = cp;
+        const bool dense_sel = kept * 4 > (long long)cp.sp.npairs_mine;   // a dense selection: the store would be most of the materialised video
+        if (dense_sel) ctx->dense_hint = 1;
+        if (!dense_sel && kept <= STORE_MAX_SLOTS && !(flags & RM_FLAG_TINY_STORE) && ctx->dbg.store_slots <= 0 && cp.sp.mode == 0) {
+            const long long want = std::min(STORE_MAX_SLOTS, kept + kept / 8 + 64);
+            ctx->store_hint_slots = std::max(ctx->store_hint_slots, want);
+            RM_TRY(ws(ctx, "value_store", (size_t)want * CT_H * CT_W, &again.store));
+            again.sp.cap_slots = (unsigned)std::min<long long>(want, (long long)again.sp.npairs_mine);
+            ctx->dbg_cap = again.sp.cap_slots;
+            RM_TRY(launch_eval_pairs(ctx, again, s));
+            RM_TRY(collapse_sum(ctx, again, temporal_thr, heat, s, T));
+        } else {
+            again.sp.mode = 1;
+            RM_TRY(collapse_sum(ctx, again, temporal_thr, heat, s, T));
+        }
         ctx->clip_frame_once = clip_once;
         rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
     }

@@ -92,8 +92,11 @@ struct RegChain {
     // known at compile time, so the block is straight-line code -- no parity test, no border select, no state copies (the
     // generic row-at-a-time form below spends more instructions on those than on arithmetic).  Levels D .. S-1 (1/16 of the
     // pixels and less) and every row near a segment start, the image top or the image bottom take the generic form.
-    static constexpr bool HOT = RegTraits<Tin>::HOT;
-    static constexpr int D = S < 2 ? S : 2;
+    static constexpr bool HOT = RegTraits<Tin>::HOT && (sizeof(Tin) == 1 || S <= 2);   // (float16 at depth 3 / 4: the hot blocks do not fit 256 registers -- compiler resource report)
+#ifndef RM_NARROW_D
+#define RM_NARROW_D 2
+#endif
+    static constexpr int D = S < RM_NARROW_D ? S : RM_NARROW_D;
     static constexpr int B = 1 << D;
     static constexpr int PF = !HOT ? RegTraits<Tin>::PF : RegTraits<Tin>::PF < B ? RegTraits<Tin>::PF : B;
     static_assert(!HOT || B % PF == 0, "a row's prefetch slot must be static inside a hot block");
@@ -450,21 +453,17 @@ struct RegChain {
 #pragma unroll
         for (int i = 0; i < PF; ++i)   // slot i <- the first row >= p_first that belongs to it
             issue(min(p_first + ((i - (p_first - base0)) & (PF - 1)), p_last), regs[i]);
+        // Three loops one after the other -- generic chunks until the levels are warm, ONE run of hot blocks, generic chunks to the
+        // end of the segment -- instead of one loop that picks the form per chunk: with the forms alternating inside a loop the
+        // register allocator moved the (a, b, c, t) state through scratch at every change of form (72 spilled registers, 1.6x the
+        // algorithmic traffic: VERDICT r3).  A segment is warm-up, steady state, bottom; a chunk that is not hot after the run of hot
+        // blocks (the image bottom, the segment's last rows) is never followed by a hot one that matters: the generic form is
+        // always valid.
         int base = base0;
-        while (base <= p_last) {
-            if (hot_ok(base)) {
-                do {
-                    hot_rows<0>(base, regs);
-#pragma unroll
-                    for (int k = 1; k < D; ++k) next[k] += B >> k;   // (next[D] was set by emit)
-                    base += B;
-                } while (hot_ok(base));
-                continue;
-            }
-            // generic rows of this chunk, one at a time (ONE copy of the row code: the slot is picked by a wave-uniform branch)
-            const int p_end = min(base + B - 1, p_last);
+        auto generic_chunk = [&](int b0) __attribute__((always_inline)) {
+            const int p_end = min(b0 + B - 1, p_last);
 #pragma nounroll
-            for (int p = max(base, p_first); p <= p_end; ++p) {
+            for (int p = max(b0, p_first); p <= p_end; ++p) {
                 const int slot = (p - base0) & (PF - 1);
                 Raw16 cur[NLD];
 #pragma unroll
@@ -480,8 +479,18 @@ struct RegChain {
                 feed<0>(p, n);
                 row_fence();
             }
+        };
+#pragma nounroll
+        while (base <= p_last && !hot_ok(base)) { generic_chunk(base); base += B; }
+#pragma nounroll
+        while (base <= p_last && hot_ok(base)) {
+            hot_rows<0>(base, regs);
+#pragma unroll
+            for (int k = 1; k < D; ++k) next[k] += B >> k;   // (next[D] was set by emit)
             base += B;
         }
+#pragma nounroll
+        while (base <= p_last) { generic_chunk(base); base += B; }
     }
 };
 
@@ -494,7 +503,8 @@ __global__ __launch_bounds__(64) void k_down_chain_narrow(const Tin *frames, siz
     down_chain_narrow_body<S, Tin>(frames, frame_stride, g, out);
 }
 
-// uint8 / float16 frame buffers: two waves per SIMD (256 registers: the hot loop holds its state without spills)
+// uint8 / float16 frame buffers: two waves per SIMD, i.e. a cap of 256 registers.  Every instantiation holds its state in registers
+// (156-214 VGPRs, no scratch: respmon_amd/csrc/build_resources.txt; tools/check_resources.py fails the build otherwise)
 template <int S, typename Tin = uint8_t>
 __global__ __launch_bounds__(64) RM_NARROW_OCC void k_down_chain_u8(const Tin *frames, size_t frame_stride, DownGeom g, double *out)
 {

@@ -734,6 +734,115 @@ __global__ __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W
     }
 }
 
+// ---- the masked time sum of a DENSE selection at skip 3 / 4: one wave per tile, frame after frame (k_dense_sum_w's form, rm_dense_sum.h) -----
+// When (nearly) every (tile, frame) pair is kept -- sensor noise in every pixel, bench.py `worst_case` -- the value store is the
+// materialised video in disguise (2.1 GB written and read back at 1080p x 256) and k_tile_sum's rounds of sixteen waves keep one CU
+// per tile busy behind two barriers a round (1.85 ms).  Here a wave owns a 64 x 16 tile of the heatmap for ALL frames: TileEval of frame t
+// from a private 4.4 KB slice of LDS, `raw >= top ? min : raw` added to 16 running sums per lane in frame order; a pair the selection
+// pruned adds `min` to every pixel without being evaluated; no barrier, no store, no separate constant fill, every SIMD of the chip
+// busy with two or three independent waves.  Same values, same order of additions as every other sum kernel: bit-identical.
+constexpr int DST_MAXW = (MAX_T / 2 + 1 + 63) / 64;   // 64-frame words of a tile's kept mask
+
+template <int S>
+__global__ __launch_bounds__(64) void k_dense_sum_t(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles, const int *slot_of,
+                                                    CollapseState *st, double threshold, double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp,
+                                                    int only_if_dense, int *ran_host)
+{
+    using F = TileFoot<S, false>;
+    HIP_DYNAMIC_SHARED(double, lds)                 // the wave's footprint slice, then the kept mask (DST_MAXW words)
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds + F::TOTAL);
+    const int lane = threadIdx.x;
+    if (only_if_dense && !sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse kernel in front took the sum)
+    if (ran_host && blockIdx.x == 0 && lane == 0) *ran_host = 2;   // (pinned: tells rm_locate that the stand-in it enqueued on a hint was needed)
+    const int tile = dense_tile_of_block((int)blockIdx.x, ntiles);   // XCD x takes the x-th eighth of the tiles (rm_dense_sum.h)
+    if (tile >= ntiles) return;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const int Th = sym_frames(T);
+    // which unique frames of this tile did the selection keep?  (tile-major slot_of: a few cache lines)
+    for (int c0 = 0; c0 < Th; c0 += 64) {
+        const int u = c0 + lane;
+        const bool kept = u < Th && slot_of[slot_index(u, tile, Th)] != SLOT_PRUNED;
+        const unsigned long long mk = __ballot(kept);
+        if (lane == 0) s_mask[c0 >> 6] = mk;
+    }
+    const double min_val = f64_unkey(fold_min_keys(st->min_keys, st->min_key)), max_val = f64_unkey(fold_max_keys(st->max_keys, st->max_key));
+    const double top = max_val - (max_val - min_val) * threshold;   // transforms.py:184-189
+    if (blockIdx.x == 0 && lane == 0) { st->min_val = min_val; st->max_val = max_val; st->top = top; }
+    TileSetup<S, false> ts;
+    tile_setup<S, false>(g, tx, ty, 0, lane, ts);
+    const size_t fs = (size_t)g.h[S] * g.w[S];
+    const int H0 = g.h[0], W0 = g.w[0];
+    wave_sync();
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    // the footprints of the next two frames travel while this one is evaluated (requested whether the pair is kept or not: one
+    // 8-byte load per lane and frame)
+    constexpr int PD = 2;
+    double nxt[PD][F::PF];
+    auto fetch = [&](int d, int t) __attribute__((always_inline)) {
+        const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
+#pragma unroll
+        for (int p = 0; p < F::PF; ++p) nxt[d][p] = src[ts.off_g[p]];
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch(d, t_first + d);
+    int nkept = 0;
+    for (int tb = t_first; tb < t_end; tb += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int t = tb + d;
+            if (t >= t_end) break;   // (uniform)
+            const int u = sym_frame(t, T);
+            const bool kept = (s_mask[u >> 6] >> (u & 63)) & 1ull;   // (uniform)
+            if (kept) {
+                wave_sync();   // the previous frame's reads of the slice are behind us
+#pragma unroll
+                for (int p = 0; p < F::PF; ++p) if (lane + 64 * p < F::NST) lds[F::off(S) + lane + 64 * p] = nxt[d][p];
+                fetch(d, t + PD);
+                wave_sync();
+                double v[16];
+                tile_eval<S, false>(ts, lds, lane, v);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
+                ++nkept;
+            } else {
+                fetch(d, t + PD);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = acc[j] + min_val;
+            }
+        }
+    }
+    // base.py:562: np.average = sum / T when the whole buffer was summed here; the heatmap's extrema for base.py:563
+    const double cnt = (double)avg_T;
+    double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = ts.Y0 + r;
+        if (y < H0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                if (ts.X + o < W0) {
+                    const double a = acc[8 * o + r];
+                    const double q = avg_T > 0 ? a / cnt : a;
+                    heat_sum[(size_t)y * W0 + ts.X + o] = q;
+                    hmn = (q < hmn) ? q : hmn; hmx = (q > hmx) ? q : hmx;
+                }
+            }
+        }
+    }
+    if (tile_nkept && lane == 0) tile_nkept[tile] = nkept;   // 0: every pixel of the tile is the same constant (sparse heatmap exchange)
+    if (avg_T > 0) {
+        hmn = wave_min(hmn); hmx = wave_max(hmx);
+        if (lane == 0) {
+            const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
+            const int sp_ = blockIdx.x & (NSTRIPE - 1);
+            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
+            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+        }
+    }
+}
+
 // ---- masked time sum, tile by tile ----------------------------------------------------------------------------------------------------
 // Work item i = (heavy tile, half) [HALF] or one heavy tile; a workgroup of TS_NW waves takes the items i = blockIdx.x, + nworkers, ...
 // The workgroups left without an item fill the tiles without kept pairs with their constant (as k_masked_sum_tiles did).

@@ -89,7 +89,8 @@ def synth_breathing_blocks(T, H, W, seed=1234, fps=10.0, breath_hz=0.4, amplitud
     return out
 
 
-def synth_breathing_dense(T, H, W, seed=4321, fps=10.0, breath_hz=0.4, amplitude=0.2, noise=0.06, block=8, workers=None):
+def synth_breathing_dense(T, H, W, seed=4321, fps=10.0, breath_hz=0.4, amplitude=0.2, noise=0.06, block=8, workers=None,
+                          centers=None, sigma=(0.10, 0.08), phase_step=np.pi / 2):
     """A stream that is hard on the pruning of the collapse passes (bench.py `dense_stream`): FOUR breathing blobs spread
     over the frame, a quarter period apart, and three times the sensor noise of synth_breathing -- low-tail voxels
     of the band-passed video are no longer confined to one corner of the image.  Block-parallel like
@@ -98,8 +99,9 @@ def synth_breathing_dense(T, H, W, seed=4321, fps=10.0, breath_hz=0.4, amplitude
     from concurrent.futures import ThreadPoolExecutor
     rng0 = np.random.Generator(np.random.PCG64(seed))
     tex = _lowpass_noise(rng0, H, W)
-    centers = [(0.25, 0.2), (0.3, 0.75), (0.7, 0.35), (0.75, 0.8)]
-    sig_y, sig_x = 0.10, 0.08
+    if centers is None:
+        centers = [(0.25, 0.2), (0.3, 0.75), (0.7, 0.35), (0.75, 0.8)]
+    sig_y, sig_x = sigma
     blobs = []
     for (cy, cx) in centers:
         yy = (np.arange(H)[:, None] - cy * H) / (sig_y * H)
@@ -119,7 +121,7 @@ def synth_breathing_dense(T, H, W, seed=4321, fps=10.0, breath_hz=0.4, amplitude
         g *= sig
         g += base[None]
         for q, blob in enumerate(blobs):
-            s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps + q * np.pi / 2).astype(np.float32)[:, None, None]
+            s = np.sin(2 * np.pi * breath_hz * np.arange(t0, t1) / fps + q * phase_step).astype(np.float32)[:, None, None]
             g += blob[None] * s
         np.rint(g, out=g)
         np.clip(g, 0, 255, out=g)
@@ -130,6 +132,18 @@ def synth_breathing_dense(T, H, W, seed=4321, fps=10.0, breath_hz=0.4, amplitude
     with ThreadPoolExecutor(workers) as ex:
         list(ex.map(fill, range(len(starts))))
     return out
+
+
+def synth_noise_only(T, H, W, seed=777, noise=0.1, workers=None):
+    """Worst case of the collapse passes' pruning (bench.py `worst_case`): the static texture plus sensor noise of sigma 0.1 in
+    EVERY pixel and no breathing region at all -- low-tail voxels of the band-passed video turn up in every tile."""
+    return synth_breathing_dense(T, H, W, seed=seed, noise=noise, workers=workers, centers=[])
+
+
+def synth_breathing_16(T, H, W, seed=888, noise=0.04, workers=None):
+    """Sixteen small breathing blobs on a 4 x 4 lattice, a sixteenth of a period apart, twice the noise of synth_breathing."""
+    centers = [((2 * i + 1) / 8.0, (2 * j + 1) / 8.0) for i in range(4) for j in range(4)]
+    return synth_breathing_dense(T, H, W, seed=seed, noise=noise, workers=workers, centers=centers, sigma=(0.05, 0.04), phase_step=np.pi / 8)
 
 
 def synth_brightness_video(T, H, W, fps=10.0, hz=0.4):

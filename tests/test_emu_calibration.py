@@ -590,6 +590,10 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             fast, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256 | 1)
             assert np.array_equal(fast, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_eval_pairs_fast, no_prune")
             emu.debug_set("collapse_fused", 1)
+            emu.debug_set("dense_tiles", 1)          # one wave per tile, frame after frame (k_dense_sum_t)
+            dense_t, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+            assert np.array_equal(dense_t, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_dense_sum_t")
+            emu.debug_set("dense_tiles", 0)          # rounds of sixteen waves per tile (k_tile_sum)
             for half in (0, 1):     # whole-tile / half-tile work items (chosen by the number of heavy tiles otherwise)
                 emu.debug_set("tile_sum_half", half)
                 fused, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
@@ -614,7 +618,7 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             emu.debug_set("sum_rows", 1)
             rows, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
             assert np.array_equal(rows, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_masked_sum_rows, chunks")
-        emu.debug_set("sum_rows", 1)
+        emu.debug_set("sum_rows", 0)
         # a breathing video: few heavy tiles (half-tile work items), pruned pairs in between, and the oracle's ROI
         from respmon_amd import synth
         v8 = synth.synth_breathing(24, 96, 160, seed=3)
@@ -623,6 +627,10 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             emu.debug_set("collapse_fused", 0)
             store, mm = emu.calibrate(fr, 10.0, levels=L, skip=S, flags=256)
             emu.debug_set("collapse_fused", 1)
+            emu.debug_set("dense_tiles", 1)
+            dense_t, mm2 = emu.calibrate(fr, 10.0, levels=L, skip=S)
+            assert np.array_equal(dense_t, store) and tuple(mm) == tuple(mm2), (L, S, "breathing video, k_dense_sum_t")
+            emu.debug_set("dense_tiles", 0)
             for half in (0, 1):
                 emu.debug_set("tile_sum_half", half)
                 fused, mm2 = emu.calibrate(fr, 10.0, levels=L, skip=S)
@@ -641,4 +649,5 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
         emu.debug_set("tile_sum_half", -1)
         emu.debug_set("eval_fast", 1)
         emu.debug_set("sum_sym", 0)
-        emu.debug_set("sum_rows", 1)
+        emu.debug_set("sum_rows", 0)
+        emu.debug_set("dense_tiles", 1)

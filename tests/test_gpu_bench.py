@@ -37,7 +37,8 @@ def test_bench_single_gpu_contract_line():
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert 0 < r["step_frac"] <= r["frac"] < 1.0                      # the whole step can only be slower than its main kernel
+    assert r["step_frac"] == r["frac"]                                # `frac` is the contract figure: the whole step
+    assert 0 < r["frac"] <= r["kernel_frac"] < 1.0                    # the whole step can only be slower than its main kernel
     assert r["algorithmic_bytes"] == 64 * 270 * 480 * 8 + 270 * 480 * 8
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["all_cores"]["cores"] == 4 and c["all_cores"]["roi_equals_single_thread"]

@@ -712,11 +712,14 @@ def test_dense_sum_equals_sparse_path(hip, oracle):
     assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "sparse"
     # the store-less passes (rm_tile_eval.h): kept pairs evaluated where they are summed -- whole tiles or half tiles, same bits
     device.debug_set("collapse_fused", 1)
+    assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "fused"      # k_dense_sum_t
+    device.debug_set("dense_tiles", 0)                                                # k_tile_sum
     for half in (-1, 0, 1):
         device.debug_set("tile_sum_half", half)
         assert torch.equal(dist.hip_calibrate(buf, 10), a) and sum_path() == "fused", half
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=1), a), ("no_prune", half)
     device.debug_set("tile_sum_half", -1)
+    device.debug_set("dense_tiles", 1)
     device.debug_set("collapse_fused", 0)
     # ... which are also what stands in for an overflowing value store at skip >= 3 (k_tile_sum behind the sparse kernel)
     device.debug_set("store_slots", 1000)
@@ -754,12 +757,16 @@ def test_fused_collapse_equals_store_path(hip, oracle):
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=256, **kw), store), (dt, T, H, W, L, S, "k_eval_pairs_fast")
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=256 | 1, **kw), store), (dt, T, H, W, L, S, "k_eval_pairs_fast, no_prune")
             device.debug_set("collapse_fused", 1)
+            device.debug_set("dense_tiles", 1)       # one wave per tile, frame after frame (k_dense_sum_t)
+            assert torch.equal(dist.hip_calibrate(buf, 10, **kw), store), (dt, T, H, W, L, S, "k_dense_sum_t")
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=1, **kw), store), (dt, T, H, W, L, S, "k_dense_sum_t, no_prune")
+            device.debug_set("dense_tiles", 0)       # rounds of sixteen waves per tile (k_tile_sum)
             for half in (0, 1, -1):
                 device.debug_set("tile_sum_half", half)
                 assert torch.equal(dist.hip_calibrate(buf, 10, **kw), store), (dt, T, H, W, L, S, half)
             assert torch.equal(dist.hip_calibrate(buf, 10, flags=1, **kw), store), (dt, T, H, W, L, S, "no_prune")
         device.debug_set("collapse_fused", 1)
-        device.debug_set("sum_rows", 1)
+        device.debug_set("sum_rows", 0)
         v8 = synth.synth_breathing(64, 270, 480, seed=5)
         fr = oracle.uint8_to_float(v8)
         buf = torch.from_numpy(fr).cuda()
@@ -775,7 +782,8 @@ def test_fused_collapse_equals_store_path(hip, oracle):
         device.debug_set("tile_sum_half", -1)
         device.debug_set("eval_fast", 1)
         device.debug_set("sum_sym", 0)
-        device.debug_set("sum_rows", 1)
+        device.debug_set("sum_rows", 0)
+        device.debug_set("dense_tiles", 1)
 
 
 def test_filter_first_per_level_equals_fused(hip):
@@ -861,3 +869,47 @@ def test_streaming_tile_bounds_equal_table_form(hip):
         assert torch.equal(got, ref) and mm == mm2, (T, H, W, L, S)
         exhaustive = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 1)
         assert torch.equal(got, exhaustive), (T, H, W, L, S, "no prune")
+
+
+def test_value_store_grows_with_the_selection(hip, oracle):
+    """rm_locate on streams that keep more pairs than the value store starts with.  (a) A moderately dense selection (a breathing video
+    against a store of 64 slots): the first call finds the store overflowed after its host synchronisation, allocates one that holds
+    the selection and runs evaluation + sum again; later calls go straight through the grown store.  (b) A dense selection (noise:
+    every pair kept): the store-less sum (k_dense_sum_t) takes over, from the second call on enqueued without waiting for the host.
+    Same ROI as the path with a slot per pair (flags=256) every time."""
+    import ctypes
+    import torch
+    from respmon_amd import _capi, device, dist, synth
+    rng = np.random.default_rng(41)
+    xywh = (ctypes.c_int32 * 4)()
+    dbg = (ctypes.c_longlong * 4)()
+
+    def run(ctx, buf, L, S):
+        T, H, W = buf.shape
+        rc = _capi.check(hip, hip.rm_locate(ctx, device.ptr(buf), device.dtype_code(buf), T, H, W, 10.0, 0.1, 1.0, 500.0, L, S, 0.7, 20, 0, xywh,
+                                            device.stream_ptr()), "rm_locate")
+        _capi.check(hip, hip.rm_debug_counters(ctx, dbg, device.stream_ptr()), "rm_debug_counters")
+        return None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
+
+    for case in ("grow", "dense"):
+        if case == "grow":
+            L, S = 7, 4
+            fr = oracle.uint8_to_float(synth.synth_breathing(64, 270, 480, seed=5))
+            buf = torch.from_numpy(fr).cuda()
+        else:
+            L, S = 7, 3
+            buf = torch.from_numpy(rng.random((64, 544, 1024))).cuda()     # 16 x 34 tiles x 33 unique frames = 17 952 pairs, all kept
+        ref = dist.hip_heatmap_to_roi(dist.hip_calibrate(buf, 10, flags=256, pyramid_levels=L, skip_levels_at_top=S), 20)
+        fresh = ctypes.c_void_p()
+        _capi.check(hip, hip.rm_ctx_create(torch.cuda.current_device(), ctypes.byref(fresh)), "rm_ctx_create")
+        if case == "grow":
+            _capi.check(hip, hip.rm_debug_set(fresh, b"store_default_slots", 64), "rm_debug_set")
+        for call in range(3):
+            roi = run(fresh, buf, L, S)
+            assert roi == ref, (case, call, roi, ref)
+            if case == "grow":
+                assert 64 < dbg[2] and dbg[2] * 4 <= dbg[0]                        # more than the starting store, not a dense selection
+                assert dbg[3] >= dbg[2], "the store must hold the selection (grown inside the first call)"
+            else:
+                assert dbg[2] > 16384 and dbg[3] == 0                              # dense: no store in use
+        _capi.check(hip, hip.rm_ctx_destroy(fresh), "rm_ctx_destroy")

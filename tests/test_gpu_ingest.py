@@ -1,0 +1,102 @@
+"""Deterministic GPU tests of the ingest rows (reference base.py:227-233): cv2.cvtColor(BGR2GRAY) on the device,
+uint8_to_float into every calibration-buffer dtype (`store_frame`), and the per-call contour options of the ROI stage."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from respmon_amd import _capi
+    return _capi.load()
+
+
+def test_bgr_to_gray_every_sampled_triple_and_a_1080p_frame(hip, oracle):
+    """rm_bgr_to_gray against the oracle's cvtColor_bgr2gray (OpenCV's fixed-point weights, base.py:230): every (B, G, R) on the
+    lattice {0, 5, .., 255}^3 plus the lattice's neighbours of the rounding boundaries, and a random 1080p frame."""
+    from respmon_amd.base import _Backend
+    be = _Backend()
+    v = np.arange(0, 256, 5, dtype=np.uint8)
+    v = np.unique(np.concatenate([v, [1, 2, 3, 127, 128, 129, 253, 254, 255]])).astype(np.uint8)
+    b, g, r = np.meshgrid(v, v, v, indexing="ij")
+    lattice = np.stack([b.ravel(), g.ravel(), r.ravel()], axis=1)          # [N, 3]
+    n = lattice.shape[0]
+    w = 512
+    h = (n + w - 1) // w
+    img = np.zeros((h * w, 3), dtype=np.uint8)
+    img[:n] = lattice
+    img = img.reshape(h, w, 3)
+    got = be.bgr_to_gray(img).cpu().numpy()
+    assert np.array_equal(got, oracle.cvtColor_bgr2gray(img))
+    rng = np.random.default_rng(7)
+    frame = rng.integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    got = be.bgr_to_gray(frame).cpu().numpy()
+    assert np.array_equal(got, oracle.cvtColor_bgr2gray(frame))
+    # all 2^24 triples: the weights are exact integers, so a closed form over the full cube is cheap on both sides
+    bb, gg, rr = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(0, 256, 1, dtype=np.uint8), indexing="ij")
+    cube = np.stack([bb, gg, rr], axis=-1).reshape(4096, 4096, 3)
+    got = be.bgr_to_gray(cube).cpu().numpy()
+    assert np.array_equal(got, oracle.cvtColor_bgr2gray(cube))
+
+
+def test_store_frame_every_buffer_dtype(hip, oracle):
+    """calibration_buffer[idx] = uint8_to_float(gray) (base.py:231, 431) for the four device buffer dtypes: float64 holds
+    k * (1 / 255) bit for bit, float32 / float16 its correctly rounded value, uint8 the level itself; all 256 levels + a random frame."""
+    import torch
+    from respmon_amd.base import _Backend
+    be = _Backend()
+    rng = np.random.default_rng(9)
+    levels = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    frame = rng.integers(0, 256, size=(270, 480), dtype=np.uint8)
+    for g8 in (levels, frame):
+        ref64 = oracle.uint8_to_float(g8)
+        gray = torch.from_numpy(g8).cuda()
+        for tdt, ndt in ((torch.float64, np.float64), (torch.float32, np.float32), (torch.float16, np.float16), (torch.uint8, np.uint8)):
+            buf = torch.zeros((3,) + g8.shape, dtype=tdt, device="cuda")
+            be.store_frame(buf, 1, gray)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()
+            assert not got[0].any() and not got[2].any()
+            want = g8 if ndt == np.uint8 else ref64.astype(ndt)
+            assert np.array_equal(got[1], want), ndt
+    # the float64 round trip reproduces the reference's 24 lossy levels (transforms.py:26-29) through the device helpers
+    buf = torch.zeros((1, 16, 16), dtype=torch.float64, device="cuda")
+    be.store_frame(buf, 0, torch.from_numpy(levels).cuda())
+    back = torch.empty((16, 16), dtype=torch.uint8, device="cuda")
+    from respmon_amd import _capi, device
+    _capi.check(hip, hip.rm_float_to_uint8(device.ctx(), device.ptr(buf[0]), device.ptr(back), 256, device.stream_ptr()), "rm_float_to_uint8")
+    torch.cuda.synchronize()
+    assert np.array_equal(back.cpu().numpy(), oracle.float_to_uint8(oracle.uint8_to_float(levels)))
+    assert int((back.cpu().numpy() != levels).sum()) == 24
+
+
+def test_contour_options_are_restored_after_a_per_call_override(hip):
+    """dist.hip_heatmap_to_roi(clip_frame=..., labelling=...) overrides the context's contour options for ONE call and puts back what
+    the context had (rm_get_contour_clip_frame / rm_get_contour_labelling)."""
+    import torch
+    from respmon_amd import _capi, device, dist
+    ctx = device.ctx()
+    heat = torch.zeros((40, 64), dtype=torch.float64, device="cuda")
+    heat[0:12, 0:20] = 1.0                       # a blob that touches the image frame: the two findContours rules differ
+    on, mode = ctypes.c_int(-7), ctypes.c_int(-7)
+    try:
+        for ctx_clip, ctx_mode in ((0, -1), (1, 1), (1, 0), (0, 1)):
+            _capi.check(hip, hip.rm_set_contour_clip_frame(ctx, ctx_clip), "set clip")
+            _capi.check(hip, hip.rm_set_contour_labelling(ctx, ctx_mode), "set labelling")
+            plain = dist.hip_heatmap_to_roi(heat, 20)
+            for clip in (False, True):
+                for lab in (None, False, True):
+                    roi = dist.hip_heatmap_to_roi(heat, 20, clip_frame=clip, labelling=lab)
+                    assert roi == ((1, 1, 19, 11) if (clip or ctx_clip) else (0, 0, 20, 12)), (ctx_clip, ctx_mode, clip, lab, roi)
+                    _capi.check(hip, hip.rm_get_contour_clip_frame(ctx, ctypes.byref(on)), "get clip")
+                    _capi.check(hip, hip.rm_get_contour_labelling(ctx, ctypes.byref(mode)), "get labelling")
+                    assert (on.value, mode.value) == (ctx_clip, ctx_mode), "the context's own options must survive a per-call override"
+            assert dist.hip_heatmap_to_roi(heat, 20) == plain
+    finally:
+        hip.rm_set_contour_clip_frame(ctx, 0)
+        hip.rm_set_contour_labelling(ctx, -1)
