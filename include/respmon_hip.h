@@ -35,6 +35,7 @@ extern "C" {
 #define RM_E_NOMEM (-3)
 #define RM_E_UNSUPPORTED (-4)
 #define RM_E_INTERNAL (-5)
+#define RM_E_COMM (-6)     /* RCCL: library missing, communicator or collective failed */
 
 /* element type of a frame buffer handed to the library */
 #define RM_U8 0  /* gray uint8; the kernels apply uint8_to_float's  k * (1./255)  (transforms.py:20-23) */
@@ -272,6 +273,43 @@ int rm_flow_begin(rm_ctx *ctx, rm_flow_state *state, const void *frame_dev, int 
 int rm_flow_step(rm_ctx *ctx, rm_flow_state *state, const void *frame_dev, int dtype, int H, int W, int x, int y, int w, int h, int win_w, int win_h,
                  int max_level, int max_count, double epsilon, float *mean_xy_host, int *n_good_host, void *stream);
 int rm_flow_points(rm_ctx *ctx, rm_flow_state *state, float *pts_host, int cap, int *n_host, void *stream);
+
+/* ---- multi-GPU steps with RCCL behind the C-ABI (the call site they replace is base.py:444, run once per GPU).
+ *      One process per GPU, one context per process.  librccl is opened at run time (dlopen), so single-GPU users never need it.
+ *        rm_comm_unique_id   rank 0 makes the id (RM_COMM_ID_BYTES bytes = ncclUniqueId) and hands it to the other ranks by any
+ *                            out-of-band way (a file, MPI, a torch.distributed broadcast: INTEGRATION.md)
+ *        rm_comm_init        ncclCommInitRank on the context's device.  world == 1 with unique_id == NULL: no library involved,
+ *                            the collectives are the identity (rm_locate_streams then equals rm_locate)
+ *        rm_comm_info        rank / world of the context and ncclCommCount of its communicator (0: none)
+ *        rm_shard_frames     Mode A frame shard [t0, t1) of `rank`: contiguous, sizes differ by at most one
+ *        rm_locate_streams   Mode B (BASELINE config 4): every rank calibrates ITS OWN [T,H,W] buffer; the float64 heatmaps are
+ *                            summed over the ranks in rank order -- one ncclAllGather of sparse packets (a stream's heatmap is one
+ *                            constant outside the tiles that survive the pruning), dense ncclAllReduce(sum) when a packet
+ *                            overflows (the cap then grows / the exchange stays dense for a while, identically on every rank) --
+ *                            and every rank extracts the same ROI.  fused_heat_dev (nullable): the summed heatmap.
+ *        rm_locate_sharded   Mode A: ONE [T,H,W] buffer whose frames rm_shard_frames(T, rank, world) are frames_local_dev on this
+ *                            rank: pyramid of the local frames -> ncclAllGather -> temporal filter + collapse + pruning for all
+ *                            frames -> ncclAllReduce(max) of {-min, max} -> masked time sum of the local frames -> sparse packets
+ *                            / dense all-reduce of the partial sums -> heatmap = sum / T -> ROI (every rank the same).
+ *      Both enqueue on `stream` and synchronise the host once (twice after a packet overflow).  *exchange_out (nullable):
+ *      RM_EXCHANGE_SPARSE / RM_EXCHANGE_DENSE.  Return RM_OK / RM_NO_CONTOUR like rm_locate; RM_E_COMM on an RCCL failure. */
+#define RM_COMM_ID_BYTES 128
+#define RM_EXCHANGE_SPARSE 1
+#define RM_EXCHANGE_DENSE 2
+#define RM_SPARSE_CAP_TILES 128   /* tiles (64x16 px) a packet carries at first: 1 MB per rank */
+#define RM_SPARSE_MAX_TILES 512   /* ... and at most: 4 MB */
+#define RM_DENSE_HOLD 64          /* steps a stream that does not fit stays on the dense all-reduce before the sparse form is tried again */
+int rm_comm_unique_id(void *id_out);
+int rm_comm_init(rm_ctx *ctx, int rank, int world, const void *unique_id);
+int rm_comm_destroy(rm_ctx *ctx);
+int rm_comm_info(rm_ctx *ctx, int *rank, int *world, int *rccl_ranks);
+int rm_shard_frames(int T, int rank, int world, int *t0, int *t1);
+int rm_locate_streams(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W, double fps, double fmin, double fmax, double amp,
+                      int levels, int skip, double temporal_thr, int threshold, unsigned flags, double *fused_heat_dev, int32_t *xywh_host,
+                      int *exchange_out, void *stream);
+int rm_locate_sharded(rm_ctx *ctx, const void *frames_local_dev, int dtype, int T, int H, int W, double fps, double fmin, double fmax, double amp,
+                      int levels, int skip, double temporal_thr, int threshold, unsigned flags, double *heatmap_dev, int32_t *xywh_host,
+                      int *exchange_out, void *stream);
 
 /* ---- base.py:230-231: cv2.cvtColor(BGR2GRAY) then uint8_to_float, on device ("next" row f3) */
 int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr_dev, size_t npix, uint8_t *gray_dev, void *stream);

@@ -10,6 +10,9 @@ import os
 RM_OK = 0
 RM_NO_CONTOUR = 1
 RM_SPARSE_FALLBACK = 2
+RM_COMM_ID_BYTES = 128
+RM_EXCHANGE_SPARSE, RM_EXCHANGE_DENSE = 1, 2
+RM_E_COMM = -6
 RM_U8, RM_F16, RM_F32, RM_F64 = 0, 1, 2, 3
 RM_FLAG_NO_PRUNE = 1
 RM_FLAG_UNFUSED_DOWN = 2
@@ -78,6 +81,13 @@ SIGNATURES = {
     "rm_mean_flow": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rm_pca_reduce": (_i, [_vp, _vp, _i, _vp, _vp]),
     "rm_bgr_to_gray": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "rm_comm_unique_id": (_i, [_vp]),
+    "rm_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "rm_comm_destroy": (_i, [_vp]),
+    "rm_comm_info": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    "rm_shard_frames": (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i)]),
+    "rm_locate_streams": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp, _c.POINTER(_i), _vp]),
+    "rm_locate_sharded": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp, _c.POINTER(_i), _vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librespmon_hip.so")

@@ -79,7 +79,13 @@ template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8
 #define RM_F32_RING 4
 #endif
 template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16_PREFETCH, RD = RM_F16_RING; static constexpr bool HOT = RM_NARROW_HOT != 0, DMA = RM_NARROW_DMA_ON != 0; };
-template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = 2, RD = RM_F32_RING; static constexpr bool HOT = false, DMA = RM_NARROW_DMA_ON != 0; };
+#ifndef RM_F32_HOT
+#define RM_F32_HOT 0
+#endif
+#ifndef RM_F32_PREFETCH
+#define RM_F32_PREFETCH 2
+#endif
+template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = RM_F32_PREFETCH, RD = RM_F32_RING; static constexpr bool HOT = RM_F32_HOT != 0, DMA = RM_NARROW_DMA_ON != 0; };
 // LDS bytes per wave of the row ring (0: rows in registers)
 template <typename Tin> constexpr size_t narrow_ring_bytes() { return RegTraits<Tin>::DMA ? (size_t)RegTraits<Tin>::RD * RegTraits<Tin>::NLD * 1024 : 0; }
 

@@ -238,6 +238,8 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
     tiles that survive the pruning: 1 MB per rank instead of a 16.6 MB all-reduce at 1080p, summed in rank order);
     `sparse=False`, a test double for the calibration, or a packet overflow uses the dense all-reduce(sum)."""
     global LAST_EXCHANGE
+    if calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and sparse is None and cabi_comm_active(group):
+        return cabi_locate_streams(buf, fps, threshold=threshold, return_heatmap=return_heatmap, **kw)
     if calibrate_fn is hip_calibrate and not return_heatmap:   # nobody sees this rank's own heatmap: no allocation per step
         from . import device as _device
         heat = hip_calibrate(buf, fps, out=_scratch("heat", buf.shape[1:], _device.torch().float64, buf.device), **kw)
@@ -385,6 +387,9 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
         raise ValueError("rank %d holds %d frames, shard_frames(%d, %d, %d) says %d" % (rank, buf_local.shape[0], T, rank, world, t1 - t0))
     if t1 - t0 < 1:
         raise ValueError("every rank needs at least one frame (T=%d, world=%d)" % (T, world))
+    if stages is None and sparse is None and cabi_comm_active(group):
+        return cabi_locate_sharded(buf_local, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
+                                   temporal_threshold, threshold, flags, return_heatmap)
     st = stages if stages is not None else HipShardStages()
     _, H, W = buf_local.shape
     L, S = int(pyramid_levels), int(skip_levels_at_top)
@@ -409,3 +414,89 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
     _all_reduce(heat_sum, dist.ReduceOp.SUM, group)
     roi, heat = st.finish(heat_sum, T, threshold)
     return (roi, heat) if return_heatmap else roi
+
+
+# ---------------------------------------------------------------------------------------------------
+# RCCL behind the C-ABI (include/respmon_hip.h rm_comm_* / rm_locate_streams / rm_locate_sharded): one call per step, one host
+# synchronisation, the collectives issued by the library on the caller's stream.  torch.distributed only ships the 128-byte
+# communicator id once.  locate_streams / locate_sharded take this path when the context of the current device holds a communicator
+# of the group's size (cabi_comm_init); gloo dry runs and test doubles keep the torch.distributed path above.
+# ---------------------------------------------------------------------------------------------------
+_CABI_COMM = {}   # device index -> (rank, world)
+
+
+def cabi_comm_init(group=None):
+    """Create the library's RCCL communicator for the current device from an initialised torch.distributed group (backend nccl):
+    rank 0 makes the id (rm_comm_unique_id), the group broadcasts it, every rank calls rm_comm_init.  Returns (rank, world,
+    rccl_ranks_seen) -- rccl_ranks_seen is ncclCommCount of the new communicator."""
+    import ctypes
+    from . import _capi, device
+    t = device.require_gpu()
+    dist = _dist()
+    lib = _capi.load()
+    rank, world = _world(group)
+    ctx = device.ctx()
+    idbuf = (ctypes.c_ubyte * _capi.RM_COMM_ID_BYTES)()
+    if rank == 0:
+        _capi.check(lib, lib.rm_comm_unique_id(idbuf), "rm_comm_unique_id")
+    if world > 1:
+        dev = t.device("cuda", t.cuda.current_device()) if dist.get_backend(group) != "gloo" else t.device("cpu")
+        tid = t.tensor(list(idbuf), dtype=t.uint8, device=dev)
+        dist.broadcast(tid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(tid.cpu().tolist())
+        ctypes.memmove(idbuf, raw, _capi.RM_COMM_ID_BYTES)
+    _capi.check(lib, lib.rm_comm_init(ctx, rank, world, idbuf), "rm_comm_init")
+    r, w, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _capi.check(lib, lib.rm_comm_info(ctx, ctypes.byref(r), ctypes.byref(w), ctypes.byref(n)), "rm_comm_info")
+    _CABI_COMM[t.cuda.current_device()] = (r.value, w.value)
+    return r.value, w.value, n.value
+
+
+def cabi_comm_destroy():
+    from . import _capi, device
+    t = device.require_gpu()
+    _capi.load().rm_comm_destroy(device.ctx())
+    _CABI_COMM.pop(t.cuda.current_device(), None)
+
+
+def cabi_comm_active(group=None):
+    from . import device
+    t = device.torch()
+    if not t.cuda.is_available():
+        return False
+    have = _CABI_COMM.get(t.cuda.current_device())
+    return have is not None and have == _world(group)
+
+
+def _cabi_step(fn_name, buf, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top, temporal_threshold, threshold,
+               flags, return_heatmap):
+    import ctypes
+    from . import _capi, device
+    global LAST_EXCHANGE
+    t = device.require_gpu()
+    lib = _capi.load()
+    _, H, W = buf.shape
+    heat = t.empty((H, W), dtype=t.float64, device=buf.device) if return_heatmap else None
+    xywh = (ctypes.c_int32 * 4)()
+    how = ctypes.c_int(0)
+    rc = _capi.check(lib, getattr(lib, fn_name)(device.ctx(), device.ptr(buf), device.dtype_code(buf), int(T), H, W, float(fps), float(freq_min),
+                                               float(freq_max), float(amplification), int(pyramid_levels), int(skip_levels_at_top),
+                                               float(temporal_threshold), int(threshold), int(flags), device.ptr(heat), xywh, ctypes.byref(how),
+                                               device.stream_ptr()), fn_name)
+    LAST_EXCHANGE = {_capi.RM_EXCHANGE_SPARSE: "sparse", _capi.RM_EXCHANGE_DENSE: "dense"}.get(how.value)
+    roi = None if rc == _capi.RM_NO_CONTOUR else (int(xywh[0]), int(xywh[1]), int(xywh[2]), int(xywh[3]))
+    return (roi, heat) if return_heatmap else roi
+
+
+def cabi_locate_streams(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4, temporal_threshold=0.7,
+                        threshold=20, flags=0, return_heatmap=False):
+    """Mode B step in ONE C-ABI call (rm_locate_streams)."""
+    return _cabi_step("rm_locate_streams", buf, buf.shape[0], fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
+                      temporal_threshold, threshold, flags, return_heatmap)
+
+
+def cabi_locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4,
+                        temporal_threshold=0.7, threshold=20, flags=0, return_heatmap=False):
+    """Mode A step in ONE C-ABI call (rm_locate_sharded); buf_local holds the frames rm_shard_frames(T, rank, world)."""
+    return _cabi_step("rm_locate_sharded", buf_local, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
+                      temporal_threshold, threshold, flags, return_heatmap)

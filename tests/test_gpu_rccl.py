@@ -92,3 +92,81 @@ def test_rccl_collectives_on_one_rank(tmp_path):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "rccl_world1.json"), "w") as f:
             json.dump(r, f)
+
+
+CHILD_CABI = r'''
+import ctypes, json, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+torch.cuda.set_device(0)
+from respmon_amd import _capi, device, dist as rdist, synth
+from respmon_amd.base import RespiratoryMonitor
+lib = _capi.load()
+T, H, W = 64, 272, 480
+vid = synth.synth_breathing(T, H, W, seed=21)
+buf = (torch.from_numpy(vid).cuda().to(torch.float64) * (1.0 / 255))
+out = {}
+for (L, S) in ((6, 2), (7, 4)):
+    kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+    roi_ref = RespiratoryMonitor.locate(buf, 10, **kw)
+    heat_ref = rdist.hip_calibrate(buf, 10, **kw).clone()
+    # (a) one rank WITHOUT a library: the collectives are the identity
+    _capi.check(lib, lib.rm_comm_init(device.ctx(), 0, 1, None), "rm_comm_init")
+    roi0, fused0 = rdist.cabi_locate_streams(buf, 10, return_heatmap=True, **kw)
+    # (b) one rank over a real RCCL communicator: every collective is issued by the library on the stream
+    rank, world, seen = rdist.cabi_comm_init()
+    res = {"roi_ref": list(roi_ref), "no_lib": {"roi": list(roi0), "heat_equal": bool(torch.equal(fused0, heat_ref))}, "rccl_ranks_seen": seen,
+           "rank_world": [rank, world], "active": bool(rdist.cabi_comm_active())}
+    for dense in (0, 1):
+        device.debug_set("exchange_dense", dense)
+        tag = "dense" if dense else "sparse"
+        roi_b, fused_b = rdist.locate_streams(buf, 10, threshold=20, return_heatmap=True, **kw)      # routed to rm_locate_streams
+        res["mode_b_" + tag] = {"roi": list(roi_b), "exchange": rdist.LAST_EXCHANGE, "heat_equal": bool(torch.equal(fused_b, heat_ref))}
+        roi_a, heat_a = rdist.locate_sharded(buf, T, 10, threshold=20, return_heatmap=True, **kw)     # routed to rm_locate_sharded
+        res["mode_a_" + tag] = {"roi": list(roi_a), "exchange": rdist.LAST_EXCHANGE, "heat_equal": bool(torch.equal(heat_a, heat_ref))}
+    device.debug_set("exchange_dense", 0)
+    if (L, S) == (6, 2):
+        for fn, key in ((lambda: RespiratoryMonitor.locate(buf, 10, **kw), "locate_ms"),
+                        (lambda: rdist.cabi_locate_streams(buf, 10, **kw), "cabi_mode_b_sparse_ms"),
+                        (lambda: rdist.cabi_locate_sharded(buf, T, 10, **kw), "cabi_mode_a_sparse_ms")):
+            for _ in range(10): fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(50): fn()
+            torch.cuda.synchronize(); res[key] = (time.perf_counter() - t0) / 50 * 1e3
+    rdist.cabi_comm_destroy()
+    res["active_after_destroy"] = bool(rdist.cabi_comm_active())
+    out["L%%d_S%%d" %% (L, S)] = res
+t0, t1 = ctypes.c_int(), ctypes.c_int()
+spans = []
+for r in range(3):
+    _capi.check(lib, lib.rm_shard_frames(10, r, 3, ctypes.byref(t0), ctypes.byref(t1)), "rm_shard_frames")
+    spans.append([t0.value, t1.value])
+out["shard_frames_10_3"] = spans
+out["shard_frames_py"] = [list(rdist.shard_frames(10, r, 3)) for r in range(3)]
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_rccl_behind_the_c_abi_on_one_rank():
+    """rm_comm_init / rm_locate_streams / rm_locate_sharded (include/respmon_hip.h): the library opens librccl itself, makes a real
+    communicator of ONE rank and issues every collective of Mode A and Mode B on the stream (ncclAllGather of the frame rows and of
+    the sparse packets, ncclAllReduce MAX / SUM).  A collective over one rank is the identity: ROI and heatmap equal rm_locate /
+    rm_calibrate bit for bit, sparse and dense exchange, skip 2 and skip 4; ncclCommCount reports the rank."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", CHILD_CABI % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert p.returncode == 0 and lines, (p.stdout[-2000:], p.stderr[-4000:])
+    r = json.loads(lines[-1][7:])
+    for cfg in ("L6_S2", "L7_S4"):
+        c = r[cfg]
+        assert c["rccl_ranks_seen"] == 1 and c["rank_world"] == [0, 1] and c["active"] and not c["active_after_destroy"], c
+        assert c["no_lib"]["roi"] == c["roi_ref"] and c["no_lib"]["heat_equal"], c
+        for key, ex in (("mode_b_sparse", "sparse"), ("mode_b_dense", "dense"), ("mode_a_sparse", "sparse"), ("mode_a_dense", "dense")):
+            assert c[key]["roi"] == c["roi_ref"] and c[key]["exchange"] == ex and c[key]["heat_equal"], (cfg, key, c)
+    assert r["shard_frames_10_3"] == r["shard_frames_py"] == [[0, 4], [4, 7], [7, 10]]
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "rccl_cabi_world1.json"), "w") as f:
+            json.dump(r, f)
