@@ -190,6 +190,26 @@ def main():
     else:
         torch.cuda.set_device(0)
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
+    # N > 1 over RCCL: the library makes its own communicator (include/respmon_hip.h rm_comm_init; torch.distributed only ships the
+    # 128-byte id) and a step is ONE C-ABI call (rm_locate_streams / rm_locate_sharded).  All ranks agree on whether that worked;
+    # otherwise every rank keeps the torch.distributed collectives of respmon_amd/dist.py.
+    comm_info = None
+    if world > 1:
+        comm_info = {"collectives": "torch.distributed (%s)" % backend_name, "rccl_ranks_seen": None}
+        if backend_name == "nccl" and not os.environ.get("RESPMON_BENCH_TORCH_COLLECTIVES"):
+            ok, err, seen = 1, None, None
+            try:
+                _, _, seen = rdist.cabi_comm_init()
+            except Exception as e:   # noqa: BLE001 -- any failure means: fall back, together
+                ok, err = 0, "%s: %s" % (type(e).__name__, e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                comm_info = {"collectives": "RCCL behind the C-ABI (rm_comm_init; one rm_locate_streams / rm_locate_sharded call per step)",
+                             "rccl_ranks_seen": seen}
+            else:
+                rdist.cabi_comm_destroy()
+                comm_info["c_abi_comm_error"] = err or "another rank could not create its communicator"
 
     T, H, W = a.frames, a.height, a.width
     sharded = world > 1 and a.mode == "sharded"
@@ -269,6 +289,17 @@ def main():
         roi = step()
     for _ in range(a.warmup):
         roi = step()
+    single_ms = None
+    if world > 1 and not sharded:
+        # what ONE stream does on this GPU without any exchange, measured in the same run (every rank at once, rank 0 reports): the
+        # N = 1 figure the scaling of `value` can be read against
+        barrier()
+        ts = time.perf_counter()
+        n_single = max(3, min(a.steps, 20))
+        for _ in range(n_single):
+            locate1(buf)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts) / n_single * 1e3
     barrier()
     _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
     t0 = time.perf_counter()
@@ -598,7 +629,11 @@ def main():
                                        "one RCCL heatmap exchange" if sharded else "one independent stream per GPU + one RCCL exchange of the heatmaps"),
                        "preset": a.config, "frame_buffer_dtype": a.in_dtype, "frames": T, "height": H, "width": W, "levels": a.levels,
                        "skip": a.skip, "prune": not a.no_prune, "mode": a.mode if world > 1 else "single"},
-            "video": a.video, "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
+            "video": a.video, "comm": comm_info,
+            "single_stream_same_run": ({"ms_per_step": single_ms, "frames_per_s": T / single_ms * 1e3,
+                                        "note": "rm_locate on this rank's own buffer, no exchange, all ranks at once: the N = 1 figure of this run"}
+                                       if single_ms else None),
+            "world": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend_name, backend_name),
             "debug_set": a.debug_set,
             # `achieved` / `frac` are the contract figure -- algorithmic bytes over the WHOLE step (all kernels + the host
             # contour stage) against the peak; the frame-buffer kernel alone is `kernel_achieved` / `kernel_frac`

@@ -92,6 +92,7 @@ struct DebugKnobs {
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
+    int roi_fast = 0;             // 1: try the device-side ROI of simple shapes first (k_heat_to_roi_fast + k_rows_finish; measured: the host stage it saves, 18 us, is what its second kernel costs)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
     int dense_tiles = 1;          // 0: k_tile_sum (rounds of sixteen waves per tile) instead of k_dense_sum_t (one wave per tile) where a store-less sum at skip >= 3 is due
@@ -124,6 +125,10 @@ struct rm_ctx {
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     void *comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator (rm_comm_init); none: one rank
     ExchangeState xp_streams, xp_sharded;
+    RoiFast *h_fast = nullptr;      // pinned: the result record of k_heat_to_roi_fast
+    int roi_rows_cap = 0;           // rows the device row summaries were initialised for
+    int roi_fast_skip = 0;          // ROI extractions left that go straight to the border-following path (the last simple-shape attempt failed)
+    int roi_fast_used = 0;          // the last ROI extraction was decided on the device (rm_contour_stats)
     int dense_hint = 0;             // the last rm_locate of this context met a dense selection (more than a quarter of the pairs kept)
     long long store_hint_slots = 0; // slots a selection of this context needed when it overflowed the value store (rm_locate grows the store to it)
     int *h_unserved = nullptr;      // pinned: set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
@@ -213,6 +218,7 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
     if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->h_unserved) (void)hipHostFree(ctx->h_unserved);
+    if (ctx->h_fast) (void)hipHostFree(ctx->h_fast);
     (void)rm_comm_destroy(ctx);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
@@ -247,6 +253,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dense_tiles") d.dense_tiles = (int)value;
     else if (k == "eval_fast") d.eval_fast = (int)value;
     else if (k == "exchange_dense") d.exchange_dense = (int)value;
+    else if (k == "roi_fast") d.roi_fast = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
@@ -1863,6 +1870,57 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     const bool same_geom = ctx->label_H == H && ctx->label_W == W;
     const bool label = !clip && npix < (size_t)0x7fffffff &&
                        (ctx->label_mode == 1 || (ctx->label_mode < 0 && same_geom && ctx->label_last_n > LABEL_MIN_CONTOURS));
+    // one launch and 32 bytes to the host when the thresholded image is a simple shape (rm_kernels.h k_heat_to_roi_fast)
+    ctx->roi_fast_used = 0;
+    if (!clip && !label && ctx->dbg.roi_fast && W % 64 == 0 && W <= ROI_FAST_MAX_W && (size_t)H * 12 <= 60 * 1024 && npix < (size_t)0x7fffffff) {
+        if (ctx->roi_fast_skip > 0) --ctx->roi_fast_skip;
+        else {
+            unsigned long long *fb = nullptr; RowSum *rows = nullptr; unsigned int *ctr = nullptr;
+            RM_TRY(ws(ctx, "roi_bits", nwords, &fb));
+            RM_TRY(ws(ctx, "roi_rows", (size_t)std::max(H, ctx->roi_rows_cap), &rows));
+            RM_TRY(ws(ctx, "roi_ctr", (size_t)4, &ctr));
+            if (!ctx->h_fast) HIP_TRY(hipHostMalloc((void **)&ctx->h_fast, sizeof(RoiFast), hipHostMallocDefault));
+            if (ctx->roi_rows_cap < H) {
+                hipLaunchKernelGGL(k_rows_init, dim3(nblk((size_t)H, 256, 64)), dim3(256), 0, s, rows, H, ctr);
+                LAUNCH_CHECK();
+                ctx->roi_rows_cap = H;
+            }
+            RoiFast *dev_fast = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void **)&dev_fast, ctx->h_fast, 0));
+            ctx->h_fast->status = -1;
+            hipLaunchKernelGGL(k_heat_to_roi_fast, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary, fb, rows);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(256), 3 * sizeof(int) * (size_t)H, s, rows, H, dev_fast);
+            LAUNCH_CHECK();
+            delete pt_roi; pt_roi = nullptr;
+            HIP_TRY(stream_wait(s));
+            const RoiFast rf = *ctx->h_fast;
+            if (rf.status == 0 || rf.status == 1) {
+                ctx->roi_fast_used = 1;
+                ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = rf.status; ctx->label_used = 0;
+                if (rf.status == 0) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
+                xywh[0] = rf.x; xywh[1] = rf.y; xywh[2] = rf.w; xywh[3] = rf.h;
+                return RM_OK;
+            }
+            if (rf.status != 2) return fail(RM_E_INTERNAL, "rm_heatmap_to_roi: the device wrote no ROI record");
+            // not a simple shape: fetch the packed image and follow the borders on the host; the next extractions of this context
+            // skip the attempt for a while
+            ctx->roi_fast_skip = 15;
+            HIP_TRY(hipMemcpyAsync(ctx->h_bin, fb, nwords * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(stream_wait(s));
+            auto t0 = std::chrono::steady_clock::now();
+            const int y0 = rf.y, y1 = rf.y + rf.h - 1;
+            RoiResult r;
+            largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
+            ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours; ctx->label_used = 0;
+            std::memset(ctx->h_bin, 0, nwords * 8);   // (the image is all-zero between calls: the border-following path relies on it)
+            if (ctx->prof_on)
+                ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
+            xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;
+            return RM_OK;
+        }
+    }
     unsigned long long *d_bits = nullptr;
     const size_t comps_cap = std::min<size_t>(npix / 4 + 2, (size_t)1 << 18);
     if (label) {

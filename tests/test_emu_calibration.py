@@ -651,3 +651,60 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
         emu.debug_set("sum_sym", 0)
         emu.debug_set("sum_rows", 0)
         emu.debug_set("dense_tiles", 1)
+
+
+def _roi_shapes(rng):
+    """Thresholded-image shapes around the simple-shape rule of k_heat_to_roi_fast (W % 64 == 0): one blob, a ring (two runs per row),
+    two blobs side by side / one above the other with a gap, runs that touch diagonally, runs that miss each other by a pixel, a
+    run crossing the 64-pixel words, a blob on the image frame, a single pixel, nothing, noise."""
+    import scipy.ndimage as ndi
+    out = []
+    for (H, W) in ((24, 64), (33, 128), (40, 192)):
+        z = np.zeros((H, W))
+        a = z.copy(); a[5:15, 10:50] = 1; out.append(("rectangle", a))
+        a = z.copy(); a[4:20, 8:40] = 1; a[8:16, 16:32] = 0; out.append(("ring", a))
+        a = z.copy(); a[5:15, 4:20] = 1; a[5:15, 30:60] = 1; out.append(("two side by side", a))
+        a = z.copy(); a[2:8, 10:30] = 1; a[12:20, 10:30] = 1; out.append(("two, one above the other", a))
+        a = z.copy()
+        for y in range(3, 20):
+            a[y, 2 * y:2 * y + 2] = 1
+        out.append(("diagonal staircase (runs touch diagonally)", a))
+        a = z.copy()
+        for y in range(3, 20):
+            a[y, 3 * y:3 * y + 2] = 1
+        out.append(("broken staircase (runs miss by a pixel)", a))
+        a = z.copy(); a[6:10, 60:W - 3] = 1; out.append(("run across word boundaries", a))
+        a = z.copy(); a[0:6, 0:30] = 1; out.append(("on the frame", a))
+        a = z.copy(); a[H - 1, W - 1] = 1; out.append(("single pixel in the corner", a))
+        a = z.copy(); a[7, 5:W - 5] = 1; out.append(("one row", a))
+        out.append(("nothing", z.copy() + 0.0))
+        a = z.copy(); a[3:12, 5:25] = 1; a[8, 10:20] = 0; a[9, 5:12] = 0; out.append(("notched blob", a))
+        out.append(("smooth random", (ndi.gaussian_filter(rng.standard_normal((H, W)), 4.0) > 0.05).astype(float)))
+        out.append(("noise", (rng.random((H, W)) > 0.6).astype(float)))
+        g = np.exp(-0.5 * (((np.arange(H)[:, None] - H * 0.55) / (H * 0.2)) ** 2 + ((np.arange(W)[None, :] - W * 0.4) / (W * 0.15)) ** 2))
+        out.append(("gaussian blob", g))
+    return out
+
+
+def test_emu_roi_fast_equals_border_following(emu, oracle):
+    """k_heat_to_roi_fast (one launch, 32 bytes to the host when the thresholded image is one hole-free blob) against the
+    border-following path and the oracle, shape by shape; the attempt that fails must hand over to the host path with the same result."""
+    rng = np.random.default_rng(17)
+    try:
+        for name, img in _roi_shapes(rng):
+            heat = img * 1.0
+            thr = 100
+            ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min())) if heat.max() > heat.min() else np.zeros(heat.shape, np.uint8)
+            want = oracle.roi_from_heatmap_u8(ref_u8, thr)
+            emu.debug_set("roi_fast", 0)
+            slow, u8s, _ = emu.heatmap_to_roi(heat, threshold=thr)
+            emu.debug_set("roi_fast", 1)
+            for attempt in range(2):    # (a failed attempt makes the next extractions skip the fast form: both must agree)
+                fast, u8f, binf = emu.heatmap_to_roi(heat, threshold=thr)
+                assert fast == slow == want, (name, heat.shape, attempt, fast, slow, want)
+                assert np.array_equal(u8f, u8s) and np.array_equal(binf, np.where(u8s > thr, 255, 0).astype(np.uint8)), (name, attempt)
+            emu.debug_set("roi_fast", 0); emu.heatmap_to_roi(np.ones((4, 64)) * 0.0 + np.eye(4, 64), threshold=thr)   # (leave the skip counter behind)
+            for _ in range(16):
+                emu.debug_set("roi_fast", 1); emu.heatmap_to_roi(np.eye(4, 64), threshold=thr)
+    finally:
+        emu.debug_set("roi_fast", 0)
