@@ -92,6 +92,7 @@ struct DebugKnobs {
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
+    int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int roi_fast = 0;             // 1: try the device-side ROI of simple shapes first (k_heat_to_roi_fast + k_rows_finish; measured: the host stage it saves, 18 us, is what its second kernel costs)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
@@ -254,6 +255,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "eval_fast") d.eval_fast = (int)value;
     else if (k == "exchange_dense") d.exchange_dense = (int)value;
     else if (k == "roi_fast") d.roi_fast = (int)value;
+    else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
@@ -1983,7 +1985,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         ctx->label_used = label && ncomp <= comps_cap;
         if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
             largest_external_contour_labelled((const uint64_t *)ctx->h_bin, H, W, (const LabelComp *)(ctx->h_comps + 1), ncomp, &r);
-        else
+        else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r)))
             largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
         ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
         if (y1 >= y0) {   // restore the all-zero image: the words that cover rows y0 .. y1

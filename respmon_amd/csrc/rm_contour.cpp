@@ -16,6 +16,7 @@
 #include "rm_contour.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -279,6 +280,49 @@ int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult 
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare_bits(bits, H, W);
     return scan_runs(g_tracer, bits, H, W, out);
+}
+
+// One hole-free blob?  If every row of [y0, y1] holds exactly ONE run of foreground and the runs of neighbouring rows touch
+// (8-connectivity: they overlap or meet diagonally), the foreground is a single 8-connected component without holes: cv2.findContours
+// (RETR_EXTERNAL) lists ONE contour and its boundingRect is the bounding box of the runs (base.py:568-575) -- no border needs following,
+// no working copy unpacking.  Rows outside [y0, y1] hold no foreground (the caller's row flags).  Returns 1 and fills `out` for
+// such an image, 0 for anything else (the caller then follows the borders).  Word arithmetic on the packed rows: ~3 us for the
+// 235 rows of the synthetic 1080p stream against ~15 us of unpacking and border following.
+int simple_shape_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out)
+{
+    if (H <= 0 || W <= 0 || y1 < y0 || y0 < 0 || y1 >= H) return 0;
+    int pf = 0, pl = -1, xmin = W, xmax = -1, ya = -1, yb = -1;
+    int state = 0;   // 0: above the blob (the window's rows are a superset: empty rows may lead and trail), 1: inside, 2: below
+    for (int y = y0; y <= y1; ++y) {
+        const size_t p0 = (size_t)y * W, end = p0 + W;
+        int first = -1, last = -1, runs = 0;
+        uint64_t prev = 0;
+        for (size_t p = p0; p < end;) {
+            const size_t off = p & 63;
+            const size_t n = std::min<size_t>(64 - off, end - p);
+            uint64_t m = bits[p >> 6] >> off;
+            if (n < 64) m &= (~0ull) >> (64 - n);
+            if (m) {
+                if (first < 0) first = (int)(p - p0) + __builtin_ctzll(m);
+                last = (int)(p - p0) + 63 - __builtin_clzll(m);
+                runs += __builtin_popcountll(m & ~((m << 1) | prev));
+                if (runs > 1) return 0;
+            }
+            prev = (m >> (n - 1)) & 1ull;
+            p += n;
+        }
+        if (runs == 0) { if (state == 1) state = 2; continue; }
+        if (state == 2) return 0;                                                    // foreground below an empty row: two components
+        if (state == 1 && !(first <= pl + 1 && last >= pf - 1)) return 0;            // the runs of the two rows do not touch
+        if (state == 0) { state = 1; ya = y; }
+        yb = y; pf = first; pl = last;
+        xmin = first < xmin ? first : xmin; xmax = last > xmax ? last : xmax;
+    }
+    if (ya < 0) return 0;   // no foreground at all: the caller's path reports "no contour"
+    out->found = 1; out->n_contours = 1;
+    out->x = xmin; out->y = ya; out->w = xmax - xmin + 1; out->h = yb - ya + 1;
+    out->area = -1.0;   // (not computed: the only contour is the largest one whatever its area)
+    return 1;
 }
 
 int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out)

@@ -563,9 +563,8 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
     (flags=256), bit for bit: skip 1..4, ragged geometries whose virtual footprints meet every border rule (top row, rows past the
     bottom, left / right columns, 2-row / 2-column levels), exhaustive evaluation, frame shards, and the oracle's ROI."""
     rng = np.random.default_rng(11)
-    cases = [(5, 64, 96, 6, 4), (3, 67, 131, 5, 3), (3, 135, 130, 6, 4), (4, 48, 64, 3, 1), (3, 70, 300, 4, 2), (3, 33, 70, 6, 4),
-             (4, 17, 129, 5, 3), (2, 31, 193, 7, 4), (3, 47, 65, 5, 4), (2, 32, 32, 6, 4), (6, 100, 200, 9, 4), (3, 16, 16, 5, 3),
-             (3, 50, 66, 5, 2), (2, 24, 40, 5, 3)]
+    cases = [(5, 64, 96, 6, 4), (3, 67, 131, 5, 3), (4, 48, 64, 3, 1), (3, 70, 130, 4, 2), (3, 33, 70, 6, 4), (2, 31, 193, 7, 4),
+             (3, 16, 16, 5, 3), (4, 100, 72, 9, 4)]   # (the GPU twin of this test, tests/test_gpu_calibration.py, runs the larger geometries)
     try:
         for (T, H, W, L, S) in cases:
             v = rng.random((T, H, W))
@@ -605,7 +604,7 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
             assert np.array_equal(auto, store) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "default")
         # more kept unique frames than one batch of k_masked_sum_sym holds (48): several batches up, the same ones down again
-        for (T, H, W, L, S) in [(130, 20, 70, 4, 2), (101, 33, 40, 5, 3)]:
+        for (T, H, W, L, S) in [(101, 20, 70, 5, 3)]:
             v = rng.random((T, H, W))
             emu.debug_set("collapse_fused", 0)
             emu.debug_set("sum_sym", 0)
@@ -621,9 +620,9 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
         emu.debug_set("sum_rows", 0)
         # a breathing video: few heavy tiles (half-tile work items), pruned pairs in between, and the oracle's ROI
         from respmon_amd import synth
-        v8 = synth.synth_breathing(24, 96, 160, seed=3)
+        v8 = synth.synth_breathing(16, 80, 128, seed=3)
         fr = oracle.uint8_to_float(v8)
-        for (L, S) in [(6, 4), (5, 3)]:
+        for (L, S) in [(6, 4)]:
             emu.debug_set("collapse_fused", 0)
             store, mm = emu.calibrate(fr, 10.0, levels=L, skip=S, flags=256)
             emu.debug_set("collapse_fused", 1)
@@ -638,7 +637,7 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
             emu.debug_set("tile_sum_half", -1)
             assert emu.locate(fr, 10.0, levels=L, skip=S) == oracle.locate(fr, 10, pyramid_levels=L, skip_levels_at_top=S)
             # frame shards: partial time sums of the store-less path equal the store path's
-            for world in (2, 3):
+            for world in (3,):
                 emu.debug_set("collapse_fused", 0)
                 r0, h0, m0 = emu.locate_sharded(fr, world, levels=L, skip=S, flags=256)
                 emu.debug_set("collapse_fused", 1)
@@ -697,7 +696,11 @@ def test_emu_roi_fast_equals_border_following(emu, oracle):
             ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min())) if heat.max() > heat.min() else np.zeros(heat.shape, np.uint8)
             want = oracle.roi_from_heatmap_u8(ref_u8, thr)
             emu.debug_set("roi_fast", 0)
+            emu.debug_set("host_simple_shape", 0)       # every border followed on the host
             slow, u8s, _ = emu.heatmap_to_roi(heat, threshold=thr)
+            emu.debug_set("host_simple_shape", 1)       # the one-blob shortcut on the packed rows (rm_contour.cpp simple_shape_bits_rows)
+            short, _, _ = emu.heatmap_to_roi(heat, threshold=thr)
+            assert short == slow, (name, heat.shape, short, slow)
             emu.debug_set("roi_fast", 1)
             for attempt in range(2):    # (a failed attempt makes the next extractions skip the fast form: both must agree)
                 fast, u8f, binf = emu.heatmap_to_roi(heat, threshold=thr)

@@ -131,7 +131,10 @@ def test_roi_fast_equals_border_following(hip, oracle):
             want = oracle.roi_from_heatmap_u8(ref_u8, thr)
             dev = torch.from_numpy(heat).cuda()
             device.debug_set("roi_fast", 0)
+            device.debug_set("host_simple_shape", 0)    # every border followed on the host
             slow = dist.hip_heatmap_to_roi(dev, thr)
+            device.debug_set("host_simple_shape", 1)    # the one-blob shortcut on the packed rows (rm_contour.cpp simple_shape_bits_rows)
+            assert dist.hip_heatmap_to_roi(dev, thr) == slow, (name, heat.shape)
             device.debug_set("roi_fast", 1)
             drain()
             for attempt in range(2):
