@@ -92,6 +92,8 @@ struct DebugKnobs {
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
+    int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
+    int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int roi_fast = 0;             // 1: try the device-side ROI of simple shapes first (k_heat_to_roi_fast + k_rows_finish; measured: the host stage it saves, 18 us, is what its second kernel costs)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
@@ -109,6 +111,7 @@ struct rm_ctx {
     CollapseState *d_state = nullptr;
     CollapseState *h_state = nullptr;  // pinned
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned: bit-packed thresholded image + H row flags (k_heat_to_u8)
+    bool tiles_const_once = false;                         // the next ROI stage reads the heatmap rm_locate's own sum kernel has just written (tile_nkept is valid for it)
     bool clip_frame = false, clip_frame_once = false;      // cv2.findContours of OpenCV <= 3.1 (rm_set_contour_clip_frame / RM_FLAG_CONTOUR_CLIP_FRAME)
     uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
     // device labelling of the thresholded image (rm_ccl.h): taken when the previous ROI extraction of this geometry met
@@ -256,6 +259,8 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "exchange_dense") d.exchange_dense = (int)value;
     else if (k == "roi_fast") d.roi_fast = (int)value;
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
+    else if (k == "ff_parts") d.ff_parts = (int)value;
+    else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
@@ -1060,8 +1065,15 @@ static int front_filter(rm_ctx *ctx, const double *lap, int T, const PyrGeom &pg
         const size_t sh = sizeof(double) * (pg.lds_levels + 2 * (size_t)h[S] * cg.tiles_x);
         if (sh > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_small_filter_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_small_filter_first, dim3(Th), dim3(SMALL_NT), sh, s, (const double *)bp, pg.sg, (int)pg.lds_levels, dst, ctx->d_state, cg,
-                           cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt);
+        // two workgroups per frame when one per frame leaves CUs idle and the frame has tile rows to share
+        int cus_ff = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus_ff, hipDeviceAttributeMultiprocessorCount, ctx->device));
+#endif
+        int parts = (2 * Th <= cus_ff && cg.tiles_y >= 8) ? 2 : 1;   // (120 KB of LDS: one workgroup per CU, so 2 Th must fit the chip in ONE round -- 258 workgroups at T = 256 took 45 us instead of 27)
+        if (ctx->dbg.ff_parts > 0) parts = std::min(ctx->dbg.ff_parts, std::max(1, cg.tiles_y / 2));
+        hipLaunchKernelGGL(k_small_filter_first, dim3(Th * parts), dim3(SMALL_NT), sh, s, (const double *)bp, pg.sg, (int)pg.lds_levels, dst, ctx->d_state, cg,
+                           cg.tiles_x * cg.tiles_y, lo, hi, sel_cnt, parts);
         LAUNCH_CHECK();
         out.state_ready = true; out.bounds_ready = true;
         out.cS = dst;
@@ -1872,6 +1884,14 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     const bool same_geom = ctx->label_H == H && ctx->label_W == W;
     const bool label = !clip && npix < (size_t)0x7fffffff &&
                        (ctx->label_mode == 1 || (ctx->label_mode < 0 && same_geom && ctx->label_last_n > LABEL_MIN_CONTOURS));
+    // rm_locate's own heatmap: the sum kernel that wrote it knows which 64 x 16 tiles are one constant (tile_nkept == 0)
+    const int *tile_const = nullptr;
+    if (ctx->tiles_const_once && ctx->nkept_H == H && ctx->nkept_W == W && W % CT_W == 0 && ctx->dbg.heat_const_tiles) {
+        int *tk = nullptr;
+        RM_TRY(ws(ctx, "tile_nkept", (size_t)((W + CT_W - 1) / CT_W) * ((H + CT_H - 1) / CT_H), &tk));
+        tile_const = tk;
+    }
+    ctx->tiles_const_once = false;
     // one launch and 32 bytes to the host when the thresholded image is a simple shape (rm_kernels.h k_heat_to_roi_fast)
     ctx->roi_fast_used = 0;
     if (!clip && !label && ctx->dbg.roi_fast && W % 64 == 0 && W <= ROI_FAST_MAX_W && (size_t)H * 12 <= 60 * 1024 && npix < (size_t)0x7fffffff) {
@@ -1960,7 +1980,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     } else {
         hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
                            (unsigned long long *)dev_bin, dev_bin + nwords * 8, (unsigned long long *)nullptr, (int *)nullptr,
-                           (CclBox *)nullptr, (unsigned int *)nullptr);
+                           (CclBox *)nullptr, (unsigned int *)nullptr, tile_const);
         LAUNCH_CHECK();
     }
     delete pt_roi; pt_roi = nullptr;
@@ -2123,6 +2143,7 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     RM_TRY(calibrate_impl(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream, &cp));
     const bool clip_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
     ctx->clip_frame_once = clip_once;
+    ctx->tiles_const_once = cp.valid && cp.S >= 1;
     int rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
     const int unserved_word = ctx->h_unserved ? *ctx->h_unserved : 0;   // 1: the sparse kernel stood down and nothing took the sum; 2: the stand-in did
     const bool unserved = unserved_word == 1;
@@ -2157,6 +2178,7 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
             RM_TRY(collapse_sum(ctx, again, temporal_thr, heat, s, T));
         }
         ctx->clip_frame_once = clip_once;
+        ctx->tiles_const_once = true;
         rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
     }
     return rc;

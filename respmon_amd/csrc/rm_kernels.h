@@ -758,12 +758,13 @@ __device__ __forceinline__ HTap make_htap(int x, int sw)   // destination column
 // level, make_htap), so there is no index division and no divergent shape.  Same values as up_at(), bit for bit.
 // sink(i, v) receives destination element i = y * dw + x.
 template <typename Sink>
-__device__ __forceinline__ void small_up_level(const double *src, int sh, int sw, int dh, int dw, int tid, Sink &&sink)
+__device__ __forceinline__ void small_up_level(const double *src, int sh, int sw, int dh, int dw, int tid, Sink &&sink, int y_begin = 0, int y_end = 0x7fffffff)
 {
     const int lane = tid & 63, wave = tid >> 6;
+    if (y_end > dh) y_end = dh;   // destination rows [y_begin, y_end): all of them by default
     for (int x = lane; x < dw; x += 64) {
         const HTap t = make_htap(x, sw);
-        for (int y = wave; y < dh; y += SMALL_NT / 64) {
+        for (int y = y_begin + wave; y < y_end; y += SMALL_NT / 64) {
             const int i = y >> 1;
             const double *ri = src + i * sw, *r2 = src + ((i == sh - 1) ? i : i + 1) * sw;
             const double hi_ = (ri[t.ia] * t.wa + ri[t.ib] * t.wb) + ri[t.ic] * t.wc;
@@ -1325,19 +1326,25 @@ __global__ __launch_bounds__(256) void k_frame_bounds_rows(const double *cS, Cha
 // What follows the collapse of a frame, with C_S of the frame in LDS at `c`: copy-out to cS[t], tile bounds (per-row extrema
 // over the footprint columns, then extrema over the footprint rows) from the LDS copy, their extrema and the lattice samples
 // into the striped state.  rmin / rmax: the row-extrema table, 2 x hS x tiles_x doubles of LDS.  One SMALL_NT-thread workgroup.
+// A workgroup may own only PART of the frame (k_small_filter_first puts two workgroups on a frame): tile rows [ty_a, ty_b), whose
+// footprints touch the level-S rows [y_lo, y_hi] (valid in `c`), and the rows [y_out_a, y_out_b) it copies out.
 __device__ __forceinline__ void frame_bounds_from_lds(const double *c, double *rmin_base, const SmallGeom &sg, const ChainGeom &g, int ntiles, int t,
                                                       double *cS, double *lo, double *hi, CollapseState *st, double (*s_red)[SMALL_NT / 64],
-                                                      int (*s_arg)[SMALL_NT / 64], int mark_kid)
+                                                      int (*s_arg)[SMALL_NT / 64], int mark_kid, int ty_a = 0, int ty_b = 0x7fffffff,
+                                                      int y_lo = 0, int y_hi = 0x7fffffff, int y_out_a = 0, int y_out_b = 0x7fffffff)
 {
     const int tid = threadIdx.x;
     const int S = sg.S;
-    const int hS = sg.h[S], wS = sg.w[S], n = hS * wS, ntx = g.tiles_x;
-    double *o = cS + (size_t)t * n;
-    // (the copy-out loop also finds where this frame's C_S is lowest / highest: the lattice samples are taken there)
+    const int hS = sg.h[S], wS = sg.w[S], ntx = g.tiles_x;
+    if (ty_b > g.tiles_y) ty_b = g.tiles_y;
+    if (y_hi > hS - 1) y_hi = hS - 1;
+    if (y_out_b > hS) y_out_b = hS;
+    double *o = cS + (size_t)t * (hS * wS);
+    // (the copy-out loop also finds where this part of the frame's C_S is lowest / highest: the lattice samples are taken there)
     const double inf = __builtin_huge_val();
     double c_mn = inf, c_mx = -inf;
-    int i_mn = 0, i_mx = 0;
-    for (int i = tid; i < n; i += SMALL_NT) {
+    int i_mn = y_out_a * wS, i_mx = y_out_a * wS;
+    for (int i = y_out_a * wS + tid; i < y_out_b * wS; i += SMALL_NT) {
         const double v = c[i];
         o[i] = v;
         if (v < c_mn) { c_mn = v; i_mn = i; }
@@ -1347,7 +1354,7 @@ __device__ __forceinline__ void frame_bounds_from_lds(const double *c, double *r
     // tile bounds from the LDS copy: per-row extrema over the footprint columns, then extrema over the footprint rows
     double *rmin = rmin_base, *rmax = rmin + (size_t)hS * ntx;
     const float inv_ntx = 1.0f / (float)ntx;
-    for (int i = tid; i < hS * ntx; i += SMALL_NT) {
+    for (int i = y_lo * ntx + tid; i < (y_hi + 1) * ntx; i += SMALL_NT) {
         int y, tx;
         split_rc(i, ntx, inv_ntx, y, tx);
         const Region R = tile_region(g, tx, S);
@@ -1364,7 +1371,8 @@ __device__ __forceinline__ void frame_bounds_from_lds(const double *c, double *r
     RM_TRACE_MARK(mark_kid, 9);
     
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
-    for (int tile = tid; tile < ntiles; tile += SMALL_NT) {
+    (void)ntiles;
+    for (int tile = ty_a * ntx + tid; tile < ty_b * ntx; tile += SMALL_NT) {
         const int tx = tile % ntx;
         const Region R = tile_region(g, tile, S);
         double mn = rmin[R.y0 * ntx + tx], mx = rmax[R.y0 * ntx + tx];
@@ -1410,8 +1418,9 @@ __device__ __forceinline__ void frame_bounds_from_lds(const double *c, double *r
         // highest C_S: on the synthetic 1080p stream they bound the extrema as tightly as sampling every pixel would
         if (hS >= 3 && wS >= 3) {
             int ya = i_mn / wS, xa = i_mn - ya * wS, yb = i_mx / wS, xb = i_mx - yb * wS;
-            ya = min(max(ya, 1), hS - 2); xa = min(max(xa, 1), wS - 2);
-            yb = min(max(yb, 1), hS - 2); xb = min(max(xb, 1), wS - 2);
+            const int y_first = max(1, y_lo + 1), y_last = max(y_first, min(hS - 2, y_hi - 1));   // rows whose 3 x 3 neighbourhood is valid in `c`
+            ya = min(max(ya, y_first), y_last); xa = min(max(xa, 1), wS - 2);
+            yb = min(max(yb, y_first), y_last); xb = min(max(xb, 1), wS - 2);
             const double *ra = c + ya * wS, *rb = c + yb * wS;
             const double va = lattice_sample(ra - wS, ra, ra + wS, xa, g.lat_a, g.lat_b);
             const double vb = lattice_sample(rb - wS, rb, rb + wS, xb, g.lat_a, g.lat_b);
@@ -1462,16 +1471,24 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
 // RM_FLAG_FILTER_LAPLACIANS selects the reference's order (k_small_pyramid / k_small_collapse_bounds above).
 // LDS: the levels S .. L-1 (sg.g_off; levels S+1 .. L-2 are overwritten on the way up), then the bounds table.
 __global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *xg, SmallGeom sg, int lds_levels, double *cS, CollapseState *st,
-                                                                  ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
+                                                                  ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt, int parts)
 {
     RM_TRACE_SCOPE(3);
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < ntiles; i += SMALL_NT) sel_cnt[i] = 0;   // k_select_pairs counts into it
     HIP_DYNAMIC_SHARED(double, lds)
     __shared__ double s_red[6][SMALL_NT / 64];
     __shared__ int s_arg[2][SMALL_NT / 64];
-    const int t = blockIdx.x, tid = threadIdx.x;
+    // `parts` workgroups per frame (gridDim.x = frames * parts): each walks the whole way down and back up to level S + 1 (those
+    // levels are a quarter of the frame and less), then takes the last step up, the subtraction, the copy-out and the bounds for ITS
+    // band of tile rows only -- with one workgroup per unique frame half of the chip's CUs had nothing to do (129 frames at T = 256)
+    const int t = blockIdx.x / parts, part = blockIdx.x - t * parts, tid = threadIdx.x;
     const int S = sg.S, L = sg.L;
     const int nS = sg.h[S] * sg.w[S];
+    const int ty_a = (int)((long long)g.tiles_y * part / parts), ty_b = (int)((long long)g.tiles_y * (part + 1) / parts);
+    const int y_lo = parts == 1 ? 0 : tile_region(g, ty_a * g.tiles_x, S).y0;
+    const int y_hi = parts == 1 ? sg.h[S] - 1 : tile_region(g, (ty_b - 1) * g.tiles_x, S).y1;
+    // rows this part copies out: the frame's rows cut where the parts' tile rows are cut (inside both neighbours' computed ranges)
+    const int y_out_a = part == 0 ? 0 : min(sg.h[S], (ty_a * CT_H) >> S), y_out_b = part == parts - 1 ? sg.h[S] : min(sg.h[S], (ty_b * CT_H) >> S);
     RM_TRACE_MARK(3, 0);
     fill_lds(lds + sg.g_off[S], xg + (size_t)t * nS, nS, tid);
     __syncthreads();
@@ -1500,11 +1517,12 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *x
         const int dh = sg.h[l], dw = sg.w[l], sh = sg.h[l + 1], sw = sg.w[l + 1];
         double *d = lds + sg.g_off[l];
         const bool last = l == S;
-        small_up_level(lds + sg.g_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = last ? d[i] - v : v; });
+        small_up_level(lds + sg.g_off[l + 1], sh, sw, dh, dw, tid, [&](int i, double v) { d[i] = last ? d[i] - v : v; }, last ? y_lo : 0,
+                       last ? y_hi + 1 : 0x7fffffff);
         __syncthreads();
     }
     RM_TRACE_MARK(3, 4);
-    frame_bounds_from_lds(lds + sg.g_off[S], lds + lds_levels, sg, g, ntiles, t, cS, lo, hi, st, s_red, s_arg, 3);
+    frame_bounds_from_lds(lds + sg.g_off[S], lds + lds_levels, sg, g, ntiles, t, cS, lo, hi, st, s_red, s_arg, 3, ty_a, ty_b, y_lo, y_hi, y_out_a, y_out_b);
 }
 
 constexpr double PRUNE_REL_MARGIN = 1e-12;  // >> the ~1e-14 relative rounding of the S-level chain
@@ -2167,11 +2185,14 @@ __global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t 
 // makes the NEXT launch ~100 us slower.)
 struct alignas(16) CclBox { int minx, maxx, maxy, pad; };   // bounding box of a labelled component (rm_ccl.h), indexed by its root
 
+// tile_const (nullable; needs W % 64 == 0): tile_nkept of the sum kernel that wrote `heat` -- 0 for a 64 x 16 tile every pixel of which
+// is the same constant (96 % of the tiles of the synthetic 1080p stream): such a word takes its ONE value from a wave-uniform load
+// and the 16.6 MB heatmap is read only where it varies
 __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
                                                     unsigned long long *bits, uint8_t *row_any,
                                                     unsigned long long *bits_dev, int *ccl_label, CclBox *ccl_box,
-                                                    unsigned int *ccl_counters)
+                                                    unsigned int *ccl_counters, const int *tile_const = nullptr)
 {
     RM_TRACE_SCOPE(7);
     if (ccl_counters && blockIdx.x == 0 && threadIdx.x == 0) ccl_counters[0] = 0;   // k_ccl_emit reserves record slots there
@@ -2182,16 +2203,36 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
     const size_t stride = (size_t)gridDim.x * 256;
     const size_t first = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u);
     double hv[HU];
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    auto fetch = [&](size_t base0) __attribute__((always_inline)) {
+        if (tile_const) {
+            // the word's tile flag and its first value (both wave-uniform), then the 64 values only where the tile is not a constant
+            int cst[HU];
+            double h0[HU];
 #pragma unroll
-    for (int k = 0; k < HU; ++k) { const size_t i = first + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
+            for (int k = 0; k < HU; ++k) {
+                const size_t base = base0 + k * stride;
+                const size_t bc = base < npix ? base : 0;
+                const int y = (int)(bc / (size_t)W), x = (int)(bc - (size_t)y * W);
+                cst[k] = tile_const[(y / CT_H) * tiles_x + x / CT_W];
+                h0[k] = heat[bc];
+            }
+#pragma unroll
+            for (int k = 0; k < HU; ++k) {
+                const size_t i = base0 + k * stride + lane;
+                hv[k] = (cst[k] != 0 && i < npix) ? heat[i] : h0[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < HU; ++k) { const size_t i = base0 + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
+        }
+    };
+    fetch(first);
     const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
     const double mx = f64_unkey(fold_max_keys(st->heat_max_keys, st->heat_max_key));
     const double range = mx - mn;
     for (size_t base0 = first; base0 < npix; base0 += HU * stride) {
-        if (base0 != first) {
-#pragma unroll
-            for (int k = 0; k < HU; ++k) { const size_t i = base0 + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
-        }
+        if (base0 != first) fetch(base0);
 #pragma unroll
         for (int k = 0; k < HU; ++k) {
             const size_t base = base0 + k * stride, i = base + lane;

@@ -711,3 +711,26 @@ def test_emu_roi_fast_equals_border_following(emu, oracle):
                 emu.debug_set("roi_fast", 1); emu.heatmap_to_roi(np.eye(4, 64), threshold=thr)
     finally:
         emu.debug_set("roi_fast", 0)
+
+
+def test_emu_small_pyramid_split_over_workgroups(emu, oracle):
+    """k_small_filter_first with one, two and three workgroups per frame (each takes the last pyrUp step, the subtraction, the copy-out
+    and the tile bounds of ITS band of tile rows): C_S and the bounds are the same numbers, so heatmap and extrema are bit-identical
+    whatever the split; the lattice samples differ (one pair per band), which may only change how many pairs are evaluated."""
+    rng = np.random.default_rng(29)
+    try:
+        for (T, H, W, L, S) in [(6, 160, 96, 8, 4), (4, 130, 70, 7, 3), (5, 97, 64, 6, 2), (3, 200, 40, 8, 4)]:
+            v = rng.random((T, H, W))
+            emu.debug_set("ff_parts", 1)
+            one, mm = emu.calibrate(v, 10.0, levels=L, skip=S)
+            roi1 = emu.locate(v, 10.0, levels=L, skip=S)
+            for parts in (2, 3):
+                emu.debug_set("ff_parts", parts)
+                got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+                assert np.array_equal(got, one) and tuple(mm) == tuple(mm2), (T, H, W, L, S, parts)
+                assert emu.locate(v, 10.0, levels=L, skip=S) == roi1
+        fr = oracle.uint8_to_float(__import__("respmon_amd.synth", fromlist=["x"]).synth_breathing(12, 144, 128, seed=4))
+        emu.debug_set("ff_parts", 2)
+        assert emu.locate(fr, 10.0, levels=7, skip=4) == oracle.locate(fr, 10, pyramid_levels=7, skip_levels_at_top=4)
+    finally:
+        emu.debug_set("ff_parts", 0)

@@ -913,3 +913,50 @@ def test_value_store_grows_with_the_selection(hip, oracle):
             else:
                 assert dbg[2] > 16384 and dbg[3] == 0                              # dense: no store in use
         _capi.check(hip, hip.rm_ctx_destroy(fresh), "rm_ctx_destroy")
+
+
+def test_small_pyramid_split_over_workgroups(hip, oracle):
+    """k_small_filter_first with one, two and four workgroups per frame: same C_S and tile bounds, so the heatmap is bit-identical
+    whatever the split (1080p x 64 takes two by default)."""
+    import torch
+    from respmon_amd import device, dist, synth
+    rng = np.random.default_rng(31)
+    try:
+        for (T, H, W, L, S) in [(64, 1080, 1920, 9, 4), (16, 540, 960, 8, 4), (9, 300, 500, 7, 3), (12, 720, 1280, 8, 3)]:
+            buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=9)).cuda() if H == 1080 else torch.from_numpy(rng.random((T, H, W))).cuda()
+            kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+            device.debug_set("ff_parts", 1)
+            one = dist.hip_calibrate(buf, 10, **kw)
+            for parts in (0, 2, 4):
+                device.debug_set("ff_parts", parts)
+                assert torch.equal(dist.hip_calibrate(buf, 10, **kw), one), (T, H, W, L, S, parts)
+    finally:
+        device.debug_set("ff_parts", 0)
+
+
+@pytest.mark.gpu
+def test_roi_stage_skips_constant_tiles(hip, oracle):
+    """rm_locate's ROI stage reads a 64 x 16 tile of its own heatmap through ONE value where the sum kernel flagged the tile as a
+    constant (tile_nkept == 0): same ROI as the stage that reads every pixel, and as the oracle."""
+    import torch
+    from respmon_amd import device, dist, synth
+    from oracle import respmon_oracle as ro
+    rng = np.random.default_rng(77)
+    cases = [(32, 1080, 1920, 9, 4, "breath"), (16, 256, 448, 7, 3, "breath"), (12, 128, 192, 6, 2, "noise"),
+             (10, 144, 256, 6, 1, "breath"), (16, 270, 640, 7, 3, "noise")]
+    try:
+        for (T, H, W, L, S, kind) in cases:
+            vid = synth.synth_breathing(T, H, W, seed=T + S) if kind == "breath" else rng.random((T, H, W))
+            buf = torch.from_numpy(np.ascontiguousarray(vid)).cuda()
+            kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+            got = {}
+            for flag in (0, 1):
+                device.debug_set("heat_const_tiles", flag)
+                from respmon_amd.base import RespiratoryMonitor
+                got[flag] = RespiratoryMonitor.locate(buf, 10, **kw)
+            assert got[0] == got[1], (T, H, W, L, S, kind, got)
+            if H <= 300:
+                want = ro.locate(vid, 10, pyramid_levels=L, skip_levels_at_top=S)
+                assert (got[1] is None and want is None) or tuple(got[1]) == tuple(int(v) for v in want), (T, H, W, L, S, kind, got[1], want)
+    finally:
+        device.debug_set("heat_const_tiles", 1)
