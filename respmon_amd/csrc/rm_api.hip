@@ -92,6 +92,7 @@ struct DebugKnobs {
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
+    int label_host_us = 250;      // host border following slower than this (+ the labelled stage's own host time) -> device labelling next time
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
@@ -117,6 +118,11 @@ struct rm_ctx {
     // device labelling of the thresholded image (rm_ccl.h): taken when the previous ROI extraction of this geometry met
     // more than LABEL_MIN_CONTOURS components (label_mode -1 = that rule, 0 = never, 1 = always: rm_set_contour_labelling)
     int label_mode = -1, label_H = 0, label_W = 0, label_last_n = 0, label_used = 0;
+    // ... or when following every border on the host took long last time (few components with long borders: a frame of noise blobs):
+    // host time of the last unlabelled stage of this geometry (< 0: none) with its contour count, host time of the last labelled
+    // stage, labelled stages in a row (every LABEL_REPROBE-th one is run unlabelled to refresh the first figure)
+    double label_unl_us = -1.0, label_lab_host_us = 0.0;
+    int label_unl_n = 0, label_streak = 0;
     CclComp *h_comps = nullptr; size_t h_comps_cap = 0;    // pinned: [0] = {count, -, -, -}, then one record per component
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
@@ -261,6 +267,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;
+    else if (k == "label_host_us") d.label_host_us = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
@@ -1839,6 +1846,7 @@ __global__ __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st)
     if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
 }
 
+constexpr int LABEL_REPROBE = 64;         // labelled stages in a row before the host-only stage is timed again
 constexpr int LABEL_MIN_CONTOURS = 512;   // ~0.13 us per followed border on the host against ~40 us of labelling kernels
 static_assert(sizeof(CclComp) == sizeof(LabelComp), "record layout shared by rm_ccl.h and rm_contour.h");
 
@@ -1882,8 +1890,12 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     // noisy images: label the components on the device so that the host follows only borders that can win (rm_ccl.h)
     const bool clip = ctx->clip_frame || clip_once;
     const bool same_geom = ctx->label_H == H && ctx->label_W == W;
+    if (!same_geom) { ctx->label_unl_us = -1.0; ctx->label_lab_host_us = 0.0; ctx->label_streak = 0; }
+    const bool many = ctx->label_last_n > LABEL_MIN_CONTOURS;
+    bool slow_host = ctx->label_unl_us >= 0.0 && ctx->label_unl_us > (double)ctx->dbg.label_host_us + ctx->label_lab_host_us;
+    if (slow_host && !many && ctx->label_mode < 0 && ctx->label_streak >= LABEL_REPROBE) { slow_host = false; ctx->label_streak = 0; }
     const bool label = !clip && npix < (size_t)0x7fffffff &&
-                       (ctx->label_mode == 1 || (ctx->label_mode < 0 && same_geom && ctx->label_last_n > LABEL_MIN_CONTOURS));
+                       (ctx->label_mode == 1 || (ctx->label_mode < 0 && same_geom && (many || slow_host)));
     // rm_locate's own heatmap: the sum kernel that wrote it knows which 64 x 16 tiles are one constant (tile_nkept == 0)
     const int *tile_const = nullptr;
     if (ctx->tiles_const_once && ctx->nkept_H == H && ctx->nkept_W == W && W % CT_W == 0 && ctx->dbg.heat_const_tiles) {
@@ -1968,7 +1980,8 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         const dim3 grid((unsigned)((npix + 255) / 256));
         hipLaunchKernelGGL(k_ccl_union, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_ccl_bbox, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label, d_box);
+        hipLaunchKernelGGL(k_ccl_bbox, dim3((unsigned)((W + 63) / 64), (unsigned)((H + CCL_BOX_ROWS - 1) / CCL_BOX_ROWS)), dim3(64 * CCL_BOX_ROWS), 0, s,
+                           d_bits, npix, H, W, d_label, d_box);
         LAUNCH_CHECK();
         const int groups = (int)std::max<size_t>(1, (npix + (size_t)256 * 1024 - 1) / ((size_t)256 * 1024));   // ~1 000 workgroups
         const dim3 egrid((unsigned)((npix + (size_t)256 * groups - 1) / ((size_t)256 * groups)));
@@ -1987,7 +2000,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     HIP_TRY(stream_wait(s));
     RoiResult r;
     {
-        auto t0 = std::chrono::steady_clock::now();
+        const auto t0 = std::chrono::steady_clock::now();
         int y0 = H, y1 = -1;   // rows that hold foreground
         for (int y = 0; y < H; ++y)
             if (h_rows[y]) { if (y < y0) y0 = y; y1 = y; h_rows[y] = 0; }
@@ -2012,8 +2025,15 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
             std::memset(ctx->h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
         }
-        if (ctx->prof_on)
-            ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (ctx->label_used) {
+            ctx->label_lab_host_us = host_us;
+            ++ctx->label_streak;
+            if ((long long)ncomp * 2 < (long long)ctx->label_unl_n) ctx->label_unl_us = -1.0;   // a different kind of image: time the host stage afresh
+        } else if (!clip) {
+            ctx->label_unl_us = host_us; ctx->label_unl_n = r.n_contours; ctx->label_streak = 0;
+        }
+        if (ctx->prof_on) ctx->prof_host_ms[3] += host_us * 1e-3;
     }
     if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
     xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;

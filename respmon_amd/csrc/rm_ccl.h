@@ -16,9 +16,9 @@
 //
 // Three launches over the H*W bits (and a small copy kernel), one thread per pixel (84 % of the threads of a 16 %-foreground
 // image leave at once); their start state comes from k_heat_to_u8, whose ballot is the pixel's word:
-//   (k_heat_to_u8) label = first pixel of the pixel's run inside its 64-bit word (rows break runs), box = the pixel itself
+//   (k_heat_to_u8) label = first pixel of the pixel's run inside its 64-bit word (rows break runs); that first pixel holds the box of its piece
 //   k_ccl_union   joins with the row above / the word to the left, lock-free (atomicMin on the larger root)
-//   k_ccl_bbox    every run end / bottom pixel folds its coordinates into its root's box
+//   k_ccl_bbox    the first pixel of every piece folds the piece's box into its root's
 //   k_ccl_emit    roots -> {root, minx, width-1, height-1} records, wave-aggregated slot reservation
 //   k_ccl_publish the record list and its length -> pinned host memory, in whole cache lines
 #pragma once
@@ -39,11 +39,26 @@ __device__ inline int ccl_find(const int *label, int a)
     return a;
 }
 
+// find with path halving: every node passed is re-hung under its grandparent.  Labels only ever move to a smaller index of the same
+// tree, so the plain stores race benignly with each other and with the atomicMin of a union (a store that overwrites a fresh hook
+// can only hit a node that was no root when the hook's atomicMin ran -- that union has seen old != b and carries on from `old`).
+// Without it a blob of h rows leaves chains h links deep (each row's run hooked under the run above before that one was hooked
+// itself), and every later find pays an L2 round trip per link: k_ccl_bbox 89 us on a 1080p frame of noise blobs.
+__device__ inline int ccl_find_halving(int *label, int a)
+{
+    int l = label[a];
+    if (l != a) {
+        int prev = a, next;
+        while (l > (next = label[l])) { label[prev] = next; prev = l; l = next; }
+    }
+    return l;
+}
+
 __device__ inline void ccl_union(int *label, int a, int b)
 {
     for (;;) {
-        a = ccl_find(label, a);
-        b = ccl_find(label, b);
+        a = ccl_find_halving(label, a);
+        b = ccl_find_halving(label, b);
         if (a == b) return;
         if (a > b) { const int t = a; a = b; b = t; }   // a < b: b's tree hangs under a
         const int old = atomicMin(&label[b], a);
@@ -76,24 +91,52 @@ __global__ __launch_bounds__(256) void k_ccl_union(const unsigned long long *bit
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_bbox(const unsigned long long *bits, size_t npix, int H, int W, int *label, CclBox *box)
+// A workgroup = a tile of 64 columns x CCL_BOX_ROWS rows, one thread per pixel.  The first pixel of a piece of a run (a run cut at
+// word boundaries: k_heat_to_u8 left the piece's box with it) finds its root and folds the piece's box into a small LDS table keyed
+// by root; the table's few entries then go to the roots' boxes.  Atomics on ONE address cost ~10 ns each whatever the grid does: a
+// frame of noise blobs has a root half the image hangs under, and one atomicMax per piece of every new row of it made this kernel
+// 89-107 us at 1080p (a thread per pixel in row-shaped workgroups); a tile sends at most three per root it touches.
+constexpr int CCL_BOX_ROWS = 16;
+constexpr int CCL_BOX_SLOTS = 32;
+
+__device__ inline void ccl_box_fold(CclBox *box, int r, int minx, int maxx, int maxy)
 {
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix || !ccl_bit(bits, p)) return;
-    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
-    const bool run_first = !(x > 0 && ccl_bit(bits, p - 1));
-    const bool run_last = !(x + 1 < W && ccl_bit(bits, p + 1));
-    // a pixel of the component's bottom row has no foreground straight below it
-    const bool bottom = !(y + 1 < H && ccl_bit(bits, p + (size_t)W));
-    if (!(run_first || run_last || bottom)) return;
-    const int r = ccl_find(label, (int)p);
-    if (r == (int)p) return;                 // the root's own coordinates are in its box since k_ccl_init
     int *b = (int *)&box[r];
-    // the box only ever grows: a (possibly stale) value that already covers this pixel makes the atomic unnecessary
+    // the box only ever grows: a (possibly stale) value that already covers this one makes the atomic unnecessary
     const CclBox cur = box[r];
-    if (run_first && x < cur.minx) atomicMin(b + 0, x);
-    if (run_last && x > cur.maxx) atomicMax(b + 1, x);
-    if (bottom && y > cur.maxy) atomicMax(b + 2, y);
+    if (minx < cur.minx) atomicMin(b + 0, minx);
+    if (maxx > cur.maxx) atomicMax(b + 1, maxx);
+    if (maxy > cur.maxy) atomicMax(b + 2, maxy);
+}
+
+__global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned long long *bits, size_t npix, int H, int W, int *label,
+                                                                 CclBox *box)
+{
+    __shared__ int s_key[CCL_BOX_SLOTS], s_minx[CCL_BOX_SLOTS], s_maxx[CCL_BOX_SLOTS], s_maxy[CCL_BOX_SLOTS];
+    const int tid = threadIdx.x;
+    if (tid < CCL_BOX_SLOTS) { s_key[tid] = -1; s_minx[tid] = 0x7fffffff; s_maxx[tid] = -1; s_maxy[tid] = -1; }
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (tid & 63), y = blockIdx.y * CCL_BOX_ROWS + (tid >> 6);
+    if (x < W && y < H) {
+        const size_t p = (size_t)y * W + x;
+        if (ccl_bit(bits, p) && ((p & 63) == 0 || x == 0 || !ccl_bit(bits, p - 1))) {
+            const int r = ccl_find(label, (int)p);
+            if (r != (int)p) {                       // (the root's own piece is in its box already)
+                const CclBox mine = box[p];
+                unsigned int h = ((unsigned int)r * 2654435761u) >> 27;
+                int k = 0;
+                for (; k < CCL_BOX_SLOTS; ++k, h = (h + 1) & (CCL_BOX_SLOTS - 1)) {
+                    const int seen = atomicCAS(&s_key[h], -1, r);
+                    if (seen == -1 || seen == r) break;
+                }
+                if (k < CCL_BOX_SLOTS) {
+                    atomicMin(&s_minx[h], mine.minx); atomicMax(&s_maxx[h], mine.maxx); atomicMax(&s_maxy[h], mine.maxy);
+                } else ccl_box_fold(box, r, mine.minx, mine.maxx, mine.maxy);   // more roots in the tile than the table holds
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < CCL_BOX_SLOTS && s_key[tid] >= 0) ccl_box_fold(box, s_key[tid], s_minx[tid], s_maxx[tid], s_maxy[tid]);
 }
 
 // counters[0]: records reserved.  `out` is a device list: 16-byte records scattered one by one into pinned host memory cost a

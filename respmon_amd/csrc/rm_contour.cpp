@@ -364,14 +364,30 @@ long long follow_bits(const BitImage &im, int sx, int sy)
     if (dir == 4) return 0;   // isolated pixel
     long long twice_area = 0;
     int cx = sx, cy = sy;
+    // away from the image frame a neighbour is one add on the pixel index; on the frame every probe is bounds-checked
+    const int W = im.W, H = im.H;
+    long long off[8];
+    for (int d = 0; d < 8; ++d) off[d] = (long long)dy[d] * W + dx[d];
+    const uint64_t *bits = im.bits;
     for (;;) {
         int nx, ny;
-        for (;;) {
-            ++dir;
-            nx = cx + dx[dir & 7]; ny = cy + dy[dir & 7];
-            if (im.fg(nx, ny)) break;
+        if (cx > 0 && cy > 0 && cx < W - 1 && cy < H - 1) {
+            const long long p = (long long)cy * W + cx;
+            for (;;) {
+                ++dir;
+                const long long q = p + off[dir & 7];
+                if ((bits[q >> 6] >> (q & 63)) & 1ull) break;
+            }
+            dir &= 7;
+            nx = cx + dx[dir]; ny = cy + dy[dir];
+        } else {
+            for (;;) {
+                ++dir;
+                nx = cx + dx[dir & 7]; ny = cy + dy[dir & 7];
+                if (im.fg(nx, ny)) break;
+            }
+            dir &= 7;
         }
-        dir &= 7;
         twice_area += (long long)cx * ny - (long long)nx * cy;
         if (nx == sx && ny == sy && cx == fx && cy == fy) break;
         cx = nx; cy = ny;

@@ -2250,15 +2250,21 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                               // union-find -- the ballot IS the pixel's word, so no separate pass has to read it back
                 if (lane == 0) bits_dev[base >> 6] = m;
                 if (b) {
-                    // label = first pixel of the run of ones that ends here (inside this word, not crossing the row start);
-                    // the box of the component this pixel may end up the root of starts at the pixel itself
+                    // label = first pixel of the run of ones that ends here (inside this word, not crossing the row start).  Only
+                    // such a first pixel can end up a root, and only it carries a box: that of its piece of the run
                     const unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);
                     int run0 = zeros_below ? 64 - __builtin_clzll(zeros_below) : 0;
                     const unsigned int y = (unsigned int)i / (unsigned int)W, x = (unsigned int)i - y * (unsigned int)W;
                     if (lane - run0 > (int)x) run0 = lane - (int)x;
                     ccl_label[i] = (int)i - (lane - run0);
-                    CclBox e; e.minx = (int)x; e.maxx = (int)x; e.maxy = (int)y; e.pad = 0;
-                    ccl_box[i] = e;
+                    if (run0 == lane) {
+                        const unsigned long long zeros_above = ~(m >> lane);              // bit k: pixel i + k is background (or past the word)
+                        int len = zeros_above ? __builtin_ctzll(zeros_above) : 64;        // (lane 0 of a full word: 64 ones)
+                        if (len > 64 - lane) len = 64 - lane;
+                        if (len > W - (int)x) len = W - (int)x;                           // the row ends inside the word
+                        CclBox e; e.minx = (int)x; e.maxx = (int)x + len - 1; e.maxy = (int)y; e.pad = 0;
+                        ccl_box[i] = e;
+                    }
                 }
             }
             if (lane == 0 && bits && m) {   // the host keeps the image all-zero between calls: only set words travel

@@ -163,6 +163,10 @@ inline int atomicMin(int *p, int v) {
     while (v < cur && !a->compare_exchange_weak(cur, v)) {}
     return cur;
 }
+inline int atomicCAS(int *p, int expected, int desired) {
+    reinterpret_cast<std::atomic<int> *>(p)->compare_exchange_strong(expected, desired);
+    return expected;   // the value found there (== the caller's `expected` when the swap happened)
+}
 inline int atomicAdd(int *p, int v) { return reinterpret_cast<std::atomic<int> *>(p)->fetch_add(v); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->fetch_add(v); }
 inline unsigned atomicExch(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->exchange(v); }
