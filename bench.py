@@ -322,6 +322,32 @@ def main():
             barrier()
             batch_ms.append((time.perf_counter() - tb) / a.steps * 1e3)
         _capi.check(lib, lib.rm_profile_read(ctx, (ctypes.c_double * 4)(), None), "rm_profile_read")
+    # back-to-back buffers through rm_locate_submit / rm_locate_result: buffer k+1 is submitted before the ROI of buffer k is fetched,
+    # so its frame-buffer kernel runs where the synchronous step leaves the GPU idle (host wait + contour stage + launch latency).
+    # EXTRA key only -- `value` is the synchronous step above
+    pipelined = None
+    if world == 1 and not a.no_batches:
+        _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+        def pipe(n):
+            rois_equal = True
+            tk = backend.locate_submit(buf, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
+            for _ in range(n - 1):
+                nxt = backend.locate_submit(buf, 10, 0.1, 1.0, 500, a.levels, a.skip, 0.7, 20, flags)
+                rois_equal &= backend.locate_result(tk) == roi
+                tk = nxt
+            rois_equal &= backend.locate_result(tk) == roi
+            return rois_equal
+        pipe(max(2, a.warmup))
+        barrier()
+        tp = time.perf_counter()
+        eq = pipe(a.steps)
+        barrier()
+        pipe_ms = (time.perf_counter() - tp) / a.steps * 1e3
+        pipelined = {"in_flight": 2, "steps": a.steps, "ms_per_step": pipe_ms, "frames_per_s": T / pipe_ms * 1e3,
+                     "every_roi_equals_the_synchronous_one": bool(eq),
+                     "note": "rm_locate_submit(k+1) before rm_locate_result(k), one stream, one context; every step still delivers its ROI to the host"}
+        _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
+        _capi.check(lib, lib.rm_profile_read(ctx, (ctypes.c_double * 4)(), None), "rm_profile_read")
     tn = ctypes.c_int(0)
     _capi.check(lib, lib.rm_heat_sparse_tiles_needed(ctx, ctypes.byref(tn)), "rm_heat_sparse_tiles_needed")
     tiles_needed = tn.value                       # largest per-rank tile count of the last sparse exchange (world > 1)
@@ -619,6 +645,7 @@ def main():
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": step_ms, "ms_per_step_batches": {"batches": batch_ms, "min": min(batch_ms), "median": float(np.median(batch_ms)),
                                                             "note": "batch 0 is the timed region `value` comes from; the others follow it"},
+            "pipelined": pipelined,
             "pre_warm_steps": pre_steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64", "frame_buffer_dtype": a.in_dtype, "data": "synthetic",

@@ -36,6 +36,7 @@ extern "C" {
 #define RM_E_UNSUPPORTED (-4)
 #define RM_E_INTERNAL (-5)
 #define RM_E_COMM (-6)     /* RCCL: library missing, communicator or collective failed */
+#define RM_E_BUSY (-7)     /* rm_locate_submit: every ticket of the context is waiting for its rm_locate_result */
 
 /* element type of a frame buffer handed to the library */
 #define RM_U8 0  /* gray uint8; the kernels apply uint8_to_float's  k * (1./255)  (transforms.py:20-23) */
@@ -192,6 +193,22 @@ int rm_locate(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int 
               double freq_min, double freq_max, double amplification, int pyramid_levels,
               int skip_levels_at_top, double temporal_threshold, int threshold, unsigned flags,
               int32_t *xywh_host, void *stream);
+
+/* ---- the same in two calls, for back-to-back calibration buffers (base.py:547-601 called once per buffer: the streams of
+ *      BASELINE config 4, the state machine's recalibrations).  rm_locate_submit enqueues the device work of rm_locate on `stream`
+ *      and returns a ticket without waiting; rm_locate_result(ticket) waits for it, runs the host contour stage (base.py:568-575)
+ *      and fills xywh_host -- same return values and bit-identical ROI as rm_locate.  A context holds up to RM_LOCATE_TICKETS
+ *      submissions (RM_E_BUSY beyond), all on ONE stream; results may be fetched in any order.  Submitting buffer k+1 before
+ *      fetching buffer k puts the frame-buffer kernel of k+1 where the synchronous call leaves the GPU idle (host wait + contour
+ *      stage + launch latency of the next call).  frames_dev must stay valid and unchanged until the ticket's rm_locate_result
+ *      (a selection that overflows the value store is taken again synchronously there); between a submit and its result the
+ *      context takes no other calls than rm_locate_submit / rm_locate_result / rm_locate on the same stream. */
+#define RM_LOCATE_TICKETS 2
+int rm_locate_submit(rm_ctx *ctx, const void *frames_dev, int dtype, int T, int H, int W, double fps,
+                     double freq_min, double freq_max, double amplification, int pyramid_levels,
+                     int skip_levels_at_top, double temporal_threshold, int threshold, unsigned flags,
+                     void *stream, int *ticket_host);
+int rm_locate_result(rm_ctx *ctx, int ticket, int32_t *xywh_host);
 
 /* ---- frame-sharded calibration (one [T,H,W] buffer split by frame index over the GPUs of a node; SURVEY 8e
  *      "Mode A", BASELINE north_star).  Same arithmetic as rm_calibrate (transforms.py:144-198, base.py:562),

@@ -12,7 +12,10 @@ RM_NO_CONTOUR = 1
 RM_SPARSE_FALLBACK = 2
 RM_COMM_ID_BYTES = 128
 RM_EXCHANGE_SPARSE, RM_EXCHANGE_DENSE = 1, 2
+RM_E_BADARG = -1
 RM_E_COMM = -6
+RM_E_BUSY = -7
+RM_LOCATE_TICKETS = 2
 RM_U8, RM_F16, RM_F32, RM_F64 = 0, 1, 2, 3
 RM_FLAG_NO_PRUNE = 1
 RM_FLAG_UNFUSED_DOWN = 2
@@ -63,6 +66,8 @@ SIGNATURES = {
     "rm_heat_sparse_merge_roi": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rm_heat_sparse_tiles_needed": (_i, [_vp, _vp]),
     "rm_locate": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
+    "rm_locate_submit": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _d, _i, _i, _d, _i, _u, _vp, _vp]),
+    "rm_locate_result": (_i, [_vp, _i, _vp]),
     "rm_shard_layout": (_i, [_i, _i, _i, _i, _c.POINTER(_sz)]),
     "rm_shard_layout_flags": (_i, [_i, _i, _i, _i, _c.c_uint, _c.POINTER(_sz)]),
     "rm_shard_pyramid": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _vp]),

@@ -85,6 +85,36 @@ class _Backend:
             return None
         return xywh[0], xywh[1], xywh[2], xywh[3]
 
+    def locate_submit(self, buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyramid_levels=9, skip_levels_at_top=4,
+                      temporal_threshold=0.7, threshold=20, flags=0):
+        """locate() without the wait: the device work is enqueued and a ticket returned (rm_locate_submit).  Up to
+        _capi.RM_LOCATE_TICKETS buffers per GPU may be in flight; `buf` must stay alive and unchanged until locate_result."""
+        import ctypes
+        T, H, W = buf.shape
+        idx = buf.device.index
+        ctx = device._CTX.get(idx) or device.ctx(idx)
+        stream = ctypes.c_void_p(self.t.cuda.current_stream(idx).cuda_stream)
+        ticket = ctypes.c_int(-1)
+        rc = self.lib.rm_locate_submit(ctx, ctypes.c_void_p(buf.data_ptr()), device.dtype_code(buf), T, H, W,
+                                       float(fps), float(freq_min), float(freq_max), float(amplification),
+                                       int(pyramid_levels), int(skip_levels_at_top), float(temporal_threshold),
+                                       int(threshold), int(flags), stream, ctypes.byref(ticket))
+        if rc < 0:
+            _capi.check(self.lib, rc, "rm_locate_submit")
+        return (idx, ticket.value, buf)     # (the buffer rides along: it must outlive the submission)
+
+    def locate_result(self, ticket):
+        """The ROI of a locate_submit: (x, y, w, h) or None, bit-identical to locate() on the same buffer (rm_locate_result)."""
+        idx, tk, _buf = ticket
+        ctx = device._CTX.get(idx) or device.ctx(idx)
+        xywh = self._xywh
+        rc = self.lib.rm_locate_result(ctx, tk, xywh)
+        if rc < 0:
+            _capi.check(self.lib, rc, "rm_locate_result")
+        if rc == _capi.RM_NO_CONTOUR:
+            return None
+        return xywh[0], xywh[1], xywh[2], xywh[3]
+
     # -- ingest -----------------------------------------------------------------------
     def bgr_to_gray(self, bgr_u8_host):
         t = self.t

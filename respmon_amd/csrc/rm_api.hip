@@ -96,7 +96,6 @@ struct DebugKnobs {
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
-    int roi_fast = 0;             // 1: try the device-side ROI of simple shapes first (k_heat_to_roi_fast + k_rows_finish; measured: the host stage it saves, 18 us, is what its second kernel costs)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
     int dense_tiles = 1;          // 0: k_tile_sum (rounds of sixteen waves per tile) instead of k_dense_sum_t (one wave per tile) where a store-less sum at skip >= 3 is due
@@ -105,16 +104,41 @@ struct DebugKnobs {
     long long store_slots = 0;    // > 0: capacity of the value store in (tile, frame) slots (forces the overflow path)
 };
 
+// pinned result areas of ONE ROI extraction in flight
+struct RoiSlot {
+    uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // bit-packed thresholded image + H row flags (k_heat_to_u8)
+    uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
+    CclComp *h_comps = nullptr; size_t h_comps_cap = 0;    // [0] = {count, -, -, -}, then one record per component
+    int *h_unserved = nullptr;      // set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
+};
+constexpr int ROI_SLOTS = 3;
+// what the host half of the ROI stage has to know about the launches it finishes
+struct RoiPending { int H = 0, W = 0, slot = 0; size_t nwords = 0, comps_cap = 0; bool label = false, clip = false; };
+// one rm_locate_submit whose rm_locate_result has not been called yet (the arguments: a selection that overflows the value store is
+// taken again through the synchronous rm_locate)
+struct LocateTicket {
+    bool active = false;
+    RoiPending roi;
+    hipEvent_t done = nullptr;
+    hipStream_t stream = nullptr;
+    const void *frames = nullptr;
+    int dtype = 0, T = 0, H = 0, W = 0, levels = 0, skip = 0, threshold = 0;
+    double fps = 0, fmin = 0, fmax = 0, amp = 0, temporal_thr = 0;
+    unsigned flags = 0;
+    bool plan_valid = false;
+};
+
 struct rm_ctx {
     int device = 0;
     DebugKnobs dbg;
     std::map<std::string, DevBuf> bufs;
     CollapseState *d_state = nullptr;
     CollapseState *h_state = nullptr;  // pinned
-    uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // pinned: bit-packed thresholded image + H row flags (k_heat_to_u8)
+    RoiSlot slots[ROI_SLOTS];                              // pinned result areas; slot 0 serves the synchronous entries
+    int cur_slot = 0;                                      // the slot the launches being enqueued write to
+    LocateTicket tickets[ROI_SLOTS - 1];                   // rm_locate_submit / rm_locate_result (ticket i uses slot i + 1)
     bool tiles_const_once = false;                         // the next ROI stage reads the heatmap rm_locate's own sum kernel has just written (tile_nkept is valid for it)
     bool clip_frame = false, clip_frame_once = false;      // cv2.findContours of OpenCV <= 3.1 (rm_set_contour_clip_frame / RM_FLAG_CONTOUR_CLIP_FRAME)
-    uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
     // device labelling of the thresholded image (rm_ccl.h): taken when the previous ROI extraction of this geometry met
     // more than LABEL_MIN_CONTOURS components (label_mode -1 = that rule, 0 = never, 1 = always: rm_set_contour_labelling)
     int label_mode = -1, label_H = 0, label_W = 0, label_last_n = 0, label_used = 0;
@@ -123,7 +147,6 @@ struct rm_ctx {
     // stage, labelled stages in a row (every LABEL_REPROBE-th one is run unlabelled to refresh the first figure)
     double label_unl_us = -1.0, label_lab_host_us = 0.0;
     int label_unl_n = 0, label_streak = 0;
-    CclComp *h_comps = nullptr; size_t h_comps_cap = 0;    // pinned: [0] = {count, -, -, -}, then one record per component
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;
     bool state_fresh = false;   // d_state was reset by the last kernel of front_pyramid and nothing has reduced into it since
@@ -135,13 +158,8 @@ struct rm_ctx {
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     void *comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator (rm_comm_init); none: one rank
     ExchangeState xp_streams, xp_sharded;
-    RoiFast *h_fast = nullptr;      // pinned: the result record of k_heat_to_roi_fast
-    int roi_rows_cap = 0;           // rows the device row summaries were initialised for
-    int roi_fast_skip = 0;          // ROI extractions left that go straight to the border-following path (the last simple-shape attempt failed)
-    int roi_fast_used = 0;          // the last ROI extraction was decided on the device (rm_contour_stats)
     int dense_hint = 0;             // the last rm_locate of this context met a dense selection (more than a quarter of the pairs kept)
     long long store_hint_slots = 0; // slots a selection of this context needed when it overflowed the value store (rm_locate grows the store to it)
-    int *h_unserved = nullptr;      // pinned: set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
     // measurement hook (rm_profile_*)
     long long dbg_pairs = 0, dbg_cap = 0, dbg_mine = 0; int dbg_mode = 0, dbg_auto_dense = 0, dbg_fused = 0;   // the SumPlan of the last collapse (host copy)
     int prof_mode = 0;                     // 0 off, 1 frame-buffer kernel only, 2 all phases
@@ -224,11 +242,14 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
-    if (ctx->h_bin) (void)hipHostFree(ctx->h_bin);
-    if (ctx->h_comps) (void)hipHostFree(ctx->h_comps);
+    for (RoiSlot &rs : ctx->slots) {
+        if (rs.h_bin) (void)hipHostFree(rs.h_bin);
+        if (rs.h_comps) (void)hipHostFree(rs.h_comps);
+        if (rs.h_unserved) (void)hipHostFree(rs.h_unserved);
+    }
+    for (LocateTicket &t : ctx->tickets)
+        if (t.done) (void)hipEventDestroy(t.done);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
-    if (ctx->h_unserved) (void)hipHostFree(ctx->h_unserved);
-    if (ctx->h_fast) (void)hipHostFree(ctx->h_fast);
     (void)rm_comm_destroy(ctx);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
         for (hipEvent_t e : ctx->prof_ev[p]) (void)hipEventDestroy(e);
@@ -263,7 +284,6 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dense_tiles") d.dense_tiles = (int)value;
     else if (k == "eval_fast") d.eval_fast = (int)value;
     else if (k == "exchange_dense") d.exchange_dense = (int)value;
-    else if (k == "roi_fast") d.roi_fast = (int)value;
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;
@@ -1460,7 +1480,7 @@ static int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int 
 
 // heat_sum[H*W] = sum over t in [t0, t1) of (raw >= top ? min : raw), with min/max as they stand in the state
 // avg_T > 0: the sum covers the whole buffer, write heat = sum / avg_T and leave the heatmap's min / max in the state
-// host_rescue: the caller synchronises the stream soon and looks at ctx->h_unserved (rm_locate): a dense kernel that could only
+// host_rescue: the caller synchronises the stream soon and looks at the slot's h_unserved (rm_locate): a dense kernel that could only
 // be chosen because the value store overflowed is then not enqueued here
 static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_sum, hipStream_t s, int avg_T = 0, bool host_rescue = false)
 {
@@ -1535,9 +1555,10 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
     //  find the store overflowed: ctx->dense_hint, set and cleared by rm_locate)
     const bool may_dense = sp.mode == 1 || auto_dense || (overflow_only && (!host_rescue || ctx->dense_hint));
     if (overflow_only && host_rescue) {
-        if (!ctx->h_unserved) HIP_TRY(hipHostMalloc((void **)&ctx->h_unserved, sizeof(int), hipHostMallocDefault));
-        *ctx->h_unserved = 0;
-        HIP_TRY(hipHostGetDevicePointer((void **)&unserved_dev, ctx->h_unserved, 0));
+        RoiSlot &rs = ctx->slots[ctx->cur_slot];
+        if (!rs.h_unserved) HIP_TRY(hipHostMalloc((void **)&rs.h_unserved, sizeof(int), hipHostMallocDefault));
+        *rs.h_unserved = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **)&unserved_dev, rs.h_unserved, 0));
     }
     if (may_sparse) {
         // worker items for the tiles with kept pairs (MS_Q each); the workgroups left without an item fill the other tiles
@@ -1850,14 +1871,19 @@ constexpr int LABEL_REPROBE = 64;         // labelled stages in a row before the
 constexpr int LABEL_MIN_CONTOURS = 512;   // ~0.13 us per followed border on the host against ~40 us of labelling kernels
 static_assert(sizeof(CclComp) == sizeof(LabelComp), "record layout shared by rm_ccl.h and rm_contour.h");
 
-static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
-                               uint8_t *binary, void *stream, bool have_minmax)
+// The ROI stage in two halves: roi_launch enqueues the device work (threshold -> packed image in the pinned memory of slot
+// ctx->cur_slot, component labelling when the rule asks for it), roi_finish -- once the stream (or the event recorded behind the
+// launches) has been waited for -- runs the host contour stage on that slot.  heatmap_to_roi_impl is the two with stream_wait
+// between them; rm_locate_submit / rm_locate_result put the next call's frame-buffer kernel there instead.
+static int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uint8_t *avg_u8, uint8_t *binary, void *stream,
+                      bool have_minmax, RoiPending &pd, bool xywh_given)
 {
     if (!ctx) return fail(RM_E_BADARG, "rm_heatmap_to_roi: bad argument");
     // the one-call clip request of rm_locate (RM_FLAG_CONTOUR_CLIP_FRAME) is consumed here, whatever happens below
     const bool clip_once = ctx->clip_frame_once;
     ctx->clip_frame_once = false;
-    if (!heat || !xywh || H < 1 || W < 1) return fail(RM_E_BADARG, "rm_heatmap_to_roi: bad argument");
+    if (!heat || !xywh_given || H < 1 || W < 1) return fail(RM_E_BADARG, "rm_heatmap_to_roi: bad argument");
+    RoiSlot &rs = ctx->slots[ctx->cur_slot];
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t npix = (size_t)H * W;
@@ -1867,18 +1893,18 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     // kernel stores both straight into pinned, device-mapped host memory (no copy-engine hop)
     const size_t nwords = (npix + 63) / 64;
     const size_t need = nwords * 8 + (size_t)H;
-    if (ctx->h_bin_cap < need) {
-        if (ctx->h_bin) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(ctx->h_bin)); }
-        ctx->h_bin = nullptr; ctx->h_bin_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&ctx->h_bin, need, hipHostMallocDefault));
-        ctx->h_bin_cap = need;
-        ctx->h_rows_dirty = nullptr;
+    if (rs.h_bin_cap < need) {
+        if (rs.h_bin) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(rs.h_bin)); }
+        rs.h_bin = nullptr; rs.h_bin_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&rs.h_bin, need, hipHostMallocDefault));
+        rs.h_bin_cap = need;
+        rs.h_rows_dirty = nullptr;
     }
-    uint8_t *h_rows = ctx->h_bin + nwords * 8;
+    uint8_t *h_rows = rs.h_bin + nwords * 8;
     // invariant between calls: image words and row flags are all zero (the rows a call read are zeroed again below)
-    if (ctx->h_rows_dirty != h_rows) { std::memset(ctx->h_bin, 0, need); ctx->h_rows_dirty = h_rows; }
+    if (rs.h_rows_dirty != h_rows) { std::memset(rs.h_bin, 0, need); rs.h_rows_dirty = h_rows; }
     uint8_t *dev_bin = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void **)&dev_bin, ctx->h_bin, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)&dev_bin, rs.h_bin, 0));
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
     struct Guard { PhaseTimer *&p; ~Guard() { delete p; p = nullptr; } } guard{pt_roi};
     if (!have_minmax) {  // rm_calibrate has just left the heatmap's min / max in the state
@@ -1904,57 +1930,6 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         tile_const = tk;
     }
     ctx->tiles_const_once = false;
-    // one launch and 32 bytes to the host when the thresholded image is a simple shape (rm_kernels.h k_heat_to_roi_fast)
-    ctx->roi_fast_used = 0;
-    if (!clip && !label && ctx->dbg.roi_fast && W % 64 == 0 && W <= ROI_FAST_MAX_W && (size_t)H * 12 <= 60 * 1024 && npix < (size_t)0x7fffffff) {
-        if (ctx->roi_fast_skip > 0) --ctx->roi_fast_skip;
-        else {
-            unsigned long long *fb = nullptr; RowSum *rows = nullptr; unsigned int *ctr = nullptr;
-            RM_TRY(ws(ctx, "roi_bits", nwords, &fb));
-            RM_TRY(ws(ctx, "roi_rows", (size_t)std::max(H, ctx->roi_rows_cap), &rows));
-            RM_TRY(ws(ctx, "roi_ctr", (size_t)4, &ctr));
-            if (!ctx->h_fast) HIP_TRY(hipHostMalloc((void **)&ctx->h_fast, sizeof(RoiFast), hipHostMallocDefault));
-            if (ctx->roi_rows_cap < H) {
-                hipLaunchKernelGGL(k_rows_init, dim3(nblk((size_t)H, 256, 64)), dim3(256), 0, s, rows, H, ctr);
-                LAUNCH_CHECK();
-                ctx->roi_rows_cap = H;
-            }
-            RoiFast *dev_fast = nullptr;
-            HIP_TRY(hipHostGetDevicePointer((void **)&dev_fast, ctx->h_fast, 0));
-            ctx->h_fast->status = -1;
-            hipLaunchKernelGGL(k_heat_to_roi_fast, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary, fb, rows);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(256), 3 * sizeof(int) * (size_t)H, s, rows, H, dev_fast);
-            LAUNCH_CHECK();
-            delete pt_roi; pt_roi = nullptr;
-            HIP_TRY(stream_wait(s));
-            const RoiFast rf = *ctx->h_fast;
-            if (rf.status == 0 || rf.status == 1) {
-                ctx->roi_fast_used = 1;
-                ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = rf.status; ctx->label_used = 0;
-                if (rf.status == 0) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
-                xywh[0] = rf.x; xywh[1] = rf.y; xywh[2] = rf.w; xywh[3] = rf.h;
-                return RM_OK;
-            }
-            if (rf.status != 2) return fail(RM_E_INTERNAL, "rm_heatmap_to_roi: the device wrote no ROI record");
-            // not a simple shape: fetch the packed image and follow the borders on the host; the next extractions of this context
-            // skip the attempt for a while
-            ctx->roi_fast_skip = 15;
-            HIP_TRY(hipMemcpyAsync(ctx->h_bin, fb, nwords * 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(stream_wait(s));
-            auto t0 = std::chrono::steady_clock::now();
-            const int y0 = rf.y, y1 = rf.y + rf.h - 1;
-            RoiResult r;
-            largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
-            ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours; ctx->label_used = 0;
-            std::memset(ctx->h_bin, 0, nwords * 8);   // (the image is all-zero between calls: the border-following path relies on it)
-            if (ctx->prof_on)
-                ctx->prof_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
-            xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;
-            return RM_OK;
-        }
-    }
     unsigned long long *d_bits = nullptr;
     const size_t comps_cap = std::min<size_t>(npix / 4 + 2, (size_t)1 << 18);
     if (label) {
@@ -1964,14 +1939,14 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         RM_TRY(ws(ctx, "ccl_label", npix, &d_label));
         RM_TRY(ws(ctx, "ccl_box", npix, &d_box));
         RM_TRY(ws(ctx, "ccl_counters", (size_t)2, &d_cnt));
-        if (ctx->h_comps_cap < comps_cap + 1) {
-            if (ctx->h_comps) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(ctx->h_comps)); }
-            ctx->h_comps = nullptr; ctx->h_comps_cap = 0;
-            HIP_TRY(hipHostMalloc((void **)&ctx->h_comps, (comps_cap + 1) * sizeof(CclComp), hipHostMallocDefault));
-            ctx->h_comps_cap = comps_cap + 1;
+        if (rs.h_comps_cap < comps_cap + 1) {
+            if (rs.h_comps) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(rs.h_comps)); }
+            rs.h_comps = nullptr; rs.h_comps_cap = 0;
+            HIP_TRY(hipHostMalloc((void **)&rs.h_comps, (comps_cap + 1) * sizeof(CclComp), hipHostMallocDefault));
+            rs.h_comps_cap = comps_cap + 1;
         }
         CclComp *dev_comps = nullptr;
-        HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, ctx->h_comps, 0));
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, rs.h_comps, 0));
         hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
                            (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits, d_label, d_box, d_cnt);
         LAUNCH_CHECK();
@@ -1997,7 +1972,17 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
         LAUNCH_CHECK();
     }
     delete pt_roi; pt_roi = nullptr;
-    HIP_TRY(stream_wait(s));
+    pd.H = H; pd.W = W; pd.slot = ctx->cur_slot; pd.nwords = nwords; pd.comps_cap = comps_cap; pd.label = label; pd.clip = clip;
+    return RM_OK;
+}
+
+static int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
+{
+    RoiSlot &rs = ctx->slots[pd.slot];
+    const int H = pd.H, W = pd.W;
+    const size_t nwords = pd.nwords, comps_cap = pd.comps_cap;
+    const bool label = pd.label, clip = pd.clip;
+    uint8_t *h_rows = rs.h_bin + nwords * 8;
     RoiResult r;
     {
         const auto t0 = std::chrono::steady_clock::now();
@@ -2006,7 +1991,7 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
             if (h_rows[y]) { if (y < y0) y0 = y; y1 = y; h_rows[y] = 0; }
         if (clip && y1 >= y0) {
             // OpenCV <= 3.1: the 1-pixel image frame is zeroed before tracing (the host copy is ours to change)
-            uint64_t *hb = (uint64_t *)ctx->h_bin;
+            uint64_t *hb = (uint64_t *)rs.h_bin;
             auto clear_bit = [&](size_t p) { hb[p >> 6] &= ~(1ull << (p & 63)); };
             for (int y = y0; y <= y1; ++y) {
                 const size_t r0 = (size_t)y * W;
@@ -2014,16 +1999,16 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
                 else { clear_bit(r0); clear_bit(r0 + W - 1); }
             }
         }
-        const size_t ncomp = label ? (size_t)(unsigned int)ctx->h_comps[0].root : 0;
+        const size_t ncomp = label ? (size_t)(unsigned int)rs.h_comps[0].root : 0;
         ctx->label_used = label && ncomp <= comps_cap;
         if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
-            largest_external_contour_labelled((const uint64_t *)ctx->h_bin, H, W, (const LabelComp *)(ctx->h_comps + 1), ncomp, &r);
-        else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r)))
-            largest_external_contour_bits_rows((const uint64_t *)ctx->h_bin, H, W, y0, y1, &r);
+            largest_external_contour_labelled((const uint64_t *)rs.h_bin, H, W, (const LabelComp *)(rs.h_comps + 1), ncomp, &r);
+        else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r)))
+            largest_external_contour_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r);
         ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
         if (y1 >= y0) {   // restore the all-zero image: the words that cover rows y0 .. y1
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
-            std::memset(ctx->h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
+            std::memset(rs.h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
         }
         const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         if (ctx->label_used) {
@@ -2038,6 +2023,15 @@ static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, in
     if (!r.found) { xywh[0] = xywh[1] = xywh[2] = xywh[3] = 0; return RM_NO_CONTOUR; }
     xywh[0] = r.x; xywh[1] = r.y; xywh[2] = r.w; xywh[3] = r.h;
     return RM_OK;
+}
+
+static int heatmap_to_roi_impl(rm_ctx *ctx, const double *heat, int H, int W, int threshold, int32_t *xywh, uint8_t *avg_u8,
+                               uint8_t *binary, void *stream, bool have_minmax)
+{
+    RoiPending pd;
+    RM_TRY(roi_launch(ctx, heat, H, W, threshold, avg_u8, binary, stream, have_minmax, pd, xywh != nullptr));
+    HIP_TRY(stream_wait((hipStream_t)stream));
+    return roi_finish(ctx, pd, xywh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2156,7 +2150,9 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
                          void *stream)
 {
     if (!ctx || !xywh) return fail(RM_E_BADARG, "rm_locate: bad argument");
-    if (ctx->h_unserved) *ctx->h_unserved = 0;   // (a failed earlier call must not leave its "dense sum wanted" behind)
+    ctx->cur_slot = 0;
+    RoiSlot &rs = ctx->slots[0];
+    if (rs.h_unserved) *rs.h_unserved = 0;   // (a failed earlier call must not leave its "dense sum wanted" behind)
     double *heat = nullptr;
     RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
     CollapsePlan cp;
@@ -2165,9 +2161,9 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     ctx->clip_frame_once = clip_once;
     ctx->tiles_const_once = cp.valid && cp.S >= 1;
     int rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
-    const int unserved_word = ctx->h_unserved ? *ctx->h_unserved : 0;   // 1: the sparse kernel stood down and nothing took the sum; 2: the stand-in did
+    const int unserved_word = rs.h_unserved ? *rs.h_unserved : 0;   // 1: the sparse kernel stood down and nothing took the sum; 2: the stand-in did
     const bool unserved = unserved_word == 1;
-    if (ctx->h_unserved) *ctx->h_unserved = 0;
+    if (rs.h_unserved) *rs.h_unserved = 0;
     if (ctx->dense_hint && unserved_word != 2) ctx->dense_hint = 0;   // (the stand-in enqueued on the hint was not needed: back to the plain path)
     if (rc >= 0 && cp.valid && unserved) {
         // the selection kept more pairs than the value store holds and the sparse sum kernel stood down (the ROI stage above ran on
@@ -2201,6 +2197,70 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
         ctx->tiles_const_once = true;
         rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
     }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// rm_locate in two calls: rm_locate_submit enqueues everything up to the packed thresholded image and returns; rm_locate_result
+// waits for it and runs the host contour stage.  Between the two the caller may submit the NEXT buffer (two tickets per context),
+// so its frame-buffer kernel runs while the host follows the borders of this one: the 30-60 us the GPU idles per synchronous step
+// (stream_wait + contour stage + the next call's launch latency) disappear from a back-to-back sequence of calibration buffers
+// (base.py:547-601 called once per buffer: BASELINE config 4's streams, the state machine's recalibrations).
+// All submissions of a context go on ONE stream (stream order is what keeps the second submission's kernels off the workspace of
+// the first); the results are pinned per ticket.  A selection that overflows the value store is taken again by the synchronous
+// rm_locate inside rm_locate_result (frames_dev must stay valid until then).
+// ------------------------------------------------------------------------------------------
+extern "C" int rm_locate_submit(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
+                                double amp, int levels, int skip, double temporal_thr, int threshold, unsigned flags, void *stream,
+                                int *ticket_out)
+{
+    if (!ctx || !ticket_out) return fail(RM_E_BADARG, "rm_locate_submit: bad argument");
+    int ti = -1;
+    for (int i = 0; i < ROI_SLOTS - 1; ++i)
+        if (!ctx->tickets[i].active) { ti = i; break; }
+    if (ti < 0) return fail(RM_E_BUSY, "rm_locate_submit: %d submissions are waiting for rm_locate_result", ROI_SLOTS - 1);
+    for (int i = 0; i < ROI_SLOTS - 1; ++i)
+        if (ctx->tickets[i].active && ctx->tickets[i].stream != (hipStream_t)stream)
+            return fail(RM_E_BADARG, "rm_locate_submit: the submissions of a context share one stream");
+    LocateTicket &t = ctx->tickets[ti];
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!t.done) HIP_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    struct SlotGuard { rm_ctx *c; ~SlotGuard() { c->cur_slot = 0; } } guard{ctx};
+    ctx->cur_slot = ti + 1;
+    RoiSlot &rs = ctx->slots[ctx->cur_slot];
+    if (rs.h_unserved) *rs.h_unserved = 0;
+    double *heat = nullptr;
+    RM_TRY(ws(ctx, "heat", (size_t)H * W, &heat));
+    CollapsePlan cp;
+    RM_TRY(calibrate_impl(ctx, frames, dtype, T, H, W, fps, fmin, fmax, amp, levels, skip, temporal_thr, flags, heat, nullptr, stream, &cp));
+    ctx->clip_frame_once = (flags & RM_FLAG_CONTOUR_CLIP_FRAME) != 0;
+    ctx->tiles_const_once = cp.valid && cp.S >= 1;
+    RM_TRY(roi_launch(ctx, heat, H, W, threshold, nullptr, nullptr, stream, true, t.roi, true));
+    HIP_TRY(hipEventRecord(t.done, (hipStream_t)stream));
+    t.stream = (hipStream_t)stream; t.frames = frames; t.dtype = dtype; t.T = T; t.H = H; t.W = W; t.fps = fps; t.fmin = fmin; t.fmax = fmax;
+    t.amp = amp; t.levels = levels; t.skip = skip; t.temporal_thr = temporal_thr; t.threshold = threshold; t.flags = flags;
+    t.plan_valid = cp.valid;
+    t.active = true;
+    *ticket_out = ti;
+    return RM_OK;
+}
+
+extern "C" int rm_locate_result(rm_ctx *ctx, int ticket, int32_t *xywh)
+{
+    if (!ctx || !xywh || ticket < 0 || ticket >= ROI_SLOTS - 1 || !ctx->tickets[ticket].active)
+        return fail(RM_E_BADARG, "rm_locate_result: bad argument (no such submission)");
+    LocateTicket &t = ctx->tickets[ticket];
+    t.active = false;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(event_wait(t.done));
+    int rc = roi_finish(ctx, t.roi, xywh);
+    RoiSlot &rs = ctx->slots[ticket + 1];
+    const int unserved_word = rs.h_unserved ? *rs.h_unserved : 0;
+    if (rs.h_unserved) *rs.h_unserved = 0;
+    if (ctx->dense_hint && unserved_word != 2) ctx->dense_hint = 0;
+    if (rc >= 0 && t.plan_valid && unserved_word == 1)   // nobody took the sum (value store overflow): the synchronous call sorts it out
+        rc = rm_locate(ctx, t.frames, t.dtype, t.T, t.H, t.W, t.fps, t.fmin, t.fmax, t.amp, t.levels, t.skip, t.temporal_thr, t.threshold, t.flags,
+                       xywh, (void *)t.stream);
     return rc;
 }
 

@@ -32,6 +32,17 @@ inline hipError_t stream_wait(hipStream_t s)
     }
 }
 
+// ... for the work in front of an event (rm_locate_result: the stream already carries the next submission)
+inline hipError_t event_wait(hipEvent_t ev)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) return hipEventSynchronize(ev);
+    }
+}
+
 
 // ----------------------------------------------------------------------------------------
 // Workgroup timeline tracing -- DEVELOPER BUILD ONLY (make librespmon_hip_trace.so, tools/trace_tail.py).  In the product
@@ -2275,137 +2286,6 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                 }
             }
         }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// base.py:563-575 in ONE launch when the thresholded image is a simple shape (round 4).  locate() keeps the external contour with the
-// largest area and returns its bounding rectangle; on the breathing streams the thresholded heatmap is ONE blob without holes, and
-// that can be known without following a border: if every image row holds at most one run of foreground, the rows that hold one
-// are consecutive, and the runs of neighbouring rows touch (8-connectivity: overlap or a diagonal step), the foreground is one
-// 8-connected component without holes -- ONE external contour, whose boundingRect is the bounding box of the runs.  The kernel
-// thresholds like k_heat_to_u8, keeps the bit-packed image on the DEVICE, folds every non-empty 64-pixel word into its row's
-// {first, last, number of runs} with atomics, and a one-workgroup kernel behind it checks the three conditions and writes 32 bytes to
-// pinned host memory: {status, x, y, w, h}.  status 0: no foreground (locate() returns None); 1: simple shape, the ROI is final;
-// 2: anything else -- the host fetches the packed image and follows the borders as before.  The common case moves 32 bytes over
-// PCIe instead of ~12 KB and spends no host time in the contour stage.  Needs W % 64 == 0 (a word never straddles two rows).
-// ----------------------------------------------------------------------------------------
-// a row's summary: first / last foreground column, runs that START in one of its 64-pixel words (a word whose bit 0 is set counts a
-// start), and which words have bit 0 / bit 63 set: a run that crosses from word k - 1 into word k was counted twice, so
-// runs = starts - popcount(b0 & (b63 << 1)).  Everything is folded in with device-scope atomics.
-struct alignas(32) RowSum { int first, last, starts, pad; unsigned long long b0, b63; };
-struct alignas(32) RoiFast { int status, x, y, w, h, n_rows, pad0, pad1; };
-constexpr int ROI_FAST_MAX_W = 4096;   // 64 words per row
-
-__global__ __launch_bounds__(256) void k_rows_init(RowSum *rows, int H, unsigned int *done_ctr)
-{
-    for (int y = blockIdx.x * 256 + threadIdx.x; y < H; y += gridDim.x * 256) rows[y] = RowSum{0x7fffffff, -1, 0, 0, 0ull, 0ull};
-    if (blockIdx.x == 0 && threadIdx.x == 0) *done_ctr = 0u;
-}
-
-__device__ __forceinline__ unsigned long long coherent_load64(const void *p)
-{
-#ifdef RM_HIPEMU
-    return *reinterpret_cast<const unsigned long long *>(p);
-#else
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-
-__global__ __launch_bounds__(256) void k_heat_to_roi_fast(const double *heat, size_t npix, int W, const CollapseState *st, int threshold,
-                                                          uint8_t *avg_u8, uint8_t *binary, unsigned long long *bits_dev, RowSum *rows)
-{
-    RM_TRACE_SCOPE(7);
-    const int lane = threadIdx.x & 63;
-    constexpr int HU = 4;
-    const size_t stride = (size_t)gridDim.x * 256;
-    const size_t first = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u);
-    double hv[HU];
-#pragma unroll
-    for (int k = 0; k < HU; ++k) { const size_t i = first + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
-    const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
-    const double mx = f64_unkey(fold_max_keys(st->heat_max_keys, st->heat_max_key));
-    const double range = mx - mn;
-    for (size_t base0 = first; base0 < npix; base0 += HU * stride) {
-        if (base0 != first) {
-#pragma unroll
-            for (int k = 0; k < HU; ++k) { const size_t i = base0 + k * stride + lane; hv[k] = i < npix ? heat[i] : 0.0; }
-        }
-#pragma unroll
-        for (int k = 0; k < HU; ++k) {
-            const size_t base = base0 + k * stride, i = base + lane;
-            if (base >= npix) break;                          // wave-uniform
-            bool b = false;
-            if (i < npix) {
-                const double nrm = (hv[k] - mn) / range;      // base.py:563 (NaN when the heatmap is flat)
-                const uint8_t u = f64_to_u8_trunc(nrm * 255); // transforms.py:26-29
-                b = u > threshold;                            // cv2.threshold THRESH_BINARY, base.py:566
-                if (avg_u8) avg_u8[i] = u;
-                if (binary) binary[i] = b ? 255 : 0;
-            }
-            const unsigned long long m = __ballot(b);
-            if (lane == 0) {
-                bits_dev[base >> 6] = m;
-                if (m) {   // this word's share of its row's summary (W % 64 == 0: the word lies inside one row)
-                    const int y = (int)(base / (size_t)W), xw = (int)(base - (size_t)y * W);
-                    RowSum *r = rows + y;
-                    atomicMin(&r->first, xw + (int)__builtin_ctzll(m));
-                    atomicMax(&r->last, xw + 63 - (int)__builtin_clzll(m));
-                    atomicAdd(&r->starts, (int)__popcll(m & ~(m << 1)));
-                    if (m & 1ull) atomicOr(&r->b0, 1ull << (xw >> 6));
-                    if (m >> 63) atomicOr(&r->b63, 1ull << (xw >> 6));
-                }
-            }
-        }
-    }
-}
-
-// the row summaries -> {status, ROI}: ONE workgroup, behind the kernel boundary (the atomics of k_heat_to_roi_fast have been performed and
-// this kernel starts with clean caches: plain loads).  An arrival counter inside k_heat_to_roi_fast instead cost more than the
-// boundary: 2 048 arrivals on one word, or a quarter of the workgroups for the 16.6 MB heatmap (28 us against 8 + 4).
-// dynamic LDS: 3 ints per image row
-__global__ __launch_bounds__(256) void k_rows_finish(RowSum *rows, int H, RoiFast *result_host)
-{
-    HIP_DYNAMIC_SHARED(int, s_rows)
-    __shared__ int s_cnt, s_ymin, s_ymax, s_xmin, s_xmax, s_bad;
-    if (threadIdx.x == 0) { s_cnt = 0; s_ymin = 0x7fffffff; s_ymax = -1; s_xmin = 0x7fffffff; s_xmax = -1; s_bad = 0; }
-    int *s_first = s_rows, *s_lastc = s_rows + H, *s_runs = s_rows + 2 * H;
-    constexpr int RPT = 4;
-    for (int y0 = threadIdx.x; y0 < H; y0 += 256 * RPT) {
-        RowSum q[RPT];
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) { const int y = y0 + 256 * k; if (y < H) q[k] = rows[y]; }
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int y = y0 + 256 * k;
-            if (y < H) {
-                s_first[y] = q[k].first; s_lastc[y] = q[k].last;
-                s_runs[y] = q[k].starts - (int)__popcll(q[k].b0 & (q[k].b63 << 1));
-                rows[y] = RowSum{0x7fffffff, -1, 0, 0, 0ull, 0ull};   // clean for the next call
-            }
-        }
-    }
-    __syncthreads();
-    int cnt = 0, ymin = 0x7fffffff, ymax = -1, xmin = 0x7fffffff, xmax = -1, bad = 0;
-    for (int y = threadIdx.x; y < H; y += 256) {
-        const int runs = s_runs[y];
-        if (runs == 0) continue;
-        const int f = s_first[y], l = s_lastc[y];
-        ++cnt; ymin = min(ymin, y); ymax = max(ymax, y); xmin = min(xmin, f); xmax = max(xmax, l);
-        if (runs != 1) bad = 1;
-        if (y + 1 < H && s_runs[y + 1] != 0 && !(s_first[y + 1] <= l + 1 && s_lastc[y + 1] >= f - 1)) bad = 1;   // the runs of the two rows do not touch
-    }
-    if (cnt) { atomicAdd(&s_cnt, cnt); atomicMin(&s_ymin, ymin); atomicMax(&s_ymax, ymax); atomicMin(&s_xmin, xmin); atomicMax(&s_xmax, xmax); }
-    if (bad) atomicMax(&s_bad, 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        RoiFast r{0, 0, 0, 0, 0, s_cnt, 0, 0};
-        if (s_cnt > 0) {
-            const bool simple = !s_bad && (s_ymax - s_ymin + 1 == s_cnt);
-            r.status = simple ? 1 : 2;
-            r.x = s_xmin; r.y = s_ymin; r.w = s_xmax - s_xmin + 1; r.h = s_ymax - s_ymin + 1;
-        }
-        *result_host = r;
     }
 }
 

@@ -118,6 +118,23 @@ class Emu:
         return None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
 
 
+    def locate_submit(self, frames, fps, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, threshold=20, flags=0):
+        """rm_locate_submit -> (ticket, the frames kept alive) or the negative return code when the library refuses."""
+        frames = np.ascontiguousarray(frames)
+        T, H, W = frames.shape
+        tk = ctypes.c_int(-1)
+        rc = self.lib.rm_locate_submit(self.ctx, ptr(frames), DT[frames.dtype], T, H, W, fps, fmin, fmax, amp, levels, skip, thr, threshold,
+                                       flags, None, ctypes.byref(tk))
+        if rc < 0:
+            return rc
+        return tk.value, frames
+
+    def locate_result(self, ticket):
+        xywh = np.zeros(4, np.int32)
+        rc = self.ck(self.lib.rm_locate_result(self.ctx, ticket[0], ptr(xywh)), "locate_result")
+        return None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
+
+
 def _shard_methods():
     def new_ctx(self):
         h = ctypes.c_void_p()

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from respmon_amd import synth
+from respmon_amd import _capi, synth
 
 
 @pytest.fixture(scope="module")
@@ -85,6 +85,34 @@ def test_emu_locate_matches_golden_roi(emu, golden):
         assert np.array_equal(u8, g["avg_u8_%d" % i])
         assert np.array_equal(binary, np.where(u8 > 20, 255, 0).astype(np.uint8))
     assert emu.locate(np.full((16, 40, 48), 0.5), 10, levels=4, skip=2) is None  # base.py:569-570
+
+
+def test_emu_locate_submit_result(emu, golden):
+    """rm_locate_submit / rm_locate_result: two buffers in flight, results fetched in either order, equal rm_locate on every golden
+    case; a third submission is refused (RM_E_BUSY); a selection that overflows the value store (RM_FLAG_TINY_STORE) is taken again
+    inside rm_locate_result; a flat video reports no contour."""
+    g = golden("g4_locate.npz")
+    vids, want = [], []
+    for i in range(int(g["ncases"])):
+        T, H, W, seed, L, S, fps = (int(v) for v in g["meta%d" % i])
+        vids.append((synth.synth_breathing(T, H, W, seed=seed), fps, L, S))
+        want.append(tuple(int(v) for v in g["roi%d" % i]))
+    n = len(vids)
+    for i in range(n):
+        j = (i + 1) % n
+        (va, fa, La, Sa), (vb, fb, Lb, Sb) = vids[i], vids[j]
+        ta = emu.locate_submit(va, fa, levels=La, skip=Sa)
+        tb = emu.locate_submit(vb, fb, levels=Lb, skip=Sb, flags=4 if i % 2 else 0)
+        assert emu.locate_submit(va, fa, levels=La, skip=Sa) == _capi.RM_E_BUSY
+        if i % 2:
+            assert emu.locate_result(tb) == want[j] and emu.locate_result(ta) == want[i]
+        else:
+            assert emu.locate_result(ta) == want[i] and emu.locate_result(tb) == want[j]
+        assert emu.locate(va, fa, levels=La, skip=Sa) == want[i]     # the synchronous entry between submissions
+    flat = emu.locate_submit(np.full((16, 40, 48), 0.5), 10, levels=4, skip=2)
+    assert emu.locate_result(flat) is None
+    xywh = np.zeros(4, np.int32)
+    assert emu.lib.rm_locate_result(emu.ctx, flat[0], xywh.ctypes.data_as(ctypes.c_void_p)) == _capi.RM_E_BADARG   # fetched already
 
 
 def test_emu_ragged_shapes_and_degenerate_levels(emu, oracle):
@@ -653,7 +681,7 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
 
 
 def _roi_shapes(rng):
-    """Thresholded-image shapes around the simple-shape rule of k_heat_to_roi_fast (W % 64 == 0): one blob, a ring (two runs per row),
+    """Thresholded-image shapes around the simple-shape rule of the host contour stage (simple_shape_bits_rows): one blob, a ring (two runs per row),
     two blobs side by side / one above the other with a gap, runs that touch diagonally, runs that miss each other by a pixel, a
     run crossing the 64-pixel words, a blob on the image frame, a single pixel, nothing, noise."""
     import scipy.ndimage as ndi
@@ -685,9 +713,9 @@ def _roi_shapes(rng):
     return out
 
 
-def test_emu_roi_fast_equals_border_following(emu, oracle):
-    """k_heat_to_roi_fast (one launch, 32 bytes to the host when the thresholded image is one hole-free blob) against the
-    border-following path and the oracle, shape by shape; the attempt that fails must hand over to the host path with the same result."""
+def test_emu_simple_shape_shortcut_equals_border_following(emu, oracle):
+    """The host stage's one-blob shortcut on the packed rows (rm_contour.cpp simple_shape_bits_rows: one run per row, neighbouring runs
+    touching -> one hole-free component, its bounding box is the ROI) against following every border and the oracle, shape by shape."""
     rng = np.random.default_rng(17)
     try:
         for name, img in _roi_shapes(rng):
@@ -695,22 +723,15 @@ def test_emu_roi_fast_equals_border_following(emu, oracle):
             thr = 100
             ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min())) if heat.max() > heat.min() else np.zeros(heat.shape, np.uint8)
             want = oracle.roi_from_heatmap_u8(ref_u8, thr)
-            emu.debug_set("roi_fast", 0)
             emu.debug_set("host_simple_shape", 0)       # every border followed on the host
             slow, u8s, _ = emu.heatmap_to_roi(heat, threshold=thr)
-            emu.debug_set("host_simple_shape", 1)       # the one-blob shortcut on the packed rows (rm_contour.cpp simple_shape_bits_rows)
-            short, _, _ = emu.heatmap_to_roi(heat, threshold=thr)
-            assert short == slow, (name, heat.shape, short, slow)
-            emu.debug_set("roi_fast", 1)
-            for attempt in range(2):    # (a failed attempt makes the next extractions skip the fast form: both must agree)
-                fast, u8f, binf = emu.heatmap_to_roi(heat, threshold=thr)
-                assert fast == slow == want, (name, heat.shape, attempt, fast, slow, want)
+            emu.debug_set("host_simple_shape", 1)
+            for attempt in range(2):
+                short, u8f, binf = emu.heatmap_to_roi(heat, threshold=thr)
+                assert short == slow == want, (name, heat.shape, attempt, short, slow, want)
                 assert np.array_equal(u8f, u8s) and np.array_equal(binf, np.where(u8s > thr, 255, 0).astype(np.uint8)), (name, attempt)
-            emu.debug_set("roi_fast", 0); emu.heatmap_to_roi(np.ones((4, 64)) * 0.0 + np.eye(4, 64), threshold=thr)   # (leave the skip counter behind)
-            for _ in range(16):
-                emu.debug_set("roi_fast", 1); emu.heatmap_to_roi(np.eye(4, 64), threshold=thr)
     finally:
-        emu.debug_set("roi_fast", 0)
+        emu.debug_set("host_simple_shape", 1)
 
 
 def test_emu_small_pyramid_split_over_workgroups(emu, oracle):

@@ -960,3 +960,40 @@ def test_roi_stage_skips_constant_tiles(hip, oracle):
                 assert (got[1] is None and want is None) or tuple(got[1]) == tuple(int(v) for v in want), (T, H, W, L, S, kind, got[1], want)
     finally:
         device.debug_set("heat_const_tiles", 1)
+
+
+@pytest.mark.gpu
+def test_locate_submit_result(hip, oracle):
+    """rm_locate_submit / rm_locate_result (two calibration buffers in flight on one stream): every ROI equals the synchronous
+    rm_locate's, in either fetch order, at full size back to back, through the value-store overflow path (RM_FLAG_TINY_STORE: taken
+    again inside rm_locate_result) and on a flat video (no contour); a third submission is refused."""
+    import torch
+    from respmon_amd import _capi, synth
+    from respmon_amd.base import RespiratoryMonitor, _Backend
+    be = _Backend()
+    small = []
+    for (T, H, W, L, S, seed) in [(16, 256, 448, 7, 3, 3), (12, 128, 192, 6, 2, 4), (10, 144, 256, 6, 1, 5), (24, 360, 640, 8, 4, 6)]:
+        buf = torch.from_numpy(synth.synth_breathing(T, H, W, seed=seed)).cuda()
+        small.append((buf, L, S, RespiratoryMonitor.locate(buf, 10, pyramid_levels=L, skip_levels_at_top=S)))
+    for i in range(len(small)):
+        (ba, La, Sa, ra), (bb, Lb, Sb, rb) = small[i], small[(i + 1) % len(small)]
+        ta = be.locate_submit(ba, 10, pyramid_levels=La, skip_levels_at_top=Sa)
+        tb = be.locate_submit(bb, 10, pyramid_levels=Lb, skip_levels_at_top=Sb, flags=_capi.RM_FLAG_TINY_STORE if i % 2 else 0)
+        with pytest.raises(_capi.RespmonError):
+            be.locate_submit(ba, 10, pyramid_levels=La, skip_levels_at_top=Sa)
+        if i % 2:
+            assert be.locate_result(tb) == rb and be.locate_result(ta) == ra
+        else:
+            assert be.locate_result(ta) == ra and be.locate_result(tb) == rb
+    flat = torch.full((16, 40, 48), 0.5, dtype=torch.float64, device="cuda")
+    assert be.locate_result(be.locate_submit(flat, 10, pyramid_levels=4, skip_levels_at_top=2)) is None
+    # full size, two different videos alternating, the next one submitted before the previous ROI is fetched
+    vids = [torch.from_numpy(synth.synth_breathing(64, 1080, 1920, seed=s, center=c)).cuda() for s, c in ((11, (0.6, 0.4)), (12, (0.3, 0.7)))]
+    want = [RespiratoryMonitor.locate(v, 10) for v in vids]
+    assert want[0] != want[1] and None not in want
+    tk = be.locate_submit(vids[0], 10)
+    for k in range(1, 12):
+        nxt = be.locate_submit(vids[k % 2], 10)
+        assert be.locate_result(tk) == want[(k - 1) % 2], k
+        tk = nxt
+    assert be.locate_result(tk) == want[11 % 2]

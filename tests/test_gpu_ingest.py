@@ -102,46 +102,32 @@ def test_contour_options_are_restored_after_a_per_call_override(hip):
         hip.rm_set_contour_labelling(ctx, -1)
 
 
-def test_roi_fast_equals_border_following(hip, oracle):
-    """k_heat_to_roi_fast (one launch, 32 bytes to the host when the thresholded heatmap is one hole-free blob) against the
-    border-following path and the oracle: hand-made shapes around the rule, random smooth heatmaps at 1080p / 720p widths, and the
-    hand-over to the host path when the shape is not simple."""
+def test_simple_shape_shortcut_equals_border_following(hip, oracle):
+    """The host stage's one-blob shortcut on the packed rows (rm_contour.cpp simple_shape_bits_rows) against following every border and
+    the oracle: hand-made shapes around the rule, random smooth heatmaps at 1080p / 720p / 4K widths."""
     import torch
     import scipy.ndimage as ndi
     from respmon_amd import device, dist
     from tests.test_emu_calibration import _roi_shapes
     rng = np.random.default_rng(19)
     cases = [(n, a) for n, a in _roi_shapes(rng)]
-    for (H, W) in ((270, 1920), (180, 1280), (135, 3840)):
+    for (H, W) in ((270, 1920), (180, 1280), (135, 3840), (97, 1000)):
         for sig in (30.0, 12.0, 4.0):
             cases.append(("smooth %dx%d s%.0f" % (H, W, sig), ndi.gaussian_filter(rng.standard_normal((H, W)), sig)))
         yy, xx = np.mgrid[0:H, 0:W]
         cases.append(("ellipse %dx%d" % (H, W), np.exp(-0.5 * (((yy - 0.6 * H) / (0.1 * H)) ** 2 + ((xx - 0.4 * W) / (0.08 * W)) ** 2))))
     thr = 100
-
-    def drain():
-        for _ in range(16):
-            dist.hip_heatmap_to_roi(torch.zeros((4, 64), dtype=torch.float64, device="cuda"), thr)
-
     try:
-        n_fast = 0
         for name, img in cases:
             heat = np.ascontiguousarray(img, dtype=np.float64)
             ref_u8 = oracle.float_to_uint8((heat - heat.min()) / (heat.max() - heat.min())) if heat.max() > heat.min() else np.zeros(heat.shape, np.uint8)
             want = oracle.roi_from_heatmap_u8(ref_u8, thr)
             dev = torch.from_numpy(heat).cuda()
-            device.debug_set("roi_fast", 0)
             device.debug_set("host_simple_shape", 0)    # every border followed on the host
-            slow = dist.hip_heatmap_to_roi(dev, thr)
-            device.debug_set("host_simple_shape", 1)    # the one-blob shortcut on the packed rows (rm_contour.cpp simple_shape_bits_rows)
-            assert dist.hip_heatmap_to_roi(dev, thr) == slow, (name, heat.shape)
-            device.debug_set("roi_fast", 1)
-            drain()
+            slow = dist.hip_heatmap_to_roi(dev, thr, labelling=False)
+            device.debug_set("host_simple_shape", 1)
             for attempt in range(2):
-                fast = dist.hip_heatmap_to_roi(dev, thr)
-                assert fast == slow == want, (name, heat.shape, attempt, fast, slow, want)
-            n_fast += 1
-        assert n_fast == len(cases)
+                short = dist.hip_heatmap_to_roi(dev, thr, labelling=False)
+                assert short == slow == want, (name, heat.shape, attempt, short, slow, want)
     finally:
-        drain()
-        device.debug_set("roi_fast", 0)
+        device.debug_set("host_simple_shape", 1)
