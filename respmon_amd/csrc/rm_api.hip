@@ -1933,7 +1933,7 @@ static int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int thresho
     unsigned long long *d_bits = nullptr;
     const size_t comps_cap = std::min<size_t>(npix / 4 + 2, (size_t)1 << 18);
     if (label) {
-        int *d_label = nullptr; CclBox *d_box = nullptr; unsigned int *d_cnt = nullptr; CclComp *d_list = nullptr;
+        int *d_label = nullptr; CclBox *d_box = nullptr; unsigned int *d_cnt = nullptr; int *d_list = nullptr;
         RM_TRY(ws(ctx, "ccl_list", comps_cap, &d_list));
         RM_TRY(ws(ctx, "ccl_bits", nwords, &d_bits));
         RM_TRY(ws(ctx, "ccl_label", npix, &d_label));
@@ -1948,7 +1948,7 @@ static int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int thresho
         CclComp *dev_comps = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, rs.h_comps, 0));
         hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
-                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits, d_label, d_box, d_cnt);
+                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits, d_label, d_box, d_cnt, tile_const);
         LAUNCH_CHECK();
         // (a thread per 64-bit word walking its set bits through the same rule was measured: 97 / 95 us instead of 21 / 19 at 720p --
         //  ten dependent find / atomic round trips per thread cost more than launching 84 % idle threads)
@@ -1956,14 +1956,9 @@ static int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int thresho
         hipLaunchKernelGGL(k_ccl_union, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_ccl_bbox, dim3((unsigned)((W + 63) / 64), (unsigned)((H + CCL_BOX_ROWS - 1) / CCL_BOX_ROWS)), dim3(64 * CCL_BOX_ROWS), 0, s,
-                           d_bits, npix, H, W, d_label, d_box);
+                           d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         LAUNCH_CHECK();
-        const int groups = (int)std::max<size_t>(1, (npix + (size_t)256 * 1024 - 1) / ((size_t)256 * 1024));   // ~1 000 workgroups
-        const dim3 egrid((unsigned)((npix + (size_t)256 * groups - 1) / ((size_t)256 * groups)));
-        hipLaunchKernelGGL(k_ccl_emit, egrid, dim3(256), 0, s, d_bits, npix, d_label, d_box, W, groups, d_cnt, d_list,
-                           (unsigned int)comps_cap);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_ccl_publish, dim3(64), dim3(256), 0, s, d_list, d_cnt, (unsigned int)comps_cap, dev_comps);
+        hipLaunchKernelGGL(k_ccl_publish, dim3(64), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps);
         LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(k_heat_to_u8, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,

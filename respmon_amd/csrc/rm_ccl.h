@@ -14,13 +14,12 @@
 // component; the host follows only borders whose bound can reach the best area found so far (rm_contour.cpp,
 // largest_external_contour_labelled) -- typically one.  Exact: same contour, same ties (last discovered = largest root).
 //
-// Three launches over the H*W bits (and a small copy kernel), one thread per pixel (84 % of the threads of a 16 %-foreground
+// Two launches over the H*W bits (and a small publishing kernel), one thread per pixel (84 % of the threads of a 16 %-foreground
 // image leave at once); their start state comes from k_heat_to_u8, whose ballot is the pixel's word:
 //   (k_heat_to_u8) label = first pixel of the pixel's run inside its 64-bit word (rows break runs); that first pixel holds the box of its piece
 //   k_ccl_union   joins with the row above / the word to the left, lock-free (atomicMin on the larger root)
 //   k_ccl_bbox    the first pixel of every piece folds the piece's box into its root's
-//   k_ccl_emit    roots -> {root, minx, width-1, height-1} records, wave-aggregated slot reservation
-//   k_ccl_publish the record list and its length -> pinned host memory, in whole cache lines
+//   k_ccl_publish the roots k_ccl_bbox listed -> {root, minx, width-1, height-1} records + their count in pinned host memory
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -109,18 +108,26 @@ __device__ inline void ccl_box_fold(CclBox *box, int r, int minx, int maxx, int 
     if (maxy > cur.maxy) atomicMax(b + 2, maxy);
 }
 
+// The roots met on the way (a root is the first pixel of its piece) are listed for k_ccl_publish: counted in LDS, ONE reservation
+// per tile on counters[0] (every atomic on the one counter takes ~10 ns of the L2's atomic unit), in no particular order -- the
+// host's choice does not depend on it.  roots[] holds `cap` entries; counters[0] keeps counting past it (the host then follows
+// every border itself).
 __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned long long *bits, size_t npix, int H, int W, int *label,
-                                                                 CclBox *box)
+                                                                 CclBox *box, unsigned int *counters, int *roots, unsigned int cap)
 {
     __shared__ int s_key[CCL_BOX_SLOTS], s_minx[CCL_BOX_SLOTS], s_maxx[CCL_BOX_SLOTS], s_maxy[CCL_BOX_SLOTS];
+    __shared__ unsigned int s_nroots, s_base;
     const int tid = threadIdx.x;
     if (tid < CCL_BOX_SLOTS) { s_key[tid] = -1; s_minx[tid] = 0x7fffffff; s_maxx[tid] = -1; s_maxy[tid] = -1; }
+    if (tid == 0) s_nroots = 0;
     __syncthreads();
     const int x = blockIdx.x * 64 + (tid & 63), y = blockIdx.y * CCL_BOX_ROWS + (tid >> 6);
+    int my_root = -1; unsigned int my_slot = 0;
     if (x < W && y < H) {
         const size_t p = (size_t)y * W + x;
         if (ccl_bit(bits, p) && ((p & 63) == 0 || x == 0 || !ccl_bit(bits, p - 1))) {
             const int r = ccl_find(label, (int)p);
+            if (r == (int)p) { my_root = r; my_slot = atomicAdd(&s_nroots, 1u); }
             if (r != (int)p) {                       // (the root's own piece is in its box already)
                 const CclBox mine = box[p];
                 unsigned int h = ((unsigned int)r * 2654435761u) >> 27;
@@ -137,59 +144,27 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
     }
     __syncthreads();
     if (tid < CCL_BOX_SLOTS && s_key[tid] >= 0) ccl_box_fold(box, s_key[tid], s_minx[tid], s_maxx[tid], s_maxy[tid]);
+    if (s_nroots == 0) return;                       // (uniform)
+    if (tid == 0) s_base = atomicAdd(&counters[0], s_nroots);
+    __syncthreads();
+    if (my_root >= 0 && s_base + my_slot < cap) roots[s_base + my_slot] = my_root;
 }
 
-// counters[0]: records reserved.  `out` is a device list: 16-byte records scattered one by one into pinned host memory cost a
-// PCIe write each (136 us for 7 466 records); k_ccl_publish moves the list in full cache lines instead.
-// Every atomicAdd on the one counter takes ~10 ns of the L2's atomic unit whatever the grid does meanwhile (one per wave:
-// 5 700 of them, 70 us at 720p), so a workgroup counts the roots of 4 x `groups` 64-pixel groups first and reserves its
-// slots with ONE atomic; the second sweep re-evaluates the predicate (bits and labels are cache hits) and stores.
-__global__ __launch_bounds__(256) void k_ccl_emit(const unsigned long long *bits, size_t npix, const int *label, const CclBox *box,
-                                                  int W, int groups, unsigned int *counters, CclComp *out, unsigned int cap)
-{
-    __shared__ unsigned int wave_cnt[4];
-    __shared__ unsigned int block_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t first = ((size_t)blockIdx.x * 4 + wave) * (size_t)groups * 64;
-    unsigned int mine = 0;
-    for (int k = 0; k < groups; ++k) {
-        const size_t p = first + (size_t)k * 64 + lane;
-        const bool root = p < npix && ccl_bit(bits, p) && label[p] == (int)p;
-        mine += (unsigned int)__popcll(__ballot(root));
-    }
-    if (lane == 0) wave_cnt[wave] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        block_base = total ? atomicAdd(&counters[0], total) : 0u;
-    }
-    __syncthreads();
-    unsigned int slot0 = block_base;
-    for (int w = 0; w < wave; ++w) slot0 += wave_cnt[w];
-    for (int k = 0; k < groups; ++k) {
-        const size_t p = first + (size_t)k * 64 + lane;
-        const bool root = p < npix && ccl_bit(bits, p) && label[p] == (int)p;
-        const unsigned long long m = __ballot(root);
-        if (root) {
-            const unsigned int slot = slot0 + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < cap) {
-                const CclBox bb = box[p];
-                CclComp c; c.root = (int)p; c.minx = bb.minx; c.w1 = bb.maxx - bb.minx; c.h1 = bb.maxy - (int)(p / (size_t)W);
-                out[slot] = c;
-            }
-        }
-        slot0 += (unsigned int)__popcll(m);
-    }
-}
-
-// device list -> pinned host memory; host[0].root = the number of components (> cap: the list overflowed and the host follows
-// every border itself), records from host[1] on
-__global__ __launch_bounds__(256) void k_ccl_publish(const CclComp *list, const unsigned int *counters, unsigned int cap, CclComp *host)
+// roots -> {root, minx, width-1, height-1} records in pinned host memory (the boxes are final behind the kernel boundary);
+// host[0].root = the number of components (> cap: the list overflowed and the host follows every border itself), records from
+// host[1] on.  16-byte records, consecutive lanes -> consecutive records: the PCIe writes leave in whole cache lines.
+__global__ __launch_bounds__(256) void k_ccl_publish(const int *roots, const CclBox *box, int W, const unsigned int *counters, unsigned int cap,
+                                                     CclComp *host)
 {
     const unsigned int total = counters[0];
     const unsigned int n = total < cap ? total : cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) { CclComp h; h.root = (int)total; h.minx = 0; h.w1 = 0; h.h1 = 0; host[0] = h; }
-    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) host[1 + i] = list[i];
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int p = roots[i];
+        const CclBox bb = box[p];
+        CclComp c; c.root = p; c.minx = bb.minx; c.w1 = bb.maxx - bb.minx; c.h1 = bb.maxy - p / W;
+        host[1 + i] = c;
+    }
 }
 
 }  // namespace rm

@@ -2206,7 +2206,7 @@ __global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t n
                                                     unsigned int *ccl_counters, const int *tile_const = nullptr)
 {
     RM_TRACE_SCOPE(7);
-    if (ccl_counters && blockIdx.x == 0 && threadIdx.x == 0) ccl_counters[0] = 0;   // k_ccl_emit reserves record slots there
+    if (ccl_counters && blockIdx.x == 0 && threadIdx.x == 0) ccl_counters[0] = 0;   // k_ccl_bbox reserves the root list's slots there
     const int lane = threadIdx.x & 63;
     // `base` is the first pixel of this wave's 64-pixel group: the same for all lanes, so the ballot is complete.
     // HU groups per trip: their heat values are requested together and BEFORE the extrema are folded from the state
