@@ -13,7 +13,14 @@ def main(d):
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if "rm::" in r["Kernel_Name"])
-    starts = [i for i, k in enumerate(ks) if "k_down_chain" in k[2]]
+    # a step starts at its frame-buffer kernel: the k_down_chain* instantiation with the largest total time (configs with a deep
+    # small pyramid run a second, smaller k_down_chain inside the step)
+    tot = {}
+    for s0, e0, nm in ks:
+        if "k_down_chain" in nm:
+            tot[nm] = tot.get(nm, 0) + e0 - s0
+    lead = max(tot, key=tot.get)
+    starts = [i for i, k in enumerate(ks) if k[2] == lead]
     per, names = [], None
     for a, b in zip(starts[-80:-1], starts[-79:]):
         seq = ks[a:b]

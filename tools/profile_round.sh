@@ -27,7 +27,7 @@ if [ "$CFG" = "P" ]; then
 else
   timeout 900 $BENCH --no-extras > $OUT/bench_n1.json 2> $OUT/bench_n1.err < /dev/null
 fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH --cpu-frames 0 --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH --cpu-frames 0 --no-extras --no-batches > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err < /dev/null
 PSTEPS=20; [ "$CFG" = "R" ] && PSTEPS=6
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python bench.py --steps $PSTEPS --warmup 2 --prewarm-steps 5 $ARGS --cpu-frames 0 --no-extras > /dev/null 2> $OUT/rocprof_fetch.err < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python bench.py --steps $PSTEPS --warmup 2 --prewarm-steps 5 $ARGS --cpu-frames 0 --no-extras > /dev/null 2> $OUT/rocprof_write.err < /dev/null
