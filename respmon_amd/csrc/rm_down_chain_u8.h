@@ -543,7 +543,7 @@ template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow
 }
 
 // geometry: strips of 960 exact columns; enough segments for ~8 waves per CU
-inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom &g, bool tiny = false)
+inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom &g, bool tiny = false, int force_segs = 0)
 {
     if (S < 1 || S > 4 || (w[0] % 16) != 0) return false;
     // every filtered level needs >= 3 rows (streaming vertical pass) and >= 3 columns: the in-lane border selects of
@@ -557,6 +557,7 @@ inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom
     const int halo0 = (1 << (S + 1)) - 2;
     const long long per_seg = (long long)T * g.strips;
     int segs = (int)((2048 + per_seg / 2) / per_seg);
+    if (force_segs > 0) segs = force_segs;   // (rm_debug_set "dc_segs")
     if (segs < 1) segs = 1;
     if (segs > rows) segs = rows;
     while (segs > 1 && ((((rows + segs - 1) / segs) << S) < 8 * halo0)) --segs;
