@@ -891,7 +891,7 @@ static int launch_down_chain(rm_ctx *ctx, const void *frames, int dtype, int T, 
     if ((dtype == RM_U8 || dtype == RM_F16 || dtype == RM_F32) && vec_ok && !ctx->dbg.dc_lds_front_end) {
         // all-register variant for narrow frame buffers (rm_down_chain_u8.h): a lane owns 16 adjacent pixels
         DownGeom g8;
-        if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs)) {
+        if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, dtype == RM_F32 ? 1536 : 2048)) {
             const size_t fs = (size_t)h[0] * w[0];
             const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
 #define RM_REG_CASE(KK, SS, TT, ptr) case SS: hipLaunchKernelGGL((KK<SS, TT>), dim3(grid), dim3(64), narrow_ring_bytes<TT>(), s, ptr, fs, g8, out); break;

