@@ -192,10 +192,13 @@ class ExchangePolicy:
         self.dense_left = 0
 
     def use_sparse(self):
+        """True: try the sparse form this step.  False: a dense step of the hold is due -- the caller reports it done with
+        dense_step_done() AFTER its collective returned (a step that raised in between is not counted on this rank only)."""
+        return self.dense_left <= 0
+
+    def dense_step_done(self):
         if self.dense_left > 0:
             self.dense_left -= 1
-            return False
-        return True
 
     def overflowed(self, needed):
         want = (int(needed * 1.25) + 63) // 64 * 64
@@ -210,8 +213,20 @@ DENSE_HOLD = 64           # steps a stream that does not fit stays on the dense 
 _POLICY = {}
 
 
-def exchange_policy(H, W, mode):
-    return _POLICY.setdefault((int(H), int(W), mode), ExchangePolicy())
+def exchange_policy(H, W, mode, group=None):
+    """The policy of ONE process group (None: the default group) for one heatmap geometry and mode: ranks of a group share a call
+    history, ranks of different groups do not, so the state is never shared between groups.  A group object that is created anew
+    starts from the defaults (the entry keeps a reference to its group: no id is reused while the entry lives);
+    reset_exchange_policy() forgets everything, e.g. after destroy_process_group()."""
+    key = (id(group) if group is not None else 0, int(H), int(W), mode)
+    ent = _POLICY.get(key)
+    if ent is None or ent[0] is not group:
+        ent = _POLICY[key] = (group, ExchangePolicy())
+    return ent[1]
+
+
+def reset_exchange_policy():
+    _POLICY.clear()
 
 
 def hip_sparse_tiles(heat, cap_tiles=SPARSE_CAP_TILES):
@@ -248,15 +263,20 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
     if sparse is None:
         sparse = calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and _collective(group)
     if sparse:
-        pol = exchange_policy(heat.shape[0], heat.shape[1], "streams")
+        pol = exchange_policy(heat.shape[0], heat.shape[1], "streams", group)
         if pol.use_sparse():
             ok, roi, fused = hip_sparse_exchange_roi(heat, threshold, group, cap_tiles=pol.cap, keep_fused=return_heatmap)
             if ok:
                 LAST_EXCHANGE = "sparse"
                 return (roi, fused) if return_heatmap else roi
             pol.overflowed(sparse_tiles_needed())
+            pol = None      # (this step's dense all-reduce is the refused attempt's, not one of the hold)
+    else:
+        pol = None
     LAST_EXCHANGE = "dense"
     all_reduce_heatmap(heat, group)
+    if pol is not None:
+        pol.dense_step_done()
     roi = roi_fn(heat, threshold)
     return (roi, heat) if return_heatmap else roi
 
@@ -403,15 +423,20 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
         sparse = stages is None and _collective(group)
     global LAST_EXCHANGE
     if sparse:   # the partial heat sums are one constant outside a few tiles too: sparse all-gather instead of a 16.6 MB all-reduce
-        pol = exchange_policy(H, W, "sharded")
+        pol = exchange_policy(H, W, "sharded", group)
         if pol.use_sparse():
             ok, roi, heat = hip_sparse_exchange_roi(heat_sum, threshold, group, cap_tiles=pol.cap, avg_T=T, keep_fused=return_heatmap)
             if ok:
                 LAST_EXCHANGE = "sparse"
                 return (roi, heat) if return_heatmap else roi
             pol.overflowed(sparse_tiles_needed())
+            pol = None
+    else:
+        pol = None
     LAST_EXCHANGE = "dense"
     _all_reduce(heat_sum, dist.ReduceOp.SUM, group)
+    if pol is not None:
+        pol.dense_step_done()
     roi, heat = st.finish(heat_sum, T, threshold)
     return (roi, heat) if return_heatmap else roi
 

@@ -83,10 +83,21 @@ def test_exchange_policy_remembers_an_overflow():
     assert pol.cap == 512 and pol.use_sparse() and pol.dense_left == 0
     pol.overflowed(2040)                      # every tile of a 1080p heatmap: no packet holds that
     assert pol.dense_left == rdist.DENSE_HOLD and pol.cap == 512
-    assert [pol.use_sparse() for _ in range(rdist.DENSE_HOLD)] == [False] * rdist.DENSE_HOLD
+    for _ in range(rdist.DENSE_HOLD):         # a dense step counts once its collective has returned (dense_step_done), not before
+        assert not pol.use_sparse() and not pol.use_sparse()
+        pol.dense_step_done()
     assert pol.use_sparse()                   # ... then one more sparse attempt
     assert rdist.exchange_policy(1080, 1920, "streams") is rdist.exchange_policy(1080, 1920, "streams")
     assert rdist.exchange_policy(1080, 1920, "streams") is not rdist.exchange_policy(1080, 1920, "sharded")
+    # one policy per process group: ranks of different groups do not share a call history
+    ga, gb = object(), object()
+    pa = rdist.exchange_policy(1080, 1920, "streams", ga)
+    assert pa is rdist.exchange_policy(1080, 1920, "streams", ga) and pa is not rdist.exchange_policy(1080, 1920, "streams", gb)
+    assert pa is not rdist.exchange_policy(1080, 1920, "streams")
+    pa.overflowed(2040)
+    assert rdist.exchange_policy(1080, 1920, "streams", gb).dense_left == 0 and rdist.exchange_policy(1080, 1920, "streams", ga).dense_left
+    rdist.reset_exchange_policy()
+    assert rdist.exchange_policy(1080, 1920, "streams", ga).dense_left == 0
 
 
 def test_frame_shards_partition_the_buffer():
