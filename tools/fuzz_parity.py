@@ -349,6 +349,17 @@ def fuzz_roi(budget, seed):
     return bad
 
 
+_PENDING = []
+_BACKEND = []
+
+
+def _submit_backend():
+    if not _BACKEND:
+        from respmon_amd.base import _Backend
+        _BACKEND.append(_Backend())
+    return _BACKEND[0]
+
+
 def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else "calib"
     big = mode == "big"
@@ -404,6 +415,15 @@ def main():
             with np.errstate(all="ignore"):
                 ref, mid = oracle.locate(ref_in, fps, return_intermediates=True, **kw)
             got = RespiratoryMonitor.locate(dev, fps, **kw)
+            if not reforder and rng.random() < 0.3:
+                # the two-call form with the previous case's buffer still in flight (rm_locate_submit / rm_locate_result): same ROIs
+                be = _submit_backend()
+                tk = be.locate_submit(dev, fps, kw.get("freq_min", 0.1), kw.get("freq_max", 1.0), kw.get("amplification", 500), L, S,
+                                      kw.get("temporal_threshold", 0.7), kw.get("threshold", 20))
+                prev = _PENDING.pop() if _PENDING else None
+                if prev is not None and be.locate_result(prev[0]) != prev[1]:
+                    raise AssertionError("rm_locate_result of the previous case differs from its rm_locate")
+                _PENDING.append((tk, got))
             heat = rdist.hip_calibrate(dev, fps, flags=64 if reforder else 0, **ckw).cpu().numpy()
             # the heatmap is what is left of band-passed images of magnitude ~ amplification * |frame| after the Laplacian
             # differences: where they cancel (a 1x1 level S has an exactly zero Laplacian) the reference's own result is rounding
