@@ -74,7 +74,7 @@ class _Backend:
         #  the runtime, the stream is the current one of that device)
         idx = buf.device.index
         ctx = device._CTX.get(idx) or device.ctx(idx)
-        stream = ctypes.c_void_p(self.t.cuda.current_stream(idx).cuda_stream)
+        stream = ctypes.c_void_p(device.raw_stream(idx))
         rc = self.lib.rm_locate(ctx, ctypes.c_void_p(buf.data_ptr()), device.dtype_code(buf), T, H, W,
                                 float(fps), float(freq_min), float(freq_max), float(amplification),
                                 int(pyramid_levels), int(skip_levels_at_top), float(temporal_threshold),
@@ -93,7 +93,7 @@ class _Backend:
         T, H, W = buf.shape
         idx = buf.device.index
         ctx = device._CTX.get(idx) or device.ctx(idx)
-        stream = ctypes.c_void_p(self.t.cuda.current_stream(idx).cuda_stream)
+        stream = ctypes.c_void_p(device.raw_stream(idx))
         ticket = ctypes.c_int(-1)
         rc = self.lib.rm_locate_submit(ctx, ctypes.c_void_p(buf.data_ptr()), device.dtype_code(buf), T, H, W,
                                        float(fps), float(freq_min), float(freq_max), float(amplification),
