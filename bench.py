@@ -338,12 +338,15 @@ def main():
             rois_equal &= backend.locate_result(tk) == roi
             return rois_equal
         pipe(max(2, a.warmup))
-        barrier()
-        tp = time.perf_counter()
-        eq = pipe(a.steps)
-        barrier()
-        pipe_ms = (time.perf_counter() - tp) / a.steps * 1e3
-        pipelined = {"in_flight": 2, "steps": a.steps, "ms_per_step": pipe_ms, "frames_per_s": T / pipe_ms * 1e3,
+        runs, eq = [], True
+        for _ in range(2):      # (two batches, both listed: the boxes of this pool drift by several per cent within a run)
+            barrier()
+            tp = time.perf_counter()
+            eq &= pipe(a.steps)
+            barrier()
+            runs.append((time.perf_counter() - tp) / a.steps * 1e3)
+        pipe_ms = min(runs)
+        pipelined = {"in_flight": 2, "steps": a.steps, "ms_per_step": pipe_ms, "batches": runs, "frames_per_s": T / pipe_ms * 1e3,
                      "every_roi_equals_the_synchronous_one": bool(eq),
                      "note": "rm_locate_submit(k+1) before rm_locate_result(k), one stream, one context; every step still delivers its ROI to the host"}
         _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
