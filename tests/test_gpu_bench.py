@@ -43,6 +43,11 @@ def test_bench_single_gpu_contract_line():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["all_cores"]["cores"] == 4 and c["all_cores"]["roi_equals_single_thread"]
     assert j["no_prune"]["roi_equals_headline"] and j["dense_stream"]["collapse_pairs"]["total"] > 0
+    p = j["pipelined"]      # rm_locate_submit / rm_locate_result: an EXTRA key, `value` is the synchronous step
+    assert p["in_flight"] == 2 and p["every_roi_equals_the_synchronous_one"] and len(p["batches"]) == 2 and p["ms_per_step"] == min(p["batches"])
+    assert len(j["ms_per_step_batches"]["batches"]) == 5 and j["ms_per_step_batches"]["batches"][0] == j["ms_per_step"]
+    w = j["worst_case"]
+    assert w["noise"]["roi_equals_oracle"] and w["blobs16"]["roi_equals_oracle"] and w["slowest_vs_headline"] >= 1.0
 
 
 @pytest.mark.parametrize("mode", ["streams", "sharded"])
