@@ -93,6 +93,7 @@ struct DebugKnobs {
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
     int label_host_us = 250;      // host border following slower than this (+ the labelled stage's own host time) -> device labelling next time
+    int ccl_table = -1;           // k_ccl_bbox: 1 with / 0 without the per-tile LDS table of boxes, -1 by the last component count
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
@@ -287,6 +288,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;
+    else if (k == "ccl_table") d.ccl_table = (int)value;
     else if (k == "label_host_us") d.label_host_us = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
@@ -1867,6 +1869,7 @@ __global__ __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st)
     if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
 }
 
+constexpr int CCL_TABLE_MAX_COMPONENTS = 2048;   // more components than this last time: k_ccl_bbox without its LDS table
 constexpr int LABEL_REPROBE = 64;         // labelled stages in a row before the host-only stage is timed again
 constexpr int LABEL_MIN_CONTOURS = 512;   // ~0.13 us per followed border on the host against ~40 us of labelling kernels
 static_assert(sizeof(CclComp) == sizeof(LabelComp), "record layout shared by rm_ccl.h and rm_contour.h");
@@ -1955,8 +1958,11 @@ static int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int thresho
         const dim3 grid((unsigned)((npix + 255) / 256));
         hipLaunchKernelGGL(k_ccl_union, grid, dim3(256), 0, s, d_bits, npix, H, W, d_label);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_ccl_bbox, dim3((unsigned)((W + 63) / 64), (unsigned)((H + CCL_BOX_ROWS - 1) / CCL_BOX_ROWS)), dim3(64 * CCL_BOX_ROWS), 0, s,
-                           d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
+        // per-tile LDS table of boxes unless the last extraction of this geometry met thousands of components (specks: see k_ccl_bbox)
+        const bool table = ctx->dbg.ccl_table >= 0 ? ctx->dbg.ccl_table != 0 : !(same_geom && ctx->label_last_n > CCL_TABLE_MAX_COMPONENTS);
+        const dim3 bgrid((unsigned)((W + 63) / 64), (unsigned)((H + CCL_BOX_ROWS - 1) / CCL_BOX_ROWS));
+        if (table) hipLaunchKernelGGL(k_ccl_bbox<true>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
+        else hipLaunchKernelGGL(k_ccl_bbox<false>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_ccl_publish, dim3(64), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps);
         LAUNCH_CHECK();

@@ -112,13 +112,16 @@ __device__ inline void ccl_box_fold(CclBox *box, int r, int minx, int maxx, int 
 // per tile on counters[0] (every atomic on the one counter takes ~10 ns of the L2's atomic unit), in no particular order -- the
 // host's choice does not depend on it.  roots[] holds `cap` entries; counters[0] keeps counting past it (the host then follows
 // every border itself).
+// TABLE = false: no LDS table, every piece folds its box straight into its root's -- for images of thousands of specks (a component
+// rarely leaves its tile, the table overflows and its probes are pure overhead: 4K x 512 skip 2, 130 us with the table).
+template <bool TABLE>
 __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned long long *bits, size_t npix, int H, int W, int *label,
                                                                  CclBox *box, unsigned int *counters, int *roots, unsigned int cap)
 {
     __shared__ int s_key[CCL_BOX_SLOTS], s_minx[CCL_BOX_SLOTS], s_maxx[CCL_BOX_SLOTS], s_maxy[CCL_BOX_SLOTS];
     __shared__ unsigned int s_nroots, s_base;
     const int tid = threadIdx.x;
-    if (tid < CCL_BOX_SLOTS) { s_key[tid] = -1; s_minx[tid] = 0x7fffffff; s_maxx[tid] = -1; s_maxy[tid] = -1; }
+    if (TABLE && tid < CCL_BOX_SLOTS) { s_key[tid] = -1; s_minx[tid] = 0x7fffffff; s_maxx[tid] = -1; s_maxy[tid] = -1; }
     if (tid == 0) s_nroots = 0;
     __syncthreads();
     const int x = blockIdx.x * 64 + (tid & 63), y = blockIdx.y * CCL_BOX_ROWS + (tid >> 6);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
             if (r != (int)p) {                       // (the root's own piece is in its box already)
                 const CclBox mine = box[p];
                 unsigned int h = ((unsigned int)r * 2654435761u) >> 27;
-                int k = 0;
+                int k = TABLE ? 0 : CCL_BOX_SLOTS;
                 for (; k < CCL_BOX_SLOTS; ++k, h = (h + 1) & (CCL_BOX_SLOTS - 1)) {
                     const int seen = atomicCAS(&s_key[h], -1, r);
                     if (seen == -1 || seen == r) break;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
         }
     }
     __syncthreads();
-    if (tid < CCL_BOX_SLOTS && s_key[tid] >= 0) ccl_box_fold(box, s_key[tid], s_minx[tid], s_maxx[tid], s_maxy[tid]);
+    if (TABLE && tid < CCL_BOX_SLOTS && s_key[tid] >= 0) ccl_box_fold(box, s_key[tid], s_minx[tid], s_maxx[tid], s_maxy[tid]);
     if (s_nroots == 0) return;                       // (uniform)
     if (tid == 0) s_base = atomicAdd(&counters[0], s_nroots);
     __syncthreads();
