@@ -6,7 +6,7 @@ OUT=gpurun_out/r04/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 600 python bench.py --steps 200 --warmup 10 --cpu-frames 0 --no-extras "$@" > $OUT/bench.json 2> $OUT/bench.err < /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python bench.py --steps 100 --warmup 10 --cpu-frames 0 --no-extras "$@" > $OUT/bench_rocprof.json 2> $OUT/rocprof.err < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python bench.py --steps 100 --warmup 10 --cpu-frames 0 --no-extras --no-batches "$@" > $OUT/bench_rocprof.json 2> $OUT/rocprof.err < /dev/null
 python tools/gpu_timeline.py $OUT/stats > $OUT/timeline.txt 2>&1
 rm -f $OUT/stats/*kernel_trace.csv $OUT/stats/*agent_info.csv
 python - <<PY
