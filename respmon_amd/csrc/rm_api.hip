@@ -239,6 +239,10 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
 {
     if (!ctx) return RM_OK;
     (void)hipSetDevice(ctx->device);
+    for (LocateTicket &t : ctx->tickets) {
+        if (t.active && t.done) (void)hipEventSynchronize(t.done);   // (a submission nobody fetched still writes into the pinned slots)
+        if (t.done) (void)hipEventDestroy(t.done);
+    }
     for (auto &kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -248,8 +252,6 @@ extern "C" int rm_ctx_destroy(rm_ctx *ctx)
         if (rs.h_comps) (void)hipHostFree(rs.h_comps);
         if (rs.h_unserved) (void)hipHostFree(rs.h_unserved);
     }
-    for (LocateTicket &t : ctx->tickets)
-        if (t.done) (void)hipEventDestroy(t.done);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     (void)rm_comm_destroy(ctx);
     for (int p = 0; p < RM_PROFILE_PHASES; ++p)
