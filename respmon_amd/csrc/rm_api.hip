@@ -99,6 +99,7 @@ struct DebugKnobs {
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
+    int dense_t_low = -1;         // k_dense_sum_t (TileEval) at skip <= 2 instead of k_dense_sum_w / wf: 1 always, 0 never, -1 on large frames
     int dense_tiles = 1;          // 0: k_tile_sum (rounds of sixteen waves per tile) instead of k_dense_sum_t (one wave per tile) where a store-less sum at skip >= 3 is due
     int tile_sum_half = -1;       // 0 / 1: k_tile_sum works on whole tiles / half tiles whatever the number of heavy tiles (-1: by that number)
     long long store_default_slots = 0;   // > 0: slots the value store starts with before any selection has made it grow (default 16 384)
@@ -290,6 +291,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;
+    else if (k == "dense_t_low") d.dense_t_low = (int)value;
     else if (k == "ccl_table") d.ccl_table = (int)value;
     else if (k == "label_host_us") d.label_host_us = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
@@ -1596,7 +1598,10 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
         }
         LAUNCH_CHECK();
     }
-    if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
+    // skip <= 2 on large frames (four waves' worth of tiles per SIMD): the TileEval kernel of the deeper chains is the faster one-wave-per-
+    // tile form there too (4K x 512 skip 2: 2.26 -> 2.18 ms); smaller frames keep the several-waves-per-tile forms below
+    const bool t_low = ctx->dbg.dense_t_low >= 0 ? ctx->dbg.dense_t_low != 0 : (cp.S == 2 && cp.ntiles >= 4096 && tile_eval_ok(cp.g));
+    if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !t_low && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
         // one wave per 64 x 16 tile, no barriers (rm_dense_sum.h k_dense_sum_w)
         const ChainGeom &g = cp.g;
         int cus = 256;
@@ -1629,7 +1634,7 @@ static int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double 
 #undef RM_DENSE_W
         LAUNCH_CHECK();
         }
-    } else if (may_dense && cp.S >= 3 && tile_eval_ok(cp.g) && !ctx->dbg.dense_rows && !ctx->dbg.dense_general) {
+    } else if (may_dense && (cp.S >= 3 || t_low) && tile_eval_ok(cp.g) && !ctx->dbg.dense_rows && !ctx->dbg.dense_general) {
         // deeper chains: every kept pair evaluated where it is summed, tile by tile (rm_tile_eval.h k_tile_sum); it looks at the
         // selection itself when the sparse kernel was enqueued in front of it
         if (ctx->dbg.dense_tiles) RM_TRY(launch_dense_t(sp.mode == 1 ? 0 : 1));

@@ -476,6 +476,10 @@ def test_emu_dense_sum_equals_sparse_path(emu):
             dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
             emu.debug_set("dense_general", 0)
             assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "general kernel")
+            emu.debug_set("dense_t_low", 1)                         # ... and the TileEval kernel of the deeper chains (taken on large frames)
+            dense, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=128)
+            emu.debug_set("dense_t_low", -1)
+            assert np.array_equal(dense, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "k_dense_sum_t at skip <= 2")
         auto, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)        # decided on the device from this call's own selection
         assert np.array_equal(auto, sparse) and tuple(mm) == tuple(mm2), (T, H, W, L, S, "auto")
         tiny, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=4)   # an 8-slot value store overflows: the dense kernel takes over

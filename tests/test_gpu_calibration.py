@@ -662,6 +662,10 @@ def test_dense_sum_equals_sparse_path(hip, oracle):
                 assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, "waves per tile", split, frames)
             device.debug_set("dense_split", 0)
             device.debug_set("dense_frames", 0)
+            for tl in (1, 0):                    # the TileEval kernel of the deeper chains (large frames take it) / never
+                device.debug_set("dense_t_low", tl)
+                assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, "dense_t_low", tl)
+            device.debug_set("dense_t_low", -1)
         device.debug_set("dense_rows", 0)        # (rows 0 above: skip <= 2 takes the wave-private k_dense_sum_w; here the workgroup kernel)
         device.debug_set("dense_wave", 0)
         assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), sparse), (dt, T, H, W, L, S, "workgroup kernel")
