@@ -81,7 +81,7 @@ int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
  *      milliseconds since the last read: ms_host[0] = the kernel that reads the [T,H,W] frame buffer
  *      (the roofline kernel), [1] = remaining pyramid + temporal kernels, [2] = collapse passes,
  *      [3] = heatmap -> ROI (device part + host contour stage); *n_host = rm_calibrate calls the sums cover
- *      (mode 2: every call; mode 1: every 4th call is bracketed, the others run without the two event records). */
+ *      (mode 2: every call; mode 1: every 8th call is bracketed, the others run without the two event records). */
 #define RM_PROFILE_PHASES 4
 int rm_profile_enable(rm_ctx *ctx, int mode);
 int rm_profile_read(rm_ctx *ctx, double *ms_host, int *n_host);

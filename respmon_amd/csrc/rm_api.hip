@@ -182,9 +182,9 @@ struct PhaseTimer {
         else (void)hipEventCreate(&e);
         return e;
     }
-    // mode 1 brackets the frame-buffer kernel of every 4th call only: the two event records in front of that launch sit on the
+    // mode 1 brackets the frame-buffer kernel of every 8th call only: the two event records in front of that launch sit on the
     // host's critical path between two steps (~4 us each time, rocprofv3 --hip-runtime-trace)
-    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_mode == 2 || (c_->prof_mode == 1 && phase_ == 0 && (c_->prof_calls & 3) == 0))
+    PhaseTimer(rm_ctx *c_, int phase_, hipStream_t s_) : c(c_), phase(phase_), s(s_), on(c_->prof_mode == 2 || (c_->prof_mode == 1 && phase_ == 0 && (c_->prof_calls & 7) == 0))
     {
         if (!on) return;
         hipEvent_t e = get(c);
@@ -326,7 +326,7 @@ extern "C" int rm_profile_read(rm_ctx *ctx, double *ms, int *n)
         v.clear();
         ms[p] = total;
     }
-    if (n) *n = ctx->prof_sampled;      // calls whose phase 0 was bracketed (every call in mode 2, every 4th in mode 1)
+    if (n) *n = ctx->prof_sampled;      // calls whose phase 0 was bracketed (every call in mode 2, every 8th in mode 1)
     ctx->prof_calls = 0; ctx->prof_sampled = 0;
     return RM_OK;
 }

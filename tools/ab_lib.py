@@ -1,6 +1,6 @@
 """Developer tool (GPU box): A/B two builds of the library on the SAME box in one process-per-variant run.
     python tools/ab_lib.py respmon_amd/csrc/librespmon_hip.so /tmp/variant.so [--config P] [--steps 200]
-Prints ms per locate() and the frame-buffer kernel's ms (HIP events, every 4th call) for each library, alternating A B A B."""
+Prints ms per locate() and the frame-buffer kernel's ms (HIP events, every 8th call) for each library, alternating A B A B."""
 import argparse
 import ctypes
 import os
