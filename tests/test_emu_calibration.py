@@ -453,8 +453,8 @@ def test_emu_dense_sum_equals_sparse_path(emu):
     selection / value-store path (flags=256), bit for bit -- every super-tile shape (RM_DENSE_ROWS), skip 1..5, shards of the
     frame range, exhaustive evaluation (flags | 1), and the automatic choice (second call of a geometry that kept every pair)."""
     rng = np.random.default_rng(5)
-    for n, (T, H, W, L, S) in enumerate([(5, 64, 96, 4, 2), (3, 67, 131, 5, 3), (3, 135, 130, 6, 4), (4, 48, 64, 3, 1), (2, 100, 160, 7, 5),
-                                         (3, 70, 300, 4, 2)]):
+    for n, (T, H, W, L, S) in enumerate([(4, 64, 96, 4, 2), (3, 67, 131, 5, 3), (3, 48, 64, 3, 1), (2, 100, 160, 7, 5),
+                                         (3, 70, 300, 4, 2)]):     # (the GPU twin in tests/test_gpu_calibration.py runs more and larger ones)
         v = rng.random((T, H, W))
         emu.debug_set("dense_rows", 0)
         sparse, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
@@ -489,8 +489,8 @@ def test_emu_dense_sum_equals_sparse_path(emu):
     emu.debug_set("dense_rows", 0)
     # k_dense_sum_w on ragged geometries: widths / heights that are not multiples of the 64 x 16 tiles, odd level sizes (the
     # virtual rows / columns of the footprints meet every border rule), single-tile images, levels of 2 rows
-    for (T, H, W, L, S) in [(3, 33, 70, 4, 2), (4, 17, 129, 3, 1), (2, 5, 7, 4, 2), (3, 64, 64, 3, 1), (3, 31, 193, 4, 2), (2, 8, 8, 4, 2),
-                            (5, 50, 66, 5, 2), (2, 3, 3, 3, 1), (3, 47, 65, 3, 2)]:
+    for (T, H, W, L, S) in [(3, 33, 70, 4, 2), (4, 17, 129, 3, 1), (2, 5, 7, 4, 2), (3, 31, 193, 4, 2), (2, 8, 8, 4, 2),
+                            (2, 3, 3, 3, 1), (3, 47, 65, 3, 2)]:
         v = rng.random((T, H, W))
         sparse, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=256)
         emu.debug_set("dense_split", 1)                             # (one wave per tile: k_dense_sum_w)
@@ -595,8 +595,7 @@ def test_emu_fused_collapse_equals_store_path(emu, oracle):
     (flags=256), bit for bit: skip 1..4, ragged geometries whose virtual footprints meet every border rule (top row, rows past the
     bottom, left / right columns, 2-row / 2-column levels), exhaustive evaluation, frame shards, and the oracle's ROI."""
     rng = np.random.default_rng(11)
-    cases = [(4, 64, 96, 6, 4), (3, 67, 131, 5, 3), (3, 48, 64, 3, 1), (3, 70, 130, 4, 2), (2, 31, 193, 7, 4),
-             (3, 16, 16, 5, 3)]   # (the GPU twin of this test, tests/test_gpu_calibration.py, runs more and larger geometries)
+    cases = [(3, 64, 96, 6, 4), (3, 67, 131, 5, 3), (3, 48, 64, 3, 1), (3, 70, 130, 4, 2), (2, 31, 193, 7, 4)]   # (the GPU twin of this test, tests/test_gpu_calibration.py, runs more and larger geometries)
     try:
         for (T, H, W, L, S) in cases:
             v = rng.random((T, H, W))
