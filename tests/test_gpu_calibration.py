@@ -1001,3 +1001,21 @@ def test_locate_submit_result(hip, oracle):
         assert be.locate_result(tk) == want[(k - 1) % 2], k
         tk = nxt
     assert be.locate_result(tk) == want[11 % 2]
+    # the submissions of a context share one stream; a context may be destroyed with a submission nobody fetched
+    import ctypes
+    from respmon_amd import device
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    _capi.check(lib, lib.rm_ctx_create(0, ctypes.byref(h)), "rm_ctx_create")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    v = small[0][0]
+    T, H, W = v.shape
+    tk1, tk2 = ctypes.c_int(-1), ctypes.c_int(-1)
+    args = (device.ptr(v), device.dtype_code(v), T, H, W, 10.0, 0.1, 1.0, 500.0, small[0][1], small[0][2], 0.7, 20, 0)
+    assert lib.rm_locate_submit(h, *args, ctypes.c_void_p(s1.cuda_stream), ctypes.byref(tk1)) == _capi.RM_OK
+    assert lib.rm_locate_submit(h, *args, ctypes.c_void_p(s2.cuda_stream), ctypes.byref(tk2)) == _capi.RM_E_BADARG
+    xywh = (ctypes.c_int32 * 4)()
+    assert lib.rm_locate_result(h, 1, xywh) == _capi.RM_E_BADARG          # no such submission
+    assert lib.rm_ctx_destroy(h) == _capi.RM_OK                            # waits for ticket 0's work, frees its pinned slot
+    torch.cuda.synchronize()
