@@ -16,6 +16,7 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work on
  *    it; functions that return host results synchronise that stream before returning.
  *  - a context is not thread-safe; use one per stream / GPU.
+ *  - developer switches, hooks for the tests and diagnostics counters are NOT part of this interface: include/respmon_hip_debug.h.
  */
 #ifndef RESPMON_HIP_H
 #define RESPMON_HIP_H
@@ -48,7 +49,6 @@ extern "C" {
 #define RM_FLAG_NO_PRUNE 1u      /* evaluate every (tile, frame) of the collapse passes (A/B + verification) */
 #define RM_FLAG_UNFUSED_DOWN 2u  /* build the Gaussian levels one pyrDown launch per level */
 #define RM_FLAG_UNFUSED_SMALL 16u /* build / collapse the small pyramid with one launch per level (A/B + fallback path) */
-#define RM_FLAG_TINY_STRIPS 8u   /* test hook: 3-column strips / 2-row segments in the fused pyrDown chain */
 #define RM_FLAG_CONTOUR_CLIP_FRAME 32u /* rm_locate: cv2.findContours as OpenCV <= 3.1 did it (see rm_set_contour_clip_frame) */
 #define RM_FLAG_FILTER_LAPLACIANS 64u /* build the small pyramid in the reference's order -- Laplacians first, filter them, collapse (bit for bit equal to the per-level
                                          path) -- instead of the filter-first form (filter G_S, then Laplacians + collapse in one kernel; equal to ~1e-15) */
@@ -57,8 +57,6 @@ extern "C" {
                                      the device from what THIS call's selection kept (nothing is remembered between calls): dense when the
                                      kept pairs outnumber the value store's slots, or at skip <= 2 when more than half are kept.
                                      Bit-identical results. */
-#define RM_FLAG_TINY_STORE 4u    /* test hook: a value store of 8 slots, so that nearly every selection overflows into the dense sum kernel */
-#define RM_FLAG_FF_PER_LEVEL 512u /* test hook: the filter-first small pyramid with one launch per level although it would fit LDS */
 
 typedef struct rm_ctx rm_ctx;
 
@@ -69,11 +67,6 @@ const char *rm_last_error_string(void);
 int rm_abi_version(void);
 /* bytes of device workspace currently held by the context */
 size_t rm_ctx_workspace_bytes(const rm_ctx *ctx);
-/* developer / test switches, per context; the library never reads the process environment.  Every switch selects between
- * implementations with identical results or shrinks a tuning constant so that a test reaches a rare path:
- *   "temporal_valu" 0|1, "temporal_wide" -1|0|1, "dc_lds_front_end" 0|1, "no_fused_bounds" 0|1, "bounds_table_bytes" n, "dense_rows" 0|16|32|64,
- *   "dense_general" 0|1, "dense_wave" 1|0, "dense_frames" 0|1|2, "dense_split" 0|1|2|4, "bounds_scalar" 0|1|2, "dc_segs" n, "dc_wpg" n, "dc_split" per mille, "store_slots" n.  Unknown key -> RM_E_BADARG. */
-int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
 
 /* ---- measurement hook for bench.py: mode 1 brackets only the frame-buffer kernel with hipEvents on the
  *      caller's stream (cheap enough for the timed region), mode 2 brackets every phase of rm_calibrate /
@@ -85,12 +78,6 @@ int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
 #define RM_PROFILE_PHASES 4
 int rm_profile_enable(rm_ctx *ctx, int mode);
 int rm_profile_read(rm_ctx *ctx, double *ms_host, int *n_host);
-
-/* counters of the last rm_calibrate on this context (diagnostics): out_host[0] = (frame, tile) pairs,
- * [1] = pairs evaluated at full resolution by the selection's evaluation pass, [2] = pairs the selection kept for the masked sum,
- * [3] = capacity of the value store (pairs); 0 = the dense sum kernel took the sum (it recomputes every pair itself, [1] then
- * counts only the pairs evaluated for the exact raw.min() / raw.max()) */
-int rm_debug_counters(rm_ctx *ctx, long long *out_host, void *stream);
 
 /* ---- dtype helpers: transforms.py:20-23 uint8_to_float, transforms.py:26-29 float_to_uint8 */
 int rm_uint8_to_float(rm_ctx *ctx, const uint8_t *src_dev, double *dst_dev, size_t n, void *stream);

@@ -31,7 +31,7 @@ RM_FLAG_FF_PER_LEVEL = 512
 _c = ctypes
 _vp, _i, _d, _sz, _u = _c.c_void_p, _c.c_int, _c.c_double, _c.c_size_t, _c.c_uint
 
-# name -> (restype, argtypes); every symbol include/respmon_hip.h declares
+# name -> (restype, argtypes); every symbol include/respmon_hip.h and include/respmon_hip_debug.h declare
 SIGNATURES = {
     "rm_ctx_create": (_i, [_i, _c.POINTER(_vp)]),
     "rm_ctx_destroy": (_i, [_vp]),
@@ -47,6 +47,7 @@ SIGNATURES = {
     "rm_contour_stats": (_i, [_vp, _vp, _vp]),
     "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_debug_counters": (_i, [_vp, _vp, _vp]),
+    "rm_debug_host_timeline": (_i, [_vp, _vp]),
     "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "rm_float_to_uint8": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "rm_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

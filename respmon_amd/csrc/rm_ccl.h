@@ -66,7 +66,7 @@ __device__ inline void ccl_union(int *label, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits, size_t npix, int H, int W, int *label)
+RM_KERNEL __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits, size_t npix, int H, int W, int *label)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= npix || !ccl_bit(bits, p)) return;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
 // roots -> {root, minx, width-1, height-1} records in pinned host memory (the boxes are final behind the kernel boundary);
 // host[0].root = the number of components (> cap: the list overflowed and the host follows every border itself), records from
 // host[1] on.  16-byte records, consecutive lanes -> consecutive records: the PCIe writes leave in whole cache lines.
-__global__ __launch_bounds__(256) void k_ccl_publish(const int *roots, const CclBox *box, int W, const unsigned int *counters, unsigned int cap,
+RM_KERNEL __launch_bounds__(256) void k_ccl_publish(const int *roots, const CclBox *box, int W, const unsigned int *counters, unsigned int cap,
                                                      CclComp *host)
 {
     const unsigned int total = counters[0];

@@ -61,7 +61,7 @@ struct FlowWorkspace {
 // goodFeaturesToTrack: cornerMinEigenVal(blockSize, ksize = 3) on uint8  
 // ----------------------------------------------------------------------------------------
 // Sobel 3x3 products: cov[.,0] = Dx*Dx, [.,1] = Dx*Dy, [.,2] = Dy*Dy   (float32)
-__global__ __launch_bounds__(256) void k_gftt_cov(const uint8_t *img, int h, int w, float k1, float k2, float *cov)
+RM_KERNEL __launch_bounds__(256) void k_gftt_cov(const uint8_t *img, int h, int w, float k1, float k2, float *cov)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= h * w) return;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_gftt_cov(const uint8_t *img, int h, int
 
 // un-normalised block x block box sums (row sums then column sums, in double like OpenCV's float path),
 // then the smaller eigenvalue of the 2x2 structure tensor in float32
-__global__ __launch_bounds__(256) void k_gftt_eig(const float *cov, int h, int w, int block, float *eig, unsigned int *max_key)
+RM_KERNEL __launch_bounds__(256) void k_gftt_eig(const float *cov, int h, int w, int block, float *eig, unsigned int *max_key)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     float e = 0.0f;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gftt_eig(const float *cov, int h, int w
 }
 
 // THRESH_TOZERO, 3x3 dilate, local-maximum test (excluding the 1-pixel frame); candidates appended unordered
-__global__ __launch_bounds__(256) void k_gftt_candidates(const float *eig, int h, int w, float thr, float *cand_val, int *cand_idx,
+RM_KERNEL __launch_bounds__(256) void k_gftt_candidates(const float *eig, int h, int w, float thr, float *cand_val, int *cand_idx,
                                                          int *n_cand, int cap)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -157,8 +157,8 @@ inline int flow_good_features(FlowWorkspace &ws, const uint8_t *img, int h, int 
     const float k1 = (float)(1.0 * scale), k2 = (float)(2.0 * scale);
     const unsigned grid = (unsigned)((n + 255) / 256);
     FLOW_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_gftt_cov, dim3(grid), dim3(256), 0, s, img, h, w, k1, k2, cov);
-    hipLaunchKernelGGL(k_gftt_eig, dim3(grid), dim3(256), 0, s, cov, h, w, block_size, eig, scal);
+    hipLaunchKernelGGL(k_gftt_cov<>, dim3(grid), dim3(256), 0, s, img, h, w, k1, k2, cov);
+    hipLaunchKernelGGL(k_gftt_eig<>, dim3(grid), dim3(256), 0, s, cov, h, w, block_size, eig, scal);
     FLOW_HIP(hipGetLastError());
     unsigned host_scal[2];
     FLOW_HIP(hipMemcpyAsync(host_scal, scal, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -169,7 +169,7 @@ inline int flow_good_features(FlowWorkspace &ws, const uint8_t *img, int h, int 
     std::memcpy(&max_val_f, &key, 4);
     const double max_val = (double)max_val_f;
     const float thr = (float)(max_val * quality);
-    hipLaunchKernelGGL(k_gftt_candidates, dim3(grid), dim3(256), 0, s, eig, h, w, thr, cval, cidx, (int *)(scal + 1), (int)n);
+    hipLaunchKernelGGL(k_gftt_candidates<>, dim3(grid), dim3(256), 0, s, eig, h, w, thr, cval, cidx, (int *)(scal + 1), (int)n);
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(host_scal, scal, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     FLOW_HIP(stream_wait(s));
@@ -218,7 +218,7 @@ inline int flow_good_features(FlowWorkspace &ws, const uint8_t *img, int h, int 
 // calcOpticalFlowPyrLK  
 // ----------------------------------------------------------------------------------------
 // uint8 pyrDown: integer 5-tap, (sum + 128) >> 8, BORDER_REFLECT_101
-__global__ __launch_bounds__(256) void k_pyr_down_u8(const uint8_t *src, int h, int w, uint8_t *dst, int dh, int dw)
+RM_KERNEL __launch_bounds__(256) void k_pyr_down_u8(const uint8_t *src, int h, int w, uint8_t *dst, int dh, int dw)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= dh * dw) return;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_u8(const uint8_t *src, int h, 
 }
 
 // calcSharrDeriv: int16 (Ix, Iy) interleaved; reflect-101 inside the image
-__global__ __launch_bounds__(256) void k_scharr(const uint8_t *src, int h, int w, short *d)
+RM_KERNEL __launch_bounds__(256) void k_scharr(const uint8_t *src, int h, int w, short *d)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= h * w) return;
@@ -447,11 +447,11 @@ inline int flow_pyr_lk_dev(FlowWorkspace &ws, const uint8_t *prev, const uint8_t
             FLOW_TRY(ws.get("lk_prev" + std::to_string(l), n, (void **)&pp, err));
             FLOW_TRY(ws.get("lk_next" + std::to_string(l), n, (void **)&nn, err));
             const unsigned grid = (unsigned)((n + 255) / 256);
-            hipLaunchKernelGGL(k_pyr_down_u8, dim3(grid), dim3(256), 0, s, L.prev[l - 1], L.h[l - 1], L.w[l - 1], pp, sh, sw);
-            hipLaunchKernelGGL(k_pyr_down_u8, dim3(grid), dim3(256), 0, s, L.next[l - 1], L.h[l - 1], L.w[l - 1], nn, sh, sw);
+            hipLaunchKernelGGL(k_pyr_down_u8<>, dim3(grid), dim3(256), 0, s, L.prev[l - 1], L.h[l - 1], L.w[l - 1], pp, sh, sw);
+            hipLaunchKernelGGL(k_pyr_down_u8<>, dim3(grid), dim3(256), 0, s, L.next[l - 1], L.h[l - 1], L.w[l - 1], nn, sh, sw);
         }
         FLOW_TRY(ws.get("lk_deriv" + std::to_string(l), n * 2 * sizeof(short), (void **)&dd, err));
-        hipLaunchKernelGGL(k_scharr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pp, sh, sw, dd);
+        hipLaunchKernelGGL(k_scharr<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pp, sh, sw, dd);
         L.prev[l] = pp; L.next[l] = nn; L.deriv[l] = dd;
         sh = (sh + 1) / 2; sw = (sw + 1) / 2;
     }
@@ -487,7 +487,7 @@ inline int flow_pyr_lk(FlowWorkspace &ws, const uint8_t *prev, const uint8_t *ne
 // lane 0 adds the differences in point order from LDS.  (One THREAD walking global memory took 150 us for 1 000 points.)
 constexpr int FLOW_FINISH_MAX = 6000;   // points whose differences fit the LDS staging (2 floats each)
 __host__ __device__ __forceinline__ int flow_finish_pitch(int n) { return (n + 3) & ~3; }   // floats per staged component
-__global__ __launch_bounds__(64) void k_flow_finish(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
+RM_KERNEL __launch_bounds__(64) void k_flow_finish(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
 {
     HIP_DYNAMIC_SHARED(float, s_d)     // [2 * flow_finish_pitch(n)]: dx of the survivors, then dy (both 16-byte aligned: lk_seq_sum2 reads float4)
     const int lane = threadIdx.x;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void k_flow_finish(const float *o, const float 
     }
 }
 // (more points than the staging holds: one thread, global memory)
-__global__ void k_flow_finish_seq(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
+RM_KERNEL void k_flow_finish_seq(const float *o, const float *nw, const uint8_t *st, int n, float *res, float *next_pts)
 {
     float sx = 0.f, sy = 0.f;
     int m = 0;
@@ -579,16 +579,16 @@ inline int flow_track_resident(FlowState &fs, int prev_side, int cur_side, const
         const unsigned grid = (unsigned)((n + 255) / 256);
         if (l > 0) {
             if (fs.pyr_levels[prev_side] < l) {
-                hipLaunchKernelGGL(k_pyr_down_u8, dim3(grid), dim3(256), 0, s, L.prev[l - 1], L.h[l - 1], L.w[l - 1], pp, sh, sw);
+                hipLaunchKernelGGL(k_pyr_down_u8<>, dim3(grid), dim3(256), 0, s, L.prev[l - 1], L.h[l - 1], L.w[l - 1], pp, sh, sw);
                 fs.pyr_levels[prev_side] = l;
             }
             if (fs.pyr_levels[cur_side] < l) {
-                hipLaunchKernelGGL(k_pyr_down_u8, dim3(grid), dim3(256), 0, s, L.next[l - 1], L.h[l - 1], L.w[l - 1], nn, sh, sw);
+                hipLaunchKernelGGL(k_pyr_down_u8<>, dim3(grid), dim3(256), 0, s, L.next[l - 1], L.h[l - 1], L.w[l - 1], nn, sh, sw);
                 fs.pyr_levels[cur_side] = l;
             }
         }
         if (fs.deriv_levels[prev_side] < l) {
-            hipLaunchKernelGGL(k_scharr, dim3(grid), dim3(256), 0, s, pp, sh, sw, dd);
+            hipLaunchKernelGGL(k_scharr<>, dim3(grid), dim3(256), 0, s, pp, sh, sw, dd);
             fs.deriv_levels[prev_side] = l;
         }
         L.prev[l] = pp; L.next[l] = nn; L.deriv[l] = dd;
@@ -603,7 +603,7 @@ inline int flow_track_resident(FlowState &fs, int prev_side, int cur_side, const
 // ----------------------------------------------------------------------------------------
 // np.mean(good_old - good_new, axis=0): float32, sequential over the points with status == 1  (base.py:377-388)
 // ----------------------------------------------------------------------------------------
-__global__ void k_mean_flow(const float *o, const float *nw, const uint8_t *st, int n, float *mean_xy, int *n_good)
+RM_KERNEL void k_mean_flow(const float *o, const float *nw, const uint8_t *st, int n, float *mean_xy, int *n_good)
 {
     float sx = 0.f, sy = 0.f;
     int m = 0;
@@ -629,7 +629,7 @@ inline int flow_mean(FlowWorkspace &ws, const float *old_pts, const float *new_p
     FLOW_HIP(hipMemcpyAsync(d_o, old_pts, sizeof(float) * 2 * npts, hipMemcpyHostToDevice, s));
     FLOW_HIP(hipMemcpyAsync(d_n, new_pts, sizeof(float) * 2 * npts, hipMemcpyHostToDevice, s));
     FLOW_HIP(hipMemcpyAsync(d_s, status, npts, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_mean_flow, dim3(1), dim3(1), 0, s, d_o, d_n, d_s, npts, d_m, d_c);
+    hipLaunchKernelGGL(k_mean_flow<>, dim3(1), dim3(1), 0, s, d_o, d_n, d_s, npts, d_m, d_c);
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(mean_xy, d_m, sizeof(float) * 2, hipMemcpyDeviceToHost, s));
     FLOW_HIP(hipMemcpyAsync(n_good, d_c, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -710,7 +710,7 @@ __device__ inline void eig2x2_dgeev(double a, double b, double c, double d, doub
     v[0][0] = v1[0] * n1; v[1][0] = v1[1] * n1; v[0][1] = v2[0] * n2; v[1][1] = v2[1] * n2;
 }
 
-__global__ __launch_bounds__(64) void k_pca_reduce(const float *motion, int n, double *out)
+RM_KERNEL __launch_bounds__(64) void k_pca_reduce(const float *motion, int n, double *out)
 {
     const int lane = threadIdx.x;
     double sx = 0, sy = 0;
@@ -743,7 +743,7 @@ inline int flow_pca(FlowWorkspace &ws, const float *motion, int n, double *out, 
     FLOW_TRY(ws.get("pca_in", sizeof(float) * 2 * n, (void **)&d_m, err));
     FLOW_TRY(ws.get("pca_out", sizeof(double), (void **)&d_o, err));
     FLOW_HIP(hipMemcpyAsync(d_m, motion, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pca_reduce, dim3(1), dim3(64), 0, s, d_m, n, d_o);
+    hipLaunchKernelGGL(k_pca_reduce<>, dim3(1), dim3(64), 0, s, d_m, n, d_o);
     FLOW_HIP(hipGetLastError());
     FLOW_HIP(hipMemcpyAsync(out, d_o, sizeof(double), hipMemcpyDeviceToHost, s));
     FLOW_HIP(stream_wait(s));

@@ -17,6 +17,10 @@
 
 #include <chrono>
 
+// Non-template kernels are function templates with one defaulted parameter (launched as k_name<>): every translation unit of the
+// library includes every kernel header, and a unit generates device code only for the kernels it launches.
+#define RM_KERNEL template <int RM_UNIT_ = 0> __global__
+
 namespace rm {
 
 // Host wait for a result on `s`.  hipStreamSynchronize sleeps on an interrupt (tens of microseconds to wake up);
@@ -95,7 +99,7 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 // The band-passed video is EVEN in time.  transforms.py:98 takes Re(ifft(.)) of a REAL (packed-rfft) array, so the filter output
 // satisfies out[s] == out[n - s] for 0 < s < n -- bit for bit in the reference (scipy's ifft of a real sequence is exactly
-// Hermitian) and here (the stage-2 operator is evaluated for s <= n / 2 only, rm_api.hip get_operator).  Every per-frame stage
+// Hermitian) and here (the stage-2 operator is evaluated for s <= n / 2 only, rm_temporal.hip get_operator).  Every per-frame stage
 // after the filter is a function of the frame alone, so C_S, the tile bounds and raw inherit the symmetry: the library computes and
 // stores the T / 2 + 1 UNIQUE frames and the time-ordered consumers (the masked sum) read frame t through sym_frame().
 __host__ __device__ __forceinline__ int sym_frames(int T) { return T / 2 + 1; }
@@ -290,7 +294,7 @@ struct GlobalImg {
 
 // mode 0: dst = up(src); 1: dst = other - up(src); 2: dst = up(src) + other
 // src_fs / dst_fs / other_fs: frame strides in doubles (frames of several levels may share one [T, NP] buffer)
-__global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int sw, size_t src_fs, double *dst, int dh, int dw,
+RM_KERNEL __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int sw, size_t src_fs, double *dst, int dh, int dw,
                                                 size_t dst_fs, int mode, const double *other, size_t other_fs)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void k_pyr_up(const double *src, int sh, int s
 // The same for large levels: a thread produces the 2 x 2 outputs that hang under source pixel (i, j).  Their taps all lie
 // in its 3 x 3 neighbourhood, so the four up_at() calls share 9 loads (instead of 9 + 6 + 6 + 4 for four threads), the
 // address arithmetic is paid once, and a lane stores 16 contiguous bytes per row.  Same expressions per output, same bits.
-__global__ __launch_bounds__(256) void k_pyr_up_2x2(const double *__restrict__ src, int sh, int sw, size_t src_fs,
+RM_KERNEL __launch_bounds__(256) void k_pyr_up_2x2(const double *__restrict__ src, int sh, int sw, size_t src_fs,
                                                     double *dst, int dh, int dw, size_t dst_fs, int mode,
                                                     const double *other, size_t other_fs)
 {
@@ -358,7 +362,7 @@ constexpr int TF_KC = 4, TF_SC = 8, TF_U = 16;
 __device__ void state_init_lane(struct CollapseState *st, int i);   // defined with the state, below
 
 // st_init (nullable): workgroup (0, 0) also resets the reduction state of the collapse passes that follow on the stream
-__global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y, struct CollapseState *st_init)
+RM_KERNEL __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, size_t NP, const double *R, int nk, double *y, struct CollapseState *st_init)
 {
     HIP_DYNAMIC_SHARED(double, s_r)  // [T][TF_KC]
     if (st_init && blockIdx.x == 0 && blockIdx.y == 0) state_init_lane(st_init, (int)threadIdx.x);
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(64) void k_temporal_fwd(const double *x, int T, siz
 
 // T = rows of C / frames written (the unique frames: sym_frames(n)); mirror_n > 0: also store row s as row mirror_n - s
 // (0 < s, 2 s < mirror_n) -- the full [n, NP] array of the module-level filter call
-__global__ __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, size_t NP, const double *C, int T, double amp,
+RM_KERNEL __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, size_t NP, const double *C, int T, double amp,
                                                      double *out, int mirror_n)
 {
     HIP_DYNAMIC_SHARED(double, s_c)  // [nk][TF_SC]
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__rest
 constexpr int IIR_MAX = 16;  // coefficients per polynomial (a band-pass of order 6 has 13)
 struct IirCoef { double b[IIR_MAX], a[IIR_MAX]; int n; };
 
-__global__ __launch_bounds__(64) void k_lfilter(const double *x, int T, size_t NP, IirCoef c, double scale, double *y)
+RM_KERNEL __launch_bounds__(64) void k_lfilter(const double *x, int T, size_t NP, IirCoef c, double scale, double *y)
 {
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (p >= NP) return;
@@ -815,7 +819,7 @@ __device__ __forceinline__ void fill_lds(double *dst, const double *src, int n, 
 }
 
 // st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
-__global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all, CollapseState *st_init)
+RM_KERNEL __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, SmallGeom g, double *lap_all, CollapseState *st_init)
 {
     RM_TRACE_SCOPE(1);
     if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_pyramid(const double *gS, Sm
 
 // st_init (nullable): workgroup 0 also resets the reduction state of the collapse passes that follow on the stream
 // (k_state_init's job: one tiny launch less on the critical path)
-__global__ __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_all, SmallGeom g, double *cS, CollapseState *st_init)
+RM_KERNEL __launch_bounds__(SMALL_NT) void k_small_collapse(const double *bp_all, SmallGeom g, double *cS, CollapseState *st_init)
 {
     HIP_DYNAMIC_SHARED(double, lds)   // the [NP] frame, levels laid out as in bp_all
     const int t = blockIdx.x, tid = threadIdx.x;
@@ -1025,7 +1029,7 @@ __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIP
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
 }
 
-__global__ __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st) { state_init_lane(st, (int)threadIdx.x); }
+RM_KERNEL __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st) { state_init_lane(st, (int)threadIdx.x); }
 
 // fold the stripes of one target (plus its unstriped word); every lane of the wave gets the result
 __device__ __forceinline__ unsigned long long fold_min_keys(const unsigned long long *stripes, unsigned long long word)
@@ -1062,7 +1066,7 @@ __device__ __forceinline__ double lattice_sample(const double *r0, const double 
 
 // The four extrema of the bounds (over ALL pairs) are reduced here as well: block-level min/max, then striped
 // atomics that are skipped when they cannot change the result.
-__global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
+RM_KERNEL __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom g, int T, int ntiles,
                                                      double *lo, double *hi, CollapseState *st, int *sel_cnt)
 {
     const double inf = __builtin_huge_val();
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom
 // and no per-thread 2-D loop over global memory.  Used when the [h_S][tiles_x] x 2 table fits LDS.
 // blockIdx.y selects a band of `band` tile rows (large levels: the row-extrema table of a whole frame would not fit LDS);
 // the table then holds only the level-S rows [y_lo, y_hi] that band's footprints touch (at most `tbl_rows` of them).
-__global__ __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi,
+RM_KERNEL __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi,
                                                       CollapseState *st, int band, int tbl_rows, int *sel_cnt)
 {
     HIP_DYNAMIC_SHARED(double, lds)
@@ -1442,7 +1446,7 @@ __device__ __forceinline__ void frame_bounds_from_lds(const double *c, double *r
     RM_TRACE_MARK(mark_kid, 12);
 }
 
-__global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double *bp_all, SmallGeom sg, double *cS, CollapseState *st,
+RM_KERNEL __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double *bp_all, SmallGeom sg, double *cS, CollapseState *st,
                                                                      ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt)
 {
     RM_TRACE_SCOPE(3);
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_small_collapse_bounds(const double
 // except on exact ties of the mask threshold -- the same class of event the explicit filter operator already belongs to).
 // RM_FLAG_FILTER_LAPLACIANS selects the reference's order (k_small_pyramid / k_small_collapse_bounds above).
 // LDS: the levels S .. L-1 (sg.g_off; levels S+1 .. L-2 are overwritten on the way up), then the bounds table.
-__global__ __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *xg, SmallGeom sg, int lds_levels, double *cS, CollapseState *st,
+RM_KERNEL __launch_bounds__(SMALL_NT) void k_small_filter_first(const double *xg, SmallGeom sg, int lds_levels, double *cS, CollapseState *st,
                                                                   ChainGeom g, int ntiles, double *lo, double *hi, int *sel_cnt, int parts)
 {
     RM_TRACE_SCOPE(3);
@@ -1546,7 +1550,7 @@ constexpr int SLOT_PRUNED = -1;    // every value of the pair is provably >= top
 // Sparse or dense sum?  (rm_dense_sum.h)  Decided ON THE DEVICE from what this call's own selection kept -- every kernel that
 // cares evaluates sum_is_dense() on the counters k_select_pairs left in the state, so the first call of a geometry behaves like
 // the hundredth and nothing is remembered between calls:
-//   * more kept pairs than the value store has slots -> dense (the store is capped: rm_api.hip collapse_eval);
+//   * more kept pairs than the value store has slots -> dense (the store is capped: rm_collapse_eval.hip collapse_eval);
 //   * skip <= 2 and more than one pair in DENSE_ONE_IN kept -> dense (measured per pair of the geometry on MI355X: sparse 3.7-4.8 ns
 //     per KEPT pair; dense 1.6 ns at 4K x 512 skip 2, 3.6 ns at 720p x 128 skip 2, 4.6 ns at 1080p x 256 skip 4 -- slower than
 //     sparse even with everything kept, so deeper chains go dense only on overflow);
@@ -1598,7 +1602,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan_256(unsigned long 
 // finishes every other tile with a constant fill.
 // A frame shard [t0, t1) of the T-frame buffer owns unique frame u when it holds t = u or t = T - u (sym_in_range).
 constexpr int SEL_TILES = 16, SEL_PH = 16, SEL_U = 9;   // 16 x 9 = 144 unique frames per chunk: one chunk at T = 256
-__global__ __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int ntiles, int Th, int T, int t0, int t1,
+RM_KERNEL __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int ntiles, int Th, int T, int t0, int t1,
                                                       CollapseState *st, unsigned int *list_a, unsigned int *list_b, int *slot_of,
                                                       int no_prune, double thr, int *sel_cnt, unsigned int *heavy)
 {
@@ -1771,14 +1775,14 @@ __device__ __forceinline__ void level0_rows(const ChainGeom &g, const Region &R0
     }
 }
 
-// Filter-first collapse of levels too large for LDS (4K, skip 2; rm_api.hip front_filter): with X_l the band-passed Gaussian levels,
+// Filter-first collapse of levels too large for LDS (4K, skip 2; rm_front.hip front_filter): with X_l the band-passed Gaussian levels,
 //     C_S = X_S - pyrUp^n(X_{L-1}),  n = L - 1 - S        (the telescoped collapse, see k_small_filter_first)
 // for one 64 x 16 tile of level S per work item: the footprint of the tile at the coarsest level is staged in LDS, the pyrUp chain
 // runs there exactly as in k_eval_pairs (`g` describes levels S .. L-1 as its levels 0 .. n), the last step lands in registers
 // (lane = column, 16 rows) and is subtracted from the tile of X_S, requested before the chain starts.  X_S is read once, C_S
 // written once, the intermediate levels U_l never exist (three k_pyr_up launches over the 2.1 GB level at 4K x 512 did 1.05 ms).
 // Same per-pixel arithmetic as k_pyr_up (modes 0 and 1): bit-identical.
-__global__ __launch_bounds__(64) void k_ff_collapse(const double *xS, const double *xL, ChainGeom g, int ntiles, int nitems, double *cS)
+RM_KERNEL __launch_bounds__(64) void k_ff_collapse(const double *xS, const double *xL, ChainGeom g, int ntiles, int nitems, double *cS)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     const int lane = threadIdx.x;
@@ -1810,7 +1814,7 @@ __global__ __launch_bounds__(64) void k_ff_collapse(const double *xS, const doub
 // Exact raw.min()/raw.max() (transforms.py:185,187) come from here (list_a); on the sparse path the values of the pairs that can
 // fall below `top` (list_a's kept pairs and all of list_b) are parked in their slot of `store` ([slot][row][lane], coalesced) for
 // the masked time sum.  On the dense path (sum_is_dense) list_b is not touched and nothing is stored.
-__global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, const unsigned int *list_b,
+RM_KERNEL __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g, int ntiles, const unsigned int *list_a, const unsigned int *list_b,
                                                    int *slot_of, CollapseState *st, double *store, SumPlan sp, int Th)
 {
     RM_TRACE_SCOPE(5);
@@ -1874,7 +1878,7 @@ __global__ __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g
 }
 
 // transforms.py:184-189: min, max, top = max - (max - min) * threshold
-__global__ __launch_bounds__(NSTRIPE) void k_finish_minmax(CollapseState *st, double threshold)
+RM_KERNEL __launch_bounds__(NSTRIPE) void k_finish_minmax(CollapseState *st, double threshold)
 {
     const unsigned long long kmn = fold_min_keys(st->min_keys, st->min_key), kmx = fold_max_keys(st->max_keys, st->max_key);
     if (threadIdx.x != 0) return;
@@ -1885,7 +1889,7 @@ __global__ __launch_bounds__(NSTRIPE) void k_finish_minmax(CollapseState *st, do
 
 // frame-sharded calibration: the exact extrema of this rank's frames leave as {-min, max} (one all-reduce(MAX)
 // serves both) and the global pair comes back the same way
-__global__ __launch_bounds__(NSTRIPE) void k_export_minmax(const CollapseState *st, double *negmin_max)
+RM_KERNEL __launch_bounds__(NSTRIPE) void k_export_minmax(const CollapseState *st, double *negmin_max)
 {
     const double inf = __builtin_huge_val();
     const unsigned long long kmn = fold_min_keys(st->min_keys, st->min_key), kmx = fold_max_keys(st->max_keys, st->max_key);
@@ -1893,7 +1897,7 @@ __global__ __launch_bounds__(NSTRIPE) void k_export_minmax(const CollapseState *
     negmin_max[0] = (kmn == ~0ull) ? -inf : -f64_unkey(kmn);
     negmin_max[1] = (kmx == 0ull) ? -inf : f64_unkey(kmx);
 }
-__global__ __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, const double *negmin_max)
+RM_KERNEL __launch_bounds__(NSTRIPE) void k_import_minmax(CollapseState *st, const double *negmin_max)
 {
     st->min_keys[threadIdx.x] = ~0ull; st->max_keys[threadIdx.x] = 0ull;   // the global pair replaces this rank's stripes
     if (threadIdx.x != 0) return;
@@ -1927,7 +1931,7 @@ constexpr int MS_RQ = CT_H / MS_Q;   // rows per worker == waves per workgroup
 #endif
 constexpr int MS_B = RM_MS_B;        // kept frames per batch (32: 220 VGPRs, two waves per SIMD -- measured 32 us against 20)
 
-__global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int t_end, int T, int ntiles, int W0, int H0,
+RM_KERNEL __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int t_end, int T, int ntiles, int W0, int H0,
                                                           const int *slot_of, const double *store,
                                                           CollapseState *st, double threshold, double *heat_sum, int avg_T,
                                                           int *tile_nkept, const int *sel_cnt, const unsigned int *heavy, int nworkers,
@@ -2089,7 +2093,7 @@ __global__ __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, in
 // ----------------------------------------------------------------------------------------
 // plain (materialised) forms: global min/max, mask, time sum  -- transforms.py:184-192, base.py:562
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_minmax_plain(const double *a, size_t n, CollapseState *st)
+RM_KERNEL __launch_bounds__(256) void k_minmax_plain(const double *a, size_t n, CollapseState *st)
 {
     double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -2104,7 +2108,7 @@ __global__ __launch_bounds__(256) void k_minmax_plain(const double *a, size_t n,
     }
 }
 
-__global__ __launch_bounds__(256) void k_mask_plain(const double *raw, size_t n, const CollapseState *st, double *masked)
+RM_KERNEL __launch_bounds__(256) void k_mask_plain(const double *raw, size_t n, const CollapseState *st, double *masked)
 {
     const double top = st->top, mn = st->min_val;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -2114,7 +2118,7 @@ __global__ __launch_bounds__(256) void k_mask_plain(const double *raw, size_t n,
 }
 
 // heat_sum[p] = sum_t (raw[t,p] >= top ? min : raw[t,p])   (sequential in t); raw holds the sym_frames(T) unique frames
-__global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int T, size_t npix, const CollapseState *st,
+RM_KERNEL __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int T, size_t npix, const CollapseState *st,
                                                           double *heat_sum)
 {
     size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -2129,7 +2133,7 @@ __global__ __launch_bounds__(256) void k_masked_sum_plain(const double *raw, int
 }
 
 // frames T/2+1 .. T-1 of a [T, npix] array from their mirror images (sym_frame): dst[t] = dst[T - t]
-__global__ __launch_bounds__(256) void k_mirror_frames(double *a, int T, size_t npix)
+RM_KERNEL __launch_bounds__(256) void k_mirror_frames(double *a, int T, size_t npix)
 {
     const int t = sym_frames(T) + (int)blockIdx.y;   // t in (T/2, T)
     const double *src = a + (size_t)(T - t) * npix;
@@ -2152,7 +2156,7 @@ __global__ __launch_bounds__(256) void k_time_average(const Tin *v, int T, size_
 // ----------------------------------------------------------------------------------------
 // base.py:562-566: avg = sum / T ; normalise ; float_to_uint8 ; threshold
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum, size_t npix, int T, double *heat,
+RM_KERNEL __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum, size_t npix, int T, double *heat,
                                                          CollapseState *st)
 {
     double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
@@ -2171,7 +2175,14 @@ __global__ __launch_bounds__(256) void k_heat_avg_minmax(const double *heat_sum,
 }
 
 // min/max of an existing heatmap (rm_heatmap_to_roi entry point)
-__global__ __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t npix, CollapseState *st)
+// reset of the heatmap extrema in the state (in front of k_heat_minmax / k_heat_avg_minmax / a sum kernel that reduces them)
+RM_KERNEL __launch_bounds__(NSTRIPE) void k_heat_state_init(CollapseState *st)
+{
+    st->heat_min_keys[threadIdx.x] = ~0ull; st->heat_max_keys[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) { st->heat_min_key = ~0ull; st->heat_max_key = 0ull; }
+}
+
+RM_KERNEL __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t npix, CollapseState *st)
 {
     double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
@@ -2199,7 +2210,7 @@ struct alignas(16) CclBox { int minx, maxx, maxy, pad; };   // bounding box of a
 // tile_const (nullable; needs W % 64 == 0): tile_nkept of the sum kernel that wrote `heat` -- 0 for a 64 x 16 tile every pixel of which
 // is the same constant (96 % of the tiles of the synthetic 1080p stream): such a word takes its ONE value from a wave-uniform load
 // and the 16.6 MB heatmap is read only where it varies
-__global__ __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
+RM_KERNEL __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t npix, int W, const CollapseState *st,
                                                     int threshold, uint8_t *avg_u8, uint8_t *binary,
                                                     unsigned long long *bits, uint8_t *row_any,
                                                     unsigned long long *bits_dev, int *ccl_label, CclBox *ccl_box,
@@ -2303,7 +2314,7 @@ constexpr int SP_HDR = 4;  // doubles
 // One wave, 64 tiles per ballot (the first tile is almost always one of them).
 struct alignas(16) F64Pair { double a, b; };
 constexpr unsigned int SP_DENSE_ONLY = 0xffffffffu;   // header count: this rank has no sparse form, use the dense exchange
-__global__ __launch_bounds__(64) void k_sparse_background(const double *heat, int W, int tiles_x, int ntiles, const int *tile_nkept,
+RM_KERNEL __launch_bounds__(64) void k_sparse_background(const double *heat, int W, int tiles_x, int ntiles, const int *tile_nkept,
                                                           int cap, double *packet)
 {
     const int lane = threadIdx.x;
@@ -2322,7 +2333,7 @@ __global__ __launch_bounds__(64) void k_sparse_background(const double *heat, in
 
 // a tile travels only if one of its pixels differs from the background (a tile with kept frames whose values were
 // all masked ends up as the same constant, bit for bit: the same sequence of additions of `min`)
-__global__ __launch_bounds__(256) void k_sparse_pack(const double *heat, int H, int W, int tiles_x, const int *tile_nkept, int cap,
+RM_KERNEL __launch_bounds__(256) void k_sparse_pack(const double *heat, int H, int W, int tiles_x, const int *tile_nkept, int cap,
                                                      double *packet)
 {
     const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -2362,7 +2373,7 @@ __global__ __launch_bounds__(256) void k_sparse_pack(const double *heat, int H, 
 // sent the tile, flag_host[0] = 1 when some rank overflowed, flag_host[1] = the largest tile count a rank needed
 // (pinned host words: the caller reads them after the ROI stage's synchronisation), and the stripes the merge
 // kernel reduces the fused heatmap's extrema into
-__global__ __launch_bounds__(256) void k_sparse_index(const double *packets, size_t packet_doubles, int world, int cap, int ntiles,
+RM_KERNEL __launch_bounds__(256) void k_sparse_index(const double *packets, size_t packet_doubles, int world, int cap, int ntiles,
                                                       int *map, int *any, int *flag_host, CollapseState *st, int avg_T)
 {
     for (int i = threadIdx.x; i < world * ntiles; i += 256) map[i] = -1;
@@ -2406,7 +2417,7 @@ __global__ __launch_bounds__(256) void k_sparse_index(const double *packets, siz
 // fused[p] = sum over ranks (in rank order) of heat_r[p]; also the fused heatmap's min / max (striped)
 // avg_T > 0: the packets hold partial time SUMS of a frame-sharded buffer; the fused value is their sum / avg_T.
 // A tile no rank sent is the constant k_sparse_index prepared (already in the extrema), stored 16 bytes per lane.
-__global__ __launch_bounds__(256) void k_sparse_merge(const double *packets, size_t packet_doubles, int world, int cap, int H, int W,
+RM_KERNEL __launch_bounds__(256) void k_sparse_merge(const double *packets, size_t packet_doubles, int world, int cap, int H, int W,
                                                       int tiles_x, int ntiles, const int *map, const int *any, double *fused,
                                                       CollapseState *st, int avg_T)
 {
@@ -2458,13 +2469,13 @@ __global__ __launch_bounds__(256) void k_sparse_merge(const double *packets, siz
 // ----------------------------------------------------------------------------------------
 // dtype helpers and ROI reductions
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_u8_to_f64(const uint8_t *src, double *dst, size_t n)
+RM_KERNEL __launch_bounds__(256) void k_u8_to_f64(const uint8_t *src, double *dst, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         dst[i] = (double)src[i] * (1.0 / 255);
 }
 
-__global__ __launch_bounds__(256) void k_f64_to_u8(const double *src, uint8_t *dst, size_t n)
+RM_KERNEL __launch_bounds__(256) void k_f64_to_u8(const double *src, uint8_t *dst, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         dst[i] = f64_to_u8_trunc(src[i] * 255);
@@ -2499,7 +2510,7 @@ __global__ __launch_bounds__(256) void k_roi_to_u8(const Tin *frame, int W, int 
 }
 
 // cv2.cvtColor(BGR2GRAY), base.py:230: Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14
-__global__ __launch_bounds__(256) void k_bgr_to_gray(const uint8_t *bgr, size_t npix, uint8_t *gray)
+RM_KERNEL __launch_bounds__(256) void k_bgr_to_gray(const uint8_t *bgr, size_t npix, uint8_t *gray)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];

@@ -344,7 +344,7 @@ __device__ __forceinline__ int lane_value(int v, int b)   // v of lane b (b: com
 #endif
 }
 
-__global__ __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
+RM_KERNEL __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
                                                                double threshold, double *heat, int *tile_nkept, const int *sel_cnt,
                                                                const unsigned int *heavy, int nworkers, SumPlan sp, int *unserved_host)
 {
@@ -550,7 +550,7 @@ __device__ __forceinline__ int lane_value_dyn(int v, int b)   // v of lane b (b 
 #endif
 }
 
-__global__ __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
+RM_KERNEL __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
                                                         double threshold, double *heat, int *tile_nkept, const int *sel_cnt,
                                                         const unsigned int *heavy, int nworkers, SumPlan sp, int *unserved_host)
 {

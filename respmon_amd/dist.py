@@ -447,7 +447,7 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
 # communicator id once.  locate_streams / locate_sharded take this path when the context of the current device holds a communicator
 # of the group's size (cabi_comm_init); gloo dry runs and test doubles keep the torch.distributed path above.
 # ---------------------------------------------------------------------------------------------------
-_CABI_COMM = {}   # device index -> (rank, world)
+_CABI_COMM = {}   # device index -> (rank, world, the torch.distributed group the communicator was made from)
 
 
 def cabi_comm_init(group=None):
@@ -473,7 +473,7 @@ def cabi_comm_init(group=None):
     _capi.check(lib, lib.rm_comm_init(ctx, rank, world, idbuf), "rm_comm_init")
     r, w, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     _capi.check(lib, lib.rm_comm_info(ctx, ctypes.byref(r), ctypes.byref(w), ctypes.byref(n)), "rm_comm_info")
-    _CABI_COMM[t.cuda.current_device()] = (r.value, w.value)
+    _CABI_COMM[t.cuda.current_device()] = (r.value, w.value, group)
     return r.value, w.value, n.value
 
 
@@ -490,7 +490,9 @@ def cabi_comm_active(group=None):
     if not t.cuda.is_available():
         return False
     have = _CABI_COMM.get(t.cuda.current_device())
-    return have is not None and have == _world(group)
+    # the communicator serves the group it was made from, and only that one: another group of the same size and rank (a subgroup, a
+    # group created after destroy_process_group) would put the wrong ranks into the collective
+    return have is not None and have[2] is group and have[:2] == _world(group)
 
 
 def _cabi_step(fn_name, buf, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top, temporal_threshold, threshold,
@@ -504,7 +506,7 @@ def _cabi_step(fn_name, buf, T, fps, freq_min, freq_max, amplification, pyramid_
     heat = t.empty((H, W), dtype=t.float64, device=buf.device) if return_heatmap else None
     xywh = (ctypes.c_int32 * 4)()
     how = ctypes.c_int(0)
-    rc = _capi.check(lib, getattr(lib, fn_name)(device.ctx(), device.ptr(buf), device.dtype_code(buf), int(T), H, W, float(fps), float(freq_min),
+    rc = _capi.check(lib, getattr(lib, fn_name)(device.ctx(buf.device.index), device.ptr(buf), device.dtype_code(buf), int(T), H, W, float(fps), float(freq_min),
                                                float(freq_max), float(amplification), int(pyramid_levels), int(skip_levels_at_top),
                                                float(temporal_threshold), int(threshold), int(flags), device.ptr(heat), xywh, ctypes.byref(how),
                                                device.stream_ptr()), fn_name)

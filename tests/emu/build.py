@@ -21,7 +21,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
+    units = ["rm_unity.hip", "rm_contour.cpp"]   # every product translation unit, as one unit (respmon_amd/csrc/rm_unity.hip)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
            "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", "-Wno-unused-function", "-o", OUT]
     for u in units:

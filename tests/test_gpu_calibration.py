@@ -308,6 +308,38 @@ def test_state_machine_full_calibration_trace(hip, golden):
         assert np.array_equal(np.array(mon.t), g["c2_t"])
 
 
+def test_reduce_bounding_box_on_a_located_roi(hip, oracle, golden):
+    """a12 (reference tools.py:48-57, base.py:457): the G7 cases (outputs of the real reference function) and a run() with a finite
+    maximum_bounding_box_area -- the ROI the state machine keeps is the reference's shrink of what locate() found on the device."""
+    from respmon_amd import synth, tools
+    from respmon_amd.base import RespiratoryMonitor
+    g = golden("g7_misc.npz")
+    for c, r in zip(g["rbb_in"], g["rbb_out"]):
+        x, y, w, h, a = c
+        assert tuple(tools.reduce_bounding_box(int(x), int(y), int(w), int(h), a)) == tuple(int(v) for v in r)
+    vid = synth.synth_breathing(150, 48, 64, seed=11)
+    frames = oracle.uint8_to_float(vid)
+    located = RespiratoryMonitor.locate(frames[1:129].copy(), 10)      # frames 1..T fill the buffer (SURVEY a20)
+    assert located is not None and located == oracle.locate(frames[1:129].copy(), 10)
+    full_area = located[2] * located[3]
+    for area in (np.inf, float(full_area), full_area / 2.0, 12.0):
+        mon = RespiratoryMonitor(capture_target=synth.FakeCapture(vid, fps=30), visualize=None, save_all_data=False,
+                                 motion_extraction_method="average", run_on_init=False)
+        mon.sync_to_fps = lambda: None
+        mon.maximum_bounding_box_area = area
+        mon.run()
+        want = oracle.reduce_bounding_box(*located, area)
+        assert (mon.x, mon.y, mon.w, mon.h) == tuple(int(v) for v in want)
+        if area < full_area:
+            assert mon.w * mon.h < full_area
+        else:
+            assert (mon.x, mon.y, mon.w, mon.h) == located
+        # the measured signal is the mean of the REDUCED crop of every later frame (base.py:471, 355-358)
+        if mon.w >= 1 and mon.h >= 1:
+            crop = frames[130:, mon.y:mon.y + mon.h, mon.x:mon.x + mon.w]
+            assert np.allclose(np.array(mon.data), crop.reshape(crop.shape[0], -1).mean(1), rtol=1e-13, atol=0)
+
+
 def test_config_q_720p_full_size_vs_oracle(hip, oracle):
     """BASELINE config 2 at full size: 128 x 720p, 4-level pyramid, skip 2 (the module defaults of
     eulerian_magnification_bandpass, transforms.py:145) -- bit-exact ROI against the oracle's materialising run."""

@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from respmon_amd import _capi
     lib = _capi.load()     # no GPU needed to load; raises if the library or a symbol is missing
-    header = open(os.path.join(ROOT, "include", "respmon_hip.h")).read()
+    # the drop-in interface and the developer / test header: every symbol either declares
+    header = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("respmon_hip.h", "respmon_hip_debug.h"))
     declared = set(re.findall(r"\b(rm_[a-z0-9_]+)\s*\(", header))
+    public = open(os.path.join(ROOT, "include", "respmon_hip.h")).read()
+    assert "rm_debug_" not in public and "test hook" not in public     # hooks live in respmon_hip_debug.h only
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
@@ -240,7 +243,8 @@ def test_flag_constants_match_the_header():
     """respmon_amd/_capi.py mirrors the RM_FLAG_* values of include/respmon_hip.h (the ctypes boundary has no compiler to do it)."""
     import re
     from respmon_amd import _capi
-    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "respmon_hip.h")).read()
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    text = open(os.path.join(inc, "respmon_hip.h")).read() + open(os.path.join(inc, "respmon_hip_debug.h")).read()
     flags = dict(re.findall(r"#define\s+(RM_FLAG_\w+)\s+(\d+)u", text))
     assert len(flags) >= 9
     for name, value in flags.items():
