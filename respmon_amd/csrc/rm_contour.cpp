@@ -325,6 +325,34 @@ int simple_shape_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, R
     return 1;
 }
 
+// The same rule from the per-row records of k_heat_rows_u8 (rm_kernels.h): rec[y] = first | last << 16 | runs << 32 | 1 << 48 for a row
+// that holds foreground, 0 for one that does not.  *y0 / *y1: first / last row with foreground (y1 < y0: none) -- what the border
+// following needs when the rule does not settle the image.  Returns 1 and fills `out` for ONE hole-free blob, 0 otherwise.
+int simple_shape_row_records(const uint64_t *rec, int H, int W, int *y0, int *y1, RoiResult *out)
+{
+    int pf = 0, pl = -1, xmin = W, xmax = -1, ya = H, yb = -1;
+    bool ok = true;
+    for (int y = 0; y < H; ++y) {
+        const uint64_t r = rec[y];
+        if (!r) continue;
+        const int first = (int)(r & 0xffffu), last = (int)((r >> 16) & 0xffffu), runs = (int)((r >> 32) & 0xffffu);
+        if (yb >= 0) {
+            if (y != yb + 1) ok = false;                                    // foreground below an empty row: two components
+            else if (!(first <= pl + 1 && last >= pf - 1)) ok = false;      // the runs of the two rows do not touch
+        }
+        if (runs != 1) ok = false;
+        if (y < ya) ya = y;
+        yb = y; pf = first; pl = last;
+        xmin = first < xmin ? first : xmin; xmax = last > xmax ? last : xmax;
+    }
+    *y0 = ya; *y1 = yb;
+    if (yb < 0 || !ok) return 0;
+    out->found = 1; out->n_contours = 1;
+    out->x = xmin; out->y = ya; out->w = xmax - xmin + 1; out->h = yb - ya + 1;
+    out->area = -1.0;   // (not computed: the only contour is the largest one whatever its area)
+    return 1;
+}
+
 int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out)
 {
     out->found = 0; out->n_contours = 0; out->area = 0.0;

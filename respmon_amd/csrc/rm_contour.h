@@ -20,6 +20,9 @@ int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y
 // the shortcut in front of it: 1 and the ROI when rows [y0, y1] (all the foreground there is) form ONE hole-free blob -- one run per row,
 // neighbouring runs touching --, 0 otherwise; nothing is followed, nothing unpacked
 int simple_shape_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out);
+// ... from the per-row records of k_heat_rows_u8 (first | last << 16 | runs << 32 | 1 << 48; 0 = no foreground in the row); also returns the
+// rows [*y0, *y1] that hold foreground (y1 < y0: none)
+int simple_shape_row_records(const uint64_t *rec, int H, int W, int *y0, int *y1, RoiResult *out);
 // ... when the device has labelled the 8-connected components (rm_ccl.h): one record per component, root = its smallest
 // pixel index (where the outer border starts), bounding box x = minx, y = root / W, width w1 + 1, height h1 + 1.  Only borders whose bound
 // (w-1)*(h-1) can reach the best area found so far are followed, straight on the packed image.  Same result as the calls above.

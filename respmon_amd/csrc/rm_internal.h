@@ -103,6 +103,7 @@ struct DebugKnobs {
     int ccl_table = -1;           // k_ccl_bbox: 1 with / 0 without the per-tile LDS table of boxes, -1 by the last component count
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
+    int heat_rows = 1;            // 0: k_heat_to_u8 (flat over the pixels, row flags) also where rows are whole words, instead of k_heat_rows_u8 (row records)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
@@ -118,11 +119,14 @@ struct RoiSlot {
     uint8_t *h_bin = nullptr; size_t h_bin_cap = 0;       // bit-packed thresholded image + H row flags (k_heat_to_u8)
     uint8_t *h_rows_dirty = nullptr;                       // the row-flag part of h_bin that is known to be all zero
     CclComp *h_comps = nullptr; size_t h_comps_cap = 0;    // [0] = {count, -, -, -}, then one record per component
+    // record path (k_heat_rows_u8): what the last extraction on this slot left non-zero -- image words [dirty_w0, dirty_w1], records
+    // [dirty_r0, dirty_r1] --, zeroed by the next roi_launch on the slot; dirty_geom: the buffer layout they belong to
+    size_t dirty_w0 = 1, dirty_w1 = 0, dirty_geom = 0; int dirty_r0 = 0, dirty_r1 = -1;
     int *h_unserved = nullptr;      // set by k_masked_sum_tiles when it left the sum to a dense kernel nobody enqueued (rm_locate)
 };
 constexpr int ROI_SLOTS = 3;
 // what the host half of the ROI stage has to know about the launches it finishes
-struct RoiPending { int H = 0, W = 0, slot = 0; size_t nwords = 0, comps_cap = 0; bool label = false, clip = false; };
+struct RoiPending { int H = 0, W = 0, slot = 0; size_t nwords = 0, comps_cap = 0, rec_off = 0; bool label = false, clip = false, rows = false; };
 // one rm_locate_submit whose rm_locate_result has not been called yet (the arguments: a selection that overflows the value store is
 // taken again through the synchronous rm_locate)
 struct LocateTicket {

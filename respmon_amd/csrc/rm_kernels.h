@@ -2300,6 +2300,94 @@ RM_KERNEL __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t np
     }
 }
 
+// The same for images whose rows are whole 64-pixel words (W % 64 == 0: 1080p, 720p, 4K), one workgroup per image row.  Beside the
+// packed image the host gets ONE 8-byte record per row that holds foreground,
+//     rec[y] = first | last << 16 | min(runs, 0xffff) << 32 | 1 << 48        (first / last foreground column, runs of foreground)
+// so the host's one-blob rule (rm_contour.cpp simple_shape_row_records: one run per row, neighbouring runs touching => one hole-free
+// 8-connected component => the ROI is the bounding box of the runs, base.py:568-575) reads H x 8 bytes instead of hunting through
+// the image rows the device has just written (lines no host cache holds: ~10 us of the 48 us the GPU idles between two synchronous
+// locate() calls at 1080p).  The image words still travel for the images the rule does not settle (the host then follows the
+// borders as before).  Wave w of the row takes the words w, w + 4, ...; the words meet in LDS, wave 0 folds them.
+constexpr int HR_MAXW = 512;   // words per row the row kernel takes (W <= 32768)
+RM_KERNEL __launch_bounds__(256) void k_heat_rows_u8(const double *heat, int H, int W, const CollapseState *st, int threshold, uint8_t *avg_u8,
+                                                      uint8_t *binary, unsigned long long *bits, unsigned long long *rec, const int *tile_const)
+{
+    RM_TRACE_SCOPE(7);
+    __shared__ unsigned long long s_words[HR_MAXW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = blockIdx.x, nw = W >> 6;
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    const double *row = heat + (size_t)y * W;
+    constexpr int HU = 4;
+    const int trow = (y / CT_H) * tiles_x;
+    double hv[HU];
+    auto fetch = [&](int j0) __attribute__((always_inline)) {   // words j0, j0 + 4, .. of this wave, requested together
+        if (tile_const) {
+            int cst[HU];
+            double h0[HU];
+#pragma unroll
+            for (int k = 0; k < HU; ++k) {
+                const int j = j0 + 4 * k, jc = j < nw ? j : 0;
+                cst[k] = tile_const[trow + (jc * 64) / CT_W];
+                h0[k] = row[jc * 64];
+            }
+#pragma unroll
+            for (int k = 0; k < HU; ++k) {
+                const int j = j0 + 4 * k;
+                hv[k] = (cst[k] != 0 && j < nw) ? row[j * 64 + lane] : h0[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < HU; ++k) { const int j = j0 + 4 * k; hv[k] = j < nw ? row[j * 64 + lane] : 0.0; }
+        }
+    };
+    fetch(wave);
+    const double mn = f64_unkey(fold_min_keys(st->heat_min_keys, st->heat_min_key));
+    const double mx = f64_unkey(fold_max_keys(st->heat_max_keys, st->heat_max_key));
+    const double range = mx - mn;
+    for (int j0 = wave; j0 < nw; j0 += 4 * HU) {
+        if (j0 != wave) fetch(j0);
+#pragma unroll
+        for (int k = 0; k < HU; ++k) {
+            const int j = j0 + 4 * k;
+            if (j >= nw) break;                               // wave-uniform
+            const size_t i = (size_t)y * W + (size_t)j * 64 + lane;
+            const double nrm = (hv[k] - mn) / range;          // base.py:563 (NaN when the heatmap is flat)
+            const uint8_t u = f64_to_u8_trunc(nrm * 255);     // transforms.py:26-29
+            const uint8_t b = (u > threshold) ? 255 : 0;      // cv2.threshold THRESH_BINARY, base.py:566
+            if (avg_u8) avg_u8[i] = u;
+            if (binary) binary[i] = b;
+            const unsigned long long m = __ballot(b != 0);
+            if (lane == 0) {
+                s_words[j] = m;
+                if (m) bits[i >> 6] = m;                      // the host keeps the image all-zero between calls: only set words travel
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    int first = 0x7fffffff, last = -1, runs = 0;
+    for (int c = 0; c < nw; c += 64) {
+        const int j = c + lane;
+        const unsigned long long m = j < nw ? s_words[j] : 0ull;
+        const unsigned long long prev = (j > 0 && j < nw) ? (s_words[j - 1] >> 63) : 0ull;
+        if (m) {
+            const int a = j * 64 + __builtin_ctzll(m), b = j * 64 + 63 - __builtin_clzll(m);
+            first = a < first ? a : first;
+            last = b > last ? b : last;
+            runs += __popcll(m & ~((m << 1) | prev));
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int f2 = __shfl_xor(first, d), l2 = __shfl_xor(last, d), r2 = __shfl_xor(runs, d);
+        first = f2 < first ? f2 : first; last = l2 > last ? l2 : last; runs += r2;
+    }
+    if (lane == 0 && runs > 0)
+        rec[y] = (unsigned long long)first | ((unsigned long long)last << 16) | ((unsigned long long)(runs > 0xffff ? 0xffff : runs) << 32) | (1ull << 48);
+    (void)H;
+}
+
 // ----------------------------------------------------------------------------------------
 // Sparse heatmap exchange between GPUs (one stream per GPU, dist.locate_streams).  A stream's heatmap is ONE
 // constant -- the time average of `min` -- in every tile none of whose frames survived the pruning (98 % of the

@@ -31,8 +31,10 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     ctx->state_fresh = false;   // the heatmap extrema are (or have been) reduced into the state
     // the thresholded image goes to the host bit-packed (npix / 8 bytes) plus one "row holds foreground" byte per row: the
     // kernel stores both straight into pinned, device-mapped host memory (no copy-engine hop)
+    // ... and, for images whose rows are whole words, one 8-byte record per row (k_heat_rows_u8) behind the row flags
     const size_t nwords = (npix + 63) / 64;
-    const size_t need = nwords * 8 + (size_t)H;
+    const size_t rec_off = (nwords * 8 + (size_t)H + 7) & ~(size_t)7;
+    const size_t need = rec_off + (size_t)H * 8;
     if (rs.h_bin_cap < need) {
         if (rs.h_bin) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(rs.h_bin)); }
         rs.h_bin = nullptr; rs.h_bin_cap = 0;
@@ -41,8 +43,15 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         rs.h_rows_dirty = nullptr;
     }
     uint8_t *h_rows = rs.h_bin + nwords * 8;
-    // invariant between calls: image words and row flags are all zero (the rows a call read are zeroed again below)
-    if (rs.h_rows_dirty != h_rows) { std::memset(rs.h_bin, 0, need); rs.h_rows_dirty = h_rows; }
+    // invariant between calls: image words, row flags and row records are all zero.  The flag path zeroes what it read in roi_finish;
+    // the record path leaves that to the NEXT launch on the slot -- here, while the GPU is busy with the frame-buffer kernel, instead
+    // of on the host path between two calibrations
+    if (rs.h_rows_dirty != h_rows || rs.dirty_geom != need) { std::memset(rs.h_bin, 0, rs.h_bin_cap); rs.h_rows_dirty = h_rows; rs.dirty_geom = need; rs.dirty_w1 = 0; rs.dirty_w0 = 1; }
+    else if (rs.dirty_w1 >= rs.dirty_w0) {
+        std::memset(rs.h_bin + rs.dirty_w0 * 8, 0, (rs.dirty_w1 - rs.dirty_w0 + 1) * 8);
+        std::memset(rs.h_bin + rec_off + (size_t)rs.dirty_r0 * 8, 0, (size_t)(rs.dirty_r1 - rs.dirty_r0 + 1) * 8);
+        rs.dirty_w1 = 0; rs.dirty_w0 = 1;
+    }
     uint8_t *dev_bin = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dev_bin, rs.h_bin, 0));
     PhaseTimer *pt_roi = new PhaseTimer(ctx, 3, s);
@@ -71,6 +80,7 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     }
     unsigned long long *d_bits = nullptr;
     const size_t comps_cap = std::min<size_t>(npix / 4 + 2, (size_t)1 << 18);
+    bool rows = false;
     if (label) {
         int *d_label = nullptr; CclBox *d_box = nullptr; unsigned int *d_cnt = nullptr; int *d_list = nullptr;
         RM_TRY(ws(ctx, "ccl_list", comps_cap, &d_list));
@@ -102,6 +112,12 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_ccl_publish<>, dim3(64), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps);
         LAUNCH_CHECK();
+    } else if ((W & 63) == 0 && (W >> 6) <= HR_MAXW && ctx->dbg.heat_rows) {
+        // rows of whole words: a workgroup per row, one record per row with foreground beside the packed image (k_heat_rows_u8)
+        rows = true;
+        hipLaunchKernelGGL(k_heat_rows_u8<>, dim3((unsigned)H), dim3(256), 0, s, heat, H, W, st, threshold, avg_u8, binary, (unsigned long long *)dev_bin,
+                           (unsigned long long *)(dev_bin + rec_off), tile_const);
+        LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(k_heat_to_u8<>, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
                            (unsigned long long *)dev_bin, dev_bin + nwords * 8, (unsigned long long *)nullptr, (int *)nullptr,
@@ -110,6 +126,7 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     }
     delete pt_roi; pt_roi = nullptr;
     pd.H = H; pd.W = W; pd.slot = ctx->cur_slot; pd.nwords = nwords; pd.comps_cap = comps_cap; pd.label = label; pd.clip = clip;
+    pd.rows = rows; pd.rec_off = rec_off;
     return RM_OK;
 }
 
@@ -124,8 +141,18 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
     {
         const auto t0 = std::chrono::steady_clock::now();
         int y0 = H, y1 = -1;   // rows that hold foreground
-        for (int y = 0; y < H; ++y)
-            if (h_rows[y]) { if (y < y0) y0 = y; y1 = y; h_rows[y] = 0; }
+        bool settled = false;
+        if (pd.rows) {
+            // one record per row with foreground: the one-blob rule needs nothing else (the image is read only when it fails)
+            settled = simple_shape_row_records((const uint64_t *)(rs.h_bin + pd.rec_off), H, W, &y0, &y1, &r) && ctx->dbg.host_simple_shape && !clip;
+            if (y1 >= y0) {   // what the next launch on this slot zeroes (roi_launch): the words of rows y0 .. y1 and their records
+                rs.dirty_w0 = ((size_t)y0 * W) >> 6; rs.dirty_w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
+                rs.dirty_r0 = y0; rs.dirty_r1 = y1;
+            }
+        } else {
+            for (int y = 0; y < H; ++y)
+                if (h_rows[y]) { if (y < y0) y0 = y; y1 = y; h_rows[y] = 0; }
+        }
         if (clip && y1 >= y0) {
             // OpenCV <= 3.1: the 1-pixel image frame is zeroed before tracing (the host copy is ours to change)
             uint64_t *hb = (uint64_t *)rs.h_bin;
@@ -138,12 +165,13 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
         }
         const size_t ncomp = label ? (size_t)(unsigned int)rs.h_comps[0].root : 0;
         ctx->label_used = label && ncomp <= comps_cap;
-        if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
+        if (settled) {
+        } else if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
             largest_external_contour_labelled((const uint64_t *)rs.h_bin, H, W, (const LabelComp *)(rs.h_comps + 1), ncomp, &r);
         else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r)))
             largest_external_contour_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r);
         ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
-        if (y1 >= y0) {   // restore the all-zero image: the words that cover rows y0 .. y1
+        if (y1 >= y0 && !pd.rows) {   // restore the all-zero image: the words that cover rows y0 .. y1
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
             std::memset(rs.h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
         }

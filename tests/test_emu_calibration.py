@@ -689,7 +689,7 @@ def _roi_shapes(rng):
     run crossing the 64-pixel words, a blob on the image frame, a single pixel, nothing, noise."""
     import scipy.ndimage as ndi
     out = []
-    for (H, W) in ((24, 64), (33, 128), (40, 192)):
+    for (H, W) in ((24, 64), (33, 128), (40, 192), (30, 100)):
         z = np.zeros((H, W))
         a = z.copy(); a[5:15, 10:50] = 1; out.append(("rectangle", a))
         a = z.copy(); a[4:20, 8:40] = 1; a[8:16, 16:32] = 0; out.append(("ring", a))
@@ -729,12 +729,18 @@ def test_emu_simple_shape_shortcut_equals_border_following(emu, oracle):
             emu.debug_set("host_simple_shape", 0)       # every border followed on the host
             slow, u8s, _ = emu.heatmap_to_roi(heat, threshold=thr)
             emu.debug_set("host_simple_shape", 1)
-            for attempt in range(2):
-                short, u8f, binf = emu.heatmap_to_roi(heat, threshold=thr)
-                assert short == slow == want, (name, heat.shape, attempt, short, slow, want)
-                assert np.array_equal(u8f, u8s) and np.array_equal(binf, np.where(u8s > thr, 255, 0).astype(np.uint8)), (name, attempt)
+            # heat_rows 1: a workgroup per image row + one record per row (k_heat_rows_u8, rows of whole words only); 0: the flat kernel
+            # + row flags (k_heat_to_u8).  Twice each: the second extraction finds what the first one left in the pinned areas
+            for rows_mode in (1, 0, 1):
+                emu.debug_set("heat_rows", rows_mode)
+                for attempt in range(2):
+                    short, u8f, binf = emu.heatmap_to_roi(heat, threshold=thr)
+                    assert short == slow == want, (name, heat.shape, rows_mode, attempt, short, slow, want)
+                    assert np.array_equal(u8f, u8s) and np.array_equal(binf, np.where(u8s > thr, 255, 0).astype(np.uint8)), (name, attempt)
+                assert emu.heatmap_to_roi(heat, threshold=thr, clip_frame=True)[0] == oracle.roi_from_heatmap_u8(ref_u8, thr, clip_frame=True), (name, rows_mode)
     finally:
         emu.debug_set("host_simple_shape", 1)
+        emu.debug_set("heat_rows", 1)
 
 
 def test_emu_small_pyramid_split_over_workgroups(emu, oracle):
