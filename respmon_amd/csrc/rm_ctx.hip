@@ -112,6 +112,8 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dc_segs") d.dc_segs = (int)value;
     else if (k == "dc_wpg") d.dc_wpg = (int)value;
     else if (k == "dc_split") d.dc_split = (int)value;
+    else if (k == "dc_prio") d.dc_prio = (int)value;
+    else if (k == "dc_prio_shift") d.dc_prio_shift = (int)value;
     else if (k == "store_slots") d.store_slots = value;
     else if (k == "store_default_slots") d.store_default_slots = value;
     else if (k == "collapse_fused") d.collapse_fused = (int)value;

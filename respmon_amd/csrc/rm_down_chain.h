@@ -41,6 +41,10 @@ struct DownGeom {
     int wpg;                         // waves (= adjacent strips of one segment) per workgroup, marching in lockstep
     int T;
     int vec;                         // 1: 16-byte aligned vector loads are legal for this buffer
+    int prio;                        // issue priority of the waves (s_setprio), see DownChain::set_prio: 2 (default) rotating every 64 input rows;
+                                     // developer settings: 0 none, 1 static (younger workgroups higher), 3 static (older higher)
+    int prio_shift;                  // log2 of the rotation period in input rows (6)
+    int prio_rank;                   // dispatch-order quartile of this workgroup (0 = oldest), set by the kernel
 };
 
 // compile-time strip width (level-S columns) per chain depth: level-0 span stays <= ~380 pixels
@@ -93,6 +97,20 @@ __device__ __forceinline__ double wave_from_next(double v)
 #else
     int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+#endif
+}
+
+// lane 0 receives lane 2's value, every other lane keeps its own (DPP quad_perm [2,1,2,3] on row 0 / bank 0 only): the reflected
+// column -2 -> 2 of a row whose first lane-load sits at the left image border (run_dpp)
+__device__ __forceinline__ double lane0_from_lane2(double v)
+{
+#ifdef RM_HIPEMU
+    const double o = __shfl(v, 2);
+    return (threadIdx.x & 63) == 0 ? o : v;
+#else
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0xE6, 0x1, 0x1, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0xE6, 0x1, 0x1, false);
     return __hiloint2double(hi, lo);
 #endif
 }
@@ -192,6 +210,23 @@ struct DownChain {
     // The waves of a workgroup are the adjacent strips of one (frame, segment): a barrier per prefetch round
     // keeps them on the same input rows, so the columns two strips share are fetched from HBM once and hit
     // in L2 for the neighbour.  Raw s_barrier: no waitcnt, the prefetched rows stay in flight across it.
+    // The SIMD's issue arbiter prefers the OLDER of its resident waves (MI355X_MICROARCH.md, "two waves per SIMD"): with one resident
+    // round of workgroups the first-dispatched quarter of a launch finishes ~8 % earlier than the last (workgroup timelines), and the
+    // chip spends the end of the kernel with too few waves to keep HBM busy.  Explicit priorities outrank age.
+    __device__ __forceinline__ void set_prio(int v) const
+    {
+#ifndef RM_HIPEMU
+        switch (v & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#else
+        (void)v;
+#endif
+    }
+
     __device__ __forceinline__ void lockstep() const
     {
 #ifndef RM_HIPEMU
@@ -431,13 +466,19 @@ struct DownChain {
         // BORDER_REFLECT_101 on the column index: only chunks that contain slots outside the image need it
         // (chunk 0 at the left image edge, the chunk(s) holding columns W, W+1 at the right edge).  Per lane
         // and flagged chunk one packed word is precomputed: source lane and component for a and for b.
+        // The two common cases need no table: (left) chunk 0 starts at column -2, so only lane 0 holds out-of-image columns (-2, -1);
+        // its clamped load brought columns (0, 1): b = s[1] is already the reflection of -1, a must become s[2] = lane 2's a -- one
+        // DPP move; (right, even W) the only out-of-image column a tap reaches is W, the first of its lane-load, and the clamped load
+        // of that lane brought columns (W-2, W-1): a = s[W-2] is its reflection already.  (The shuffles of the table form cost the
+        // two outer strips of a row ~6 % -- and their lockstep partners with them: workgroup timelines, round 5.)
+        const bool fast_l = fix_l && P == -2, fast_r = fix_r && (W & 1) == 0;
         unsigned fixq = 0;       // bit q: chunk q has out-of-image slots (wave-uniform)
         int fixw[NQ1];           // per lane: bits 0-5 src lane of a, 6 src comp, 7 fix a; 8-13 / 14 / 15 the same for b
 #pragma unroll
         for (int q = 0; q < NQ1; ++q) {
             const int base = P + 124 * q;
             fixw[q] = 0;
-            if ((fix_l && base < 0) || (fix_r && base + 127 >= W)) {
+            if ((fix_l && base < 0 && !fast_l) || (fix_r && base + 127 >= W && !fast_r)) {
                 fixq |= 1u << q;
                 const int ca = base + 2 * lane, cb = ca + 1;
                 const int ra = reflect101(ca, W) - base, rb = reflect101(cb, W) - base;
@@ -456,6 +497,7 @@ struct DownChain {
                     if (fw & 0x80) a = (fw & 0x40) ? a_from_b : a_from_a;
                     if (fw & 0x8000) b = (fw & 0x4000) ? b_from_b : b_from_a;
                 }
+                if (q == 0 && fast_l) a = lane0_from_lane2(a);
                 const double a_prev = wave_from_prev(a), b_prev = wave_from_prev(b), a_next = wave_from_next(a);
                 n[q] = a * 6 + (b_prev + b) * 4 + a_prev + a_next;
             }
@@ -463,7 +505,10 @@ struct DownChain {
         Raw16 regs[DC_PREFETCH][NQ1];
 #pragma unroll
         for (int i = 0; i < DC_PREFETCH; ++i) issue(min(p_first + i, p_last), regs[i]);
+        if (g.prio == 1) set_prio(g.prio_rank);
+        else if (g.prio == 3) set_prio(3 - g.prio_rank);
         for (int base = p_first; base <= p_last; base += DC_PREFETCH) {
+            if (g.prio == 2 && ((base - p_first) & ((1 << g.prio_shift) - 1)) == 0) set_prio(g.prio_rank + ((base - p_first) >> g.prio_shift));
             lockstep();
 #pragma unroll
             for (int i = 0; i < DC_PREFETCH; ++i) {
@@ -624,6 +669,7 @@ __global__ __launch_bounds__(64 * DC_MAX_WPG) void k_down_chain(const Tin *frame
     const int strip = grp * g.wpg + wave;
     if (strip >= g.strips) return;  // a terminated wave no longer counts at s_barrier
     double *lds = lds_all + wave * down_chain_lds_doubles<Tin, S>();
+    g.prio_rank = (int)(((blockIdx.x >> 3) * 4u) / max(1u, gridDim.x >> 3));   // quartile of the dispatch order inside this workgroup's XCD
     DownChain<Tin, S, VB> dc(g, lds);
     dc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }
@@ -664,7 +710,7 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
                            int force_segs = 0, int force_wpg = 0, int split_permille = 0)
 {
     if (S < 1 || S > 5 || y_end <= y_begin) return false;
-    g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end;
+    g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end; g.prio = 0; g.prio_rank = 0; g.prio_shift = 6;
     for (int k = 0; k <= S; ++k) { g.h[k] = h[k]; g.w[k] = w[k]; }
     const int SW = S == 1 ? StripWidth<1>::SW : S == 2 ? StripWidth<2>::SW : S == 3 ? StripWidth<3>::SW
                  : S == 4 ? StripWidth<4>::SW : StripWidth<5>::SW;

@@ -34,6 +34,8 @@ static int launch_down_chain_t(rm_ctx *ctx, const void *frames, int T, const std
     const Tin *f = (const Tin *)frames;
     DownGeom g;
     if (!make_down_geom(S, h.data(), w.data(), T, vec_ok, 0, h[S], g, tiny, ctx->dbg.dc_segs, ctx->dbg.dc_wpg, ctx->dbg.dc_split)) return fail(RM_E_UNSUPPORTED, "down chain geometry");
+    g.prio = ctx->dbg.dc_prio;
+    if (ctx->dbg.dc_prio_shift >= 1 && ctx->dbg.dc_prio_shift <= 12) g.prio_shift = ctx->dbg.dc_prio_shift;
     if (down_chain_hot_ok(S, h.data())) return launch_down_chain_g<Tin, false>(f, T, g, out, s);
     return launch_down_chain_g<Tin, true>(f, T, g, out, s);
 }
