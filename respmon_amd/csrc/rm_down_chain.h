@@ -82,37 +82,24 @@ template <int S, int SW, int V> struct DCLayout {
 // the end lane keeps its own value (callers never use it)
 __device__ __forceinline__ double wave_from_prev(double v)
 {
-#ifdef RM_HIPEMU
-    return __shfl_up(v, 1);
-#else
     int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xF, 0xF, false);
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
-#endif
 }
 __device__ __forceinline__ double wave_from_next(double v)
 {
-#ifdef RM_HIPEMU
-    return __shfl_down(v, 1);
-#else
     int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
-#endif
 }
 
 // lane 0 receives lane 2's value, every other lane keeps its own (DPP quad_perm [2,1,2,3] on row 0 / bank 0 only): the reflected
 // column -2 -> 2 of a row whose first lane-load sits at the left image border (run_dpp)
 __device__ __forceinline__ double lane0_from_lane2(double v)
 {
-#ifdef RM_HIPEMU
-    const double o = __shfl(v, 2);
-    return (threadIdx.x & 63) == 0 ? o : v;
-#else
     int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0xE6, 0x1, 0x1, false);
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0xE6, 0x1, 0x1, false);
     return __hiloint2double(hi, lo);
-#endif
 }
 
 template <typename Tin> struct VecTraits;
@@ -135,10 +122,10 @@ struct alignas(16) Raw16 { unsigned int x, y, z, w; };
 __device__ __forceinline__ Raw16 load_raw16(const void *p) { return *reinterpret_cast<const Raw16 *>(p); }
 __device__ __forceinline__ Raw16 load_raw16_stream(const void *p)
 {
-#if defined(RM_DC_NT_LOADS) && !defined(RM_HIPEMU)
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#if defined(RM_DC_NT_LOADS)
+    typedef RM_VEC(unsigned int, 4) u32x4;
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    Raw16 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    Raw16 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; r.w = v[3];
     return r;
 #else
     return *reinterpret_cast<const Raw16 *>(p);
@@ -215,23 +202,17 @@ struct DownChain {
     // chip spends the end of the kernel with too few waves to keep HBM busy.  Explicit priorities outrank age.
     __device__ __forceinline__ void set_prio(int v) const
     {
-#ifndef RM_HIPEMU
         switch (v & 3) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
         }
-#else
-        (void)v;
-#endif
     }
 
     __device__ __forceinline__ void lockstep() const
     {
-#ifndef RM_HIPEMU
         if (g.wpg > 1) __builtin_amdgcn_s_barrier();
-#endif
     }
 
     // index of column c inside row buffer K (columns c0-2 .. are stored de-interleaved)
@@ -661,11 +642,7 @@ __global__ __launch_bounds__(64 * DC_MAX_WPG) void k_down_chain(const Tin *frame
         seg = inner / groups; grp = inner - seg * groups;
     }
     if (t >= g.T) return;
-#ifdef RM_HIPEMU
-    const int wave = threadIdx.x >> 6;
-#else
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep the geometry in SGPRs
-#endif
     const int strip = grp * g.wpg + wave;
     if (strip >= g.strips) return;  // a terminated wave no longer counts at s_barrier
     double *lds = lds_all + wave * down_chain_lds_doubles<Tin, S>();
@@ -747,9 +724,6 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
     g.wpg = RM_DC_WPG;
 #endif
     if (force_wpg >= 1 && force_wpg <= DC_MAX_WPG) g.wpg = force_wpg;
-#ifdef RM_HIPEMU
-    g.wpg = 1;
-#endif
     return true;
 }
 

@@ -268,7 +268,7 @@ struct RegChain {
     // hoists the unpacking of all B rows of a block to the front (128 more live registers, one wave per SIMD)
     static __device__ __forceinline__ void row_fence()
     {
-#if !defined(RM_HIPEMU) && RM_NARROW_FENCE
+#if RM_NARROW_FENCE
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }

@@ -20,6 +20,12 @@
 // Non-template kernels are function templates with one defaulted parameter (launched as k_name<>): every translation unit of the
 // library includes every kernel header, and a unit generates device code only for the kernels it launches.
 #define RM_KERNEL template <int RM_UNIT_ = 0> __global__
+// N-element vector type (clang spells it ext_vector_type, the g++ of the tests' host emulation vector_size): MFMA accumulators, 16-byte loads
+#ifdef RM_HIPEMU
+#define RM_VEC(T, N) T __attribute__((vector_size(sizeof(T) * (N))))
+#else
+#define RM_VEC(T, N) T __attribute__((ext_vector_type(N)))
+#endif
 
 namespace rm {
 
@@ -146,20 +152,6 @@ __device__ __forceinline__ uint8_t f64_to_u8_trunc(double v255)
 // dependent LDS round trips per 32-bit word -- the latency-bound tail kernels spent 1-3 us each in their folds and extrema.
 //   row_shr:1,2,4,8 leave the reduction of each 16-lane row in its last lane (a lane without a source keeps its own value:
 //   harmless for min / max), row_bcast:15 folds rows 0->1 and 2->3, row_bcast:31 folds the lower half into lane 63.
-#ifdef RM_HIPEMU
-template <typename T, typename Op> __device__ __forceinline__ T wave_reduce(T v, Op op)
-{
-    for (int m = 32; m >= 1; m >>= 1) { const T o = __shfl_xor(v, m); v = op(o, v); }
-    return v;
-}
-template <typename Less> __device__ __forceinline__ void wave_arg_reduce(double &v, int &idx, Less less)
-{
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = __shfl_xor(v, m); const int oi = __shfl_xor(idx, m);
-        if (less(ov, v)) { v = ov; idx = oi; }
-    }
-}
-#else
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i32(int v)
 {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
@@ -210,7 +202,6 @@ template <typename Less> __device__ __forceinline__ void wave_arg_reduce(double 
     from_bits(((unsigned long long)hi << 32) | lo, v);
     idx = __builtin_amdgcn_readlane(idx, 63);
 }
-#endif
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, [](double o, double w) { return (o < w) ? o : w; }); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, [](double o, double w) { return (o > w) ? o : w; }); }
 
@@ -457,8 +448,7 @@ RM_KERNEL __launch_bounds__(64) void k_temporal_inv(const double *y, int nk, siz
 constexpr int TM_W = 4;            // waves per workgroup
 constexpr int TM_MAX_HALF = 3;     // up to 48 merged rows per symmetry class (n = 1024 at 10 fps has 47 + 47)
 
-#ifndef RM_HIPEMU   // (the host emulation of tests/emu runs the two-stage VALU kernels above)
-typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef RM_VEC(double, 4) v4f64;
 
 // mirror_n > 0: also store output frame s as frame mirror_n - s (the full [n, NP] array of the module-level filter call)
 template <int NH>
@@ -577,9 +567,7 @@ __global__ __launch_bounds__(64 * TM_W, NH == 1 ? 3 : 2) void k_temporal_sym(con
     }
     RM_TRACE_MARK(2, 3);
 }
-#endif
 
-#ifndef RM_HIPEMU
 // The same products for LARGE levels (4K x 512, skip 2: 518 400 pixels per frame, 2.1 GB in, 1.07 GB out): throughput, not
 // latency, is what counts there, and k_temporal_sym's K-split costs it an LDS exchange plus a barrier per 16 pixels and a
 // frontier of only 128 contiguous bytes per frame and workgroup in DRAM.  Here a WAVE owns 16 pixel columns for the whole
@@ -681,7 +669,6 @@ __global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__rest
         }
     }
 }
-#endif
 
 // ----------------------------------------------------------------------------------------
 // transforms.py:72-79 temporal_bandpass_filter (the IIR alternative to the FFT filter, selectable through
@@ -963,23 +950,15 @@ __device__ __forceinline__ void split_rc(int i, int nw, float inv_nw, int &r, in
 // emulation models lanes as fibers and needs a real barrier.)
 __device__ __forceinline__ void wave_sync()
 {
-#ifdef RM_HIPEMU
-    __syncthreads();
-#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
 }
 
 // wave-uniform value into a scalar register (index math derived from it then runs on the scalar unit)
 __device__ __forceinline__ int uniform(int v)
 {
-#ifdef RM_HIPEMU
-    return v;
-#else
     return __builtin_amdgcn_readfirstlane(v);
-#endif
 }
 
 // per (frame, tile) bounds of the level-S footprint: every full-resolution value of the tile
@@ -1213,11 +1192,7 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom
 // Same bounds (min / max are exact in any order); the lattice samples are taken where a LANE met its extreme values, so the
 // sample set -- and with it how many pairs the selection keeps, never the result -- differs from k_frame_bounds'.
 constexpr int FB_MAXNL = 16;   // row length <= 64 * FB_MAXNL level-S columns
-#ifdef RM_HIPEMU
-#define RM_WAVES_PER_EU(n)
-#else
 #define RM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget of 512 / n per lane
-#endif
 // FB_TR (template): tile rows per wave -- 8 where that still gives every SIMD a few waves (halo rows: 12 %), 2 for small images
 __host__ __device__ __forceinline__ int fb_row_pitch(int wS) { return wS + (wS >> 4) + 2; }
 

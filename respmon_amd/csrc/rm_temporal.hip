@@ -224,7 +224,6 @@ int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const Tempor
         return RM_OK;
     }
     const int mirror_n = full ? T : 0;
-#ifndef RM_HIPEMU
     // large levels: one wave per 16 pixel columns, no K-split (k_temporal_sym_px); the choice depends on (T, NP) only
     int cus_t = 256;
     (void)hipDeviceGetAttribute(&cus_t, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -245,7 +244,6 @@ int launch_temporal(rm_ctx *ctx, const double *x, int T, size_t NP, const Tempor
         LAUNCH_CHECK();
         return RM_OK;
     }
-#endif
     const size_t sh1 = sizeof(double) * (size_t)T * TF_KC, sh2 = sizeof(double) * (size_t)op.nk * TF_SC;
     if (sh1 > 64 * 1024 || sh2 > 64 * 1024) return fail(RM_E_UNSUPPORTED, "temporal filter: T=%d exceeds the LDS-staged operator (T <= 2048)", T);
     double *y = nullptr;

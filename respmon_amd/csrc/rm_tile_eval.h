@@ -337,11 +337,7 @@ constexpr int MS2_B = 48;
 
 __device__ __forceinline__ int lane_value(int v, int b)   // v of lane b (b: compile-time after unrolling), wave-uniform
 {
-#ifdef RM_HIPEMU
-    return __shfl(v, b);
-#else
     return __builtin_amdgcn_readlane(v, b);
-#endif
 }
 
 RM_KERNEL __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,
@@ -543,11 +539,7 @@ __device__ __forceinline__ double masked_gap(double acc, int n, double min_val) 
 
 __device__ __forceinline__ int lane_value_dyn(int v, int b)   // v of lane b (b wave-uniform, not compile-time)
 {
-#ifdef RM_HIPEMU
-    return __shfl(v, b);
-#else
     return __builtin_amdgcn_readlane(v, b);
-#endif
 }
 
 RM_KERNEL __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W0, int H0, const int *slot_of, const double *store, CollapseState *st,

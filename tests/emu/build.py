@@ -23,7 +23,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     units = ["rm_unity.hip", "rm_contour.cpp"]   # every product translation unit, as one unit (respmon_amd/csrc/rm_unity.hip)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
-           "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", "-Wno-unused-function", "-o", OUT]
+           "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", "-Wno-unused-function", "-Wno-attributes", "-Wno-psabi", "-o", OUT]
     for u in units:
         cmd += ["-x", "c++", os.path.join(CSRC, u)]
     subprocess.check_call(cmd)

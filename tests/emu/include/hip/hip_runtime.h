@@ -9,7 +9,12 @@
  * product package never loads the emulated build.
  *
  * Model: blocks run one after another on the calling thread; the threads of a block are
- * ucontext fibers resumed round-robin, __syncthreads() is a yield; __shared__ variables are
+ * fibers (a 20-line x86-64 stack switch: swapcontext's two signal-mask system calls per yield were most of
+ * the CPU suite's run time) resumed round-robin.  Cross-lane operations of a WAVE (shuffles, DPP, ballots, MFMA,
+ * wave barriers) are a write, a yield, a read, a yield: every lane of the wave runs the same sequence, so one
+ * round of the scheduler separates the phases.  __syncthreads() / s_barrier park a fiber until every LIVE fiber
+ * of the block has arrived (waves may reach it after different numbers of wave-level yields; a finished wave
+ * no longer takes part); __shared__ variables are
  * function-local statics (shared by the block's threads because blocks are sequential).
  * "Device memory" is host memory.
  */
@@ -27,7 +32,6 @@
 #include <functional>
 #include <mutex>
 #include <thread>
-#include <ucontext.h>
 #include <vector>
 
 #define RM_HIPEMU 1
@@ -46,9 +50,9 @@ struct dim3 {
 struct uint3_emu { unsigned x, y, z; };
 
 namespace hipemu {
-struct Fiber { ucontext_t ctx; char *stack; bool done; };
+struct Fiber { void *sp; char *stack; bool done; bool at_barrier; };
 struct Sched {
-    ucontext_t main_ctx;
+    void *main_sp = nullptr;
     std::vector<Fiber> fibers;
     Fiber *cur = nullptr;
     std::function<void()> *body = nullptr;
@@ -56,11 +60,36 @@ struct Sched {
 inline Sched &sched() { static thread_local Sched s; return s; }
 inline double *shfl_buf() { static double buf[1024]; return buf; }
 inline char *dyn_smem() { static char *p = (char *)aligned_alloc(64, 160 * 1024); return p; }
+}  // namespace hipemu
+// saves the callee-saved registers and the stack pointer of the running context in *save_sp, continues the context whose stack
+// pointer is load_sp (System V x86-64: rbx, rbp, r12-r15; the floating-point control words never change here)
+extern "C" void hipemu_swap(void **save_sp, void *load_sp);
+#ifdef RM_HIPEMU_DEFINE_TLS
+#if !defined(__x86_64__)
+#error "the host emulation's fiber switch is written for x86-64"
+#endif
+asm(".text\n.weak hipemu_swap\n.type hipemu_swap,@function\nhipemu_swap:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size hipemu_swap, .-hipemu_swap\n");
+#endif
+namespace hipemu {
 inline void fiber_entry() {
     Sched &S = sched();
     (*S.body)();
     S.cur->done = true;
-    swapcontext(&S.cur->ctx, &S.main_ctx);
+    hipemu_swap(&S.cur->sp, S.main_sp);
+    abort();   // a finished fiber is never resumed
+}
+// a fresh fiber: its first resume pops six zeroed registers and returns into fiber_entry with the stack the ABI expects at a function's
+// first instruction (16-byte aligned before the return address was pushed)
+inline void fiber_init(Fiber &f, size_t stack_bytes) {
+    uintptr_t top = ((uintptr_t)f.stack + stack_bytes) & ~(uintptr_t)15;
+    void **sp = (void **)(top - 16);          // [sp + 8] unused pad, [sp] = return address slot -> after `ret` rsp = top - 8 (== 8 mod 16)
+    *sp = (void *)&fiber_entry;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    f.sp = (void *)sp;
 }
 }  // namespace hipemu
 
@@ -79,7 +108,8 @@ thread_local dim3 gridDim;
 
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
-inline void __syncthreads() { hipemu::Sched &S = hipemu::sched(); swapcontext(&S.cur->ctx, &S.main_ctx); }
+namespace hipemu { inline void yield() { Sched &S = sched(); hipemu_swap(&S.cur->sp, S.main_sp); } }
+inline void __syncthreads() { hipemu::Sched &S = hipemu::sched(); S.cur->at_barrier = true; hipemu_swap(&S.cur->sp, S.main_sp); }
 static const int warpSize = 64;
 
 template <typename T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
@@ -87,38 +117,38 @@ template <typename T> inline T __shfl_down(T v, unsigned delta, int width = 64) 
     double *buf = hipemu::shfl_buf();
     static_assert(sizeof(T) <= sizeof(double), "shfl emu");
     std::memcpy(&buf[tid], &v, sizeof(T));
-    __syncthreads();
+    hipemu::yield();
     unsigned lane = tid % 64, src = lane + delta;
     T r = v;
     unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
     if ((lane % width) + delta < (unsigned)width && src < 64 && tid - lane + src < nthreads)
         std::memcpy(&r, &buf[tid - lane + src], sizeof(T));
-    __syncthreads();
+    hipemu::yield();
     return r;
 }
 template <typename T> inline T __shfl(T v, int src_lane, int width = 64) {
     unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     double *buf = hipemu::shfl_buf();
     std::memcpy(&buf[tid], &v, sizeof(T));
-    __syncthreads();
+    hipemu::yield();
     unsigned lane = tid % 64, src = (unsigned)src_lane & 63u;
     T r = v;
     unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
     (void)width;
     if (tid - lane + src < nthreads) std::memcpy(&r, &buf[tid - lane + src], sizeof(T));
-    __syncthreads();
+    hipemu::yield();
     return r;
 }
 inline unsigned long long __ballot(int pred) {
     unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     double *buf = hipemu::shfl_buf();
     buf[tid] = pred ? 1.0 : 0.0;
-    __syncthreads();
+    hipemu::yield();
     unsigned lane = tid % 64, nthreads = blockDim.x * blockDim.y * blockDim.z;
     unsigned long long m = 0;
     for (unsigned l = 0; l < 64; ++l)
         if (tid - lane + l < nthreads && buf[tid - lane + l] != 0.0) m |= 1ull << l;
-    __syncthreads();
+    hipemu::yield();
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
@@ -132,16 +162,88 @@ template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) {
     unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     double *buf = hipemu::shfl_buf();
     std::memcpy(&buf[tid], &v, sizeof(T));
-    __syncthreads();
+    hipemu::yield();
     unsigned lane = tid % 64, src = lane ^ (unsigned)mask;
     T r = v;
     unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
     (void)width;
     if (src < 64 && tid - lane + src < nthreads) std::memcpy(&r, &buf[tid - lane + src], sizeof(T));
-    __syncthreads();
+    hipemu::yield();
     return r;
 }
 
+/* ---- gfx950 cross-lane intrinsics the product kernels use directly (so that the code that ships is the code the CPU suite runs) ----
+ * DPP (data-parallel primitives): lane i reads the `src` of another lane chosen by dpp_ctrl; a lane whose row / bank is masked out,
+ * or whose source does not exist (bound_ctrl false), keeps `old`.  Controls modelled: quad_perm (0x00-0xFF), row_shl / row_shr /
+ * row_ror (0x101-0x12F), wave_shl:1 0x130, wave_rol:1 0x134, wave_shr:1 0x138, wave_ror:1 0x13C, row_mirror 0x140,
+ * row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143 (CDNA ISA, "DPP_CTRL"). */
+inline int hipemu_dpp_source(int lane, int ctrl) {
+    const int row = lane & ~15, l = lane & 15;
+    if (ctrl <= 0xFF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; return l + n <= 15 ? lane + n : -1; }
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; return l - n >= 0 ? lane - n : -1; }
+    if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; return row | ((l - n) & 15); }
+    if (ctrl == 0x130) return lane < 63 ? lane + 1 : -1;
+    if (ctrl == 0x134) return (lane + 1) & 63;
+    if (ctrl == 0x138) return lane > 0 ? lane - 1 : -1;
+    if (ctrl == 0x13C) return (lane - 1) & 63;
+    if (ctrl == 0x140) return row | (15 - l);
+    if (ctrl == 0x141) return row | (l & 8) | (7 - (l & 7));
+    if (ctrl == 0x142) return lane >= 16 ? row - 1 : -1;          /* lane 15 of the previous row */
+    if (ctrl == 0x143) return lane >= 32 ? 31 : -1;               /* lane 31 into the upper half */
+    fprintf(stderr, "hipemu: dpp_ctrl 0x%x is not modelled\n", ctrl); abort();
+}
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    double *buf = hipemu::shfl_buf();
+    std::memcpy(&buf[tid], &src, sizeof(int));
+    hipemu::yield();
+    const int lane = (int)(tid % 64);
+    int r = old;
+    if (((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane >> 2) & 3)) & 1)) {
+        const int sl = hipemu_dpp_source(lane, ctrl);
+        const unsigned nthreads = blockDim.x * blockDim.y * blockDim.z;
+        if (sl >= 0 && tid - lane + sl < nthreads) std::memcpy(&r, &buf[tid - lane + sl], sizeof(int));
+        else if (bound_ctrl) r = 0;
+    }
+    hipemu::yield();
+    return r;
+}
+inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(unsigned)(b & 0xffffffffll); }
+inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(unsigned)((unsigned long long)b >> 32); }
+inline double __hiloint2double(int hi, int lo) { unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double d; std::memcpy(&d, &b, 8); return d; }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+/* (used on wave-uniform values only -- the product's contract for putting them into scalar registers: the value itself) */
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+/* s_barrier: workgroup barrier without the memory waits of __syncthreads(); a finished wave no longer takes part (fiber model: a yield) */
+inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
+/* wave-level ordering points: lanes are fibers here, so the wave barrier must really hand over; fences order nothing extra */
+inline void __builtin_amdgcn_wave_barrier() { hipemu::yield(); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+template <typename T> inline T __builtin_nontemporal_load(const T *p) { return *p; }
+/* v_mfma_f64_16x16x4_f64: D[16x16] = A[16x4] B[4x16] + C.  Lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and the four
+ * elements D[4 r + l / 16][l % 16], r = 0..3 (CDNA3/4 ISA, "MFMA 16x16x4 F64").  The products of one instruction are accumulated
+ * k = 0..3 with fused multiply-adds; the hardware's internal order is not documented, which is why the tests of the kernels that use
+ * it compare against scipy within 1e-11 and never bit for bit. */
+typedef double hipemu_v4f64 __attribute__((vector_size(32)));
+inline hipemu_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_v4f64 c, int, int, int) {
+    static double abuf[1024], bbuf[1024];
+    unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    abuf[tid] = a; bbuf[tid] = b;
+    hipemu::yield();
+    const unsigned lane = tid % 64, w0 = tid - lane, j = lane % 16;
+    hipemu_v4f64 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const unsigned i = 4 * r + lane / 16;
+        double acc = c[r];
+        for (unsigned k = 0; k < 4; ++k) acc = std::fma(abuf[w0 + k * 16 + i], bbuf[w0 + k * 16 + j], acc);
+        d[r] = acc;
+    }
+    hipemu::yield();
+    return d;
+}
 inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) {
     auto *a = reinterpret_cast<std::atomic<unsigned long long> *>(p);
     unsigned long long o = a->load();
@@ -240,6 +342,8 @@ inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 template <typename F> inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
+#define hipDeviceAttributeMultiprocessorCount 63
+inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 256; return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 
@@ -265,22 +369,24 @@ template <typename F> void run_grid(dim3 grid, dim3 block, F &&body) {
                 blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
                 for (unsigned t = 0; t < nthreads; ++t) {
                     Fiber &f = S.fibers[t];
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &S.main_ctx;
-                    f.done = false;
-                    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+                    f.done = false; f.at_barrier = false;
+                    fiber_init(f, STACK);
                 }
                 unsigned live = nthreads;
                 while (live) {
                     live = 0;
+                    unsigned parked = 0;
                     for (unsigned t = 0; t < nthreads; ++t) {
                         Fiber &f = S.fibers[t];
                         if (f.done) continue;
+                        if (f.at_barrier) { ++live; ++parked; continue; }   // waits for the rest of the block
                         threadIdx.x = t % block.x; threadIdx.y = (t / block.x) % block.y; threadIdx.z = t / (block.x * block.y);
                         S.cur = &f;
-                        swapcontext(&S.main_ctx, &f.ctx);
-                        if (!f.done) ++live;
+                        hipemu_swap(&S.main_sp, f.sp);
+                        if (!f.done) { ++live; if (f.at_barrier) ++parked; }
                     }
+                    if (live && parked == live)   // every live fiber has arrived: the barrier opens
+                        for (unsigned t = 0; t < nthreads; ++t) S.fibers[t].at_barrier = false;
                 }
             }
 }
