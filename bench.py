@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--configs", default="Q,R,F,P32", help="which of those summaries to run (comma separated)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the same workload timed on the CPU oracle (0 = skip; -1 = all T "
                     "frames if host memory allows, else 64)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU needed: print the per-rank launch plan of `--gpus N` (devices, frame shards, "
+                    "the C-ABI call of a step, the collectives it issues with their byte counts) as one JSON object and exit")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="threads of the all-cores CPU figure (0 = skip, -1 = min(64, host cores))")
     a = ap.parse_args()
     T, H, W, L, S, dt = CONFIGS[a.config]
@@ -162,8 +164,66 @@ def mode_b_exchange(rdist, need):
         pol.cap, 8e-6 * (4 + pol.cap * 1025))
 
 
+def dry_run_plan(a):
+    """What `bench.py --gpus N` will do, rank by rank, computed with the library's own host-side layout functions (rm_shard_frames,
+    rm_shard_layout_flags, rm_heat_sparse_packet_doubles: no GPU needed).  First contact with an 8-GPU node then only has to
+    confirm it: the launch line, the per-rank devices and frame shards, the collectives of a step and their sizes."""
+    import ctypes
+    from respmon_amd import _capi
+    lib = _capi.load()
+    N, T, H, W, L, S = a.gpus, a.frames, a.height, a.width, a.levels, a.skip
+    esz = DT_BYTES[a.in_dtype]
+    np_ = ctypes.c_size_t()
+    _capi.check(lib, lib.rm_shard_layout_flags(H, W, L, S, 0, ctypes.byref(np_)), "rm_shard_layout_flags")
+    NP = int(np_.value)
+    cap0, cap_max = 128, 512   # RM_SPARSE_CAP_TILES / RM_SPARSE_MAX_TILES (include/respmon_hip.h)
+    pk0, pk_max = int(lib.rm_heat_sparse_packet_doubles(cap0)) * 8, int(lib.rm_heat_sparse_packet_doubles(cap_max)) * 8
+    heat_bytes = H * W * 8
+    cmax = (T + N - 1) // N
+    ranks = []
+    for r in range(N):
+        t0, t1 = ctypes.c_int(), ctypes.c_int()
+        _capi.check(lib, lib.rm_shard_frames(T, r, N, ctypes.byref(t0), ctypes.byref(t1)), "rm_shard_frames")
+        if a.mode == "sharded":
+            ranks.append({"rank": r, "device": "cuda:%d" % r, "frames": [t0.value, t1.value], "frame_buffer_bytes": (t1.value - t0.value) * H * W * esz,
+                          "all_gather_send_bytes": cmax * NP * 8, "padded_frames": cmax - (t1.value - t0.value)})
+        else:
+            ranks.append({"rank": r, "device": "cuda:%d" % r, "frames": [0, T], "stream_seed": 1234 + r, "frame_buffer_bytes": T * H * W * esz})
+    if a.mode == "sharded":
+        step = ["rm_locate_sharded (ONE C-ABI call per step, everything on the caller's stream):",
+                "  rm_shard_pyramid: frame-buffer kernel over the local frames -> G_S [cmax=%d, NP=%d] float64" % (cmax, NP),
+                "  ncclAllGather %d B per rank -> [%d, %d, NP] (%s)" % (cmax * NP * 8, N, cmax, "frames in order" if T % N == 0 else "padded shards, compacted by %d device copies" % N),
+                "  rm_shard_collapse: temporal filter + small pyramid + bounds + pruning for all %d frames, evaluation of the local ones" % T,
+                "  ncclAllReduce(max) 16 B: {-min, max} of raw",
+                "  rm_shard_heat: masked time sum of the local frames -> heat_sum [%d, %d] float64" % (H, W),
+                "  sparse exchange: ncclAllGather of %d B packets (cap %d tiles; grows to %d tiles = %d B) -> merge in rank order, / T, ROI on every rank" % (pk0, cap0, cap_max, pk_max),
+                "  on a packet overflow: ncclAllReduce(sum) of %d B (dense), then the dense form is held for 64 steps or the cap grows" % heat_bytes]
+        scaling = "strong"
+    else:
+        step = ["rm_locate_streams (ONE C-ABI call per step, everything on the caller's stream):",
+                "  rm_calibrate of this rank's own [%d, %d, %d] %s buffer -> heatmap [%d, %d] float64" % (T, H, W, a.in_dtype, H, W),
+                "  rm_heat_sparse_pack -> ncclAllGather of %d B packets (cap %d tiles; grows to %d tiles = %d B)" % (pk0, cap0, cap_max, pk_max),
+                "  rm_heat_sparse_merge_roi: sum over the ranks in rank order + ROI (every rank the same); ONE host synchronisation",
+                "  on a packet overflow: ncclAllReduce(sum) of the %d B heatmaps, second host synchronisation" % heat_bytes]
+        scaling = "weak"
+    return {"dry_run": True, "n_gpus": N, "mode": a.mode if N > 1 else "single", "scaling": scaling,
+            "launch": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port <P> bench.py --gpus %d --steps %d --warmup %d%s"
+                      % (N, N, a.steps, a.warmup, " --mode sharded" if a.mode == "sharded" else ""),
+            "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0 (dmabuf IPC between the ranks' processes)", "MASTER_ADDR": "127.0.0.1"},
+            "communicator": "rank 0: rm_comm_unique_id (128 B) -> torch.distributed broadcast -> every rank rm_comm_init (ncclCommInitRank); all ranks "
+                            "agree on success (all_reduce MIN), else every rank keeps torch.distributed collectives",
+            "workload": {"frames": T, "height": H, "width": W, "dtype": a.in_dtype, "levels": L, "skip": S, "NP": NP},
+            "step": step, "ranks": ranks,
+            "value": "frames of ALL ranks per second: %d x steps / max-over-ranks time (barrier + synchronize on both sides)" % ((1 if a.mode == "sharded" else N) * T),
+            "xgmi_note": "per step and rank: %.2f MB over xGMI on the sparse path, %.1f MB on the dense one" % (
+                (pk0 * (N - 1) + (cmax * NP * 8 * (N - 1) if a.mode == "sharded" else 0)) / 1e6, 2 * heat_bytes * (N - 1) / N / 1e6)}
+
+
 def main():
     a = parse()
+    if a.dry_run:
+        print(json.dumps(dry_run_plan(a)))
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))
 

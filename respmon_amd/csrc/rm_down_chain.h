@@ -41,9 +41,9 @@ struct DownGeom {
     int wpg;                         // waves (= adjacent strips of one segment) per workgroup, marching in lockstep
     int T;
     int vec;                         // 1: 16-byte aligned vector loads are legal for this buffer
-    int prio;                        // issue priority of the waves (s_setprio), see DownChain::set_prio: 2 (default) rotating every 64 input rows;
+    int prio;                        // issue priority of the waves (s_setprio), see DownChain::set_prio: 2 (default) rotating every 2^prio_shift input rows;
                                      // developer settings: 0 none, 1 static (younger workgroups higher), 3 static (older higher)
-    int prio_shift;                  // log2 of the rotation period in input rows (6)
+    int prio_shift;                  // log2 of the rotation period in input rows (4: measured 16 / 32 / 64 / 128 rows in one process, tools/ab_inproc.py -- 0.6817 / 0.6837 / 0.6848 / 0.6883 ms against 0.7028 without priorities)
     int prio_rank;                   // dispatch-order quartile of this workgroup (0 = oldest), set by the kernel
 };
 
@@ -687,7 +687,7 @@ inline bool make_down_geom(int S, const int *h, const int *w, int T, int vec_ok,
                            int force_segs = 0, int force_wpg = 0, int split_permille = 0)
 {
     if (S < 1 || S > 5 || y_end <= y_begin) return false;
-    g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end; g.prio = 0; g.prio_rank = 0; g.prio_shift = 6;
+    g.S = S; g.T = T; g.vec = vec_ok; g.y_begin = y_begin; g.y_end = y_end; g.prio = 0; g.prio_rank = 0; g.prio_shift = 4;
     for (int k = 0; k <= S; ++k) { g.h[k] = h[k]; g.w[k] = w[k]; }
     const int SW = S == 1 ? StripWidth<1>::SW : S == 2 ? StripWidth<2>::SW : S == 3 ? StripWidth<3>::SW
                  : S == 4 ? StripWidth<4>::SW : StripWidth<5>::SW;

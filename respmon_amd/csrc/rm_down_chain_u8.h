@@ -550,7 +550,7 @@ inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom
     // hfilter() realise BORDER_REFLECT_101 as -2 -> 2, -1 -> 1, w -> w-2, which is only what OpenCV does for w >= 3
     // (found by tools/fuzz_parity.py: 16-pixel-wide frames with 4 levels reach a 2-column level)
     for (int k = 0; k < S; ++k) if (h[k] < 3 || w[k] < 3) return false;
-    g.S = S; g.T = T; g.vec = 1; g.y_begin = 0; g.y_end = h[S]; g.seg_split = 0; g.wpg = 1; g.prio = 0; g.prio_rank = 0; g.prio_shift = 6;
+    g.S = S; g.T = T; g.vec = 1; g.y_begin = 0; g.y_end = h[S]; g.seg_split = 0; g.wpg = 1; g.prio = 0; g.prio_rank = 0; g.prio_shift = 4;
     for (int k = 0; k <= S; ++k) { g.h[k] = h[k]; g.w[k] = w[k]; }
     g.strips = (w[0] + U8_STRIP_PX - 1) / U8_STRIP_PX;
     const int rows = h[S];

@@ -95,7 +95,7 @@ struct DebugKnobs {
     int dense_split = 0;          // 1 / 2 / 4: waves per tile (k_dense_sum_wf for 2 and 4; 0: by the number of tiles)
     int dense_wave = 1;           // 0: the workgroup kernels (k_dense_sum_s2 / k_dense_sum) instead of the wave-private k_dense_sum_w at skip <= 2
     int dc_segs = 0, dc_wpg = 0;  // > 0: segments per frame / waves per workgroup of k_down_chain
-    int dc_prio_shift = 0;        // 1 .. 12: log2 of the rotation period of dc_prio 2 in input rows (default 6)
+    int dc_prio_shift = 0;        // 1 .. 12: log2 of the rotation period of dc_prio 2 in input rows (default 4)
     int dc_prio = 2;              // k_down_chain: issue priority of its waves (2 rotating -- the default --, 0 none, 1 younger workgroups higher, 3 older higher)
     int dc_split = 0;             // > 0: share (per mille) of the level-S rows the upper of exactly two segments takes (default 513)
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3

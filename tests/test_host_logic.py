@@ -251,3 +251,40 @@ def test_flag_constants_match_the_header():
         assert getattr(_capi, name) == int(value), name
     assert len(set(flags.values())) == len(flags)          # one bit each
     assert all(int(v) & (int(v) - 1) == 0 for v in flags.values())
+
+
+def test_multi_gpu_dry_run_plan_and_shard_coverage():
+    """bench.py --gpus 8 --dry-run (no GPU): the per-rank plan a first 8-GPU run has to confirm -- and rm_shard_frames x 8 covers the
+    T = 256 / 512 / ragged buffers exactly once, with the padded all-gather layout rm_locate_sharded uses."""
+    import json
+    import subprocess
+    import sys
+    from respmon_amd import _capi
+    lib = _capi.load()
+    for T in (256, 512, 257, 9):
+        for world in (1, 2, 3, 8):
+            seen = []
+            sizes = []
+            for r in range(world):
+                t0, t1 = ctypes.c_int(), ctypes.c_int()
+                assert lib.rm_shard_frames(T, r, world, ctypes.byref(t0), ctypes.byref(t1)) == 0
+                seen += list(range(t0.value, t1.value))
+                sizes.append(t1.value - t0.value)
+            assert seen == list(range(T)), (T, world)                   # contiguous, in rank order, every frame once
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == (T + world - 1) // world       # cmax: what every rank sends
+    assert lib.rm_shard_frames(4, 4, 4, ctypes.byref(ctypes.c_int()), ctypes.byref(ctypes.c_int())) < 0
+    for mode, cfg in (("streams", "P"), ("sharded", "P"), ("sharded", "R")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--mode", mode, "--config", cfg],
+                             capture_output=True, text=True, check=True).stdout
+        plan = json.loads(out.strip().split("\n")[-1])
+        assert plan["dry_run"] and plan["n_gpus"] == 8 and len(plan["ranks"]) == 8
+        assert "--nproc-per-node 8" in plan["launch"] and "127.0.0.1" in plan["launch"]
+        T = plan["workload"]["frames"]
+        if mode == "sharded":
+            assert [r["frames"] for r in plan["ranks"]] == [[T // 8 * i, T // 8 * (i + 1)] for i in range(8)]
+            assert all(r["all_gather_send_bytes"] == (T // 8) * plan["workload"]["NP"] * 8 for r in plan["ranks"])
+            assert plan["scaling"] == "strong"
+        else:
+            assert all(r["frames"] == [0, T] for r in plan["ranks"]) and plan["scaling"] == "weak"
+            assert sorted(r["stream_seed"] for r in plan["ranks"]) == list(range(1234, 1242))
+        assert any("ncclAllGather" in line for line in plan["step"])
