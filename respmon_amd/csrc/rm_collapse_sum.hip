@@ -57,7 +57,7 @@ int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_s
         do {                                                                                                                             \
             using FootD = TileFoot<SS, false>;                                                                                           \
             hipLaunchKernelGGL((k_dense_sum_t<SS>), dim3(dense_tile_grid(cp.ntiles)), dim3(64), sizeof(double) * (FootD::TOTAL + DST_MAXW), s, cp.cS, cp.g, cp.t0, \
-                               cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr, heat_sum, avg_T, tile_nkept, cp.sp, only_if_dense, unserved_dev); \
+                               cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr, heat_sum, avg_T, tile_nkept, cp.sp, only_if_dense, unserved_dev, (ctx->dbg.dense_exact_top && !cp.no_prune) ? cp.lo : nullptr); \
         } while (0)
         switch (cp.S) { case 1: RM_DENSE_T(1); break; case 2: RM_DENSE_T(2); break; case 3: RM_DENSE_T(3); break; default: RM_DENSE_T(4); break; }
 #undef RM_DENSE_T

@@ -126,6 +126,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;
     else if (k == "dense_t_low") d.dense_t_low = (int)value;
+    else if (k == "dense_exact_top") d.dense_exact_top = (int)value;
     else if (k == "ccl_table") d.ccl_table = (int)value;
     else if (k == "label_host_us") d.label_host_us = (int)value;
     else if (k == "sum_sym") d.sum_sym = (int)value;

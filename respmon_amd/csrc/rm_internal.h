@@ -109,6 +109,7 @@ struct DebugKnobs {
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
+    int dense_exact_top = 1;      // 0: the store-less sum kernels evaluate every pair the selection kept (no second look with the exact `top`)
     int dense_t_low = -1;         // k_dense_sum_t (TileEval) at skip <= 2 instead of k_dense_sum_w / wf: 1 always, 0 never, -1 on large frames
     int dense_tiles = 1;          // 0: k_tile_sum (rounds of sixteen waves per tile) instead of k_dense_sum_t (one wave per tile) where a store-less sum at skip >= 3 is due
     int tile_sum_half = -1;       // 0 / 1: k_tile_sum works on whole tiles / half tiles whatever the number of heavy tiles (-1: by that number)
