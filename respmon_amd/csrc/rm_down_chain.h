@@ -102,6 +102,22 @@ __device__ __forceinline__ double lane0_from_lane2(double v)
     return __hiloint2double(hi, lo);
 }
 
+// The SIMD's issue arbiter prefers the OLDER of its resident waves (MI355X_MICROARCH.md, "two waves per SIMD"): with one resident
+// round of workgroups the first-dispatched quarter of a launch finishes ~8 % earlier than the last (workgroup timelines), and the
+// chip spends the end of the kernel with too few waves to keep HBM busy.  Explicit priorities outrank age: the frame-buffer kernels
+// rotate theirs every few input rows, starting from the workgroup's dispatch-order quartile, so every wave spends the same share
+// of its life at every level.
+__device__ __forceinline__ void dc_set_prio(int v)
+{
+    switch (v & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+__device__ __forceinline__ int dc_dispatch_quartile() { return (int)(((blockIdx.x >> 3) * 4u) / max(1u, gridDim.x >> 3)); }   // inside this workgroup's XCD
+
 template <typename Tin> struct VecTraits;
 template <> struct VecTraits<double> { static constexpr int V = 2; };
 template <> struct VecTraits<float> { static constexpr int V = 4; };
@@ -197,19 +213,6 @@ struct DownChain {
     // The waves of a workgroup are the adjacent strips of one (frame, segment): a barrier per prefetch round
     // keeps them on the same input rows, so the columns two strips share are fetched from HBM once and hit
     // in L2 for the neighbour.  Raw s_barrier: no waitcnt, the prefetched rows stay in flight across it.
-    // The SIMD's issue arbiter prefers the OLDER of its resident waves (MI355X_MICROARCH.md, "two waves per SIMD"): with one resident
-    // round of workgroups the first-dispatched quarter of a launch finishes ~8 % earlier than the last (workgroup timelines), and the
-    // chip spends the end of the kernel with too few waves to keep HBM busy.  Explicit priorities outrank age.
-    __device__ __forceinline__ void set_prio(int v) const
-    {
-        switch (v & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-        }
-    }
-
     __device__ __forceinline__ void lockstep() const
     {
         if (g.wpg > 1) __builtin_amdgcn_s_barrier();
@@ -486,10 +489,10 @@ struct DownChain {
         Raw16 regs[DC_PREFETCH][NQ1];
 #pragma unroll
         for (int i = 0; i < DC_PREFETCH; ++i) issue(min(p_first + i, p_last), regs[i]);
-        if (g.prio == 1) set_prio(g.prio_rank);
-        else if (g.prio == 3) set_prio(3 - g.prio_rank);
+        if (g.prio == 1) dc_set_prio(g.prio_rank);
+        else if (g.prio == 3) dc_set_prio(3 - g.prio_rank);
         for (int base = p_first; base <= p_last; base += DC_PREFETCH) {
-            if (g.prio == 2 && ((base - p_first) & ((1 << g.prio_shift) - 1)) == 0) set_prio(g.prio_rank + ((base - p_first) >> g.prio_shift));
+            if (g.prio == 2 && ((base - p_first) & ((1 << g.prio_shift) - 1)) == 0) dc_set_prio(g.prio_rank + ((base - p_first) >> g.prio_shift));
             lockstep();
 #pragma unroll
             for (int i = 0; i < DC_PREFETCH; ++i) {
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(64 * DC_MAX_WPG) void k_down_chain(const Tin *frame
     const int strip = grp * g.wpg + wave;
     if (strip >= g.strips) return;  // a terminated wave no longer counts at s_barrier
     double *lds = lds_all + wave * down_chain_lds_doubles<Tin, S>();
-    g.prio_rank = (int)(((blockIdx.x >> 3) * 4u) / max(1u, gridDim.x >> 3));   // quartile of the dispatch order inside this workgroup's XCD
+    g.prio_rank = dc_dispatch_quartile();
     DownChain<Tin, S, VB> dc(g, lds);
     dc.run(frames + (size_t)t * frame_stride, out + (size_t)t * g.h[S] * g.w[S], strip, seg);
 }

@@ -104,6 +104,7 @@ struct RegChain {
 #endif
     static constexpr int D = S < RM_NARROW_D ? S : RM_NARROW_D;
     static constexpr int B = 1 << D;
+    static constexpr int PRIO_BLOCKS_SHIFT = D >= 4 ? 0 : 4 - D;   // the issue priority rotates every 16 input rows (rm_down_chain.h dc_set_prio)
     static constexpr int PF = !HOT ? RegTraits<Tin>::PF : RegTraits<Tin>::PF < B ? RegTraits<Tin>::PF : B;
     static_assert(!HOT || B % PF == 0, "a row's prefetch slot must be static inside a hot block");
     // Every pyrDown ends with an exact scaling by 1/256 (pyramid.py:14 -> cv2.pyrDown); it commutes with the roundings of the
@@ -111,6 +112,7 @@ struct RegChain {
     // chain carries UNSCALED values and the store applies 2^(-8 S) once.
     static constexpr double OUT_SCALE = S == 1 ? 1.0 / 256 : S == 2 ? 1.0 / 65536 : S == 3 ? 1.0 / 16777216 : 1.0 / 4294967296.0;
     const DownGeom &g;
+    int prio_rank_ = 0;
     const int lane;
     int next[S + 1], last[S + 1];
     int p_first, p_last, W;
@@ -438,6 +440,7 @@ struct RegChain {
 #pragma unroll
             for (int i = 0; i < PF; ++i) issue(min(p_first + i, p_last), regs[i]);
             for (int base = p_first; base <= p_last; base += PF) {
+                if (g.prio == 2 && ((base - p_first) & 15) < PF) dc_set_prio(prio_rank_ + ((base - p_first) >> 4));   // every 16 input rows (rm_down_chain.h dc_set_prio)
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const int p = base + i;
@@ -488,8 +491,11 @@ struct RegChain {
         };
 #pragma nounroll
         while (base <= p_last && !hot_ok(base)) { generic_chunk(base); base += B; }
+        int nb = 0;
 #pragma nounroll
         while (base <= p_last && hot_ok(base)) {
+            if (g.prio == 2 && (nb & ((1 << PRIO_BLOCKS_SHIFT) - 1)) == 0) dc_set_prio(prio_rank_ + (nb >> PRIO_BLOCKS_SHIFT));   // (rm_down_chain.h dc_set_prio)
+            ++nb;
             hot_rows<0>(base, regs);
 #pragma unroll
             for (int k = 1; k < D; ++k) next[k] += B >> k;   // (next[D] was set by emit)
@@ -526,6 +532,7 @@ template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow
     const int inner = j % per_frame;
     const int seg = inner / g.strips, strip = inner - seg * g.strips;
     RegChain<S, Tin> rc(g);
+    rc.prio_rank_ = dc_dispatch_quartile();
     if constexpr (RegTraits<Tin>::DMA) {
         HIP_DYNAMIC_SHARED(char, ring)
 #if !defined(RM_HIPEMU)

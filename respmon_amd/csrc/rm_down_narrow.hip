@@ -9,6 +9,7 @@ int launch_down_chain_narrow(rm_ctx *ctx, const void *frames, int dtype, int T, 
 {
     DownGeom g8;
     if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, dtype == RM_F32 ? 1536 : 2048)) {
+        g8.prio = ctx->dbg.dc_prio;
         const size_t fs = (size_t)h[0] * w[0];
         const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
 #define RM_REG_CASE(KK, SS, TT, ptr) case SS: hipLaunchKernelGGL((KK<SS, TT>), dim3(grid), dim3(64), narrow_ring_bytes<TT>(), s, ptr, fs, g8, out); break;
