@@ -22,11 +22,12 @@ def main(d):
     lead = max(tot, key=tot.get)
     starts = [i for i, k in enumerate(ks) if k[2] == lead]
     per, names = [], None
-    for a, b in zip(starts[-80:-1], starts[-79:]):
+    starts = starts[-80:]
+    for a, b in zip(starts[:-1], starts[1:]):
         seq = ks[a:b]
         if names is None:
             names = [k[2].split("(")[0].replace("void ", "").replace("rm::", "") for k in seq]
-        if [k[2].split("(")[0].replace("void ", "").replace("rm::", "") for k in seq] != names:
+        if [k[2].split("(")[0].replace("void ", "").replace("rm::", "") for k in seq] != names or b >= len(ks):
             continue
         per.append([ks[b][0] - seq[0][0], ks[b][0] - seq[-1][1]] + [e - s for s, e, _ in seq] + [seq[i + 1][0] - seq[i][1] for i in range(len(seq) - 1)])
     per = np.array(per) / 1e3

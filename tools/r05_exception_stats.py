@@ -37,6 +37,8 @@ def study(name, v8, L, S, dt=torch.float64):
 which = sys.argv[1:] or ["noise", "Q", "R"]
 if "noise" in which:
     study("P noise (1080p x 256, L9 S4)", synth.synth_noise_only(256, 1080, 1920), 9, 4)
+if "P" in which:
+    study("P breathing (headline)", synth.synth_breathing(256, 1080, 1920, seed=1234), 9, 4)
 if "blobs16" in which:
     study("P blobs16", synth.synth_breathing_16(256, 1080, 1920), 9, 4)
 if "Q" in which:
