@@ -154,19 +154,56 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
 }
 
 // roots -> {root, minx, width-1, height-1} records in pinned host memory (the boxes are final behind the kernel boundary);
-// host[0].root = the number of components (> cap: the list overflowed and the host follows every border itself), records from
-// host[1] on.  16-byte records, consecutive lanes -> consecutive records: the PCIe writes leave in whole cache lines.
+// host[0].root = the number of components (> cap: the list overflowed and the host follows every border itself).
+// host[1 .. 2 CCL_PUB_BLOCKS]: per workgroup b of this launch, host[1 + 2 b] = the record with the largest bound 2 (w-1)(h-1) among the
+// components the workgroup published (root -1: none) and host[2 + 2 b] = {low, high word of the SECOND largest bound there, -, -}.
+// The host follows the border of the best of these 64 records and is done when its area beats every second bound and every other
+// top (a blob among thousands of specks: one border, 1.5 KB read) -- reading the whole list the device has just written
+// (120 KB of lines no host cache holds at 7 466 components) was most of the 62 us the GPU idled per 720p step.
+// The full list follows from host[1 + 2 CCL_PUB_BLOCKS] on, 16-byte records, consecutive lanes -> consecutive records.
+constexpr int CCL_PUB_BLOCKS = 64;
 RM_KERNEL __launch_bounds__(256) void k_ccl_publish(const int *roots, const CclBox *box, int W, const unsigned int *counters, unsigned int cap,
                                                      CclComp *host)
 {
+    __shared__ long long s_b1[256], s_b2[256];
+    __shared__ int s_i1[256];
     const unsigned int total = counters[0];
     const unsigned int n = total < cap ? total : cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) { CclComp h; h.root = (int)total; h.minx = 0; h.w1 = 0; h.h1 = 0; host[0] = h; }
+    CclComp *list = host + 1 + 2 * CCL_PUB_BLOCKS;
+    long long b1 = -1, b2 = -1;     // largest / second largest bound this thread met
+    int i1 = -1;                    // list index of the largest
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int p = roots[i];
         const CclBox bb = box[p];
         CclComp c; c.root = p; c.minx = bb.minx; c.w1 = bb.maxx - bb.minx; c.h1 = bb.maxy - p / W;
-        host[1 + i] = c;
+        list[i] = c;
+        const long long b = 2ll * (long long)c.w1 * (long long)c.h1;
+        if (b > b1) { b2 = b1; b1 = b; i1 = (int)i; } else if (b > b2) b2 = b;
+    }
+    const int tid = threadIdx.x;
+    s_b1[tid] = b1; s_b2[tid] = b2; s_i1[tid] = i1;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) {
+            const long long o1 = s_b1[tid + d], o2 = s_b2[tid + d];
+            long long m1 = s_b1[tid], m2 = s_b2[tid];
+            int mi = s_i1[tid];
+            if (o1 > m1) { m2 = m1 > o2 ? m1 : o2; m1 = o1; mi = s_i1[tid + d]; } else { m2 = o1 > m2 ? o1 : m2; }
+            s_b1[tid] = m1; s_b2[tid] = m2; s_i1[tid] = mi;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && blockIdx.x < CCL_PUB_BLOCKS) {
+        CclComp t; t.root = -1; t.minx = 0; t.w1 = 0; t.h1 = 0;
+        if (s_i1[0] >= 0) {
+            const int p = roots[s_i1[0]];
+            const CclBox bb = box[p];
+            t.root = p; t.minx = bb.minx; t.w1 = bb.maxx - bb.minx; t.h1 = bb.maxy - p / W;
+        }
+        CclComp sec; sec.root = (int)(unsigned int)(s_b2[0] & 0xffffffffll); sec.minx = (int)(s_b2[0] >> 32); sec.w1 = 0; sec.h1 = 0;
+        host[1 + 2 * blockIdx.x] = t;
+        host[2 + 2 * blockIdx.x] = sec;
     }
 }
 

@@ -458,6 +458,45 @@ int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const 
     return 0;
 }
 
+// The same from the per-workgroup summaries of k_ccl_publish (rm_ccl.h): tops[2 b] = the record with the largest bound among the
+// components workgroup b published (root -1: none), tops[2 b + 1] = {low, high word of the second largest bound there}.  Follows the
+// best top's border, then every other top that can still reach its area; when that area also beats every second bound no unread
+// component can win or tie, and the full list (`comps`, read only then) is not touched.  Same result as the function above.
+int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, const LabelComp *tops, int nblocks, const LabelComp *comps, size_t n,
+                                           RoiResult *out)
+{
+    out->found = 0; out->n_contours = (int)n; out->area = 0.0;
+    out->x = out->y = out->w = out->h = 0;
+    if (H <= 0 || W <= 0 || n == 0) return 0;
+    const BitImage im{bits, H, W};
+    auto bound2 = [](const LabelComp &c) { return 2ll * (long long)c.w1 * (long long)c.h1; };
+    long long best2 = -1; int best_b = -1;
+    auto consider = [&](int b) {
+        const LabelComp &c = tops[2 * b];
+        long long a2 = 0;
+        if (c.w1 > 0 && c.h1 > 0) { a2 = follow_bits(im, c.root % W, c.root / W); if (a2 < 0) a2 = -a2; }
+        if (a2 > best2 || (a2 == best2 && c.root > tops[2 * best_b].root)) { best2 = a2; best_b = b; }
+    };
+    long long top = -1; int top_b = -1;
+    for (int b = 0; b < nblocks; ++b)
+        if (tops[2 * b].root >= 0 && bound2(tops[2 * b]) > top) { top = bound2(tops[2 * b]); top_b = b; }
+    if (top_b < 0) return largest_external_contour_labelled(bits, H, W, comps, n, out);
+    consider(top_b);
+    for (int b = 0; b < nblocks; ++b)
+        if (b != top_b && tops[2 * b].root >= 0 && bound2(tops[2 * b]) >= best2) consider(b);
+    for (int b = 0; b < nblocks; ++b) {
+        const LabelComp &s = tops[2 * b + 1];
+        const long long second = (long long)(((unsigned long long)(unsigned int)s.minx << 32) | (unsigned int)s.root);
+        if (second >= best2) return largest_external_contour_labelled(bits, H, W, comps, n, out);   // an unread component may win or tie
+    }
+    const LabelComp &c = tops[2 * best_b];
+    out->found = 1;
+    out->x = c.minx; out->y = c.root / W;
+    out->w = c.w1 + 1; out->h = c.h1 + 1;
+    out->area = 0.5 * (double)best2;
+    return 0;
+}
+
 // `have_ranges`: pixels left of row_x0 / right of row_x1 are background without marks (borders only visit
 // foreground pixels), so the raster scan of a row may start at its first and stop after its last foreground pixel
 static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *out, bool have_ranges)

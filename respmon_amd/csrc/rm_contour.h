@@ -28,4 +28,7 @@ int simple_shape_row_records(const uint64_t *rec, int H, int W, int *y0, int *y1
 // (w-1)*(h-1) can reach the best area found so far are followed, straight on the packed image.  Same result as the calls above.
 struct LabelComp { int root, minx, w1, h1; };
 int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const LabelComp *comps, size_t n, RoiResult *out);
+// ... reading the 2 x nblocks summary records of k_ccl_publish first, the full list only when they do not settle the winner
+int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, const LabelComp *tops, int nblocks, const LabelComp *comps, size_t n,
+                                           RoiResult *out);
 }  // namespace rm

@@ -88,11 +88,11 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         RM_TRY(ws(ctx, "ccl_label", npix, &d_label));
         RM_TRY(ws(ctx, "ccl_box", npix, &d_box));
         RM_TRY(ws(ctx, "ccl_counters", (size_t)2, &d_cnt));
-        if (rs.h_comps_cap < comps_cap + 1) {
+        if (rs.h_comps_cap < comps_cap + 1 + 2 * CCL_PUB_BLOCKS) {
             if (rs.h_comps) { HIP_TRY(stream_wait(s)); HIP_TRY(hipHostFree(rs.h_comps)); }
             rs.h_comps = nullptr; rs.h_comps_cap = 0;
-            HIP_TRY(hipHostMalloc((void **)&rs.h_comps, (comps_cap + 1) * sizeof(CclComp), hipHostMallocDefault));
-            rs.h_comps_cap = comps_cap + 1;
+            HIP_TRY(hipHostMalloc((void **)&rs.h_comps, (comps_cap + 1 + 2 * CCL_PUB_BLOCKS) * sizeof(CclComp), hipHostMallocDefault));
+            rs.h_comps_cap = comps_cap + 1 + 2 * CCL_PUB_BLOCKS;
         }
         CclComp *dev_comps = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, rs.h_comps, 0));
@@ -110,7 +110,7 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         if (table) hipLaunchKernelGGL(k_ccl_bbox<true>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         else hipLaunchKernelGGL(k_ccl_bbox<false>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_ccl_publish<>, dim3(64), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps);
+        hipLaunchKernelGGL(k_ccl_publish<>, dim3(CCL_PUB_BLOCKS), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps);
         LAUNCH_CHECK();
     } else if ((W & 63) == 0 && (W >> 6) <= HR_MAXW && ctx->dbg.heat_rows) {
         // rows of whole words: a workgroup per row, one record per row with foreground beside the packed image (k_heat_rows_u8)
@@ -167,7 +167,8 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
         ctx->label_used = label && ncomp <= comps_cap;
         if (settled) {
         } else if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
-            largest_external_contour_labelled((const uint64_t *)rs.h_bin, H, W, (const LabelComp *)(rs.h_comps + 1), ncomp, &r);
+            largest_external_contour_labelled_tops((const uint64_t *)rs.h_bin, H, W, (const LabelComp *)(rs.h_comps + 1), CCL_PUB_BLOCKS,
+                                                   (const LabelComp *)(rs.h_comps + 1 + 2 * CCL_PUB_BLOCKS), ncomp, &r);
         else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r)))
             largest_external_contour_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r);
         ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
