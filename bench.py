@@ -443,6 +443,22 @@ def main():
 
     extras = world == 1 and not a.no_extras
     n_extra = max(3, min(a.steps, 20))
+    # where the host time of a synchronous step goes (include/respmon_hip_debug.h rm_debug_host_timeline): medians over a separate
+    # batch of steps -- the read-out itself costs ~1 us per step, so it stays out of the timed region
+    host_timeline = None
+    if extras:
+        marks = np.zeros((max(20, min(a.steps, 100)), 5))
+        hm = (ctypes.c_double * 5)()
+        for i in range(marks.shape[0]):
+            step()
+            lib.rm_debug_host_timeline(ctx, hm)
+            marks[i] = list(hm)
+        m = np.median(marks[3:], axis=0)
+        host_timeline = {"between_calls": m[0], "entry_to_first_launch_issued": m[1], "all_launches_issued": m[2], "device_done_seen": m[3],
+                         "contour_stage_done": m[4], "host_contour_stage": m[4] - m[3],
+                         "note": "microseconds after the entry of rm_locate (between_calls: what the caller spent since the previous return); "
+                                 "the GPU idles from the end of its last kernel until the next call's first kernel starts: completion "
+                                 "seen by the poll + host_contour_stage + between_calls + entry_to_first_launch_issued + launch latency"}
     # same video kept as uint8 in HBM (what a camera delivers; kernels apply uint8_to_float on the fly):
     # bit-identical ROI at 1/8 of the frame-buffer bytes.  Reported beside the headline, never as `value`.
     alt = None
@@ -750,6 +766,7 @@ def main():
             "contour_stage": contour_stage,
             "no_prune": no_prune,
             "dense_stream": dense,
+            "host_timeline_us": host_timeline,
             "worst_case": worst,
             "configs": other,
         }
