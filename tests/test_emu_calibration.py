@@ -109,6 +109,19 @@ def test_emu_locate_submit_result(emu, golden):
         else:
             assert emu.locate_result(ta) == want[i] and emu.locate_result(tb) == want[j]
         assert emu.locate(va, fa, levels=La, skip=Sa) == want[i]     # the synchronous entry between submissions
+    # a submission in flight on one stream: work for the same context on ANOTHER stream is refused (the context's workspaces are
+    # protected by stream order only), the same call on the submission's stream goes through
+    va, fa, La, Sa = vids[0]
+    tk = emu.locate_submit(va, fa, levels=La, skip=Sa)
+    heat = np.zeros((va.shape[1], va.shape[2])); xy = np.zeros(4, np.int32)
+    other = ctypes.c_void_p(0x40)
+    rc = emu.lib.rm_heatmap_to_roi(emu.ctx, heat.ctypes.data_as(ctypes.c_void_p), heat.shape[0], heat.shape[1], 20, xy.ctypes.data_as(ctypes.c_void_p), None, None, other)
+    assert rc == _capi.RM_E_BUSY and b"in flight" in emu.lib.rm_last_error_string()
+    rc = emu.lib.rm_calibrate(emu.ctx, va.ctypes.data_as(ctypes.c_void_p), 0, va.shape[0], va.shape[1], va.shape[2], 10.0, 0.1, 1.0, 500.0, La, Sa, 0.7, 0,
+                              heat.ctypes.data_as(ctypes.c_void_p), None, other)
+    assert rc == _capi.RM_E_BUSY
+    assert emu.locate(va, fa, levels=La, skip=Sa) == want[0]
+    assert emu.locate_result(tk) == want[0]
     flat = emu.locate_submit(np.full((16, 40, 48), 0.5), 10, levels=4, skip=2)
     assert emu.locate_result(flat) is None
     xywh = np.zeros(4, np.int32)

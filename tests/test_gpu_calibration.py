@@ -1051,3 +1051,50 @@ def test_locate_submit_result(hip, oracle):
     assert lib.rm_locate_result(h, 1, xywh) == _capi.RM_E_BADARG          # no such submission
     assert lib.rm_ctx_destroy(h) == _capi.RM_OK                            # waits for ticket 0's work, frees its pinned slot
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_round5_switches_leave_results_bit_identical(hip, oracle):
+    """Round-5 forms against the ones they replaced, on the device: the row-record ROI kernel (k_heat_rows_u8) against the flat one,
+    the store-less sum with the exact-top mask / level-1 stop / second-visit skip against evaluating every kept pair to the end, and
+    the rotating wave priority of the frame-buffer kernels (a scheduling hint: the same bits whatever its setting)."""
+    import torch
+    from respmon_amd import device, dist, synth
+    from respmon_amd.base import RespiratoryMonitor
+    try:
+        # ROI stage: shapes around the one-blob rule, rows of whole words (the record path) -- and the labelled path with its top candidates
+        rng = np.random.default_rng(5)
+        for name, img in [("blob", None), ("two blobs", None), ("ring", None), ("noise", None), ("nothing", None)]:
+            z = np.zeros((96, 256))
+            if name == "blob": z[20:60, 40:200] = 1
+            if name == "two blobs": z[10:30, 10:90] = 1; z[50:90, 100:250] = 1
+            if name == "ring": z[10:80, 20:220] = 1; z[30:60, 60:180] = 0
+            if name == "noise": z = (rng.random((96, 256)) > 0.55).astype(float)
+            heat = torch.from_numpy(z * 1.0).cuda()
+            want = oracle.roi_from_heatmap_u8(oracle.float_to_uint8(z / z.max()) if z.max() > 0 else np.zeros(z.shape, np.uint8), 100)
+            for rows in (1, 0, 1):
+                device.debug_set("heat_rows", rows)
+                for lab in (False, True):
+                    for _ in range(2):
+                        assert dist.hip_heatmap_to_roi(heat, 100, labelling=lab) == want, (name, rows, lab)
+        # store-less sum on a stream of noise (every pair kept by the selection) at skip 2 and 4, odd and even T
+        for (T, H, W, L, S) in [(32, 270, 480, 6, 2), (33, 272, 448, 9, 4), (64, 135, 256, 7, 3)]:
+            v8 = synth.synth_noise_only(T, H, W)
+            buf = torch.from_numpy(oracle.uint8_to_float(v8)).cuda()
+            kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+            device.debug_set("dense_t_low", 1)
+            device.debug_set("dense_exact_top", 0)
+            ref = dist.hip_calibrate(buf, 10, flags=128, **kw)                 # RM_FLAG_DENSE_SUM: k_dense_sum_t, every kept pair to the end
+            store = dist.hip_calibrate(buf, 10, flags=256, **kw)               # the value-store path
+            device.debug_set("dense_exact_top", 1)
+            got = dist.hip_calibrate(buf, 10, flags=128, **kw)
+            assert torch.equal(ref, store) and torch.equal(got, ref), (T, H, W, L, S)
+            for prio in (0, 1, 3, 2):
+                device.debug_set("dc_prio", prio)
+                assert torch.equal(dist.hip_calibrate(buf, 10, flags=128, **kw), ref), prio
+            assert RespiratoryMonitor.locate(buf, 10, **kw) == oracle.locate(oracle.uint8_to_float(v8), 10, **kw)
+    finally:
+        device.debug_set("heat_rows", 1)
+        device.debug_set("dense_exact_top", 1)
+        device.debug_set("dense_t_low", -1)
+        device.debug_set("dc_prio", 2)
