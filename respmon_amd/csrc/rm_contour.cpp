@@ -379,6 +379,17 @@ struct BitImage {
     }
 };
 
+// The packed image sits in pinned memory the device has just written: no host cache holds its lines, and a long border visits them
+// in an order no hardware prefetcher follows (~150 us for the frame-spanning blob of a noise image, nearly all of it cache misses).
+// Requesting the rows of the component's bounding box up front turns that into one streaming read that overlaps the walk.
+static void prefetch_rows(const BitImage &im, int y0, int y1)
+{
+    if (y1 - y0 < 8) return;
+    const char *p = (const char *)(im.bits + (((size_t)y0 * im.W) >> 6));
+    const char *e = (const char *)(im.bits + ((((size_t)(y1 + 1) * im.W) + 63) >> 6));
+    for (; p < e; p += 64) __builtin_prefetch(p, 0, 3);
+}
+
 // twice the signed shoelace area of the outer border that starts at (sx, sy): Tracer::follow without marks
 long long follow_bits(const BitImage &im, int sx, int sy)
 {
@@ -436,7 +447,7 @@ int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const 
     auto consider = [&](size_t i) {
         const LabelComp &c = comps[i];
         long long a2 = 0;
-        if (c.w1 > 0 && c.h1 > 0) { a2 = follow_bits(im, c.root % W, c.root / W); if (a2 < 0) a2 = -a2; }
+        if (c.w1 > 0 && c.h1 > 0) { prefetch_rows(im, c.root / W, c.root / W + c.h1); a2 = follow_bits(im, c.root % W, c.root / W); if (a2 < 0) a2 = -a2; }
         // max() over cv2's reversed list keeps, among equal areas, the border discovered last = the largest start index
         if (a2 > best2 || (a2 == best2 && c.root > comps[best_i].root)) { best2 = a2; best_i = i; }
     };
@@ -474,7 +485,7 @@ int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, c
     auto consider = [&](int b) {
         const LabelComp &c = tops[2 * b];
         long long a2 = 0;
-        if (c.w1 > 0 && c.h1 > 0) { a2 = follow_bits(im, c.root % W, c.root / W); if (a2 < 0) a2 = -a2; }
+        if (c.w1 > 0 && c.h1 > 0) { prefetch_rows(im, c.root / W, c.root / W + c.h1); a2 = follow_bits(im, c.root % W, c.root / W); if (a2 < 0) a2 = -a2; }
         if (a2 > best2 || (a2 == best2 && c.root > tops[2 * best_b].root)) { best2 = a2; best_b = b; }
     };
     long long top = -1; int top_b = -1;
