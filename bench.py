@@ -447,6 +447,7 @@ def main():
     # batch of steps -- the read-out itself costs ~1 us per step, so it stays out of the timed region
     host_timeline = None
     if extras:
+        _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")   # (no event records on the host path being measured)
         marks = np.zeros((max(20, min(a.steps, 100)), 5))
         hm = (ctypes.c_double * 5)()
         for i in range(marks.shape[0]):
@@ -467,7 +468,7 @@ def main():
         for _ in range(a.warmup):
             locate1(buf8)
         _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
-        roi8, ms8 = timed(lambda: locate1(buf8), n_extra)
+        roi8, ms8 = timed(lambda: locate1(buf8), max(n_extra, 100))   # (0.3 ms steps: a batch of 20 is shorter than the clocks take to settle)
         _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
         _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
         k8 = ms[0] / max(ncalls.value, 1)
