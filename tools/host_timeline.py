@@ -1,5 +1,5 @@
 """Developer tool: where the host time of a synchronous rm_locate goes (include/respmon_hip_debug.h rm_debug_host_timeline).
-    python tools/host_timeline.py [steps]
+    python tools/host_timeline.py [steps] [P|Q|R]
 Prints the medians over `steps` back-to-back locate() calls on the headline workload (1080p x 256 float64):
   between calls (caller), entry -> first launch issued, -> all launches issued, -> device done (wait), -> contour stage done."""
 import ctypes
@@ -18,22 +18,25 @@ from respmon_amd.base import _Backend  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    T, H, W = 256, 1080, 1920
-    v8 = synth.synth_breathing(T, H, W, seed=1234)
-    buf = torch.empty((T, H, W), dtype=torch.float64, device="cuda")
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "P"
+    import bench
+    T, H, W, L, S, dt = bench.CONFIGS[cfg]
+    v8 = (synth.synth_breathing_blocks if T * H * W > 1 << 30 else synth.synth_breathing)(T, H, W, seed=1234)
+    tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[dt]
+    buf = torch.empty((T, H, W), dtype=tdt, device="cuda")
     for t0 in range(0, T, 16):
-        buf[t0:t0 + 16] = torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)
+        buf[t0:t0 + 16] = (torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)).to(tdt)
     torch.cuda.synchronize()
     lib = _capi.load()
     be = _Backend()
     ctx = device.ctx()
-    for _ in range(300):
-        roi = be.locate(buf, 10, 0.1, 1.0, 500, 9, 4, 0.7, 20, 0)
+    for _ in range(300 if cfg == "P" else 30):
+        roi = be.locate(buf, 10, 0.1, 1.0, 500, L, S, 0.7, 20, 0)
     marks = np.zeros((steps, 5))
     out = (ctypes.c_double * 5)()
     t0 = time.perf_counter()
     for i in range(steps):
-        roi = be.locate(buf, 10, 0.1, 1.0, 500, 9, 4, 0.7, 20, 0)
+        roi = be.locate(buf, 10, 0.1, 1.0, 500, L, S, 0.7, 20, 0)
         lib.rm_debug_host_timeline(ctx, out)
         marks[i] = list(out)
     dt = (time.perf_counter() - t0) / steps * 1e3
