@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--no-bgr-alt", action="store_true", help="skip the [T,H,W,3] uint8 BGR frame-buffer leg of the uint8 summary")
     ap.add_argument("--in-dtype", default=None, choices=list(DT_BYTES), help="device frame-buffer element type; "
                     "f64 is the reference's calibration_buffer dtype (base.py:119)")
     ap.add_argument("--levels", type=int, default=None)
@@ -477,6 +478,24 @@ def main():
                # this kernel is bound by instruction issue, not by bytes: its second roofline
                "valu_roofline": valu_roofline("u8", T, H, W, k8)}
         del buf8
+        # ... and as captured: [T,H,W,3] uint8 BGR (north_star's [T,H,W,C] buffer; RM_BGR8).  The frame-buffer kernel applies base.py:230's
+        # cvtColor while it unpacks a row (3 bytes per pixel, 5.5 more integer instructions).  Three equal planes: gray(x, x, x) == x, so
+        # the ROI must equal the headline's; the arithmetic does not depend on the data.
+        if not a.no_bgr_alt:
+            buf3 = torch.from_numpy(vid_u8).cuda().unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+            for _ in range(a.warmup):
+                locate1(buf3)
+            _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
+            roi3, ms3 = timed(lambda: locate1(buf3), max(n_extra, 100))
+            _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
+            _capi.check(lib, lib.rm_profile_enable(ctx, 0), "rm_profile_enable")
+            k3 = ms[0] / max(ncalls.value, 1)
+            b3 = T * H * W * 3 + H * W * 8
+            alt["bgr8"] = {"frame_buffer": "[T,H,W,3] uint8 (RM_BGR8)", "value": T / ms3 * 1e3, "unit": "frames/s", "ms_per_step": ms3, "kernel_ms": k3,
+                           "algorithmic_bytes": b3, "frac": b3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernel_frac": b3 / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else None,
+                           "roi": roi3, "roi_equals_headline": list(roi3 or []) == list(roi or [])}
+            del buf3
     # BASELINE config 4 is "calibration + ROI flow": the per-frame motion extraction (base.py:354-407, 'flow' method) on the
     # ROI just found -- Shi-Tomasi corners once, then pyramidal LK + mean flow + PCA per frame.  Latency bound
     # (no roofline fraction is meaningful); reported beside the headline, never part of `value`.

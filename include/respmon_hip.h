@@ -44,6 +44,11 @@ extern "C" {
 #define RM_F16 1 /* IEEE half, widened exactly */
 #define RM_F32 2 /* float, widened exactly */
 #define RM_F64 3 /* double: the reference's calibration_buffer dtype (base.py:119-120) */
+/* Frame BUFFERS only -- the `frames` argument of rm_calibrate, rm_locate, rm_locate_submit, rm_locate_streams, rm_locate_sharded,
+ * rm_shard_pyramid and rm_eulerian_magnification_bandpass: [T,H,W,3] uint8 in cv2.VideoCapture's channel order.  The kernels apply
+ * base.py:230-231 (cv2.cvtColor(BGR2GRAY), then uint8_to_float) as they read the buffer: results are bit-identical to the same call on
+ * the RM_U8 buffer that rm_bgr_to_gray makes of it.  Every other entry point takes gray frames and answers RM_E_BADARG. */
+#define RM_BGR8 4
 
 /* rm_calibrate flags */
 #define RM_FLAG_NO_PRUNE 1u      /* evaluate every (tile, frame) of the collapse passes (A/B + verification) */

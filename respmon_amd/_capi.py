@@ -17,6 +17,7 @@ RM_E_COMM = -6
 RM_E_BUSY = -7
 RM_LOCATE_TICKETS = 2
 RM_U8, RM_F16, RM_F32, RM_F64 = 0, 1, 2, 3
+RM_BGR8 = 4   # frame buffers only: [T,H,W,3] uint8 in cv2.VideoCapture's channel order (include/respmon_hip.h)
 RM_FLAG_NO_PRUNE = 1
 RM_FLAG_UNFUSED_DOWN = 2
 RM_FLAG_TINY_STORE = 4

@@ -68,14 +68,14 @@ class _Backend:
     def locate(self, buf, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
                temporal_threshold, threshold, flags=0):
         import ctypes
-        T, H, W = buf.shape
+        T, H, W = device.buffer_shape(buf)
         xywh = self._xywh
         # (this call sits on the host path between two calibrations: the context of the buffer's device is looked up without asking
         #  the runtime, the stream is the current one of that device)
         idx = buf.device.index
         ctx = device._CTX.get(idx) or device.ctx(idx)
         stream = ctypes.c_void_p(device.raw_stream(idx))
-        rc = self.lib.rm_locate(ctx, ctypes.c_void_p(buf.data_ptr()), device.dtype_code(buf), T, H, W,
+        rc = self.lib.rm_locate(ctx, ctypes.c_void_p(buf.data_ptr()), device.buffer_dtype_code(buf), T, H, W,
                                 float(fps), float(freq_min), float(freq_max), float(amplification),
                                 int(pyramid_levels), int(skip_levels_at_top), float(temporal_threshold),
                                 int(threshold), int(flags), xywh, stream)
@@ -90,12 +90,12 @@ class _Backend:
         """locate() without the wait: the device work is enqueued and a ticket returned (rm_locate_submit).  Up to
         _capi.RM_LOCATE_TICKETS buffers per GPU may be in flight; `buf` must stay alive and unchanged until locate_result."""
         import ctypes
-        T, H, W = buf.shape
+        T, H, W = device.buffer_shape(buf)
         idx = buf.device.index
         ctx = device._CTX.get(idx) or device.ctx(idx)
         stream = ctypes.c_void_p(device.raw_stream(idx))
         ticket = ctypes.c_int(-1)
-        rc = self.lib.rm_locate_submit(ctx, ctypes.c_void_p(buf.data_ptr()), device.dtype_code(buf), T, H, W,
+        rc = self.lib.rm_locate_submit(ctx, ctypes.c_void_p(buf.data_ptr()), device.buffer_dtype_code(buf), T, H, W,
                                        float(fps), float(freq_min), float(freq_max), float(amplification),
                                        int(pyramid_levels), int(skip_levels_at_top), float(temporal_threshold),
                                        int(threshold), int(flags), stream, ctypes.byref(ticket))
@@ -123,12 +123,19 @@ class _Backend:
         gray = t.empty((H, W), dtype=t.uint8, device=src.device)
         _capi.check(self.lib, self.lib.rm_bgr_to_gray(device.ctx(), device.ptr(src), H * W, device.ptr(gray),
                                                       device.stream_ptr()), "rm_bgr_to_gray")
+        self._last_bgr = (gray, src)     # a 'bgr8' calibration buffer stores the frame as captured (store_frame)
         return gray
 
     def store_frame(self, buf, idx, gray_u8):
         """calibration_buffer[idx][:] = uint8_to_float(gray) (base.py:231, 431)."""
         t = self.t
-        if buf.dtype == t.uint8:
+        if buf.dim() == 4:
+            # buffer_dtype 'bgr8': the frame as captured; rm_locate applies base.py:230-231 when it reads the buffer (RM_BGR8)
+            last = getattr(self, "_last_bgr", None)
+            if last is None or last[0] is not gray_u8:
+                raise _capi.RespmonError("a 'bgr8' calibration buffer stores the frame next_frame() returned last")
+            buf[idx].copy_(last[1])
+        elif buf.dtype == t.uint8:
             buf[idx].copy_(gray_u8)
         else:
             dst64 = buf[idx] if buf.dtype == t.float64 else t.empty(gray_u8.shape, dtype=t.float64, device=gray_u8.device)
@@ -266,7 +273,7 @@ class RespiratoryMonitor:
             "error_reset_delay must be a positive int or float"
         assert isinstance(save_all_data, bool), "save_all_data should be bool"
         assert motion_extraction_method in ("average", "flow"), "motion_extraction_method must be 'average' or 'flow'"
-        assert buffer_dtype in ("float64", "float32", "float16", "uint8")
+        assert buffer_dtype in ("float64", "float32", "float16", "uint8", "bgr8")
 
         self.benchmarker = Benchmarker()
         self.error_reset_delay = error_reset_delay
@@ -351,6 +358,8 @@ class RespiratoryMonitor:
     def _alloc_buffer(self):
         if isinstance(self._backend, _Backend):
             t = device.require_gpu()
+            if self.buffer_dtype == "bgr8":    # north_star's [T,H,W,C] frame buffer: frames as captured, 3 bytes per pixel
+                return t.zeros((self.calibration_buffer_target_length, self.height, self.width, 3), dtype=t.uint8, device="cuda")
             dt = {"float64": t.float64, "float32": t.float32, "float16": t.float16, "uint8": t.uint8}[self.buffer_dtype]
             return t.zeros((self.calibration_buffer_target_length, self.height, self.width), dtype=dt, device="cuda")
         return self._backend.alloc_buffer(self.calibration_buffer_target_length, self.height, self.width, self.buffer_dtype)

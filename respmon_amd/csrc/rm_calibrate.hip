@@ -23,7 +23,7 @@ int calibrate_impl(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int
                           double fmax, double amp, int levels, int skip, double thr, unsigned flags, double *heat,
                           double *minmax_host, void *stream, CollapsePlan *plan_out)
 {
-    if (!ctx || !frames || !heat || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_dtype(dtype))
+    if (!ctx || !frames || !heat || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_buffer_dtype(dtype))
         return fail(RM_E_BADARG, "rm_calibrate: bad argument");
     if (T > MAX_T) return fail(RM_E_UNSUPPORTED, "rm_calibrate: T=%d > %d", T, MAX_T);
     hipStream_t s = (hipStream_t)stream;
@@ -79,7 +79,7 @@ extern "C" int rm_shard_layout(int H, int W, int levels, int skip, size_t *np_ou
 extern "C" int rm_shard_pyramid(rm_ctx *ctx, const void *frames, int dtype, int Tl, int H, int W, int levels, int skip,
                                 unsigned flags, double *lap_local, void *stream)
 {
-    if (!ctx || !frames || !lap_local || Tl < 1 || H < 1 || W < 1 || levels < 1 || skip < 1 || !valid_dtype(dtype))
+    if (!ctx || !frames || !lap_local || Tl < 1 || H < 1 || W < 1 || levels < 1 || skip < 1 || !valid_buffer_dtype(dtype))
         return fail(RM_E_BADARG, "rm_shard_pyramid: bad argument (frame-sharded calibration needs skip_levels_at_top >= 1)");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -157,7 +157,7 @@ extern "C" int rm_eulerian_magnification_bandpass(rm_ctx *ctx, const void *frame
                                                   double fmin, double fmax, double amp, int levels, int skip, double thr,
                                                   double *masked, double *raw, double *minmax_host, void *stream)
 {
-    if (!ctx || !frames || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_dtype(dtype))
+    if (!ctx || !frames || T < 1 || H < 1 || W < 1 || levels < 1 || skip < 0 || !(fps > 0) || !valid_buffer_dtype(dtype))
         return fail(RM_E_BADARG, "rm_eulerian_magnification_bandpass: bad argument");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -101,6 +101,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     if (k == "temporal_valu") d.temporal_valu = (int)value;
     else if (k == "temporal_wide") d.temporal_wide = (int)value;
     else if (k == "dc_lds_front_end") d.dc_lds_front_end = (int)value;
+    else if (k == "bgr_unfused") d.bgr_unfused = (int)value;
     else if (k == "no_fused_bounds") d.no_fused_bounds = (int)value;
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
     else if (k == "bounds_scalar") d.bounds_scalar = (int)value;
@@ -210,12 +211,37 @@ extern "C" int rm_float_to_uint8(rm_ctx *ctx, const double *src, uint8_t *dst, s
     return RM_OK;
 }
 
+int launch_bgr_to_gray(const uint8_t *bgr, size_t npix, uint8_t *gray, hipStream_t s)
+{
+    if (npix == 0) return RM_OK;
+    size_t done = 0;
+    if ((((uintptr_t)bgr | (uintptr_t)gray) & 3) == 0 && npix >= 4) {
+        const size_t nquads = npix / 4;
+        hipLaunchKernelGGL(k_bgr_to_gray_quads<>, dim3(nblk(nquads, 256, 1 << 16)), dim3(256), 0, s, (const unsigned *)bgr, nquads, (unsigned *)gray);
+        LAUNCH_CHECK();
+        done = nquads * 4;
+    }
+    if (done < npix) {
+        hipLaunchKernelGGL(k_bgr_to_gray<>, dim3(nblk(npix - done, 256, 1 << 16)), dim3(256), 0, s, bgr + 3 * done, npix - done, gray + done);
+        LAUNCH_CHECK();
+    }
+    return RM_OK;
+}
+
 extern "C" int rm_bgr_to_gray(rm_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray, void *stream)
 {
     if (!ctx || !bgr || !gray) return fail(RM_E_BADARG, "rm_bgr_to_gray: NULL argument");
-    if (npix == 0) return RM_OK;
-    hipLaunchKernelGGL(k_bgr_to_gray<>, dim3(nblk(npix, 256)), dim3(256), 0, (hipStream_t)stream, bgr, npix, gray);
-    LAUNCH_CHECK();
+    return launch_bgr_to_gray(bgr, npix, gray, (hipStream_t)stream);
+}
+
+// RM_BGR8 frame buffers on the paths that have no fused conversion (rm_down_chain_u8.h bgr8_t): cvtColor of the whole buffer into a
+// gray uint8 workspace of the context, which then stands for the frame buffer
+int bgr_buffer_to_gray(rm_ctx *ctx, const void *frames, size_t npix, const void **gray_out, hipStream_t s)
+{
+    uint8_t *gray = nullptr;
+    RM_TRY(ws(ctx, "gray_of_bgr", (npix + 7) / 8, (double **)&gray));
+    RM_TRY(launch_bgr_to_gray((const uint8_t *)frames, npix, gray, s));
+    *gray_out = gray;
     return RM_OK;
 }
 

@@ -1,0 +1,25 @@
+// respmon_amd/csrc/rm_down_bgr.hip -- the all-register chain for [T,H,W,3] uint8 BGR frame buffers (rm_down_chain_u8.h bgr8_t): base.py:230-231's
+// cvtColor(BGR2GRAY) + uint8_to_float fused into the first row pass of the Gaussian chain
+// (one translation unit of librespmon_hip.so; shared host-side declarations: rm_internal.h)
+#include "rm_internal.h"
+
+using namespace rm;
+
+int launch_down_chain_bgr(rm_ctx *ctx, const void *frames, int T, const std::vector<int> &h, const std::vector<int> &w, int S, double *out,
+                          hipStream_t s, bool tiny)
+{
+    DownGeom g8;
+    if (!make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, 2048)) return 1;
+    g8.prio = ctx->dbg.dc_prio;
+    const size_t fs = (size_t)h[0] * w[0];   // in pixels: the kernel's pointer arithmetic is in bgr8_t
+    const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
+    const bgr8_t *f = (const bgr8_t *)frames;
+    switch (S) {
+    case 1: hipLaunchKernelGGL((k_down_chain_u8<1, bgr8_t>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+    case 2: hipLaunchKernelGGL((k_down_chain_u8<2, bgr8_t>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+    case 3: hipLaunchKernelGGL((k_down_chain_u8<3, bgr8_t>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+    default: hipLaunchKernelGGL((k_down_chain_u8<4, bgr8_t>), dim3(grid), dim3(64), 0, s, f, fs, g8, out); break;
+    }
+    LAUNCH_CHECK();
+    return RM_OK;
+}

@@ -1,5 +1,6 @@
 // respmon_amd/csrc/rm_down_chain_u8.h -- fused Gaussian pyramid chain for NARROW frame buffers (uint8, float16, float32)
 // frames[T,H,W] (W % 16 == 0) -> G_S[T,h_S,w_S] float64, S <= 4                   (pyramid.py:9-17)
+// ... and for [T,H,W,3] uint8 BGR frame buffers (bgr8_t below: base.py:230's cvtColor fused into the first row pass)
 //
 // Written for uint8 first (the text below); float16 / float32 buffers use the same register-resident chain with
 // 2 / 4 sixteen-byte loads per lane and row instead of one (a lane still owns 16 adjacent pixels), and their
@@ -50,6 +51,17 @@ template <int S, int K> struct VStateU8 : VStateU8<S, K + 1> {
 };
 template <int S> struct VStateU8<S, S> {};
 
+// [H,W,3] uint8 pixels as cv2.VideoCapture.read() delivers them (base.py:229) -- RM_BGR8, north_star's [T,H,W,C] frame buffer.  The
+// chain applies base.py:230-231 while it unpacks a row: cv2.cvtColor(BGR2GRAY) is OpenCV's 14-bit fixed point
+//     Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14
+// and uint8_to_float is the table look-up of the gray path.  A lane still owns 16 adjacent pixels: 48 bytes, three 16-byte loads.
+// The weights do not fit a byte, so the sum is two v_dot4_u32_u8 (low and high bytes of the weights; the fourth byte of the word
+// meets a zero weight) joined by one v_lshl_add_u32; pixels whose three bytes straddle two words are brought together by
+// v_alignbyte_b32 first: 5.5 integer instructions per pixel instead of the 1 of a gray row, bit-identical to k_bgr_to_gray.
+struct bgr8_t { uint8_t b, g, r; };
+static_assert(sizeof(bgr8_t) == 3, "packed BGR pixel");
+template <typename Tin> struct IsBgr { static constexpr bool value = false; };
+template <> struct IsBgr<bgr8_t> { static constexpr bool value = true; };
 template <typename Tin> struct RegTraits;   // NLD: 16-byte loads per lane and row; PF: rows in flight (a divisor of the hot block, 4)
 // HOT: the static steady-state blocks of RegChain pay (measured, bench_micro/dc8_bench.hip, kernel ms old -> new): uint8 1080p x 256
 // 0.365 -> 0.30, float16 4K x 512 2.19 -> 2.03; the float32 chain is bound by bytes in flight, not by instruction issue, and
@@ -85,6 +97,10 @@ template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16
 #ifndef RM_F32_PREFETCH
 #define RM_F32_PREFETCH 2
 #endif
+#ifndef RM_BGR_PREFETCH
+#define RM_BGR_PREFETCH 2
+#endif
+template <> struct RegTraits<bgr8_t> { static constexpr int NLD = 3, PF = RM_BGR_PREFETCH, RD = 8; static constexpr bool HOT = RM_NARROW_HOT != 0, DMA = false; };
 template <> struct RegTraits<float> { static constexpr int NLD = 4, PF = RM_F32_PREFETCH, RD = RM_F32_RING; static constexpr bool HOT = RM_F32_HOT != 0, DMA = RM_NARROW_DMA_ON != 0; };
 // LDS bytes per wave of the row ring (0: rows in registers)
 template <typename Tin> constexpr size_t narrow_ring_bytes() { return RegTraits<Tin>::DMA ? (size_t)RegTraits<Tin>::RD * RegTraits<Tin>::NLD * 1024 : 0; }
@@ -92,20 +108,24 @@ template <typename Tin> constexpr size_t narrow_ring_bytes() { return RegTraits<
 template <int S, typename Tin = uint8_t>
 struct RegChain {
     static_assert(S >= 1 && S <= 4, "a lane owns 16 >> K columns of level K");
-    static constexpr int NLD = RegTraits<Tin>::NLD, VPER = 16 / NLD;  // VPER pixels per 16-byte load
+    static constexpr int NLD = RegTraits<Tin>::NLD, VPER = 16 / NLD;  // VPER pixels per 16-byte load (BGR: pixels straddle the loads)
+    static constexpr bool BGR = IsBgr<Tin>::value, BYTES = sizeof(Tin) == 1 || BGR;   // 8-bit samples: table look-up, deep hot blocks
     // Levels 0 .. D-1 have a STATIC steady state ("hot blocks" of B = 2^D input rows): away from the image top / bottom and
     // once a level's (a, b, c, t) state is warm, the even / odd role of every row of these levels inside an aligned block is
     // known at compile time, so the block is straight-line code -- no parity test, no border select, no state copies (the
     // generic row-at-a-time form below spends more instructions on those than on arithmetic).  Levels D .. S-1 (1/16 of the
     // pixels and less) and every row near a segment start, the image top or the image bottom take the generic form.
-    static constexpr bool HOT = RegTraits<Tin>::HOT && (sizeof(Tin) == 1 || S <= 2);   // (float16 at depth 3 / 4: the hot blocks do not fit 256 registers -- compiler resource report)
+    static constexpr bool HOT = RegTraits<Tin>::HOT && (BYTES || S <= 2);   // (float16 at depth 3 / 4: the hot blocks do not fit 256 registers -- compiler resource report)
 #ifndef RM_NARROW_D
 #define RM_NARROW_D 2
 #endif
     static constexpr int D = S < RM_NARROW_D ? S : RM_NARROW_D;
     static constexpr int B = 1 << D;
     static constexpr int PRIO_BLOCKS_SHIFT = D >= 4 ? 0 : 4 - D;   // the issue priority rotates every 16 input rows (rm_down_chain.h dc_set_prio)
-    static constexpr int PF = !HOT ? RegTraits<Tin>::PF : RegTraits<Tin>::PF < B ? RegTraits<Tin>::PF : B;
+    // (BGR at depth 2 -- the instantiation with the most live state, 250 registers for gray uint8 -- keeps ONE row in flight: a second
+    //  one spills 48 bytes per lane)
+    static constexpr int PF_T = (BGR && S == 2) ? 1 : RegTraits<Tin>::PF;
+    static constexpr int PF = !HOT ? PF_T : PF_T < B ? PF_T : B;
     static_assert(!HOT || B % PF == 0, "a row's prefetch slot must be static inside a hot block");
     // Every pyrDown ends with an exact scaling by 1/256 (pyramid.py:14 -> cv2.pyrDown); it commutes with the roundings of the
     // levels above it (powers of two, magnitudes nowhere near the exponent limits for uint8 / float16 / float32 data), so the
@@ -332,9 +352,9 @@ struct RegChain {
 
     __device__ __forceinline__ void issue(int row, Raw16 (&r)[NLD]) const
     {
-        const Tin *rp = src + (size_t)row * W;
+        const char *rp = reinterpret_cast<const char *>(src + (size_t)row * W);
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(rp + j * VPER);   // (plain: this kernel lives on cache hits for its strip halos -- non-temporal loads measured 0.43 -> 0.70 ms on the float32 buffer)
+        for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const Raw16 *>(rp + 16 * j);   // (plain: this kernel lives on cache hits for its strip halos -- non-temporal loads measured 0.43 -> 0.70 ms on the float32 buffer)
     }
 
     // uint8 with RM_U8_LUT: uint8_to_float's 256 possible values k * (1./255) come from a 2 KB table in LDS -- one SDWA shift
@@ -364,9 +384,28 @@ struct RegChain {
         }
     }
 
+    // BGR: pixel E starts at byte 3 E of the lane's 48
+    template <int Q> static __device__ __forceinline__ unsigned word_of(const Raw16 (&r)[NLD])
+    {
+        constexpr int J = Q >> 2 < NLD ? Q >> 2 : NLD - 1;
+        return (Q & 3) == 0 ? r[J].x : (Q & 3) == 1 ? r[J].y : (Q & 3) == 2 ? r[J].z : r[J].w;
+    }
+    template <int E> __device__ __forceinline__ void unpack_bgr(const Raw16 (&r)[NLD], double (&v)[16]) const
+    {
+        if constexpr (E < 16) {
+            constexpr int Q = (3 * E) >> 2, SH = (3 * E) & 3;
+            const unsigned off = bgr_gray_x8<SH>(word_of<Q>(r), word_of<(Q + 1 < 4 * NLD ? Q + 1 : Q)>(r));
+            if constexpr (RM_U8_LUT) v[E] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lut) + off);
+            else v[E] = (double)(off >> 3) * (1.0 / 255);
+            unpack_bgr<E + 1>(r, v);
+        }
+    }
+
     __device__ __forceinline__ void unpack_row(const Raw16 (&r)[NLD], double (&v)[16]) const
     {
-        if constexpr (sizeof(Tin) == 1 && RM_U8_LUT) {
+        if constexpr (BGR) {
+            unpack_bgr<0>(r, v);
+        } else if constexpr (sizeof(Tin) == 1 && RM_U8_LUT) {
             unpack_lut<0>(r[0], v);
         } else {
 #pragma unroll
@@ -540,7 +579,7 @@ template <int S, typename Tin> __device__ __forceinline__ void down_chain_narrow
 #endif
         rc.ring_ptr = ring + 16 * threadIdx.x;
     }
-    if constexpr (sizeof(Tin) == 1 && RM_U8_LUT) {
+    if constexpr (RegChain<S, Tin>::BYTES && RM_U8_LUT) {
         __shared__ double s_lut[256];
         for (int i = threadIdx.x; i < 256; i += 64) s_lut[i] = (double)i * (1.0 / 255);   // uint8_to_float, transforms.py:20-23
         wave_sync();

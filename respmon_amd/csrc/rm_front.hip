@@ -62,6 +62,11 @@ int front_pyramid(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int 
     // Gaussian chain (pyramid.py:9-17).  Levels < S are stepping stones (ping-pong scratch);
     // levels S..L-1 are kept for the Laplacians.
     std::vector<double *> g(L, nullptr);
+    if (dtype == RM_BGR8 && !pg.chain) {
+        // [T,H,W,3] uint8 on the paths that do not start with the fused chain (skip 0, unfused test flags): cvtColor of the whole buffer first
+        RM_TRY(bgr_buffer_to_gray(ctx, frames, (size_t)T * H * W, &frames, s));
+        dtype = RM_U8;
+    }
     const void *cur = frames; int cur_dtype = dtype;
     int first = 1;
     if (pg.filter_first || pg.ff_levels) {

@@ -85,6 +85,7 @@ struct CollapsePlan {
 struct DebugKnobs {
     int temporal_valu = 0;        // 1: the two-stage VALU temporal kernels instead of k_temporal_sym
     int temporal_wide = -1;       // 0 / 1: k_temporal_sym / k_temporal_sym_px whatever the level size (-1: by size)
+    int bgr_unfused = 0;          // 1: RM_BGR8 buffers are converted to gray as a whole before the chain (the path of shapes the fused kernel does not take)
     int dc_lds_front_end = 0;     // 1: narrow frame buffers through the LDS front end of k_down_chain instead of rm_down_chain_u8.h
     int no_fused_bounds = 0;      // 1: k_small_collapse + k_frame_bounds instead of k_small_collapse_bounds
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
@@ -245,8 +246,14 @@ static inline unsigned nblk(size_t n, unsigned per, unsigned cap = 8192)
     return (unsigned)(b > cap ? cap : b);
 }
 static inline bool valid_dtype(int d) { return d == RM_U8 || d == RM_F16 || d == RM_F32 || d == RM_F64; }
-static inline int dtype_vec(int dtype) { return dtype == RM_F64 ? 2 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 8 : 16; }
-static inline size_t dtype_size(int dtype) { return dtype == RM_F64 ? 8 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 2 : 1; }
+// frame BUFFERS of the calibration entry points may also be RM_BGR8 ([T,H,W,3] uint8: base.py:230's cvtColor happens on the device)
+static inline bool valid_buffer_dtype(int d) { return valid_dtype(d) || d == RM_BGR8; }
+static inline int dtype_vec(int dtype) { return dtype == RM_F64 ? 2 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 8 : 16; }   // pixels per 16-byte aligned lane-load unit
+static inline size_t dtype_size(int dtype) { return dtype == RM_F64 ? 8 : dtype == RM_F32 ? 4 : dtype == RM_F16 ? 2 : dtype == RM_BGR8 ? 3 : 1; }
+
+// ---- rm_ctx.hip
+int launch_bgr_to_gray(const uint8_t *bgr, size_t npix, uint8_t *gray, hipStream_t s);
+int bgr_buffer_to_gray(rm_ctx *ctx, const void *frames, size_t npix, const void **gray_out, hipStream_t s);
 
 // ---- rm_pyramid.hip
 int launch_pyr_down(const void *src, int dtype, int T, int h, int w, double *dst, hipStream_t s);

@@ -2581,4 +2581,29 @@ RM_KERNEL __launch_bounds__(256) void k_bgr_to_gray(const uint8_t *bgr, size_t n
     }
 }
 
+// The same sum on whole words.  The weights do not fit a byte, so it is two v_dot4_u32_u8 (low and high bytes of the weights; the
+// fourth byte of the word meets a zero weight) joined by one v_lshl_add_u32; a pixel whose three bytes straddle two words is brought
+// together by v_alignbyte_b32 first.
+constexpr unsigned BGR_W_LO = 0x0023914Cu, BGR_W_HI = 0x00132507u;   // 1868 = 0x074C, 9617 = 0x2591, 4899 = 0x1323: byte 0 = B, 1 = G, 2 = R
+
+// gray value of the pixel whose B sits in byte SH of word d0 (its G / R may continue in d1), times 8: the byte offset into the table
+template <int SH> __device__ __forceinline__ unsigned bgr_gray_x8(unsigned d0, unsigned d1)
+{
+    unsigned x = d0, wlo = BGR_W_LO, whi = BGR_W_HI;
+    if constexpr (SH == 1) { wlo = BGR_W_LO << 8; whi = BGR_W_HI << 8; }        // bytes 1..3 of d0: move the weights, not the pixel
+    else if constexpr (SH >= 2) x = __builtin_amdgcn_alignbyte(d1, d0, SH);     // {d1, d0} >> 8 SH
+    const unsigned lo = __builtin_amdgcn_udot4(x, wlo, 8192u, false), hi = __builtin_amdgcn_udot4(x, whi, 0u, false);
+    return (((hi << 8) + lo) >> 11) & 0x7f8u;                                  // (sum >> 14) << 3
+}
+
+// four pixels (three words) per thread and trip -> one word of gray; `nquads` = npix / 4, both pointers 4-byte aligned
+RM_KERNEL __launch_bounds__(256) void k_bgr_to_gray_quads(const unsigned *bgr, size_t nquads, unsigned *gray)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (size_t)gridDim.x * 256) {
+        const unsigned d0 = bgr[3 * i], d1 = bgr[3 * i + 1], d2 = bgr[3 * i + 2];
+        const unsigned g0 = bgr_gray_x8<0>(d0, d1), g1 = bgr_gray_x8<3>(d0, d1), g2 = bgr_gray_x8<2>(d1, d2), g3 = bgr_gray_x8<1>(d2, d2);
+        gray[i] = (g0 >> 3) | (g1 << 5) | (g2 << 13) | (g3 << 21);
+    }
+}
+
 }  // namespace rm

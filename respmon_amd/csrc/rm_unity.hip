@@ -8,6 +8,7 @@
 #include "rm_down_f64.hip"
 #include "rm_down_generic.hip"
 #include "rm_down_narrow.hip"
+#include "rm_down_bgr.hip"
 #include "rm_front.hip"
 #include "rm_collapse_eval.hip"
 #include "rm_collapse_sum.hip"

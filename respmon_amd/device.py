@@ -67,6 +67,27 @@ def dtype_code(tensor):
     return table[tensor.dtype]
 
 
+def is_bgr_buffer(tensor):
+    """[T,H,W,3] uint8: frames as cv2.VideoCapture.read() delivers them (base.py:229), stored unconverted (RM_BGR8)."""
+    return tensor.dim() == 4 and tensor.shape[-1] == 3 and tensor.dtype == torch().uint8
+
+
+def buffer_dtype_code(buf):
+    """dtype code of a calibration frame BUFFER: dtype_code of a [T,H,W] tensor, RM_BGR8 of a [T,H,W,3] uint8 one."""
+    if buf.dim() == 4:
+        if not is_bgr_buffer(buf):
+            raise TypeError("a 4-D frame buffer must be [T,H,W,3] uint8 (BGR), got %s %s" % (tuple(buf.shape), buf.dtype))
+        return _capi.RM_BGR8
+    return dtype_code(buf)
+
+
+def buffer_shape(buf):
+    """(T, H, W) of a [T,H,W] or [T,H,W,3] frame buffer."""
+    if buf.dim() not in (3, 4):
+        raise ValueError("frame buffer must be [T,H,W] or [T,H,W,3], got %s" % (tuple(buf.shape),))
+    return int(buf.shape[0]), int(buf.shape[1]), int(buf.shape[2])
+
+
 def to_device(a, dtype=None):
     """numpy array or torch tensor -> contiguous CUDA(HIP) tensor (no copy if already there)."""
     t = require_gpu()

@@ -76,10 +76,10 @@ def hip_calibrate(buf, fps, freq_min=0.1, freq_max=1.0, amplification=500, pyram
     from . import _capi, device
     t = device.require_gpu()
     lib = _capi.load()
-    T, H, W = buf.shape
+    T, H, W = device.buffer_shape(buf)
     heat = out if out is not None else t.empty((H, W), dtype=t.float64, device=buf.device)
     mm = (ctypes.c_double * 2)() if return_minmax else None
-    _capi.check(lib, lib.rm_calibrate(device.ctx(), device.ptr(buf), device.dtype_code(buf), T, H, W, float(fps),
+    _capi.check(lib, lib.rm_calibrate(device.ctx(), device.ptr(buf), device.buffer_dtype_code(buf), T, H, W, float(fps),
                                       float(freq_min), float(freq_max), float(amplification), int(pyramid_levels),
                                       int(skip_levels_at_top), float(temporal_threshold), int(flags), device.ptr(heat), mm,
                                       device.stream_ptr()), "rm_calibrate")
@@ -257,7 +257,7 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
         return cabi_locate_streams(buf, fps, threshold=threshold, return_heatmap=return_heatmap, **kw)
     if calibrate_fn is hip_calibrate and not return_heatmap:   # nobody sees this rank's own heatmap: no allocation per step
         from . import device as _device
-        heat = hip_calibrate(buf, fps, out=_scratch("heat", buf.shape[1:], _device.torch().float64, buf.device), **kw)
+        heat = hip_calibrate(buf, fps, out=_scratch("heat", buf.shape[1:3], _device.torch().float64, buf.device), **kw)
     else:
         heat = calibrate_fn(buf, fps, **kw)
     if sparse is None:
@@ -362,10 +362,10 @@ class HipShardStages:
 
     def pyramid(self, buf_local, levels, skip, flags, NP):
         d, t = self._device, self.t
-        Tl, H, W = buf_local.shape
+        Tl, H, W = d.buffer_shape(buf_local)
         lap = t.empty((Tl, NP), dtype=t.float64, device=buf_local.device)
         if NP:
-            self._capi.check(self.lib, self.lib.rm_shard_pyramid(d.ctx(), d.ptr(buf_local), d.dtype_code(buf_local), Tl, H, W, levels,
+            self._capi.check(self.lib, self.lib.rm_shard_pyramid(d.ctx(), d.ptr(buf_local), d.buffer_dtype_code(buf_local), Tl, H, W, levels,
                                                                  skip, int(flags), d.ptr(lap), d.stream_ptr()), "rm_shard_pyramid")
         return lap
 
@@ -411,7 +411,7 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
         return cabi_locate_sharded(buf_local, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
                                    temporal_threshold, threshold, flags, return_heatmap)
     st = stages if stages is not None else HipShardStages()
-    _, H, W = buf_local.shape
+    H, W = int(buf_local.shape[1]), int(buf_local.shape[2])
     L, S = int(pyramid_levels), int(skip_levels_at_top)
     NP = st.layout(H, W, L, S, flags)   # doubles per frame the ranks exchange: G_S (default) or the Laplacian levels S .. L-2
     lap_local = st.pyramid(buf_local, L, S, flags, NP)
@@ -502,11 +502,11 @@ def _cabi_step(fn_name, buf, T, fps, freq_min, freq_max, amplification, pyramid_
     global LAST_EXCHANGE
     t = device.require_gpu()
     lib = _capi.load()
-    _, H, W = buf.shape
+    _, H, W = device.buffer_shape(buf)
     heat = t.empty((H, W), dtype=t.float64, device=buf.device) if return_heatmap else None
     xywh = (ctypes.c_int32 * 4)()
     how = ctypes.c_int(0)
-    rc = _capi.check(lib, getattr(lib, fn_name)(device.ctx(buf.device.index), device.ptr(buf), device.dtype_code(buf), int(T), H, W, float(fps), float(freq_min),
+    rc = _capi.check(lib, getattr(lib, fn_name)(device.ctx(buf.device.index), device.ptr(buf), device.buffer_dtype_code(buf), int(T), H, W, float(fps), float(freq_min),
                                                float(freq_max), float(amplification), int(pyramid_levels), int(skip_levels_at_top),
                                                float(temporal_threshold), int(threshold), int(flags), device.ptr(heat), xywh, ctypes.byref(how),
                                                device.stream_ptr()), fn_name)

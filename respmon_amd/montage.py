@@ -25,6 +25,9 @@ def time_average(video):
     t = device.require_gpu()
     lib = _capi.load()
     v = device.to_device(video)
+    if v.dim() == 4:     # a [T,H,W,3] uint8 frame buffer: the average of its gray frames (base.py:230)
+        from . import transforms
+        v = transforms.bgr_buffer_to_gray(v)
     T = v.shape[0]
     out = t.empty(tuple(v.shape[1:]), dtype=t.float64, device=v.device)
     _capi.check(lib, lib.rm_time_average(device.ctx(), device.ptr(v), device.dtype_code(v), T, out.numel(), device.ptr(out),

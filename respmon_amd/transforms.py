@@ -30,6 +30,19 @@ def float_to_uint8(img):
     return device.like_input(dst, img)
 
 
+def bgr_buffer_to_gray(buf):
+    """[T,H,W,3] uint8 -> [T,H,W] uint8: cv2.cvtColor(BGR2GRAY) of every frame (base.py:230) on the device (rm_bgr_to_gray) -- what the
+    calibration kernels do on the fly with an RM_BGR8 buffer, for the entry points that take gray frames."""
+    t = device.require_gpu()
+    lib = _capi.load()
+    src = device.to_device(buf)
+    if not device.is_bgr_buffer(src):
+        raise TypeError("expected a [T,H,W,3] uint8 buffer")
+    gray = t.empty(tuple(src.shape[:3]), dtype=t.uint8, device=src.device)
+    _capi.check(lib, lib.rm_bgr_to_gray(device.ctx(), device.ptr(src), gray.numel(), device.ptr(gray), device.stream_ptr()), "rm_bgr_to_gray")
+    return gray
+
+
 def temporal_operator(n, fps, freq_min, freq_max):
     """The reference's rfft / mask / Re(ifft) filter (transforms.py:86-98) as its explicit n x n matrix
     (without the amplification) plus (bound_low, bound_high).  Host only; needs no GPU."""
@@ -133,12 +146,14 @@ def eulerian_magnification_bandpass(vid_data, fps, freq_min, freq_max, amplifica
     t = device.require_gpu()
     lib = _capi.load()
     vid = device.to_device(vid_data)
-    T, H, W = vid.shape
+    T, H, W = device.buffer_shape(vid)
+    if vid.dim() == 4 and not (temporal_filter_function is None or temporal_filter_function is temporal_bandpass_filter_fft):
+        vid = bgr_buffer_to_gray(vid)
     masked = t.empty((T, H, W), dtype=t.float64, device=vid.device)
     mm = (ctypes.c_double * 2)()
     if temporal_filter_function is None or temporal_filter_function is temporal_bandpass_filter_fft:
         raw = t.empty((T, H, W), dtype=t.float64, device=vid.device)
-        _capi.check(lib, lib.rm_eulerian_magnification_bandpass(device.ctx(), device.ptr(vid), device.dtype_code(vid), T, H, W,
+        _capi.check(lib, lib.rm_eulerian_magnification_bandpass(device.ctx(), device.ptr(vid), device.buffer_dtype_code(vid), T, H, W,
                                                                 float(fps), float(freq_min), float(freq_max), float(amplification),
                                                                 int(pyramid_levels), int(skip_levels_at_top), float(threshold),
                                                                 device.ptr(masked), device.ptr(raw), mm, device.stream_ptr()),

@@ -222,6 +222,14 @@ inline void __builtin_amdgcn_wave_barrier() { hipemu::yield(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+// v_alignbyte_b32: ({hi, lo} >> 8 * (shift & 3)) & 0xffffffff;  v_dot4_u32_u8: four byte products + c (no clamp used)
+inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned shift) {
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (shift & 3)));
+}
+inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
+    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+    return c;
+}
 template <typename T> inline T __builtin_nontemporal_load(const T *p) { return *p; }
 /* v_mfma_f64_16x16x4_f64: D[16x16] = A[16x4] B[4x16] + C.  Lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and the four
  * elements D[4 r + l / 16][l % 16], r = 0..3 (CDNA3/4 ISA, "MFMA 16x16x4 F64").  The products of one instruction are accumulated

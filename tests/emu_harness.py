@@ -18,6 +18,15 @@ def ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 
 
+def buf_args(frames):
+    """(T, H, W, dtype code) of a frame buffer: [T,H,W] of a supported dtype, or [T,H,W,3] uint8 = RM_BGR8."""
+    if frames.ndim == 4:
+        assert frames.dtype == np.uint8 and frames.shape[3] == 3
+        return frames.shape[0], frames.shape[1], frames.shape[2], _capi.RM_BGR8
+    T, H, W = frames.shape
+    return T, H, W, DT[frames.dtype]
+
+
 class Emu:
     def __init__(self):
         from tests.emu import build as emu_build
@@ -79,17 +88,17 @@ class Emu:
 
     def eulerian(self, frames, fps, fmin, fmax, amp, levels, skip, thr=0.7):
         frames = np.ascontiguousarray(frames)
-        T, H, W = frames.shape
+        T, H, W, code = buf_args(frames)
         masked = np.empty((T, H, W)); raw = np.empty((T, H, W)); mm = np.empty(2)
-        self.ck(self.lib.rm_eulerian_magnification_bandpass(self.ctx, ptr(frames), DT[frames.dtype], T, H, W, fps, fmin, fmax,
+        self.ck(self.lib.rm_eulerian_magnification_bandpass(self.ctx, ptr(frames), code, T, H, W, fps, fmin, fmax,
                                                             amp, levels, skip, thr, ptr(masked), ptr(raw), ptr(mm), None), "eulerian")
         return masked, raw, mm
 
     def calibrate(self, frames, fps, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, flags=0):
         frames = np.ascontiguousarray(frames)
-        T, H, W = frames.shape
+        T, H, W, code = buf_args(frames)
         heat = np.empty((H, W)); mm = np.empty(2)
-        self.ck(self.lib.rm_calibrate(self.ctx, ptr(frames), DT[frames.dtype], T, H, W, fps, fmin, fmax, amp, levels, skip, thr,
+        self.ck(self.lib.rm_calibrate(self.ctx, ptr(frames), code, T, H, W, fps, fmin, fmax, amp, levels, skip, thr,
                                       flags, ptr(heat), ptr(mm), None), "calibrate")
         return heat, mm
 
@@ -111,9 +120,9 @@ class Emu:
 
     def locate(self, frames, fps, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, threshold=20, flags=0):
         frames = np.ascontiguousarray(frames)
-        T, H, W = frames.shape
+        T, H, W, code = buf_args(frames)
         xywh = np.zeros(4, np.int32)
-        rc = self.ck(self.lib.rm_locate(self.ctx, ptr(frames), DT[frames.dtype], T, H, W, fps, fmin, fmax, amp, levels, skip, thr,
+        rc = self.ck(self.lib.rm_locate(self.ctx, ptr(frames), code, T, H, W, fps, fmin, fmax, amp, levels, skip, thr,
                                         threshold, flags, ptr(xywh), None), "locate")
         return None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)
 
@@ -121,9 +130,9 @@ class Emu:
     def locate_submit(self, frames, fps, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, threshold=20, flags=0):
         """rm_locate_submit -> (ticket, the frames kept alive) or the negative return code when the library refuses."""
         frames = np.ascontiguousarray(frames)
-        T, H, W = frames.shape
+        T, H, W, code = buf_args(frames)
         tk = ctypes.c_int(-1)
-        rc = self.lib.rm_locate_submit(self.ctx, ptr(frames), DT[frames.dtype], T, H, W, fps, fmin, fmax, amp, levels, skip, thr, threshold,
+        rc = self.lib.rm_locate_submit(self.ctx, ptr(frames), code, T, H, W, fps, fmin, fmax, amp, levels, skip, thr, threshold,
                                        flags, None, ctypes.byref(tk))
         if rc < 0:
             return rc
@@ -144,7 +153,7 @@ def _shard_methods():
     def locate_sharded(self, frames, world, fps=10.0, fmin=0.1, fmax=1.0, amp=500.0, levels=9, skip=4, thr=0.7, threshold=20, flags=0):
         """The rm_shard_* stages for `world` emulated ranks (a context each), collectives done with numpy."""
         frames = np.ascontiguousarray(frames)
-        T, H, W = frames.shape
+        T, H, W, code = buf_args(frames)
         n = ctypes.c_size_t()
         self.ck(self.lib.rm_shard_layout_flags(H, W, levels, skip, flags, ctypes.byref(n)), "shard_layout")
         NP = int(n.value)
@@ -159,7 +168,7 @@ def _shard_methods():
             local = np.ascontiguousarray(frames[t0:t1])
             lap = np.empty((t1 - t0, NP))
             if NP:
-                self.ck(self.lib.rm_shard_pyramid(c, ptr(local), DT[local.dtype], t1 - t0, H, W, levels, skip, flags, ptr(lap), None),
+                self.ck(self.lib.rm_shard_pyramid(c, ptr(local), code, t1 - t0, H, W, levels, skip, flags, ptr(lap), None),
                         "shard_pyramid")
             lap_all[t0:t1] = lap
         mms = []

@@ -208,6 +208,47 @@ def test_emu_fused_down_chain_equals_per_level(emu):
                 assert np.array_equal(ff, ff_other), (dt, T, H, W, L, S)
 
 
+def test_emu_bgr_frame_buffer_equals_its_gray_buffer(emu, oracle):
+    """RM_BGR8 ([T,H,W,3] uint8, frames as cv2.VideoCapture delivers them): the calibration applies base.py:230-231 (cvtColor(BGR2GRAY),
+    uint8_to_float) while it reads the buffer -- bit-identical to the same call on the gray uint8 buffer the ORACLE's cvtColor makes of it,
+    on the fused register chain (W % 16 == 0, depths 1..4, tiny strips), on the whole-buffer conversion in front of the other chains
+    (ragged widths, skip 0, the per-level flags), for rm_locate, the two-call form, the frame-sharded stages and the materialising form."""
+    rng = np.random.default_rng(41)
+    cases = [(3, 64, 96, 4, 2, 0), (2, 67, 131, 5, 3, 0), (1, 135, 240, 6, 4, 0), (1, 40, 1936, 4, 1, 0), (2, 70, 112, 6, 3, 8),
+             (2, 33, 48, 3, 0, 0), (2, 48, 64, 4, 2, 2), (1, 36, 401, 5, 3, 64)]
+    for (T, H, W, L, S, flags) in cases:
+        bgr = rng.integers(0, 256, size=(T, H, W, 3), dtype=np.uint8)
+        gray = np.stack([oracle.cvtColor_bgr2gray(f) for f in bgr])
+        want, mm_w = emu.calibrate(gray, 10.0, levels=L, skip=S, flags=flags)
+        got, mm_g = emu.calibrate(bgr, 10.0, levels=L, skip=S, flags=flags)
+        assert np.array_equal(got, want) and np.array_equal(mm_g, mm_w), (T, H, W, L, S, flags)
+        emu.debug_set("bgr_unfused", 1)     # the whole-buffer conversion also where the fused chain applies
+        try:
+            got2, _ = emu.calibrate(bgr, 10.0, levels=L, skip=S, flags=flags)
+        finally:
+            emu.debug_set("bgr_unfused", 0)
+        assert np.array_equal(got2, want), (T, H, W, L, S, flags)
+    # a breathing video whose colour planes differ: ROI through every entry point that takes a frame buffer
+    v8 = synth.synth_breathing(24, 96, 160, seed=5)
+    bgr = np.stack([np.clip(v8.astype(np.int32) + 12, 0, 255), v8, np.clip(v8.astype(np.int32) - 9, 0, 255)], axis=-1).astype(np.uint8)
+    gray = np.stack([oracle.cvtColor_bgr2gray(f) for f in bgr])
+    kw = dict(levels=5, skip=2)
+    want = oracle.locate(oracle.uint8_to_float(gray), 10.0, pyramid_levels=5, skip_levels_at_top=2)
+    assert want is not None
+    assert emu.locate(bgr, 10.0, **kw) == want
+    tk = emu.locate_submit(bgr, 10.0, **kw)
+    assert emu.locate_result(tk) == want
+    roi_s, heat_s, _ = emu.locate_sharded(bgr, 3, **kw)
+    assert roi_s == want
+    m_b, r_b, mm_b = emu.eulerian(bgr[:8], 10.0, 0.1, 1.0, 500.0, 4, 2)
+    m_g, r_g, mm_g = emu.eulerian(gray[:8], 10.0, 0.1, 1.0, 500.0, 4, 2)
+    assert np.array_equal(m_b, m_g) and np.array_equal(r_b, r_g) and np.array_equal(mm_b, mm_g)
+    # gray-only entry points refuse the code
+    from tests.emu_harness import ptr
+    out = np.empty((1, 32, 48))
+    assert emu.lib.rm_pyr_down(emu.ctx, ptr(bgr), _capi.RM_BGR8, 1, 64, 96, ptr(out), None) == _capi.RM_E_BADARG
+
+
 def test_emu_frame_sharded_stages(emu, oracle):
     """rm_shard_* (Mode A): one rank == rm_calibrate bit for bit; several emulated ranks give the same ROI and
     extrema, the heatmap up to the association of the time sum."""

@@ -289,7 +289,7 @@ def test_state_machine_full_calibration_trace(hip, golden):
     from respmon_amd.base import RespiratoryMonitor
     g = golden("g6_run_trace.npz")
     vid = synth.synth_breathing(150, 48, 64, seed=11)
-    for bdt in ("float64", "uint8"):
+    for bdt in ("float64", "uint8", "bgr8"):    # 'bgr8': the frames stored as captured ([T,H,W,3]); rm_locate converts as it reads
         mon = RespiratoryMonitor(capture_target=synth.FakeCapture(vid, fps=30), visualize=None, save_all_data=False,
                                  motion_extraction_method="average", run_on_init=False, buffer_dtype=bdt)
         mon.sync_to_fps = lambda: None

@@ -40,8 +40,67 @@ def test_bgr_to_gray_every_sampled_triple_and_a_1080p_frame(hip, oracle):
     # all 2^24 triples: the weights are exact integers, so a closed form over the full cube is cheap on both sides
     bb, gg, rr = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(0, 256, 1, dtype=np.uint8), indexing="ij")
     cube = np.stack([bb, gg, rr], axis=-1).reshape(4096, 4096, 3)
+    want = oracle.cvtColor_bgr2gray(cube)
     got = be.bgr_to_gray(cube).cpu().numpy()
-    assert np.array_equal(got, oracle.cvtColor_bgr2gray(cube))
+    assert np.array_equal(got, want)
+    # ... and every triple at each of the four byte positions a pixel can take inside the words the kernels read (k_bgr_to_gray_quads and
+    # the RM_BGR8 frame-buffer chain share bgr_gray_x8: whole-word dot products, rm_kernels.h)
+    flat = cube.reshape(-1, 3)
+    for shift in (1, 2, 3):
+        rolled = np.roll(flat, shift, axis=0).reshape(4096, 4096, 3)
+        got = be.bgr_to_gray(rolled).cpu().numpy()
+        assert np.array_equal(got.reshape(-1), np.roll(want.reshape(-1), shift))
+    odd = np.ascontiguousarray(flat[:4099 * 3].reshape(3, 4099, 3))      # a pixel count that is not a multiple of four: scalar tail
+    assert np.array_equal(be.bgr_to_gray(odd).cpu().numpy(), oracle.cvtColor_bgr2gray(odd))
+
+
+def test_bgr_frame_buffer_equals_its_gray_buffer(hip, oracle):
+    """RM_BGR8 -- north_star's [T,H,W,C] frame buffer, frames as cv2.VideoCapture delivers them (base.py:229): the calibration applies
+    base.py:230-231 while it reads the buffer.  Heatmaps bit-identical to the same call on the gray uint8 buffer the ORACLE's cvtColor
+    makes of it: the fused register chain (W % 16 == 0, depths 1..4, one / several strips and segments), the whole-buffer conversion in
+    front of the other chains (ragged widths, skip 0, per-level flags) and forced (`bgr_unfused`); ROI == oracle through locate(), the
+    two-call form and the materialising form; the gray-only entry points refuse the code."""
+    import torch
+    from respmon_amd import _capi, device, dist, synth, transforms
+    from respmon_amd.base import RespiratoryMonitor, _Backend
+    rng = np.random.default_rng(43)
+    cases = [(8, 270, 480, 5, 2, 0), (4, 135, 2000, 6, 4, 0), (3, 540, 960, 7, 3, 0), (5, 97, 1936, 4, 1, 0), (16, 1080, 1920, 9, 4, 0),
+             (4, 67, 131, 5, 3, 0), (3, 48, 64, 3, 0, 0), (3, 64, 96, 4, 2, _capi.RM_FLAG_UNFUSED_DOWN), (2, 120, 160, 5, 2, _capi.RM_FLAG_FILTER_LAPLACIANS),
+             (6, 720, 1280, 4, 2, 0)]
+    for (T, H, W, L, S, flags) in cases:
+        bgr = rng.integers(0, 256, size=(T, H, W, 3), dtype=np.uint8)
+        gray = np.stack([oracle.cvtColor_bgr2gray(f) for f in bgr])
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S, flags=flags, return_minmax=True)
+        dev_b, dev_g = torch.from_numpy(bgr).cuda(), torch.from_numpy(gray).cuda()
+        assert torch.equal(transforms.bgr_buffer_to_gray(dev_b), dev_g)
+        want, mm_w = dist.hip_calibrate(dev_g, 10.0, **kw)
+        got, mm_g = dist.hip_calibrate(dev_b, 10.0, **kw)
+        assert torch.equal(got, want) and mm_g == mm_w, (T, H, W, L, S, flags)
+        device.debug_set("bgr_unfused", 1)
+        try:
+            got2, _ = dist.hip_calibrate(dev_b, 10.0, **kw)
+        finally:
+            device.debug_set("bgr_unfused", 0)
+        assert torch.equal(got2, want), (T, H, W, L, S, flags)
+    # a breathing video whose colour planes differ
+    v8 = synth.synth_breathing(64, 270, 480, seed=5)
+    bgr = np.stack([np.clip(v8.astype(np.int32) + 12, 0, 255), v8, np.clip(v8.astype(np.int32) - 9, 0, 255)], axis=-1).astype(np.uint8)
+    gray = np.stack([oracle.cvtColor_bgr2gray(f) for f in bgr])
+    want = oracle.locate(oracle.uint8_to_float(gray), 10.0, pyramid_levels=6, skip_levels_at_top=2)
+    assert want is not None
+    dev_b = torch.from_numpy(bgr).cuda()
+    assert RespiratoryMonitor.locate(dev_b, 10.0, pyramid_levels=6, skip_levels_at_top=2) == want
+    assert RespiratoryMonitor.locate(bgr, 10.0, pyramid_levels=6, skip_levels_at_top=2) == want       # a host array: uploaded as it is
+    be = _Backend()
+    tk = be.locate_submit(dev_b, 10.0, pyramid_levels=6, skip_levels_at_top=2)
+    assert be.locate_result(tk) == want
+    m_b, r_b = transforms.eulerian_magnification_bandpass(dev_b[:16], 10.0, 0.1, 1.0, 500, pyramid_levels=4, skip_levels_at_top=2)
+    m_g, r_g = transforms.eulerian_magnification_bandpass(torch.from_numpy(gray[:16]).cuda(), 10.0, 0.1, 1.0, 500, pyramid_levels=4, skip_levels_at_top=2)
+    assert torch.equal(m_b, m_g) and torch.equal(r_b, r_g)
+    out = torch.empty((1, 135, 240), dtype=torch.float64, device="cuda")
+    assert hip.rm_pyr_down(device.ctx(), device.ptr(dev_b), _capi.RM_BGR8, 1, 270, 480, device.ptr(out), device.stream_ptr()) == _capi.RM_E_BADARG
+    with pytest.raises(TypeError):
+        device.buffer_dtype_code(torch.zeros((2, 8, 8, 4), dtype=torch.uint8, device="cuda"))
 
 
 def test_store_frame_every_buffer_dtype(hip, oracle):

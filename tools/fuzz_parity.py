@@ -327,8 +327,21 @@ def fuzz_roi(budget, seed):
         H = int(rng.integers(1, 300)); W = int(rng.integers(1, 500))
         if rng.random() < 0.1:
             H = int(rng.integers(300, 1200)); W = int(rng.integers(500, 2000))   # several workgroups per labelling kernel
-        kind = int(rng.integers(0, 3))
-        if kind == 0:
+        if rng.random() < 0.5:
+            W = max(64, (W + 32) // 64 * 64)    # rows of whole 64-pixel words: the row-record kernel (k_heat_rows_u8) and its host rule
+        kind = int(rng.integers(0, 4))
+        if kind == 3:
+            # one or two solid blobs (ellipses, sometimes touching, sometimes with a hole): the shapes the one-blob rule decides on
+            yy, xx = np.mgrid[0:H, 0:W]
+            heat = np.zeros((H, W))
+            for _ in range(int(rng.integers(1, 3))):
+                cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+                ry, rx = rng.uniform(1, max(2, H / 2)), rng.uniform(1, max(2, W / 2))
+                heat[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = 1.0
+            if rng.random() < 0.3:
+                cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+                heat[((yy - cy) / max(1.0, H / 8)) ** 2 + ((xx - cx) / max(1.0, W / 8)) ** 2 <= 1.0] = 0.0
+        elif kind == 0:
             heat = (rng.random((H, W)) < rng.uniform(0.02, 0.7)).astype(np.float64)
         elif kind == 1:
             heat = ndi.gaussian_filter(rng.standard_normal((H, W)), float(rng.uniform(0.5, 4.0)))
@@ -393,11 +406,19 @@ def main():
         L = int(rng.integers(2, 9)); S = int(rng.integers(0, L))
         if big:
             L = int(rng.integers(6, 10)); S = int(rng.integers(2, 5))
-        dt = str(rng.choice(["f64", "u8", "f32", "f16"]))
+        dt = str(rng.choice(["f64", "u8", "f32", "f16", "bgr8"]))
         v8 = synth.synth_breathing(T, H, W, seed=int(rng.integers(1 << 30)), amplitude=float(rng.uniform(0.05, 0.3)),
-                                   noise=float(rng.uniform(0.0, 0.04)), center=(float(rng.uniform(0.1, 0.9)), float(rng.uniform(0.1, 0.9))))
+                                   noise=float(rng.uniform(0.0, 0.04) if rng.random() < 0.8 else rng.uniform(0.06, 0.5)),   # one in five: a dense stream (store-less sums)
+                                   center=(float(rng.uniform(0.1, 0.9)), float(rng.uniform(0.1, 0.9))))
         f64 = oracle.uint8_to_float(v8)
-        if dt == "u8":
+        if dt == "bgr8":    # frames as captured, [T,H,W,3]: base.py:230's cvtColor is the oracle's own, frame by frame
+            off = rng.integers(-40, 41, size=3)
+            bgr = np.stack([np.clip(v8.astype(np.int32) + int(o), 0, 255) for o in off], axis=-1).astype(np.uint8)
+            if rng.random() < 0.3:
+                bgr = rng.integers(0, 256, size=bgr.shape, dtype=np.uint8) // 4 + (bgr // 4) * 3
+            f64 = oracle.uint8_to_float(np.stack([oracle.cvtColor_bgr2gray(f) for f in bgr]))
+            dev, ref_in = torch.from_numpy(bgr).cuda(), f64
+        elif dt == "u8":
             dev, ref_in = torch.from_numpy(v8).cuda(), f64
         elif dt == "f64":
             dev, ref_in = torch.from_numpy(f64).cuda(), f64
@@ -517,7 +538,7 @@ def main():
                 ok = True
                 key = "tt=%g S=%d" % (kw.get("temporal_threshold", 0.7), S)
                 ill_knobs[key] = ill_knobs.get(key, 0) + 1
-            print("  detail: err/range %.2e" % err_rng, "u8 maps equal", np.array_equal(u8_ours, u8_ref), "| fg ours", len(fg_o), fg_o[:4].tolist(), "| fg ref", len(fg_r), fg_r[:4].tolist(),
+            print("  detail:", dict(T=T, H=H, W=W, L=L, S=S, dtype=dt, kw=kw) if ok else "", "err/range %.2e" % err_rng, "u8 maps equal", np.array_equal(u8_ours, u8_ref), "| fg ours", len(fg_o), fg_o[:4].tolist(), "| fg ref", len(fg_r), fg_r[:4].tolist(),
                   "| roi of the GPU heatmap by the oracle's contour code", oracle.roi_from_heatmap_u8(u8_ours, thr_b), flush=True)
         if not ok:
             bad += 1
