@@ -9,7 +9,10 @@ int launch_down_chain_bgr(rm_ctx *ctx, const void *frames, int T, const std::vec
                           hipStream_t s, bool tiny)
 {
     DownGeom g8;
-    if (!make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, 2048)) return 1;
+    // three times the bytes of a gray row per lane: one wave per SIMD with four rows (192 bytes per lane) in flight beats two waves with two,
+    // and half the segments re-read half the halo rows (1080p x 256: two segments per frame, 11 % of the rows twice instead of 22 %)
+    // (depth 2 keeps one row in flight -- RegChain::PF_T -- and wants the waves: 720p x 128 0.121 ms with 2048, 0.188 with 1024)
+    if (!make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, S == 2 ? 2048 : 1024)) return 1;
     g8.prio = ctx->dbg.dc_prio;
     const size_t fs = (size_t)h[0] * w[0];   // in pixels: the kernel's pointer arithmetic is in bgr8_t
     const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);

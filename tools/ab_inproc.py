@@ -33,11 +33,14 @@ def main():
     gen = {"breathing": synth.synth_breathing_blocks if T * H * W > 1 << 30 else synth.synth_breathing, "noise": synth.synth_noise_only,
            "dense": synth.synth_breathing_dense, "blobs16": synth.synth_breathing_16}[a.video]
     v8 = gen(T, H, W, seed=1234) if a.video == "breathing" else gen(T, H, W)
-    tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8}[dt]
-    buf = torch.empty((T, H, W), dtype=tdt, device="cuda")
+    tdt = {"f64": torch.float64, "f32": torch.float32, "f16": torch.float16, "u8": torch.uint8, "bgr8": torch.uint8}[dt]
+    buf = torch.empty((T, H, W, 3) if dt == "bgr8" else (T, H, W), dtype=tdt, device="cuda")
     for t0 in range(0, T, 16):
         chunk = torch.from_numpy(v8[t0:t0 + 16]).cuda()
-        buf[t0:t0 + 16] = chunk if dt == "u8" else (chunk.to(torch.float64) * (1.0 / 255)).to(tdt)
+        if dt == "bgr8":     # three equal planes: gray(x, x, x) == x
+            buf[t0:t0 + 16] = chunk.unsqueeze(-1).expand(-1, -1, -1, 3)
+        else:
+            buf[t0:t0 + 16] = chunk if dt == "u8" else (chunk.to(torch.float64) * (1.0 / 255)).to(tdt)
     del v8
     torch.cuda.synchronize()
     lib = _capi.load()
