@@ -38,6 +38,14 @@ int rm_debug_counters(rm_ctx *ctx, long long *out_host, void *stream);
 #define RM_HOST_MARKS 5
 int rm_debug_host_timeline(rm_ctx *ctx, double *out_host);
 
+/* how the host contour stage of the last ROI extraction on this context found its contour (base.py:568-575) */
+#define RM_ROI_PATH_NONE 0          /* no extraction yet, or settled without the host stage */
+#define RM_ROI_PATH_ONE_BLOB 1      /* the one-blob rule on the row records / packed rows */
+#define RM_ROI_PATH_SCAN 2          /* every border followed on the host */
+#define RM_ROI_PATH_LABELLED 3      /* device labelling: the borders that can win followed */
+#define RM_ROI_PATH_AREA_BOUND 4    /* device labelling: the top component's area bound beat every rival's box, no border followed */
+int rm_debug_roi_path(rm_ctx *ctx, int *path_out);
+
 #ifdef __cplusplus
 }
 #endif

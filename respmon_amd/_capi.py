@@ -49,6 +49,7 @@ SIGNATURES = {
     "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_debug_counters": (_i, [_vp, _vp, _vp]),
     "rm_debug_host_timeline": (_i, [_vp, _vp]),
+    "rm_debug_roi_path": (_i, [_vp, _vp]),
     "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "rm_float_to_uint8": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "rm_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

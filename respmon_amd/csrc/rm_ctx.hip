@@ -45,6 +45,13 @@ int ctx_stream_ok(rm_ctx *ctx, void *stream, const char *who)
     return RM_OK;
 }
 
+extern "C" int rm_debug_roi_path(rm_ctx *ctx, int *path_out)
+{
+    if (!ctx || !path_out) return fail(RM_E_BADARG, "rm_debug_roi_path: bad argument");
+    *path_out = ctx->roi_path;
+    return RM_OK;
+}
+
 extern "C" int rm_debug_host_timeline(rm_ctx *ctx, double *out)
 {
     if (!ctx || !out) return fail(RM_E_BADARG, "rm_debug_host_timeline: bad argument");
@@ -123,6 +130,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "eval_fast") d.eval_fast = (int)value;
     else if (k == "exchange_dense") d.exchange_dense = (int)value;
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
+    else if (k == "host_area_bound") d.host_area_bound = (int)value;
     else if (k == "heat_rows") d.heat_rows = (int)value;
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;

@@ -107,6 +107,7 @@ struct DebugKnobs {
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
     int heat_rows = 1;            // 0: k_heat_to_u8 (flat over the pixels, row flags) also where rows are whole words, instead of k_heat_rows_u8 (row records)
+    int host_area_bound = 1;      // 0: the labelled path always follows the top component's border (no shortcut on its area's lower bound, rm_ccl.h)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
     int eval_fast = 1;            // 0: the generic k_eval_pairs instead of k_eval_pairs_fast (rm_tile_eval.h) where the latter applies
@@ -159,6 +160,7 @@ struct rm_ctx {
     // device labelling of the thresholded image (rm_ccl.h): taken when the previous ROI extraction of this geometry met
     // more than LABEL_MIN_CONTOURS components (label_mode -1 = that rule, 0 = never, 1 = always: rm_set_contour_labelling)
     int label_mode = -1, label_H = 0, label_W = 0, label_last_n = 0, label_used = 0;
+    int roi_path = 0;             // RM_ROI_PATH_* of the last host contour stage (rm_debug_roi_path)
     // ... or when following every border on the host took long last time (few components with long borders: a frame of noise blobs):
     // host time of the last unlabelled stage of this geometry (< 0: none) with its contour count, host time of the last labelled
     // stage, labelled stages in a row (every LABEL_REPROBE-th one is run unlabelled to refresh the first figure)

@@ -2180,7 +2180,7 @@ RM_KERNEL __launch_bounds__(256) void k_heat_minmax(const double *heat, size_t n
 // have a bit set (~12 KB instead of 259 KB over PCIe: the launch's end-of-kernel flush of host-memory writes shrinks with it).  (Tried and dropped: a sparse list of the non-zero words with a `done` word the host spins on instead of the
 // runtime's completion query -- the kernel's own hand-off cost 14 us more, and a stream the runtime never sees complete
 // makes the NEXT launch ~100 us slower.)
-struct alignas(16) CclBox { int minx, maxx, maxy, pad; };   // bounding box of a labelled component (rm_ccl.h), indexed by its root
+struct alignas(16) CclBox { int minx, maxx, maxy, cnt; };   // bounding box of a labelled component (rm_ccl.h), indexed by its root; cnt: 2 * pixels - cracks (rm_ccl.h ccl_piece_2n_minus_p)
 
 // tile_const (nullable; needs W % 64 == 0): tile_nkept of the sum kernel that wrote `heat` -- 0 for a 64 x 16 tile every pixel of which
 // is the same constant (96 % of the tiles of the synthetic 1080p stream): such a word takes its ONE value from a wave-uniform load
@@ -2259,7 +2259,7 @@ RM_KERNEL __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t np
                         int len = zeros_above ? __builtin_ctzll(zeros_above) : 64;        // (lane 0 of a full word: 64 ones)
                         if (len > 64 - lane) len = 64 - lane;
                         if (len > W - (int)x) len = W - (int)x;                           // the row ends inside the word
-                        CclBox e; e.minx = (int)x; e.maxx = (int)x + len - 1; e.maxy = (int)y; e.pad = 0;
+                        CclBox e; e.minx = (int)x; e.maxx = (int)x + len - 1; e.maxy = (int)y; e.cnt = 0;
                         ccl_box[i] = e;
                     }
                 }

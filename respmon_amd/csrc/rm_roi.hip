@@ -165,12 +165,16 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
         }
         const size_t ncomp = label ? (size_t)(unsigned int)rs.h_comps[0].root : 0;
         ctx->label_used = label && ncomp <= comps_cap;
+        ctx->roi_path = RM_ROI_PATH_ONE_BLOB;
         if (settled) {
-        } else if (ctx->label_used)   // (an overflowing record list falls through to the full scan: the image is here either way)
+        } else if (ctx->label_used) {  // (an overflowing record list falls through to the full scan: the image is here either way)
             largest_external_contour_labelled_tops((const uint64_t *)rs.h_bin, H, W, (const LabelComp *)(rs.h_comps + 1), CCL_PUB_BLOCKS,
-                                                   (const LabelComp *)(rs.h_comps + 1 + 2 * CCL_PUB_BLOCKS), ncomp, &r);
-        else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r)))
+                                                   (const LabelComp *)(rs.h_comps + 1 + 2 * CCL_PUB_BLOCKS), ncomp, &r, ctx->dbg.host_area_bound != 0);
+            ctx->roi_path = (r.found && r.area < 0.0) ? RM_ROI_PATH_AREA_BOUND : RM_ROI_PATH_LABELLED;
+        } else if (!(ctx->dbg.host_simple_shape && y1 >= y0 && simple_shape_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r))) {
             largest_external_contour_bits_rows((const uint64_t *)rs.h_bin, H, W, y0, y1, &r);
+            ctx->roi_path = RM_ROI_PATH_SCAN;
+        }
         ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
         if (y1 >= y0 && !pd.rows) {   // restore the all-zero image: the words that cover rows y0 .. y1
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;

@@ -127,6 +127,16 @@ def contour_stats():
     return n.value, bool(lab.value)
 
 
+def roi_path():
+    """RM_ROI_PATH_* of the last host contour stage of this process's context (include/respmon_hip_debug.h rm_debug_roi_path): 1 the
+    one-blob rule, 2 every border followed, 3 labelled components + the borders that can win, 4 labelled + area bound, no border."""
+    import ctypes
+    from . import _capi, device
+    v = ctypes.c_int(-1)
+    _capi.check(_capi.load(), _capi.load().rm_debug_roi_path(device.ctx(), ctypes.byref(v)), "rm_debug_roi_path")
+    return v.value
+
+
 LAST_EXCHANGE = None      # "sparse" / "dense": how the last locate_streams summed the heatmaps (bench.py reports it)
 SPARSE_CAP_TILES = 128   # tiles (64x16 px) a packet can carry: 1 MB per rank; the synthetic 1080p x 256 stream needs ~80
 

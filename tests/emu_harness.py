@@ -113,6 +113,12 @@ class Emu:
         self.lib.rm_set_contour_labelling(self.ctx, -1)
         return (None if rc == _capi.RM_NO_CONTOUR else tuple(int(v) for v in xywh)), u8, b
 
+    def roi_path(self):
+        """RM_ROI_PATH_* of the last host contour stage (include/respmon_hip_debug.h)."""
+        v = ctypes.c_int(-1)
+        self.ck(self.lib.rm_debug_roi_path(self.ctx, ctypes.byref(v)), "roi_path")
+        return v.value
+
     def contour_stats(self):
         n, lab = ctypes.c_int(), ctypes.c_int()
         self.ck(self.lib.rm_contour_stats(self.ctx, ctypes.byref(n), ctypes.byref(lab)), "contour_stats")

@@ -618,11 +618,45 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
     full = np.ones((17, 66), bool); full[8, 33] = False
     masks.append(full)
     masks.append(np.zeros((12, 40), bool))
-    for m in masks:
+    # the area bound of the labelled path (rm_ccl.h ccl_piece_2n_minus_p): components whose BOX is the largest but whose contour
+    # encloses little -- a 1-pixel U, a spiral, a frame-shaped ring around everything, a comb -- next to solid rivals that win or lose;
+    # pieces that end exactly at word / row ends; a solid blob that spans the frame among specks (the shortcut must fire there)
+    u_shape = np.zeros((50, 140), bool); u_shape[5:45, 10] = True; u_shape[5:45, 60] = True; u_shape[44, 10:61] = True; u_shape[10:22, 80:95] = True
+    masks.append(u_shape)
+    spiral = np.zeros((64, 192), bool)
+    for k, (a, b) in enumerate([(2, 60), (6, 56), (10, 52), (14, 48)]):
+        spiral[a, a:190 - a] = True; spiral[b, a + 4:190 - a] = True; spiral[a:b + 1, 189 - a] = True; spiral[a + 4:b + 1, a + 4] = True
+    spiral[20:44, 60:130] = True
+    masks.append(spiral)
+    comb = np.zeros((40, 128), bool); comb[2, :] = True; comb[2:38, ::2] = True; comb[30:39, 1:20] = True
+    masks.append(comb)
+    frame_ring = np.zeros((48, 130), bool); frame_ring[0, :] = True; frame_ring[-1, :] = True; frame_ring[:, 0] = True; frame_ring[:, -1] = True
+    frame_ring[10:30, 20:90] = True
+    masks.append(frame_ring)
+    wordends = np.zeros((6, 128), bool); wordends[1, 60:64] = True; wordends[2, 64:70] = True; wordends[3, 0:128] = True; wordends[4, 127] = True; wordends[5, 0] = True
+    masks.append(wordends)
+    fire = []
+    for k in range(4):
+        m = rng.random((72, 200)) < 0.1
+        m |= ndi.gaussian_filter(rng.standard_normal((72, 200)), 9.0) > -0.02
+        masks.append(m); fire.append(len(masks) - 1)
+    n_fired = 0
+    for im, m in enumerate(masks):
         heat = m.astype(np.float64)
         if not m.any() or m.all():
             heat = heat + 0.0   # flat heatmap: NaN normalisation -> nothing above the threshold
+        emu.debug_set("host_area_bound", 0)      # the top component's border always followed
+        try:
+            roi_f, _, _ = emu.heatmap_to_roi(heat, threshold=20, labelling=1)
+            path_f = emu.roi_path()
+        finally:
+            emu.debug_set("host_area_bound", 1)
         roi_l, u8, binary = emu.heatmap_to_roi(heat, threshold=20, labelling=1)
+        path_l = emu.roi_path()
+        assert roi_l == roi_f and path_f != 4, (m.shape, roi_l, roi_f, path_f)
+        n_fired += path_l == 4
+        if im in fire:
+            assert path_l == 4, (im, path_l)
         n_l, used = emu.contour_stats()
         roi_h, _, _ = emu.heatmap_to_roi(heat, threshold=20, labelling=0)
         n_h, used_h = emu.contour_stats()
@@ -634,6 +668,17 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
             import scipy.ndimage as ndi2
             assert n_l == ndi2.label(m, structure=np.ones((3, 3)))[1]      # every 8-connected component has one record
             assert n_h <= n_l                                              # RETR_EXTERNAL skips nested components
+    assert n_fired >= len(fire)
+    # the bound itself, to the unit: a solid a x b rectangle has 2 N - P - 2 = 2 (a - 1)(b - 1) - 4, and the shortcut fires exactly when
+    # that exceeds a rival's box bound 2 (c - 1)(d - 1) -- rectangles across word ends, at the frame, in rows that are no whole words
+    for (W_, x0) in ((200, 58), (130, 0), (192, 120), (77, 60)):
+        for (c, d, fires) in ((4, 30, True), (9, 12, False)):        # rival bounds 174 < 176 and 176 >= 176 against a 10 x 11 top
+            m = np.zeros((48, W_), bool)
+            m[3:13, x0:x0 + 11] = True                                # 10 rows x 11 columns: twice its area 180, lower bound 176
+            m[20:20 + c, 5:5 + d] = True
+            heat = m.astype(np.float64)
+            roi = emu.heatmap_to_roi(heat, threshold=20, labelling=1)[0]
+            assert (emu.roi_path() == 4) == fires and roi == (x0, 3, 11, 10), (W_, x0, c, d, emu.roi_path(), roi)
     # the automatic rule: a geometry whose last extraction met many components switches to the labelled path
     noisy = (rng.random((64, 256)) < 0.2).astype(np.float64)
     emu.heatmap_to_roi(noisy, threshold=20)

@@ -862,9 +862,35 @@ def test_contour_stage_device_labelling(hip, oracle):
         spiral[k, k:600 - k] = True; spiral[k:600 - k, 599 - k] = True
         spiral[599 - k, k + 2:600 - k] = True; spiral[k + 4:600 - k, k + 2] = True
     cases.append(spiral)
-    for m in cases:
+    # smooth blobs that span the frame among specks (what a full-frame noise video thresholds to): the area bound of the labelled path
+    # settles the winner without following a border (rm_ccl.h ccl_piece_2n_minus_p)
+    fire = []
+    for (h, w) in [(1080, 1920), (720, 1280), (540, 1000)]:
+        m = rng.random((h, w)) < 0.05
+        m |= ndi.gaussian_filter(rng.standard_normal((h, w)), 40.0) > 0.0
+        fire.append(len(cases)); cases.append(m)
+    from respmon_amd import device
+    for im, m in enumerate(cases):
         heat = torch.from_numpy(m.astype(np.float64)).cuda()
+        device.debug_set("host_area_bound", 0)         # the top component's border always followed
+        try:
+            roi_f = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
+            assert dist.roi_path() == 3
+        finally:
+            device.debug_set("host_area_bound", 1)
         roi_l = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
+        assert roi_l == roi_f and dist.roi_path() in (3, 4), (m.shape, roi_l, roi_f)
+        # ... exactly when scipy's labels say it can: 2 N - P - 2 of the component with the largest box beats every other box bound
+        lab, n = ndi.label(m, structure=np.ones((3, 3)))
+        pad = np.pad(m, 1); c = pad[1:-1, 1:-1]
+        cracks = (c & ~pad[:-2, 1:-1]).astype(np.int64) + (c & ~pad[2:, 1:-1]) + (c & ~pad[1:-1, :-2]) + (c & ~pad[1:-1, 2:])
+        low2 = 2 * np.bincount(lab.ravel(), minlength=n + 1) - np.bincount(lab.ravel(), weights=cracks.ravel(), minlength=n + 1).astype(np.int64) - 2
+        bound2 = np.array([-1] + [2 * (s[0].stop - s[0].start - 1) * (s[1].stop - s[1].start - 1) for s in ndi.find_objects(lab)])
+        top = int(np.argmax(bound2))
+        rivals = np.delete(bound2, [0, top])
+        expect = n >= 1 and low2[top] > 0 and (rivals.size == 0 or low2[top] > rivals.max())
+        assert (dist.roi_path() == 4) == bool(expect), (m.shape, dist.roi_path(), int(low2[top]), int(rivals.max()) if rivals.size else None)
+        fired = locals().get("fired", 0) + (dist.roi_path() == 4)
         n_l, used = dist.contour_stats()
         assert used
         roi_h = dist.hip_heatmap_to_roi(heat, 20, labelling=False)
@@ -873,6 +899,7 @@ def test_contour_stage_device_labelling(hip, oracle):
         assert n_l == ndi.label(m, structure=np.ones((3, 3)))[1], m.shape
         if m.size <= 1300 * 800:
             assert roi_l == oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20), m.shape
+    assert fired >= 1
     # more components than the record list holds (2^18): the host follows every border of the image it has anyway
     m = rng.random((2160, 3840)) < 0.16
     heat = torch.from_numpy(m.astype(np.float64)).cuda()
