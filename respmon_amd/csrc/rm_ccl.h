@@ -141,6 +141,33 @@ __device__ inline int ccl_piece_2n_minus_p(const unsigned long long *bits, size_
     return 2 * L - cracks;
 }
 
+// The same for rows of whole words (W % 64 == 0: 720p, 1080p, 4K), where a wave of k_ccl_bbox covers exactly one word: the word, its
+// neighbours in the row and the words above / below are wave-uniform loads shared by every piece of the word, instead of five dependent
+// loads per piece (k_ccl_bbox<false> at 4K x 512: 147 -> see DESIGN 4.4).  `lane` = the piece's first bit.
+struct CclWords { unsigned long long cur, up, down; bool left_fg, right_fg; };   // left_fg / right_fg: the pixel before bit 0 / after bit 63 is foreground
+__device__ inline CclWords ccl_words(const unsigned long long *bits, int H, int W, int y, int x0)
+{
+    const size_t i = ((size_t)y * W + x0) >> 6, wpr = (size_t)(W >> 6);
+    CclWords w;
+    w.cur = bits[i];
+    w.up = y > 0 ? bits[i - wpr] : 0ull;
+    w.down = y < H - 1 ? bits[i + wpr] : 0ull;
+    w.left_fg = x0 > 0 && (bits[i - 1] >> 63);
+    w.right_fg = x0 + 64 < W && (bits[i + 1] & 1ull);
+    return w;
+}
+__device__ inline int ccl_piece_2n_minus_p_words(const CclWords &w, int lane)
+{
+    const unsigned long long inv = ~(w.cur >> lane);
+    int L = inv ? __builtin_ctzll(inv) : 64;
+    if (L > 64 - lane) L = 64 - lane;
+    const unsigned long long mask = (L == 64 ? ~0ull : ((1ull << L) - 1ull)) << lane;
+    int cracks = (lane > 0 || !w.left_fg) ? 1 : 0;
+    cracks += (lane + L < 64 || !w.right_fg) ? 1 : 0;
+    cracks += __builtin_popcountll(mask & ~w.up) + __builtin_popcountll(mask & ~w.down);
+    return 2 * L - cracks;
+}
+
 // The roots met on the way (a root is the first pixel of its piece) are listed for k_ccl_publish: counted in LDS, ONE reservation
 // per tile on counters[0] (every atomic on the one counter takes ~10 ns of the L2's atomic unit), in no particular order -- the
 // host's choice does not depend on it.  roots[] holds `cap` entries; counters[0] keeps counting past it (the host then follows
@@ -153,17 +180,24 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
 {
     __shared__ int s_key[CCL_BOX_SLOTS], s_minx[CCL_BOX_SLOTS], s_maxx[CCL_BOX_SLOTS], s_maxy[CCL_BOX_SLOTS], s_cnt[CCL_BOX_SLOTS];
     __shared__ unsigned int s_nroots, s_base;
+    __shared__ int s_hot, s_hot_cnt;   // TABLE = false: the counts of ONE root per tile (the first one met) meet in LDS -- see below
     const int tid = threadIdx.x;
+    if (tid == 0) { s_hot = -1; s_hot_cnt = 0; }
     if (TABLE && tid < CCL_BOX_SLOTS) { s_key[tid] = -1; s_minx[tid] = 0x7fffffff; s_maxx[tid] = -1; s_maxy[tid] = -1; s_cnt[tid] = 0; }
     if (tid == 0) s_nroots = 0;
     __syncthreads();
     const int x = blockIdx.x * 64 + (tid & 63), y = blockIdx.y * CCL_BOX_ROWS + (tid >> 6);
     int my_root = -1; unsigned int my_slot = 0;
+    const bool whole_words = (W & 63) == 0;     // a wave = one word of one row
+    CclWords ww = {0ull, 0ull, 0ull, false, false};
+    if (whole_words && y < H) ww = ccl_words(bits, H, W, y, blockIdx.x * 64);   // (wave-uniform)
     if (x < W && y < H) {
         const size_t p = (size_t)y * W + x;
-        if (ccl_bit(bits, p) && ((p & 63) == 0 || x == 0 || !ccl_bit(bits, p - 1))) {
+        if (whole_words ? (((ww.cur >> (tid & 63)) & 1ull) && ((tid & 63) == 0 || !((ww.cur >> ((tid & 63) - 1)) & 1ull)))
+                        : (ccl_bit(bits, p) && ((p & 63) == 0 || x == 0 || !ccl_bit(bits, p - 1)))) {
             const int r = ccl_find(label, (int)p);
-            const int cnt = ccl_piece_2n_minus_p(bits, npix, H, W, p, x, y);   // -> box[root].cnt (k_heat_to_u8 left 0 there)
+            // -> box[root].cnt (k_heat_to_u8 left 0 there)
+            const int cnt = whole_words ? ccl_piece_2n_minus_p_words(ww, tid & 63) : ccl_piece_2n_minus_p(bits, npix, H, W, p, x, y);
             if (r == (int)p) { my_root = r; my_slot = atomicAdd(&s_nroots, 1u); atomicAdd(&box[p].cnt, cnt); }
             if (r != (int)p) {                       // (the root's own piece is in its box already)
                 const CclBox mine = box[p];
@@ -175,7 +209,14 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
                 }
                 if (k < CCL_BOX_SLOTS) {
                     atomicMin(&s_minx[h], mine.minx); atomicMax(&s_maxx[h], mine.maxx); atomicMax(&s_maxy[h], mine.maxy); atomicAdd(&s_cnt[h], cnt);
-                } else { ccl_box_fold(box, r, mine.minx, mine.maxx, mine.maxy); atomicAdd(&box[r].cnt, cnt); }   // more roots in the tile than the table holds
+                } else {   // more roots in the tile than the table holds / no table
+                    ccl_box_fold(box, r, mine.minx, mine.maxx, mine.maxy);
+                    // the count cannot skip its atomic the way the box does, and a blob among the specks sends thousands of pieces to ONE
+                    // address (~10 ns each: 4K x 512, k_ccl_bbox 116 -> 259 us).  The pieces of the first root a tile meets add up in LDS
+                    // and leave as one atomic per tile; the specks' pieces go to addresses of their own.
+                    const int seen = atomicCAS(&s_hot, -1, r);
+                    if (seen == -1 || seen == r) atomicAdd(&s_hot_cnt, cnt); else atomicAdd(&box[r].cnt, cnt);
+                }
             }
         }
     }
@@ -184,6 +225,7 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
         ccl_box_fold(box, s_key[tid], s_minx[tid], s_maxx[tid], s_maxy[tid]);
         atomicAdd(&box[s_key[tid]].cnt, s_cnt[tid]);
     }
+    if (tid == 0 && s_hot >= 0) atomicAdd(&box[s_hot].cnt, s_hot_cnt);
     if (s_nroots == 0) return;                       // (uniform)
     if (tid == 0) s_base = atomicAdd(&counters[0], s_nroots);
     __syncthreads();

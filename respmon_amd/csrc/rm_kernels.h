@@ -571,11 +571,16 @@ __global__ __launch_bounds__(64 * TM_W, NH == 1 ? 3 : 2) void k_temporal_sym(con
 // The same products for LARGE levels (4K x 512, skip 2: 518 400 pixels per frame, 2.1 GB in, 1.07 GB out): throughput, not
 // latency, is what counts there, and k_temporal_sym's K-split costs it an LDS exchange plus a barrier per 16 pixels and a
 // frontier of only 128 contiguous bytes per frame and workgroup in DRAM.  Here a WAVE owns 16 pixel columns for the whole
-// contraction (no LDS, no barrier; the four waves of a workgroup sit on adjacent columns: 512 contiguous bytes per frame), x
-// streams through two register buffers of TP_XC K-steps (the next chunk is requested before the current one is multiplied),
-// and stage 2 walks all output tiles with the next tile's operator fragments in flight.  The products into each accumulator
-// happen in the same order as in k_temporal_sym?  No: there the partial sums of the four K-phases are added in wave order --
-// here K runs straight through.  The two kernels agree to rounding (~1e-16), and a given (T, level size) always takes the same one.
+// contraction (the four waves of a workgroup sit on adjacent columns: 512 contiguous bytes per frame) and x streams through two
+// register buffers of TP_XC K-steps (the next chunk is requested before the current one is multiplied).
+// Round 5: the operator fragments travel through LDS, fetched ONCE per workgroup.  Every wave needs all of Rf and Cf (272 KB at T = 512)
+// for its 16 pixels; with each wave loading them itself the CU's vector memory path moved 3 KB per K-step and wave against 256 MFMA
+// cycles per SIMD -- PMC at 4K x 512: TA busy 69 %, MFMA pipe 39 %, waves 70 % in issue stalls, 14 % in s_waitcnt.  Now the workgroup's 256
+// threads copy a chunk of TP_XC K-steps (stage 2: one output tile) into one of two LDS buffers with 16-byte loads while the previous
+// chunk is multiplied, one barrier per chunk, and the waves read their A operands with conflict-free ds_read_b64.
+// The products into each accumulator happen in the same order as in k_temporal_sym?  No: there the partial sums of the four K-phases
+// are added in wave order -- here K runs straight through.  The two kernels agree to rounding (~1e-16), and a given (T, level size)
+// always takes the same one.
 template <int NH>
 __global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__restrict__ x, int T, size_t NP, const double *__restrict__ Rf,
                                                             const double *__restrict__ Cf, double amp, double *__restrict__ out, int mirror_n,
@@ -583,12 +588,17 @@ __global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__rest
 {
     if (st_init && blockIdx.x == 0 && threadIdx.x < 64) state_init_lane(st_init, (int)threadIdx.x);
     constexpr int NT = 2 * NH;
-    constexpr int TP_XC = 8;   // K-steps per x chunk
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
-    const size_t p = ((size_t)blockIdx.x * 4 + wave) * 16 + lo;
-    if (((size_t)blockIdx.x * 4 + wave) * 16 >= NP) return;   // (wave-uniform; no barrier in this kernel)
+    constexpr int TP_XC = 8;                       // K-steps per chunk (x registers and operator fragments alike)
+    constexpr int RCH = TP_XC * NT * 64;           // doubles of one stage-1 fragment chunk (NH = 2: 16 KB)
+    constexpr int CCH = 4 * NT * 64;               // doubles of one output tile's stage-2 fragments (NH = 2: 8 KB)
+    constexpr int RL = RCH / 512, CL = CCH / 512;  // 16-byte loads per thread and chunk
+    __shared__ double s_frag[2][RCH];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6)), lo = lane & 15, hi = lane >> 4;
+    const size_t p = ((size_t)blockIdx.x * 4 + wave) * 16 + lo;   // (waves past NP multiply a clamped column and store nothing: they keep the barriers)
     const size_t pc = p < NP ? p : NP - 1;
     const int Th = sym_frames(T), nks = (Th + 3) >> 2;
+    const int nchunks = (nks + TP_XC - 1) / TP_XC;
     v4f64 acc[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[q] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -602,59 +612,82 @@ __global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__rest
             xb[buf][i] = x[(size_t)tp * NP + pc];
         }
     };
-    load_x(0, 0);
-    for (int k0 = 0; k0 < nks; k0 += 2 * TP_XC) {
+    // this thread's share of a fragment chunk: global -> registers (in flight while the previous chunk is multiplied) -> LDS
+    typedef RM_VEC(double, 2) v2f64;
+    const size_t r_last = (size_t)nks * NT * 64 - 2;              // (chunks are whole TP_XC K-steps: the last one reads clamped, unused values)
+    v2f64 gl[RL];
+    auto fetch_r = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int kb = k0 + b * TP_XC;
-            if (kb >= nks) break;   // (uniform)
-            load_x(b ^ 1, kb + TP_XC);
+        for (int j = 0; j < RL; ++j) {
+            size_t i = (size_t)c * RCH + 2 * tid + 512 * j;
+            i = i < r_last ? i : r_last;
+            gl[j] = *reinterpret_cast<const v2f64 *>(Rf + i);
+        }
+    };
+    auto stash_r = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i0 = 0; i0 < TP_XC; i0 += 4) {
-                double rr[4][NT];
+        for (int j = 0; j < RL; ++j) *reinterpret_cast<v2f64 *>(&s_frag[buf][2 * tid + 512 * j]) = gl[j];
+    };
+    auto products = [&](int xbuf, int c) __attribute__((always_inline)) {
+        const double *sr = &s_frag[c & 1][lane];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ks = kb + i0 + u;
-                    const double *rf = Rf + (size_t)(ks < nks ? ks : nks - 1) * NT * 64 + lane;
+        for (int u = 0; u < TP_XC; ++u) {
+            const int ks = c * TP_XC + u;
+            if (ks < nks) {   // (uniform)
+                double rr[NT];
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) rr[u][q] = rf[q * 64];
-                }
+                for (int q = 0; q < NT; ++q) rr[q] = sr[(u * NT + q) * 64];
+                const int t = 4 * ks + hi;
+                const bool self = t == 0 || 2 * t == T, valid = t < Th;
+                double e = self ? xa[xbuf][u] : xa[xbuf][u] + xb[xbuf][u], o = self ? 0.0 : xa[xbuf][u] - xb[xbuf][u];
+                if (!valid) { e = 0.0; o = 0.0; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ks = kb + i0 + u;
-                    if (ks < nks) {   // (uniform)
-                        const int t = 4 * ks + hi;
-                        const bool self = t == 0 || 2 * t == T, valid = t < Th;
-                        double e = self ? xa[b][i0 + u] : xa[b][i0 + u] + xb[b][i0 + u], o = self ? 0.0 : xa[b][i0 + u] - xb[b][i0 + u];
-                        if (!valid) { e = 0.0; o = 0.0; }
+                for (int q = 0; q < NH; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[q], e, acc[q], 0, 0, 0);
 #pragma unroll
-                        for (int q = 0; q < NH; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], e, acc[q], 0, 0, 0);
-#pragma unroll
-                        for (int q = NH; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[u][q], o, acc[q], 0, 0, 0);
-                    }
-                }
+                for (int q = NH; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[q], o, acc[q], 0, 0, 0);
             }
         }
+    };
+    fetch_r(0);
+    load_x(0, 0);
+    stash_r(0);
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {      // two chunks per trip: the x register buffers are static
+        if (c0 + 1 < nchunks) fetch_r(c0 + 1);
+        load_x(1, (c0 + 1) * TP_XC);
+        products(0, c0);
+        if (c0 + 1 < nchunks) stash_r(1);          // (every wave left buffer 1 before the barrier that ended the previous chunk)
+        __syncthreads();
+        if (c0 + 1 >= nchunks) break;              // (uniform)
+        if (c0 + 2 < nchunks) fetch_r(c0 + 2);
+        load_x(0, (c0 + 2) * TP_XC);
+        products(1, c0 + 1);
+        if (c0 + 2 < nchunks) stash_r(0);
+        __syncthreads();
     }
+    // stage 2: out tile m (16 unique frames) = Cz[m] z, the A operands of a tile through the same two LDS buffers
     const int mt = (Th + 15) >> 4;
-    double cfv[4 * NT];
-    {
-        const double *cf = Cf + lane;
+    v2f64 gc[CL];
+    auto fetch_c = [&](int m) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
-    }
+        for (int j = 0; j < CL; ++j) gc[j] = *reinterpret_cast<const v2f64 *>(Cf + (size_t)m * CCH + 2 * tid + 512 * j);
+    };
+    auto stash_c = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < CL; ++j) *reinterpret_cast<v2f64 *>(&s_frag[buf][2 * tid + 512 * j]) = gc[j];
+    };
+    fetch_c(0);
+    stash_c(0);                                    // (the barrier that ended the last chunk of stage 1 freed both buffers)
+    __syncthreads();
     for (int m = 0; m < mt; ++m) {
+        if (m + 1 < mt) fetch_c(m + 1);            // the next tile's operands travel while this one is multiplied and stored
+        const double *sc = &s_frag[m & 1][lane];
         const int s0 = 16 * m;
         v4f64 o = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(cfv[4 * q + r], acc[q][r], o, 0, 0, 0);
-        }
-        if (m + 1 < mt) {   // the next tile's operands travel while this one is stored
-            const double *cf = Cf + (size_t)(m + 1) * 4 * NT * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < 4 * NT; ++q) cfv[q] = cf[q * 64];
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f64_16x16x4f64(sc[(4 * q + r) * 64], acc[q][r], o, 0, 0, 0);
         }
         if (p < NP) {
 #pragma unroll
@@ -667,6 +700,8 @@ __global__ __launch_bounds__(256, 2) void k_temporal_sym_px(const double *__rest
                 }
             }
         }
+        if (m + 1 < mt) stash_c((m + 1) & 1);
+        __syncthreads();
     }
 }
 

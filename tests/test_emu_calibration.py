@@ -46,6 +46,31 @@ def test_emu_temporal_operator_and_filter(emu, oracle, golden):
         y = emu.temporal(g["x%d" % i], fps, fmin, fmax, amp)
         ref = g["y%d" % i]
         assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+        # the form large levels take (k_temporal_sym_px: a wave per 16 pixel columns, operator fragments requested a group ahead) and the
+        # VALU twin, forced on the same data: both within rounding of the golden as well
+        for knob in ("temporal_wide", "temporal_valu"):
+            emu.debug_set(knob, 1)
+            try:
+                y2 = emu.temporal(g["x%d" % i], fps, fmin, fmax, amp)
+            finally:
+                emu.debug_set(knob, -1 if knob == "temporal_wide" else 0)
+            assert np.abs(y2 - ref).max() <= 1e-12 * np.abs(ref).max(), (knob, n)
+    # lengths around the group size of the fragment pipeline (4 K-steps of 4 frames: T / 2 + 1 unique frames), odd and tiny ones, wide bands
+    rng = np.random.default_rng(12)
+    for (T, fps, fmin, fmax) in [(2, 10, 0.1, 6.0), (3, 10, 0.1, 6.0), (7, 10, 0.5, 3.0), (30, 10, 0.1, 1.0), (31, 30, 0.5, 9.0), (33, 10, 0.1, 5.0),
+                                 (62, 10, 0.1, 1.0), (64, 10, 0.1, 4.9), (66, 10, 0.3, 1.0), (97, 5.01, 0.1, 1.0), (126, 10, 0.1, 1.0), (130, 10, 0.1, 2.5)]:
+        x = rng.standard_normal((T, 37))
+        want = oracle.temporal_bandpass_filter_fft(x, fps, freq_min=fmin, freq_max=fmax, amplification_factor=50)
+        scale = max(np.abs(want).max(), 1e-300)
+        for knob in (None, "temporal_wide", "temporal_valu"):
+            if knob:
+                emu.debug_set(knob, 1)
+            try:
+                got = emu.temporal(x, fps, fmin, fmax, 50.0)
+            finally:
+                if knob:
+                    emu.debug_set(knob, -1 if knob == "temporal_wide" else 0)
+            assert np.abs(got - want).max() <= 1e-12 * scale, (T, fps, fmin, fmax, knob)
 
 
 def test_emu_eulerian_and_fused_calibrate_match_golden(emu, golden):
@@ -654,6 +679,12 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
         roi_l, u8, binary = emu.heatmap_to_roi(heat, threshold=20, labelling=1)
         path_l = emu.roi_path()
         assert roi_l == roi_f and path_f != 4, (m.shape, roi_l, roi_f, path_f)
+        for table in (0, 1):     # k_ccl_bbox without / with its per-tile LDS table (the default picks by the last component count)
+            emu.debug_set("ccl_table", table)
+            try:
+                assert emu.heatmap_to_roi(heat, threshold=20, labelling=1)[0] == roi_l and emu.roi_path() == path_l, (m.shape, table)
+            finally:
+                emu.debug_set("ccl_table", -1)
         n_fired += path_l == 4
         if im in fire:
             assert path_l == 4, (im, path_l)
@@ -677,8 +708,13 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
             m[3:13, x0:x0 + 11] = True                                # 10 rows x 11 columns: twice its area 180, lower bound 176
             m[20:20 + c, 5:5 + d] = True
             heat = m.astype(np.float64)
-            roi = emu.heatmap_to_roi(heat, threshold=20, labelling=1)[0]
-            assert (emu.roi_path() == 4) == fires and roi == (x0, 3, 11, 10), (W_, x0, c, d, emu.roi_path(), roi)
+            for table in (-1, 0, 1):
+                emu.debug_set("ccl_table", table)
+                try:
+                    roi = emu.heatmap_to_roi(heat, threshold=20, labelling=1)[0]
+                finally:
+                    emu.debug_set("ccl_table", -1)
+                assert (emu.roi_path() == 4) == fires and roi == (x0, 3, 11, 10), (W_, x0, c, d, table, emu.roi_path(), roi)
     # the automatic rule: a geometry whose last extraction met many components switches to the labelled path
     noisy = (rng.random((64, 256)) < 0.2).astype(np.float64)
     emu.heatmap_to_roi(noisy, threshold=20)

@@ -64,7 +64,7 @@ def test_pyramid_functions_bit_exact(hip, oracle):
         assert _rel(col, vid) < 1e-12  # Laplacian pyramid round trip reconstructs the video
 
 
-def test_temporal_filter_golden(hip, golden):
+def test_temporal_filter_golden(hip, golden, oracle):
     from respmon_amd import transforms
     g = golden("g1_temporal_fft.npz")
     for i in range(int(g["ncases"])):
@@ -74,6 +74,31 @@ def test_temporal_filter_golden(hip, golden):
         M, lo, hi = transforms.temporal_operator(int(n), fps, fmin, fmax)
         if "M%d" % i in g.files:
             assert np.abs(M - g["M%d" % i]).max() < 1e-15
+        # the three forms of the product -- K-split per 16 pixels (small levels), a wave per 16 pixel columns with the operator fragments
+        # requested a group ahead (large levels: 4K x 512), the VALU twin (north_star: "no MFMA") -- forced on the same data
+        from respmon_amd import device
+        for knob in ("temporal_wide", "temporal_valu"):
+            device.debug_set(knob, 1)
+            try:
+                y2 = transforms.temporal_bandpass_filter_fft(g["x%d" % i], fps, freq_min=fmin, freq_max=fmax, amplification_factor=amp)
+            finally:
+                device.debug_set(knob, -1 if knob == "temporal_wide" else 0)
+            assert _rel(y2, g["y%d" % i]) < 1e-11, (knob, int(n))
+    rng = np.random.default_rng(12)
+    for (T, fps, fmin, fmax, npx) in [(2, 10, 0.1, 6.0, 37), (3, 10, 0.1, 6.0, 37), (7, 10, 0.5, 3.0, 100), (31, 30, 0.5, 9.0, 1000), (62, 10, 0.1, 1.0, 5000),
+                                      (66, 10, 0.3, 1.0, 4099), (97, 5.01, 0.1, 1.0, 777), (130, 10, 0.1, 2.5, 20000), (512, 10, 0.1, 1.0, 70000),
+                                      (511, 10, 0.1, 1.0, 3000), (518, 30, 0.2, 3.0, 3000)]:
+        x = rng.standard_normal((T, npx))
+        want = oracle.temporal_bandpass_filter_fft(x, fps, freq_min=fmin, freq_max=fmax, amplification_factor=50)
+        for knob in (None, "temporal_wide", "temporal_valu"):
+            if knob:
+                device.debug_set(knob, 1)
+            try:
+                got = transforms.temporal_bandpass_filter_fft(x, fps, freq_min=fmin, freq_max=fmax, amplification_factor=50)
+            finally:
+                if knob:
+                    device.debug_set(knob, -1 if knob == "temporal_wide" else 0)
+            assert np.abs(np.asarray(got) - want).max() <= 1e-11 * max(np.abs(want).max(), 1e-300), (T, fps, fmin, fmax, knob)
 
 
 def test_eulerian_golden_and_fused_equals_materialised(hip, golden):
@@ -880,6 +905,13 @@ def test_contour_stage_device_labelling(hip, oracle):
             device.debug_set("host_area_bound", 1)
         roi_l = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
         assert roi_l == roi_f and dist.roi_path() in (3, 4), (m.shape, roi_l, roi_f)
+        path_l = dist.roi_path()
+        for table in (0, 1):     # k_ccl_bbox without / with its per-tile LDS table (the default picks by the last component count)
+            device.debug_set("ccl_table", table)
+            try:
+                assert dist.hip_heatmap_to_roi(heat, 20, labelling=True) == roi_l and dist.roi_path() == path_l, (m.shape, table)
+            finally:
+                device.debug_set("ccl_table", -1)
         # ... exactly when scipy's labels say it can: 2 N - P - 2 of the component with the largest box beats every other box bound
         lab, n = ndi.label(m, structure=np.ones((3, 3)))
         pad = np.pad(m, 1); c = pad[1:-1, 1:-1]
