@@ -785,9 +785,11 @@ __global__ __launch_bounds__(64) void k_dense_sum_t(const double *cS, ChainGeom 
     // Which unique frames of this tile can hold a value below `top`?  The selection (k_select_pairs) had to decide with an UPPER
     // bound of top -- the exact extrema did not exist yet -- and with a loose one it keeps (nearly) every pair of a noisy stream.  Here
     // the exact top is known: a pair whose lower bound lo (minimum of its level-S footprint; every pyrUp output is a convex
-    // combination of it) clears top by the pruning margin adds `min` to every pixel, evaluated or not.  On the streams measured this
-    // keeps 2 % (4K, skip 2), 38 % (1080p noise, skip 4) and 64 % (720p, skip 2) of the pairs.  (tile-major slot_of: a few cache
-    // lines; lo is [unique frame][tile].)
+    // combination of it) clears top by the pruning margin adds `min` to every pixel, evaluated or not.  Effect of this test alone (same
+    // process, switch on / off): 1080p full-frame noise, skip 4: step 1.44 -> 1.20 ms; 720p skip 2 with this kernel forced: 0.567 ->
+    // 0.552 (its level-2 bounds are loose -- the same test in k_dense_sum_wf, the kernel 720p takes, with a compacted frame list to keep
+    // its four waves balanced, measured 115.3 against 115.0 us and was dropped).  (tile-major slot_of: a few cache lines; lo is
+    // [unique frame][tile].)
     const double margin = st->margin;
     // (the exhaustive baseline and the developer switch evaluate every kept pair to the end: no level-1 minimum reaches +inf)
     const double top_m = lo != nullptr ? top + margin : __builtin_huge_val();

@@ -41,7 +41,9 @@ def main():
         marks[i] = list(out)
     dt = (time.perf_counter() - t0) / steps * 1e3
     m = np.median(marks[5:], axis=0)
-    print("roi", roi, "ms_per_step (incl. the timeline read) %.4f" % dt)
+    from respmon_amd import dist
+    print("roi", roi, "ms_per_step (incl. the timeline read) %.4f" % dt, "| host contour stage path (RM_ROI_PATH_*)", dist.roi_path(),
+          "| components, labelled", dist.contour_stats())
     print("between calls %.1f us | entry -> first launch issued %.1f | -> all launches issued %.1f | -> device done %.1f | -> contour stage done %.1f"
           % (m[0], m[1], m[2], m[3], m[4]))
     print("host contour stage %.1f us; host work after the device finished + before the next first launch: %.1f us (+ wake-up latency of the wait)"
