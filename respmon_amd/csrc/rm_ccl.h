@@ -242,15 +242,16 @@ __global__ __launch_bounds__(64 * CCL_BOX_ROWS) void k_ccl_bbox(const unsigned l
 // (120 KB of lines no host cache holds at 7 466 components) was most of the 62 us the GPU idled per 720p step.
 // The full list follows from host[1 + 2 CCL_PUB_BLOCKS] on, 16-byte records, consecutive lanes -> consecutive records.
 constexpr int CCL_PUB_BLOCKS = 64;
+// `list`: where the full list goes -- behind the summaries in the pinned memory, or a device buffer the host copies only when the summaries do
+// not settle the winner (rm_roi.hip: the "lazy" labelled stage).
 RM_KERNEL __launch_bounds__(256) void k_ccl_publish(const int *roots, const CclBox *box, int W, const unsigned int *counters, unsigned int cap,
-                                                     CclComp *host)
+                                                     CclComp *host, CclComp *list)
 {
     __shared__ long long s_b1[256], s_b2[256];
     __shared__ int s_i1[256];
     const unsigned int total = counters[0];
     const unsigned int n = total < cap ? total : cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) { CclComp h; h.root = (int)total; h.minx = 0; h.w1 = 0; h.h1 = 0; host[0] = h; }
-    CclComp *list = host + 1 + 2 * CCL_PUB_BLOCKS;
     long long b1 = -1, b2 = -1;     // largest / second largest bound this thread met
     int i1 = -1;                    // list index of the largest
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {

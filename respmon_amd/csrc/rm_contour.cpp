@@ -473,6 +473,31 @@ int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const 
 // components workgroup b published (root -1: none), tops[2 b + 1] = {low, high word of the second largest bound there}.  Follows the
 // best top's border, then every other top that can still reach its area; when that area also beats every second bound no unread
 // component can win or tie, and the full list (`comps`, read only then) is not touched.  Same result as the function above.
+// the summary records alone: true (and the ROI in *out) when twice the area of the top record's contour -- at least 2 N - P - 2,
+// rm_ccl.h ccl_piece_2n_minus_p -- already beats the box bound of every other component, i.e. the other tops and every workgroup's
+// second bound: the winner is known without following its border (a blob that spans a noisy frame: tens of thousands of steps)
+bool labelled_tops_settled(const LabelComp *tops, int nblocks, int W, size_t n, RoiResult *out)
+{
+    auto bound2 = [](const LabelComp &c) { return 2ll * (long long)c.w1 * (long long)c.h1; };
+    long long top = -1; int top_b = -1;
+    for (int b = 0; b < nblocks; ++b)
+        if (tops[2 * b].root >= 0 && bound2(tops[2 * b]) > top) { top = bound2(tops[2 * b]); top_b = b; }
+    if (top_b < 0 || W <= 0) return false;
+    const long long low2 = (long long)tops[2 * top_b + 1].w1 - 2;
+    if (low2 <= 0) return false;
+    for (int b = 0; b < nblocks; ++b) {
+        if (b != top_b && tops[2 * b].root >= 0 && bound2(tops[2 * b]) >= low2) return false;
+        const LabelComp &s = tops[2 * b + 1];
+        if ((long long)(((unsigned long long)(unsigned int)s.minx << 32) | (unsigned int)s.root) >= low2) return false;
+    }
+    const LabelComp &c = tops[2 * top_b];
+    out->found = 1; out->n_contours = (int)n;
+    out->x = c.minx; out->y = c.root / W;
+    out->w = c.w1 + 1; out->h = c.h1 + 1;
+    out->area = -1.0;   // (not computed: no other contour can reach this one's lower bound)
+    return true;
+}
+
 int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, const LabelComp *tops, int nblocks, const LabelComp *comps, size_t n,
                                            RoiResult *out, bool area_bound_shortcut)
 {
@@ -492,26 +517,7 @@ int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, c
     for (int b = 0; b < nblocks; ++b)
         if (tops[2 * b].root >= 0 && bound2(tops[2 * b]) > top) { top = bound2(tops[2 * b]); top_b = b; }
     if (top_b < 0) return largest_external_contour_labelled(bits, H, W, comps, n, out);
-    if (area_bound_shortcut) {
-        // twice the area of the top record's contour is at least 2 N - P - 2 (rm_ccl.h ccl_piece_2n_minus_p): when that already beats the
-        // box bound of every other component -- the other tops and every workgroup's second bound -- the winner is known without
-        // following its border (a blob that spans a noisy frame: tens of thousands of steps)
-        const long long low2 = (long long)tops[2 * top_b + 1].w1 - 2;
-        bool settled = low2 > 0;
-        for (int b = 0; b < nblocks && settled; ++b) {
-            if (b != top_b && tops[2 * b].root >= 0 && bound2(tops[2 * b]) >= low2) settled = false;
-            const LabelComp &s = tops[2 * b + 1];
-            if ((long long)(((unsigned long long)(unsigned int)s.minx << 32) | (unsigned int)s.root) >= low2) settled = false;
-        }
-        if (settled) {
-            const LabelComp &c = tops[2 * top_b];
-            out->found = 1;
-            out->x = c.minx; out->y = c.root / W;
-            out->w = c.w1 + 1; out->h = c.h1 + 1;
-            out->area = -1.0;   // (not computed: no other contour can reach this one's lower bound)
-            return 0;
-        }
-    }
+    if (area_bound_shortcut && labelled_tops_settled(tops, nblocks, W, n, out)) return 0;
     consider(top_b);
     for (int b = 0; b < nblocks; ++b)
         if (b != top_b && tops[2 * b].root >= 0 && bound2(tops[2 * b]) >= best2) consider(b);

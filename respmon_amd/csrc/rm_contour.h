@@ -29,6 +29,7 @@ int simple_shape_row_records(const uint64_t *rec, int H, int W, int *y0, int *y1
 struct LabelComp { int root, minx, w1, h1; };
 int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const LabelComp *comps, size_t n, RoiResult *out);
 // ... reading the 2 x nblocks summary records of k_ccl_publish first, the full list only when they do not settle the winner
+bool labelled_tops_settled(const LabelComp *tops, int nblocks, int W, size_t n, RoiResult *out);
 // (area_bound_shortcut: the top record's workgroup also published 2 N - P of its component in tops[2 b + 1].w1 -- a lower bound of the
 //  contour's area that can settle the winner without following any border)
 int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, const LabelComp *tops, int nblocks, const LabelComp *comps, size_t n,

@@ -131,6 +131,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "exchange_dense") d.exchange_dense = (int)value;
     else if (k == "host_simple_shape") d.host_simple_shape = (int)value;
     else if (k == "host_area_bound") d.host_area_bound = (int)value;
+    else if (k == "label_lazy") d.label_lazy = (int)value;
     else if (k == "heat_rows") d.heat_rows = (int)value;
     else if (k == "ff_parts") d.ff_parts = (int)value;
     else if (k == "heat_const_tiles") d.heat_const_tiles = (int)value;

@@ -107,6 +107,7 @@ struct DebugKnobs {
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
     int heat_rows = 1;            // 0: k_heat_to_u8 (flat over the pixels, row flags) also where rows are whole words, instead of k_heat_rows_u8 (row records)
+    int label_lazy = 1;           // 0: the labelled path always sends the packed image and the full component list to the host
     int host_area_bound = 1;      // 0: the labelled path always follows the top component's border (no shortcut on its area's lower bound, rm_ccl.h)
     int host_simple_shape = 1;    // 0: the host contour stage always follows the borders (no one-blob shortcut on the packed rows)
     int exchange_dense = 0;       // 1: rm_locate_streams / rm_locate_sharded exchange the heatmaps by the dense all-reduce only
@@ -131,7 +132,12 @@ struct RoiSlot {
 };
 constexpr int ROI_SLOTS = 3;
 // what the host half of the ROI stage has to know about the launches it finishes
-struct RoiPending { int H = 0, W = 0, slot = 0; size_t nwords = 0, comps_cap = 0, rec_off = 0; bool label = false, clip = false, rows = false; };
+struct RoiPending {
+    int H = 0, W = 0, slot = 0; size_t nwords = 0, comps_cap = 0, rec_off = 0; bool label = false, clip = false, rows = false;
+    // lazy labelled stage: the packed image and the full component list stayed on the device (d_bits / d_list, buffers of this slot); only
+    // the summary records travelled.  roi_finish copies the rest over `stream` when the summaries do not settle the winner.
+    bool lazy = false; hipStream_t stream = nullptr; const void *d_bits = nullptr, *d_list = nullptr;
+};
 // one rm_locate_submit whose rm_locate_result has not been called yet (the arguments: a selection that overflows the value store is
 // taken again through the synchronous rm_locate)
 struct LocateTicket {
@@ -160,6 +166,7 @@ struct rm_ctx {
     // device labelling of the thresholded image (rm_ccl.h): taken when the previous ROI extraction of this geometry met
     // more than LABEL_MIN_CONTOURS components (label_mode -1 = that rule, 0 = never, 1 = always: rm_set_contour_labelling)
     int label_mode = -1, label_H = 0, label_W = 0, label_last_n = 0, label_used = 0;
+    bool label_lazy = false;      // the last labelled extraction of this geometry was settled by the summary records alone: the next one keeps image and list on the device
     int roi_path = 0;             // RM_ROI_PATH_* of the last host contour stage (rm_debug_roi_path)
     // ... or when following every border on the host took long last time (few components with long borders: a frame of noise blobs):
     // host time of the last unlabelled stage of this geometry (< 0: none) with its contour count, host time of the last labelled

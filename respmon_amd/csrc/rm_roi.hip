@@ -65,7 +65,7 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     // noisy images: label the components on the device so that the host follows only borders that can win (rm_ccl.h)
     const bool clip = ctx->clip_frame || clip_once;
     const bool same_geom = ctx->label_H == H && ctx->label_W == W;
-    if (!same_geom) { ctx->label_unl_us = -1.0; ctx->label_lab_host_us = 0.0; ctx->label_streak = 0; }
+    if (!same_geom) { ctx->label_unl_us = -1.0; ctx->label_lab_host_us = 0.0; ctx->label_streak = 0; ctx->label_lazy = false; }
     const bool many = ctx->label_last_n > LABEL_MIN_CONTOURS;
     bool slow_host = ctx->label_unl_us >= 0.0 && ctx->label_unl_us > (double)ctx->dbg.label_host_us + ctx->label_lab_host_us;
     if (slow_host && !many && ctx->label_mode < 0 && ctx->label_streak >= LABEL_REPROBE) { slow_host = false; ctx->label_streak = 0; }
@@ -81,10 +81,17 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     unsigned long long *d_bits = nullptr;
     const size_t comps_cap = std::min<size_t>(npix / 4 + 2, (size_t)1 << 18);
     bool rows = false;
+    // Lazy: the last labelled extraction of this geometry needed nothing but the 2 KB of summary records (the area bound of the top
+    // component beat every rival's box: rm_ccl.h) -- this one keeps the packed image and the full list in device buffers of the slot and
+    // sends the summaries only.  At 4K x 512 that is 1.7 MB less over PCIe behind the last kernel and a 1 MB memset less on the host
+    // between two calibrations; roi_finish fetches both if the summaries do not settle the winner after all.
+    const bool lazy = label && ctx->label_lazy && ctx->dbg.label_lazy != 0;
+    CclComp *d_complist = nullptr;
     if (label) {
         int *d_label = nullptr; CclBox *d_box = nullptr; unsigned int *d_cnt = nullptr; int *d_list = nullptr;
         RM_TRY(ws(ctx, "ccl_list", comps_cap, &d_list));
-        RM_TRY(ws(ctx, "ccl_bits", nwords, &d_bits));
+        RM_TRY(ws(ctx, "ccl_bits_slot" + std::to_string(ctx->cur_slot), nwords, &d_bits));   // (per slot: a lazy fetch may follow the NEXT submission's kernels)
+        if (lazy) RM_TRY(ws(ctx, "ccl_comps_slot" + std::to_string(ctx->cur_slot), comps_cap * 2, (double **)&d_complist));
         RM_TRY(ws(ctx, "ccl_label", npix, &d_label));
         RM_TRY(ws(ctx, "ccl_box", npix, &d_box));
         RM_TRY(ws(ctx, "ccl_counters", (size_t)2, &d_cnt));
@@ -97,7 +104,8 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         CclComp *dev_comps = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, rs.h_comps, 0));
         hipLaunchKernelGGL(k_heat_to_u8<>, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
-                           (unsigned long long *)dev_bin, dev_bin + nwords * 8, d_bits, d_label, d_box, d_cnt, tile_const);
+                           lazy ? (unsigned long long *)nullptr : (unsigned long long *)dev_bin, lazy ? (uint8_t *)nullptr : dev_bin + nwords * 8,
+                           d_bits, d_label, d_box, d_cnt, tile_const);
         LAUNCH_CHECK();
         // (a thread per 64-bit word walking its set bits through the same rule was measured: 97 / 95 us instead of 21 / 19 at 720p --
         //  ten dependent find / atomic round trips per thread cost more than launching 84 % idle threads)
@@ -110,7 +118,8 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         if (table) hipLaunchKernelGGL(k_ccl_bbox<true>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         else hipLaunchKernelGGL(k_ccl_bbox<false>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_ccl_publish<>, dim3(CCL_PUB_BLOCKS), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps);
+        hipLaunchKernelGGL(k_ccl_publish<>, dim3(CCL_PUB_BLOCKS), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps,
+                           lazy ? d_complist : dev_comps + 1 + 2 * CCL_PUB_BLOCKS);
         LAUNCH_CHECK();
     } else if ((W & 63) == 0 && (W >> 6) <= HR_MAXW && ctx->dbg.heat_rows) {
         // rows of whole words: a workgroup per row, one record per row with foreground beside the packed image (k_heat_rows_u8)
@@ -127,6 +136,7 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     delete pt_roi; pt_roi = nullptr;
     pd.H = H; pd.W = W; pd.slot = ctx->cur_slot; pd.nwords = nwords; pd.comps_cap = comps_cap; pd.label = label; pd.clip = clip;
     pd.rows = rows; pd.rec_off = rec_off;
+    pd.lazy = lazy; pd.stream = s; pd.d_bits = d_bits; pd.d_list = d_complist;
     return RM_OK;
 }
 
@@ -166,6 +176,20 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
         const size_t ncomp = label ? (size_t)(unsigned int)rs.h_comps[0].root : 0;
         ctx->label_used = label && ncomp <= comps_cap;
         ctx->roi_path = RM_ROI_PATH_ONE_BLOB;
+        if (pd.lazy) {
+            // the summaries alone first; image and list only when they leave the winner open (or the list overflowed: full scan)
+            if (ctx->label_used && ctx->dbg.host_area_bound &&
+                labelled_tops_settled((const LabelComp *)(rs.h_comps + 1), CCL_PUB_BLOCKS, W, ncomp, &r)) {
+                settled = true;
+                ctx->roi_path = RM_ROI_PATH_AREA_BOUND;
+            } else {
+                HIP_TRY(hipMemcpyAsync(rs.h_bin, pd.d_bits, nwords * 8, hipMemcpyDeviceToHost, pd.stream));
+                if (ctx->label_used && ncomp > 0)
+                    HIP_TRY(hipMemcpyAsync(rs.h_comps + 1 + 2 * CCL_PUB_BLOCKS, pd.d_list, ncomp * sizeof(CclComp), hipMemcpyDeviceToHost, pd.stream));
+                HIP_TRY(stream_wait(pd.stream));
+                y0 = 0; y1 = H - 1;   // (the whole image arrived: all of it is put back to zero below)
+            }
+        }
         if (settled) {
         } else if (ctx->label_used) {  // (an overflowing record list falls through to the full scan: the image is here either way)
             largest_external_contour_labelled_tops((const uint64_t *)rs.h_bin, H, W, (const LabelComp *)(rs.h_comps + 1), CCL_PUB_BLOCKS,
@@ -176,6 +200,7 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
             ctx->roi_path = RM_ROI_PATH_SCAN;
         }
         ctx->label_H = H; ctx->label_W = W; ctx->label_last_n = r.n_contours;
+        ctx->label_lazy = label && ctx->roi_path == RM_ROI_PATH_AREA_BOUND;
         if (y1 >= y0 && !pd.rows) {   // restore the all-zero image: the words that cover rows y0 .. y1
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
             std::memset(rs.h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);

@@ -149,6 +149,27 @@ def test_emu_locate_submit_result(emu, golden):
     assert emu.locate_result(tk) == want[0]
     flat = emu.locate_submit(np.full((16, 40, 48), 0.5), 10, levels=4, skip=2)
     assert emu.locate_result(flat) is None
+    # two buffers in flight through the LABELLED ROI stage, lazy (image and component list stay on the device until the summary records
+    # leave the winner open): the fetch of the first buffer's image then runs behind the second buffer's kernels -- per-slot buffers
+    rng = np.random.default_rng(91)
+    noisy = []
+    for k in range(6):
+        v = rng.random((8, 48, 128))
+        if k % 2 == 0:
+            v[:, 8:40, 20:100] += 0.6 * np.sin(np.arange(8) * 0.9)[:, None, None]     # a breathing block among the noise: the summaries settle it
+        noisy.append(v)
+    emu.ck(emu.lib.rm_set_contour_labelling(emu.ctx, 1), "labelling")
+    try:
+        sync = [emu.locate(v, 10, levels=3, skip=1) for v in noisy]
+        paths = set()
+        for i in range(len(noisy) - 1):
+            ta = emu.locate_submit(noisy[i], 10, levels=3, skip=1)
+            tb = emu.locate_submit(noisy[i + 1], 10, levels=3, skip=1)
+            assert emu.locate_result(ta) == sync[i]; paths.add(emu.roi_path())
+            assert emu.locate_result(tb) == sync[i + 1]; paths.add(emu.roi_path())
+        assert emu.contour_stats()[1] == 1
+    finally:
+        emu.lib.rm_set_contour_labelling(emu.ctx, -1)
     xywh = np.zeros(4, np.int32)
     assert emu.lib.rm_locate_result(emu.ctx, flat[0], xywh.ctypes.data_as(ctypes.c_void_p)) == _capi.RM_E_BADARG   # fetched already
 
@@ -700,6 +721,27 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
             assert n_l == ndi2.label(m, structure=np.ones((3, 3)))[1]      # every 8-connected component has one record
             assert n_h <= n_l                                              # RETR_EXTERNAL skips nested components
     assert n_fired >= len(fire)
+    # the lazy stage: once the summary records alone settled an extraction, the next one of that geometry keeps the packed image and the
+    # component list on the device -- and fetches them when ITS summaries leave the winner open (two rivals whose boxes beat the top's bound),
+    # when the list overflows is covered on the GPU; the eager stage (label_lazy 0) must agree everywhere
+    settled_img = masks[fire[0]]
+    open_img = np.zeros_like(settled_img); open_img[5:35, 10:60] = True; open_img[40:70, 100:152] = True; open_img[::7, ::9] = True
+    empty_img = np.zeros_like(settled_img)
+    for seq in ([settled_img, settled_img, open_img, settled_img, empty_img, settled_img], [open_img, settled_img, open_img, open_img]):
+        got, paths = [], []
+        for lazy in (1, 0):
+            emu.debug_set("label_lazy", lazy)
+            try:
+                rois, pp = [], []
+                for m in seq:
+                    rois.append(emu.heatmap_to_roi(m.astype(np.float64), threshold=20, labelling=1)[0]); pp.append(emu.roi_path())
+            finally:
+                emu.debug_set("label_lazy", 1)
+            got.append(rois); paths.append(pp)
+        assert got[0] == got[1] and paths[0] == paths[1], (got, paths)
+        for m, roi in zip(seq, got[0]):
+            assert roi == (oracle.roi_from_heatmap_u8(np.where(m, 255, 0).astype(np.uint8), 20) if m.any() else None)
+        assert 4 in paths[0] and 3 in paths[0]
     # the bound itself, to the unit: a solid a x b rectangle has 2 N - P - 2 = 2 (a - 1)(b - 1) - 4, and the shortcut fires exactly when
     # that exceeds a rival's box bound 2 (c - 1)(d - 1) -- rectangles across word ends, at the frame, in rows that are no whole words
     for (W_, x0) in ((200, 58), (130, 0), (192, 120), (77, 60)):

@@ -937,6 +937,26 @@ def test_contour_stage_device_labelling(hip, oracle):
     heat = torch.from_numpy(m.astype(np.float64)).cuda()
     roi_l = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
     assert not dist.contour_stats()[1] and roi_l == dist.hip_heatmap_to_roi(heat, 20, labelling=False)
+    # the lazy stage (rm_roi.hip): after an extraction the summary records settled alone, the next one of that geometry leaves the packed
+    # image and the component list on the device -- and fetches them when its own summaries leave the winner open, or the list overflows
+    blob4k = np.zeros((2160, 3840), bool); blob4k[300:1500, 500:3000] = True; blob4k |= rng.random((2160, 3840)) < 0.01
+    two4k = np.zeros((2160, 3840), bool); two4k[100:900, 200:1800] = True          # a solid block, and a hollow frame with the larger box:
+    two4k[1000:2100, 1900:3800] = True; two4k[1003:2097, 1903:3797] = False         # its count bound is tiny, the block's box beats it
+    two4k |= rng.random((2160, 3840)) < 0.002
+    want = {}
+    for name, img in (("blob", blob4k), ("two", two4k), ("overflow", m)):
+        want[name] = dist.hip_heatmap_to_roi(torch.from_numpy(img.astype(np.float64)).cuda(), 20, labelling=False)
+    for lazy in (1, 0):
+        device.debug_set("label_lazy", lazy)
+        try:
+            seen = []
+            for name in ("blob", "blob", "two", "blob", "blob", "overflow", "blob", "blob"):
+                img = {"blob": blob4k, "two": two4k, "overflow": m}[name]
+                assert dist.hip_heatmap_to_roi(torch.from_numpy(img.astype(np.float64)).cuda(), 20, labelling=True) == want[name], (name, lazy)
+                seen.append(dist.roi_path())
+            assert seen[0] == 4 and seen[1] == 4 and seen[2] == 3 and seen[5] == 2 and seen[7] == 4, seen
+        finally:
+            device.debug_set("label_lazy", 1)
     # the automatic rule switches a noisy geometry to the labelled path from its second extraction on, and back
     noisy = torch.from_numpy((rng.random((720, 1280)) < 0.16).astype(np.float64)).cuda()
     clean = torch.zeros((720, 1280), dtype=torch.float64, device="cuda"); clean[100:300, 200:500] = 1.0
