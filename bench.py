@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-DT_BYTES = {"f64": 8, "f32": 4, "f16": 2, "u8": 1}
+DT_BYTES = {"f64": 8, "f32": 4, "f16": 2, "u8": 1, "bgr8": 3}   # bgr8: [T,H,W,3] uint8 as captured (RM_BGR8; the synthetic video in three equal planes)
 CONFIGS = {   # frames, height, width, levels, skip, frame-buffer dtype
     "P": (256, 1080, 1920, 9, 4, "f64"),
     "Q": (128, 720, 1280, 4, 2, "f64"),
@@ -291,6 +291,11 @@ def main():
         dt_name = dt_name or a.in_dtype
         if dt_name == "u8":
             return torch.from_numpy(v8).cuda()
+        if dt_name == "bgr8":   # gray(x, x, x) == x: the same video, stored as captured
+            b3 = torch.empty(tuple(v8.shape) + (3,), dtype=torch.uint8, device="cuda")
+            for t0 in range(0, b3.shape[0], 16):
+                b3[t0:t0 + 16] = torch.from_numpy(v8[t0:t0 + 16]).cuda().unsqueeze(-1).expand(-1, -1, -1, 3)
+            return b3
         td = TORCH_DT[dt_name]
         b = torch.empty(tuple(v8.shape), dtype=td, device="cuda")
         for t0 in range(0, b.shape[0], 16):  # uint8_to_float in float64 (base.py:231), then the storage dtype

@@ -18,6 +18,7 @@ case $CFG in
   R) OUT=$OUT/R; ARGS="--config R"; STEPS=20 ;;
   P32) OUT=$OUT/P32; ARGS="--in-dtype f32" ;;
   P8) OUT=$OUT/P8; ARGS="--in-dtype u8" ;;
+  PBGR) OUT=$OUT/PBGR; ARGS="--in-dtype bgr8" ;;
 esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
