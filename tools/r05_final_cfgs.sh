@@ -16,7 +16,7 @@ for v in noise blobs16; do
   rm -f gpurun_out/r05/wc_$v/*kernel_trace.csv gpurun_out/r05/wc_$v/*agent_info.csv
   head -1 gpurun_out/r05/gpu_timeline_worst_case_$v.txt
 done
-for c in Q P32 P8 R; do
+for c in Q P32 P8 PBGR R; do
   bash tools/profile_round.sh r05 $c > gpurun_out/r05/profile_$c.log 2>&1
   python tools/gpu_timeline.py gpurun_out/r05/$c/stats > gpurun_out/r05/gpu_timeline_config_$c.txt 2>&1
   rm -f gpurun_out/r05/$c/stats/*kernel_trace.csv
