@@ -97,6 +97,11 @@ def test_bgr_frame_buffer_equals_its_gray_buffer(hip, oracle):
     m_b, r_b = transforms.eulerian_magnification_bandpass(dev_b[:16], 10.0, 0.1, 1.0, 500, pyramid_levels=4, skip_levels_at_top=2)
     m_g, r_g = transforms.eulerian_magnification_bandpass(torch.from_numpy(gray[:16]).cuda(), 10.0, 0.1, 1.0, 500, pyramid_levels=4, skip_levels_at_top=2)
     assert torch.equal(m_b, m_g) and torch.equal(r_b, r_g)
+    # the calibration image panels (base.py:577-596) of a BGR buffer are those of its gray buffer
+    from respmon_amd import montage
+    p_b, roi_b = montage.calibration_panels(dev_b[:32], 10.0, pyramid_levels=5, skip_levels_at_top=2)
+    p_g, roi_g = montage.calibration_panels(torch.from_numpy(gray[:32]).cuda(), 10.0, pyramid_levels=5, skip_levels_at_top=2)
+    assert roi_b == roi_g and all(np.array_equal(p_b[k], p_g[k]) for k in p_g)
     out = torch.empty((1, 135, 240), dtype=torch.float64, device="cuda")
     assert hip.rm_pyr_down(device.ctx(), device.ptr(dev_b), _capi.RM_BGR8, 1, 270, 480, device.ptr(out), device.stream_ptr()) == _capi.RM_E_BADARG
     with pytest.raises(TypeError):
