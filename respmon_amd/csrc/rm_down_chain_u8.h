@@ -95,7 +95,7 @@ template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16
 #define RM_F32_HOT 0
 #endif
 #ifndef RM_F32_PREFETCH
-#define RM_F32_PREFETCH 2
+#define RM_F32_PREFETCH 4   // (1080p x 256, same box, alternating processes: 2 rows in flight / 3 segments 0.4466-0.4473 ms, 4 rows / 2 segments 0.4325-0.4335: tools/r05_f32_pf.sh)
 #endif
 #ifndef RM_BGR_PREFETCH
 #define RM_BGR_PREFETCH 4   // (measured at 1080p x 256, depth 4: 2 rows in flight 0.364-0.370 ms, 4 rows and HALF the waves -- two row segments per frame instead of four -- 0.343-0.347)
@@ -602,8 +602,8 @@ inline bool make_down_geom_u8(int S, const int *h, const int *w, int T, DownGeom
     const int rows = h[S];
     const int halo0 = (1 << (S + 1)) - 2;
     const long long per_seg = (long long)T * g.strips;
-    // (float32 buffers ask for 1 536: at 1080p x 256 three segments instead of four -- 11 % of the rows read twice instead of 17 % --
-    //  measured 0.446 against 0.462 ms; the uint8 kernel, bound by its arithmetic, loses 20 % below four)
+    // (target_waves by dtype and depth: rm_down_narrow.hip / rm_down_bgr.hip; the uint8 kernel, bound by its arithmetic, loses 20 % below four
+    //  segments per 1080p frame)
     int segs = (int)((target_waves + per_seg / 2) / per_seg);
     if (force_segs > 0) segs = force_segs;   // (rm_debug_set "dc_segs")
     if (segs < 1) segs = 1;

@@ -8,7 +8,10 @@ int launch_down_chain_narrow(rm_ctx *ctx, const void *frames, int dtype, int T, 
                              hipStream_t s, bool tiny)
 {
     DownGeom g8;
-    if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, dtype == RM_F32 ? 1536 : 2048)) {
+    // (float32: four rows = 256 bytes per lane in flight.  Deep chains, whose segments re-read 2 (2^(S+1) - 2) rows each, take one wave
+    //  per SIMD -- 1080p x 256 skip 4: two segments per frame 0.378 ms, three 0.416; at skip 2 the halo is 12 rows and more waves win --
+    //  720p x 128: six segments 0.139 ms, four 0.151, three 0.180)
+    if (make_down_geom_u8(S, h.data(), w.data(), T, g8, tiny, ctx->dbg.dc_segs, dtype == RM_F32 ? (S >= 3 ? 1024 : 1536) : 2048)) {
         g8.prio = ctx->dbg.dc_prio;
         const size_t fs = (size_t)h[0] * w[0];
         const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * g8.strips * g8.segs);
