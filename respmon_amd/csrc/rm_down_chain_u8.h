@@ -90,7 +90,10 @@ template <> struct RegTraits<uint8_t> { static constexpr int NLD = 1, PF = RM_U8
 #ifndef RM_F32_RING
 #define RM_F32_RING 4
 #endif
-template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16_PREFETCH, RD = RM_F16_RING; static constexpr bool HOT = RM_NARROW_HOT != 0, DMA = RM_NARROW_DMA_ON != 0; };
+#ifndef RM_F16_HOT
+#define RM_F16_HOT RM_NARROW_HOT
+#endif
+template <> struct RegTraits<__half> { static constexpr int NLD = 2, PF = RM_F16_PREFETCH, RD = RM_F16_RING; static constexpr bool HOT = RM_F16_HOT != 0, DMA = RM_NARROW_DMA_ON != 0; };
 #ifndef RM_F32_HOT
 #define RM_F32_HOT 0
 #endif
