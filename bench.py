@@ -80,6 +80,8 @@ def parse():
                     "frames if host memory allows, else 64)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU needed: print the per-rank launch plan of `--gpus N` (devices, frame shards, "
                     "the C-ABI call of a step, the collectives it issues with their byte counts) as one JSON object and exit")
+    ap.add_argument("--stage-timeout", type=float, default=600.0, help="N>1: rank 0 prints an error line and ends the job when a stage "
+                    "before the timed loop (rendezvous, communicator, first step, ...) makes no progress for this many seconds (0 = never)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="threads of the all-cores CPU figure (0 = skip, -1 = min(64, host cores))")
     a = ap.parse_args()
     T, H, W, L, S, dt = CONFIGS[a.config]
@@ -92,17 +94,187 @@ def parse():
     return a
 
 
+def _json_lines(text):
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    return out
+
+
 def self_launch(a):
-    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this driver)
-    env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1).
+    First contact with a multi-GPU node must leave a diagnosable record: the ranks' output is captured; when the
+    job dies before rank 0 could print its line (a rank killed inside ncclCommInitRank, IPC refused, out of memory) the launcher
+    prints ONE JSON line -- n_gpus, "error", the stage every rank had reached, the tails of their stderr -- after ONE retry with the
+    collectives of torch.distributed instead of the library's own communicator (RESPMON_BENCH_TORCH_COLLECTIVES=1).  A successful
+    retry prints the normal line with the first attempt's diagnosis under "first_attempt"."""
+    def attempt(extra_env):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this driver)
+        env.setdefault("OMP_NUM_THREADS", "8")
+        env.update(extra_env)
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace")
+        lines = _json_lines(p.stdout)
+        good = [j for j in lines if "error" not in j and "value" in j]
+        diag = {"returncode": p.returncode, "rank_reports": [j for j in lines if "error" in j][-1:],
+                "launcher_stderr_tail": p.stderr[-3000:], "ranks": RankReporter.collect(port, a.gpus)}
+        return good[-1] if good else None, diag, p
+    line, diag, p = attempt({})
+    if line is not None:
+        sys.stderr.write(p.stderr)
+        print(json.dumps(line))
+        return p.returncode
+    if os.environ.get("RESPMON_BENCH_TORCH_COLLECTIVES"):
+        second = None
+    else:
+        line, second, p2 = attempt({"RESPMON_BENCH_TORCH_COLLECTIVES": "1"})
+        if line is not None:
+            line["first_attempt"] = diag
+            sys.stderr.write(p2.stderr)
+            print(json.dumps(line))
+            return p2.returncode
+    rep = (diag["rank_reports"] or [{}])[0]
+    print(json.dumps({"metric": "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s", "value": None, "unit": "frames/s",
+                      "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "error": rep.get("error") or "the job ended without a result line",
+                      "stage": rep.get("stage") or RankReporter.earliest_stage(diag["ranks"]), "first_attempt": diag,
+                      "retry_with_torch_distributed_collectives": second}))
+    return p.returncode or 1
+
+
+class RankReporter:
+    """Makes a failing multi-GPU run leave ONE JSON line.  Every rank keeps the stage it has reached -- and, when
+    it fails, the tail of its traceback -- in a file of a directory named after the rendezvous port; rank 0 prints the error line:
+    from its own exception handler, from the SIGTERM the launcher sends the survivors when another rank has died (a watcher thread
+    on the signal wake-up descriptor: the main thread may be blocked inside a collective), or from a watchdog when a stage before
+    the timed loop makes no progress for --stage-timeout seconds (a hung ncclCommInitRank)."""
+    STAGES = ["start", "rendezvous", "rendezvous_done", "device", "communicator", "frame_buffer", "first_step", "warmup", "timed", "report", "done"]
+
+    @staticmethod
+    def directory(port):
+        return os.path.join(os.environ.get("TMPDIR", "/tmp"), "respmon_bench_%s" % port)
+
+    @classmethod
+    def collect(cls, port, world):
+        out = {}
+        d = cls.directory(port)
+        for r in range(world):
+            rec = {"stage": None, "stderr_tail": None}
+            try:
+                rec.update(json.load(open(os.path.join(d, "rank%d.json" % r))))
+            except Exception:   # noqa: BLE001 -- a rank that never got as far as writing its file
+                pass
+            out[str(r)] = rec
+        return out
+
+    @classmethod
+    def earliest_stage(cls, ranks):
+        idx = [cls.STAGES.index(v["stage"]) for v in ranks.values() if v.get("stage") in cls.STAGES]
+        return cls.STAGES[min(idx)] if idx else None
+
+    def __init__(self, a):
+        import faulthandler
+        import signal
+        import threading
+        self.a = a
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.port = os.environ.get("MASTER_PORT", str(os.getpid()))
+        self.cur = "start"
+        self.t_stage = time.time()
+        self.printed = False
+        self.lock = threading.Lock()
+        self.fault = os.environ.get("RESPMON_BENCH_FAULT", "")   # "<rank>:<stage>:kill|raise|hang" -- test hook (tests/test_host_logic.py)
+        if self.world > 1:
+            os.makedirs(self.directory(self.port), exist_ok=True)
+            self.errfile = open(os.path.join(self.directory(self.port), "rank%d.fault" % self.rank), "w")
+            faulthandler.enable(self.errfile)       # a segfault inside librccl still leaves its Python stack in the rank's file
+            self._write()
+            if self.rank == 0:
+                r, w = os.pipe()
+                os.set_blocking(w, False)
+                signal.signal(signal.SIGTERM, lambda *_: None)
+                signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+                threading.Thread(target=self._watch_signal, args=(r,), daemon=True).start()
+                threading.Thread(target=self._watchdog, daemon=True).start()
+
+    def _write(self, err=None):
+        if self.world <= 1:
+            return
+        try:
+            with open(os.path.join(self.directory(self.port), "rank%d.json" % self.rank), "w") as f:
+                json.dump({"stage": self.cur, "stderr_tail": err, "pid": os.getpid()}, f)
+        except OSError:
+            pass
+
+    def stage(self, name):
+        self.cur = name
+        self.t_stage = time.time()
+        self._write()
+        for spec in filter(None, self.fault.split(",")):
+            r, st, kind = (spec.split(":") + ["", ""])[:3]
+            if int(r) == self.rank and st == name:
+                if kind == "kill":
+                    self._write("fault injected: os._exit(17) at stage %s" % name)
+                    os._exit(17)
+                if kind == "hang":
+                    time.sleep(3600)
+                raise RuntimeError("fault injected at stage %s" % name)
+
+    def error_line(self, why):
+        a = self.a
+        ranks = self.collect(self.port, self.world)
+        return {"metric": "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s", "value": None, "unit": "frames/s",
+                "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "error": why, "stage": self.cur,
+                "earliest_stage_of_any_rank": self.earliest_stage(ranks), "ranks": ranks,
+                "hint": "stages: %s; `communicator` = rm_comm_init (ncclCommInitRank) -- RESPMON_BENCH_TORCH_COLLECTIVES=1 keeps the "
+                        "collectives of torch.distributed instead" % " > ".join(self.STAGES)}
+
+    def emit(self, why):
+        with self.lock:
+            if self.printed or self.rank != 0:
+                return
+            self.printed = True
+            sys.stdout.write(json.dumps(self.error_line(why)) + "\n")
+            sys.stdout.flush()
+
+    def _watch_signal(self, r):
+        import signal
+        while True:
+            try:
+                data = os.read(r, 16)
+            except OSError:
+                return
+            if any(b == signal.SIGTERM for b in data) and self.cur != "done":
+                time.sleep(0.2)    # (the rank that died may still be writing its file)
+                self.emit("SIGTERM from the launcher while at stage `%s`: another rank has ended" % self.cur)
+                os._exit(143)
+
+    def _watchdog(self):
+        limit = float(getattr(self.a, "stage_timeout", 0) or 0)
+        while limit > 0:
+            time.sleep(1.0)
+            if self.cur in ("timed", "report", "done"):
+                return
+            if time.time() - self.t_stage > limit:
+                self.emit("no progress for %.0f s at stage `%s`" % (limit, self.cur))
+                os._exit(124)
+
+    def failed(self, exc):
+        import traceback
+        tb = "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-3000:]
+        self._write(tb)
+        if self.world > 1 or not isinstance(exc, SystemExit):
+            self.emit("%s: %s" % (type(exc).__name__, exc))
 
 
 def oracle_single(vid_u8, n_frames, levels, skip, in_dtype):
@@ -227,11 +399,19 @@ def main():
         return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))
+    rep = RankReporter(a)
+    try:
+        run(a, rep)
+    except BaseException as e:   # noqa: BLE001 -- whatever ends a rank early must leave its trace (and, on rank 0, the JSON line)
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        rep.failed(e)
+        raise
 
+
+def run(a, rep):
     import torch
     import torch.distributed as dist
-    from respmon_amd import _capi, device, synth
-    from respmon_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -239,18 +419,29 @@ def main():
     backend_name = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one rank per GPU; the modulo only matters for the single-GPU dry run of this path
-        # (RESPMON_BENCH_BACKEND=gloo, several ranks on one device), never for the 8-GPU node
-        dev_index = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(dev_index)
         backend_name = os.environ.get("RESPMON_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        rep.stage("rendezvous")
         if backend_name == "nccl":
+            # one rank per GPU; the modulo only matters for the single-GPU dry run of this path, never for the 8-GPU node
+            dev_index = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(dev_index)
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend_name)
+        rep.stage("rendezvous_done")
+        if backend_name != "nccl":
+            dist.barrier()
+    rep.stage("device")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X: torch.cuda.is_available() is False"
+    from respmon_amd import _capi, device, synth
+    from respmon_amd import dist as rdist
+    if world > 1:
+        dev_index = local_rank % torch.cuda.device_count()   # (RESPMON_BENCH_BACKEND=gloo: several ranks may share one device)
+        torch.cuda.set_device(dev_index)
     else:
         torch.cuda.set_device(0)
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
+    rep.stage("communicator")
     # N > 1 over RCCL: the library makes its own communicator (include/respmon_hip.h rm_comm_init; torch.distributed only ships the
     # 128-byte id) and a step is ONE C-ABI call (rm_locate_streams / rm_locate_sharded).  All ranks agree on whether that worked;
     # otherwise every rank keeps the torch.distributed collectives of respmon_amd/dist.py.
@@ -302,6 +493,7 @@ def main():
             b[t0:t0 + 16] = (torch.from_numpy(v8[t0:t0 + 16]).cuda().to(torch.float64) * (1.0 / 255)).to(td)
         return b
 
+    rep.stage("frame_buffer")
     buf = to_device(vid_u8)
     torch.cuda.synchronize()
 
@@ -340,12 +532,14 @@ def main():
         torch.cuda.synchronize()
         return r, (time.perf_counter() - t0) / max(n, 1) * 1e3
 
+    rep.stage("first_step")
     roi = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     roi = step()
     torch.cuda.synchronize()
     one = max(time.perf_counter() - t0, 1e-5)
+    rep.stage("warmup")
     pre_steps = a.prewarm_steps if a.prewarm_steps is not None else int(min(600, max(10, 0.7 / one)))   # clock ramp of a fresh box
     if world > 1:   # every rank must issue the same number of collectives
         n_t = torch.tensor([pre_steps], dtype=torch.int64, device="cuda")
@@ -367,12 +561,14 @@ def main():
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - ts) / n_single * 1e3
     barrier()
+    rep.stage("timed")
     _capi.check(lib, lib.rm_profile_enable(ctx, 1), "rm_profile_enable")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         roi = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    rep.stage("report")
     ms = (ctypes.c_double * 4)()
     ncalls = ctypes.c_int()
     _capi.check(lib, lib.rm_profile_read(ctx, ms, ctypes.byref(ncalls)), "rm_profile_read")
@@ -807,8 +1003,11 @@ def main():
                 out["cpu_baseline"]["roi_equals_gpu"] = list(out["cpu_baseline"]["roi"] or []) == list(roi or [])
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-        sys.stdout.flush()
+        with rep.lock:
+            rep.printed = True
+            print(json.dumps(out))
+            sys.stdout.flush()
+    rep.stage("done")
     if world > 1:
         dist.destroy_process_group()
 

@@ -338,8 +338,9 @@ int rm_get_contour_clip_frame(rm_ctx *ctx, int *on);   /* so that a per-call ove
  *      bounding boxes and the host follows only the borders whose (w-1)*(h-1) bound can reach the best area -- same contour,
  *      same tie rule, no per-speck border following (csrc/rm_ccl.h).
  *      mode = -1 (default): taken when the previous ROI extraction of this geometry met more than 512 components, or when its
- *      host stage took longer than ~250 us (few components with long borders, e.g. a frame of noise blobs; the host-only stage is
- *      timed again every 64th call);
+ *      host stage walked more than 24 000 border steps (few components with long borders, e.g. a frame of noise blobs; the
+ *      host-only stage runs again every 64th call to refresh the count).  Counts only, no clock: a stream takes the same path in
+ *      every run;
  *      0: never (every border is followed on the host); 1: always.  The ROI does not depend on the mode.
  *      rm_contour_stats: components / contours met by the last ROI extraction and whether it ran labelled (diagnostics). */
 int rm_set_contour_labelling(rm_ctx *ctx, int mode);

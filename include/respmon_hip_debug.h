@@ -31,6 +31,10 @@ int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
  * exact raw.min() / raw.max()) */
 int rm_debug_counters(rm_ctx *ctx, long long *out_host, void *stream);
 
+/* a copy of the first `bytes` bytes of the context's workspace buffer `name` as the last call left it ("tile_lo", "tile_hi": the
+ * [unique frame][tile] bounds of the selection; "cS": the collapsed band-passed level) -- tests check the bounds themselves with it */
+int rm_debug_workspace(rm_ctx *ctx, const char *name, void *out_host, size_t bytes, void *stream);
+
 /* host timeline of the last rm_locate on this context, microseconds on the steady clock relative to the entry of that call:
  * out_host[0] = entry of the call minus the return of the PREVIOUS rm_locate (what the caller spent between two calls),
  * [1] = first kernel launch issued, [2] = every launch issued, [3] = device work seen complete, [4] = host contour stage done

@@ -158,7 +158,16 @@ int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, dou
         while (band > 4 && (long long)Th * ((g.tiles_y + band - 1) / band) < 1024) band = (band + 1) / 2;
         const int tbl_rows = tbl_rows_of(band);
         const size_t tbl = (size_t)tbl_rows * row_bytes;
-        if (by_rows) {
+        if (ctx->dbg.bounds_l1 && bounds_l1_ok(g) && ntiles < (1 << 24)) {
+            // skip 2: the extrema of the LEVEL-1 footprints, streaming (rm_bounds_l1.h) -- a wave per three tile columns and band of tile rows
+            const int nchunks = (g.tiles_x + BL1_TILES - 1) / BL1_TILES;
+            int trb = 16;
+            while (trb > 4 && (long long)Th * nchunks * ((g.tiles_y + trb - 1) / trb) < 6144) trb >>= 1;   // (small frames: more, shorter waves)
+            if (ctx->dbg.bounds_l1_rows > 0) trb = ctx->dbg.bounds_l1_rows;
+            const int nbands = (g.tiles_y + trb - 1) / trb;
+            hipLaunchKernelGGL(k_frame_bounds_l1<>, dim3(Th, (unsigned)((nchunks * nbands + 3) / 4)), dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt,
+                               nchunks, nbands, trb);
+        } else if (by_rows) {
             hipLaunchKernelGGL(k_frame_bounds_rows<8>, dim3(Th, (unsigned)((g.tiles_y + 31) / 32)), dim3(256), rowbufs, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt);
         } else if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {
             const unsigned nbands = (unsigned)((g.tiles_y + band - 1) / band);

@@ -163,6 +163,7 @@ struct Tracer {
         for (int i = 0; i < 8; ++i) nbr[i] = nbr[i + 8] = dy[i] * step + dx[i];
     }
 
+    long long steps = 0;   // border steps walked since the entry point reset it
     // follow the outer border that starts at `start` (padded coords px,py); returns twice the signed area
     long long follow(signed char *start, int px, int py, int &minx, int &miny, int &maxx, int &maxy)
     {
@@ -191,6 +192,7 @@ struct Tracer {
             else if (*cur == FG) *cur = SEEN;
             int nx = cx + dx[dir], ny = cy + dy[dir];
             twice_area += (long long)cx * ny - (long long)nx * cy;
+            ++steps;
             cx = nx; cy = ny;
             if (cx < minx) minx = cx;
             if (cx > maxx) maxx = cx;
@@ -211,11 +213,14 @@ static int scan_prepared(Tracer &tr, int H, const uint32_t *row_any, RoiResult *
 
 int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out)
 {
-    out->found = 0; out->n_contours = 0; out->area = 0.0;
+    out->found = 0; out->n_contours = 0; out->area = 0.0; out->steps = 0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare(bin, H, W, row_any);
-    return scan_prepared(g_tracer, H, row_any, out, false);
+    g_tracer.steps = 0;
+    const int rc = scan_prepared(g_tracer, H, row_any, out, false);
+    out->steps = g_tracer.steps;
+    return rc;
 }
 
 // Raster scan for border starts driven by the PACKED image: the foreground runs of a row come from bit tricks on
@@ -275,11 +280,14 @@ static int scan_runs(Tracer &tr, const uint64_t *bits, int H, int W, RoiResult *
 
 int largest_external_contour_bits(const uint64_t *bits, int H, int W, RoiResult *out)
 {
-    out->found = 0; out->n_contours = 0; out->area = 0.0;
+    out->found = 0; out->n_contours = 0; out->area = 0.0; out->steps = 0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare_bits(bits, H, W);
-    return scan_runs(g_tracer, bits, H, W, out);
+    g_tracer.steps = 0;
+    const int rc = scan_runs(g_tracer, bits, H, W, out);
+    out->steps = g_tracer.steps;
+    return rc;
 }
 
 // One hole-free blob?  If every row of [y0, y1] holds exactly ONE run of foreground and the runs of neighbouring rows touch
@@ -319,7 +327,7 @@ int simple_shape_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, R
         xmin = first < xmin ? first : xmin; xmax = last > xmax ? last : xmax;
     }
     if (ya < 0) return 0;   // no foreground at all: the caller's path reports "no contour"
-    out->found = 1; out->n_contours = 1;
+    out->found = 1; out->n_contours = 1; out->steps = 0;
     out->x = xmin; out->y = ya; out->w = xmax - xmin + 1; out->h = yb - ya + 1;
     out->area = -1.0;   // (not computed: the only contour is the largest one whatever its area)
     return 1;
@@ -347,7 +355,7 @@ int simple_shape_row_records(const uint64_t *rec, int H, int W, int *y0, int *y1
     }
     *y0 = ya; *y1 = yb;
     if (yb < 0 || !ok) return 0;
-    out->found = 1; out->n_contours = 1;
+    out->found = 1; out->n_contours = 1; out->steps = 0;
     out->x = xmin; out->y = ya; out->w = xmax - xmin + 1; out->h = yb - ya + 1;
     out->area = -1.0;   // (not computed: the only contour is the largest one whatever its area)
     return 1;
@@ -355,12 +363,15 @@ int simple_shape_row_records(const uint64_t *rec, int H, int W, int *y0, int *y1
 
 int largest_external_contour_bits_rows(const uint64_t *bits, int H, int W, int y0, int y1, RoiResult *out)
 {
-    out->found = 0; out->n_contours = 0; out->area = 0.0;
+    out->found = 0; out->n_contours = 0; out->area = 0.0; out->steps = 0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0) return 0;
     g_tracer.prepare_bits(bits, H, W, y0, y1 < y0 ? y0 - 1 : y1);
     if (y1 < y0) return 0;
-    return scan_runs(g_tracer, bits, H, W, out, y0, y1);
+    g_tracer.steps = 0;
+    const int rc = scan_runs(g_tracer, bits, H, W, out, y0, y1);
+    out->steps = g_tracer.steps;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -390,6 +401,7 @@ static void prefetch_rows(const BitImage &im, int y0, int y1)
     for (; p < e; p += 64) __builtin_prefetch(p, 0, 3);
 }
 
+static thread_local long long g_bits_steps = 0;   // border steps follow_bits() walked since the entry point reset it
 // twice the signed shoelace area of the outer border that starts at (sx, sy): Tracer::follow without marks
 long long follow_bits(const BitImage &im, int sx, int sy)
 {
@@ -428,6 +440,7 @@ long long follow_bits(const BitImage &im, int sx, int sy)
             dir &= 7;
         }
         twice_area += (long long)cx * ny - (long long)nx * cy;
+        ++g_bits_steps;
         if (nx == sx && ny == sy && cx == fx && cy == fy) break;
         cx = nx; cy = ny;
         dir = (dir + 4) & 7;
@@ -438,9 +451,10 @@ long long follow_bits(const BitImage &im, int sx, int sy)
 
 int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const LabelComp *comps, size_t n, RoiResult *out)
 {
-    out->found = 0; out->n_contours = (int)n; out->area = 0.0;
+    out->found = 0; out->n_contours = (int)n; out->area = 0.0; out->steps = 0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0 || n == 0) return 0;
+    g_bits_steps = 0;
     const BitImage im{bits, H, W};
     auto bound2 = [](const LabelComp &c) { return 2ll * (long long)c.w1 * (long long)c.h1; };   // twice the largest area inside the box
     long long best2 = -1; size_t best_i = 0;
@@ -466,6 +480,7 @@ int largest_external_contour_labelled(const uint64_t *bits, int H, int W, const 
     out->x = c.minx; out->y = c.root / W;
     out->w = c.w1 + 1; out->h = c.h1 + 1;
     out->area = 0.5 * (double)best2;
+    out->steps = g_bits_steps;
     return 0;
 }
 
@@ -491,7 +506,7 @@ bool labelled_tops_settled(const LabelComp *tops, int nblocks, int W, size_t n, 
         if ((long long)(((unsigned long long)(unsigned int)s.minx << 32) | (unsigned int)s.root) >= low2) return false;
     }
     const LabelComp &c = tops[2 * top_b];
-    out->found = 1; out->n_contours = (int)n;
+    out->found = 1; out->n_contours = (int)n; out->steps = 0;
     out->x = c.minx; out->y = c.root / W;
     out->w = c.w1 + 1; out->h = c.h1 + 1;
     out->area = -1.0;   // (not computed: no other contour can reach this one's lower bound)
@@ -501,9 +516,10 @@ bool labelled_tops_settled(const LabelComp *tops, int nblocks, int W, size_t n, 
 int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, const LabelComp *tops, int nblocks, const LabelComp *comps, size_t n,
                                            RoiResult *out, bool area_bound_shortcut)
 {
-    out->found = 0; out->n_contours = (int)n; out->area = 0.0;
+    out->found = 0; out->n_contours = (int)n; out->area = 0.0; out->steps = 0;
     out->x = out->y = out->w = out->h = 0;
     if (H <= 0 || W <= 0 || n == 0) return 0;
+    g_bits_steps = 0;
     const BitImage im{bits, H, W};
     auto bound2 = [](const LabelComp &c) { return 2ll * (long long)c.w1 * (long long)c.h1; };
     long long best2 = -1; int best_b = -1;
@@ -524,13 +540,19 @@ int largest_external_contour_labelled_tops(const uint64_t *bits, int H, int W, c
     for (int b = 0; b < nblocks; ++b) {
         const LabelComp &s = tops[2 * b + 1];
         const long long second = (long long)(((unsigned long long)(unsigned int)s.minx << 32) | (unsigned int)s.root);
-        if (second >= best2) return largest_external_contour_labelled(bits, H, W, comps, n, out);   // an unread component may win or tie
+        if (second >= best2) {   // an unread component may win or tie
+            const long long walked = g_bits_steps;
+            const int rc = largest_external_contour_labelled(bits, H, W, comps, n, out);
+            out->steps += walked;
+            return rc;
+        }
     }
     const LabelComp &c = tops[2 * best_b];
     out->found = 1;
     out->x = c.minx; out->y = c.root / W;
     out->w = c.w1 + 1; out->h = c.h1 + 1;
     out->area = 0.5 * (double)best2;
+    out->steps = g_bits_steps;
     return 0;
 }
 

@@ -9,6 +9,7 @@ struct RoiResult {
     int x, y, w, h;  // cv2.boundingRect of the selected contour
     double area;     // cv2.contourArea of the selected contour
     int n_contours;
+    long long steps; // border steps this call walked on the host (what its time is proportional to: rm_roi.hip decides from it, not from a clock)
 };
 // bin: H*W bytes (non-zero = foreground); row_any (nullable): per-row "has foreground" flags
 int largest_external_contour(const uint8_t *bin, int H, int W, const uint32_t *row_any, RoiResult *out);

@@ -112,6 +112,8 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "no_fused_bounds") d.no_fused_bounds = (int)value;
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
     else if (k == "bounds_scalar") d.bounds_scalar = (int)value;
+    else if (k == "bounds_l1") d.bounds_l1 = (int)value;
+    else if (k == "bounds_l1_rows") d.bounds_l1_rows = (int)value;
     else if (k == "dense_rows") d.dense_rows = (int)value;
     else if (k == "dense_general") d.dense_general = (int)value;
     else if (k == "dense_wave") d.dense_wave = (int)value;
@@ -138,7 +140,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dense_t_low") d.dense_t_low = (int)value;
     else if (k == "dense_exact_top") d.dense_exact_top = (int)value;
     else if (k == "ccl_table") d.ccl_table = (int)value;
-    else if (k == "label_host_us") d.label_host_us = (int)value;
+    else if (k == "label_host_steps") d.label_host_steps = value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;
     else return fail(RM_E_BADARG, "rm_debug_set: unknown key '%s'", key);
@@ -188,6 +190,19 @@ extern "C" int rm_debug_counters(rm_ctx *ctx, long long *out, void *stream)
     out[0] = ctx->dbg_pairs; out[1] = (long long)h.n_list_a + (dense ? 0 : (long long)h.n_list_b); out[2] = h.n_slots;
     out[3] = dense ? 0 : ctx->dbg_cap;
     if (ctx->dbg_fused) { out[1] = (long long)h.n_list_a; out[3] = -1; }   // store-less path: C pairs evaluated for the extrema; the kept pairs where they are summed
+    return RM_OK;
+}
+
+extern "C" int rm_debug_workspace(rm_ctx *ctx, const char *name, void *out_host, size_t bytes, void *stream)
+{
+    if (!ctx || !name || !out_host) return fail(RM_E_BADARG, "rm_debug_workspace: bad argument");
+    auto it = ctx->bufs.find(name);
+    if (it == ctx->bufs.end() || !it->second.p) return fail(RM_E_BADARG, "rm_debug_workspace: no workspace buffer '%s'", name);
+    if (bytes > it->second.cap) return fail(RM_E_BADARG, "rm_debug_workspace: '%s' holds %zu bytes, %zu asked for", name, it->second.cap, bytes);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(out_host, it->second.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(stream_wait(s));
     return RM_OK;
 }
 

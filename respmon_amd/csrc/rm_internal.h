@@ -39,6 +39,7 @@
 #include "rm_down_chain_u8.h"
 #include "rm_dense_sum.h"
 #include "rm_tile_eval.h"
+#include "rm_bounds_l1.h"
 #include "rm_ccl.h"
 #include "rm_flow.h"
 
@@ -89,6 +90,8 @@ struct DebugKnobs {
     int dc_lds_front_end = 0;     // 1: narrow frame buffers through the LDS front end of k_down_chain instead of rm_down_chain_u8.h
     int no_fused_bounds = 0;      // 1: k_small_collapse + k_frame_bounds instead of k_small_collapse_bounds
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
+    int bounds_l1 = 1;            // 0: skip 2 takes its tile bounds from the level-2 footprint (k_frame_bounds / k_frame_bounds_rows) instead of the level-1 footprint (rm_bounds_l1.h)
+    int bounds_l1_rows = 0;       // > 0: tile rows per wave of k_frame_bounds_l1 (default: 16, fewer on small frames)
     int bounds_scalar = 0;        // 1: k_frame_bounds (a thread per row and tile column) also for wide levels instead of k_frame_bounds_rows
     int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
     int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2
@@ -102,7 +105,7 @@ struct DebugKnobs {
     int collapse_fused = 0;       // 1: collapse passes without a value store wherever TileEval applies (rm_tile_eval.h k_eval_c + k_tile_sum); 0: only as the stand-in for an overflowing store at skip >= 3
     int sum_rows = 0;             // 1: k_masked_sum_rows (one wave per tile row, LDS-DMA staging) instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 35 us against 21)
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
-    int label_host_us = 250;      // host border following slower than this (+ the labelled stage's own host time) -> device labelling next time
+    long long label_host_steps = 0;   // > 0: border steps of an unlabelled host stage beyond which the next extraction is labelled on the device (default LABEL_MIN_STEPS)
     int ccl_table = -1;           // k_ccl_bbox: 1 with / 0 without the per-tile LDS table of boxes, -1 by the last component count
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)
@@ -168,10 +171,11 @@ struct rm_ctx {
     int label_mode = -1, label_H = 0, label_W = 0, label_last_n = 0, label_used = 0;
     bool label_lazy = false;      // the last labelled extraction of this geometry was settled by the summary records alone: the next one keeps image and list on the device
     int roi_path = 0;             // RM_ROI_PATH_* of the last host contour stage (rm_debug_roi_path)
-    // ... or when following every border on the host took long last time (few components with long borders: a frame of noise blobs):
-    // host time of the last unlabelled stage of this geometry (< 0: none) with its contour count, host time of the last labelled
-    // stage, labelled stages in a row (every LABEL_REPROBE-th one is run unlabelled to refresh the first figure)
-    double label_unl_us = -1.0, label_lab_host_us = 0.0;
+    // ... or when following every border on the host was long last time (few components with long borders: a frame of noise blobs):
+    // border steps the last unlabelled stage of this geometry walked (< 0: none) with its contour count, labelled stages in a row
+    // (every LABEL_REPROBE-th one is run unlabelled to refresh the first figure).  Counts, not clock readings (round 6): the same
+    // stream takes the same path in every run.
+    long long label_unl_steps = -1;
     int label_unl_n = 0, label_streak = 0;
     // cached temporal operator
     int op_T = 0, op_nk = 0; double op_fps = 0, op_fmin = 0, op_fmax = 0;

@@ -7,6 +7,7 @@ using namespace rm;
 constexpr int CCL_TABLE_MAX_COMPONENTS = 2048;   // more components than this last time: k_ccl_bbox without its LDS table
 constexpr int LABEL_REPROBE = 64;         // labelled stages in a row before the host-only stage is timed again
 constexpr int LABEL_MIN_CONTOURS = 512;   // ~0.13 us per followed border on the host against ~40 us of labelling kernels
+constexpr long long LABEL_MIN_STEPS = 24000;   // ... or this many border steps (5-10 ns each, cache misses included) against ~100 us of labelling kernels
 static_assert(sizeof(CclComp) == sizeof(LabelComp), "record layout shared by rm_ccl.h and rm_contour.h");
 
 // The ROI stage in two halves: roi_launch enqueues the device work (threshold -> packed image in the pinned memory of slot
@@ -65,9 +66,11 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     // noisy images: label the components on the device so that the host follows only borders that can win (rm_ccl.h)
     const bool clip = ctx->clip_frame || clip_once;
     const bool same_geom = ctx->label_H == H && ctx->label_W == W;
-    if (!same_geom) { ctx->label_unl_us = -1.0; ctx->label_lab_host_us = 0.0; ctx->label_streak = 0; ctx->label_lazy = false; }
+    if (!same_geom) { ctx->label_unl_steps = -1; ctx->label_streak = 0; ctx->label_lazy = false; }
     const bool many = ctx->label_last_n > LABEL_MIN_CONTOURS;
-    bool slow_host = ctx->label_unl_us >= 0.0 && ctx->label_unl_us > (double)ctx->dbg.label_host_us + ctx->label_lab_host_us;
+    // (decided from what the previous extraction of this geometry COUNTED -- contours met, border steps walked --, never from how long
+    //  it took: the path a stream takes, and with it its step time, is the same in every run)
+    bool slow_host = ctx->label_unl_steps > (ctx->dbg.label_host_steps > 0 ? ctx->dbg.label_host_steps : LABEL_MIN_STEPS);
     if (slow_host && !many && ctx->label_mode < 0 && ctx->label_streak >= LABEL_REPROBE) { slow_host = false; ctx->label_streak = 0; }
     const bool label = !clip && npix < (size_t)0x7fffffff &&
                        (ctx->label_mode == 1 || (ctx->label_mode < 0 && same_geom && (many || slow_host)));
@@ -147,7 +150,7 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
     const size_t nwords = pd.nwords, comps_cap = pd.comps_cap;
     const bool label = pd.label, clip = pd.clip;
     uint8_t *h_rows = rs.h_bin + nwords * 8;
-    RoiResult r;
+    RoiResult r{};
     {
         const auto t0 = std::chrono::steady_clock::now();
         int y0 = H, y1 = -1;   // rows that hold foreground
@@ -207,11 +210,10 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
         }
         const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         if (ctx->label_used) {
-            ctx->label_lab_host_us = host_us;
             ++ctx->label_streak;
-            if ((long long)ncomp * 2 < (long long)ctx->label_unl_n) ctx->label_unl_us = -1.0;   // a different kind of image: time the host stage afresh
+            if ((long long)ncomp * 2 < (long long)ctx->label_unl_n) ctx->label_unl_steps = -1;   // a different kind of image: count the host stage's steps afresh
         } else if (!clip) {
-            ctx->label_unl_us = host_us; ctx->label_unl_n = r.n_contours; ctx->label_streak = 0;
+            ctx->label_unl_steps = r.steps; ctx->label_unl_n = r.n_contours; ctx->label_streak = 0;
         }
         if (ctx->prof_on) ctx->prof_host_ms[3] += host_us * 1e-3;
     }

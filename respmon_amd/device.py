@@ -44,6 +44,23 @@ def debug_set(key, value, device_index=None):
     _capi.check(lib, lib.rm_debug_set(ctx(device_index), key.encode(), int(value)), "rm_debug_set")
 
 
+def debug_workspace(name, shape, dtype=np.float64, device_index=None):
+    """Developer / test hook: a host copy of this GPU's workspace buffer `name` as the last call left it (rm_debug_workspace)."""
+    lib = _capi.load()
+    out = np.empty(shape, dtype=dtype)
+    _capi.check(lib, lib.rm_debug_workspace(ctx(device_index), name.encode(), ctypes.c_void_p(out.ctypes.data), out.nbytes, stream_ptr()),
+                "rm_debug_workspace")
+    return out
+
+
+def debug_counters(device_index=None):
+    """(pairs, evaluated, kept, store capacity) of the last calibration on this GPU's context (rm_debug_counters)."""
+    lib = _capi.load()
+    out = (ctypes.c_longlong * 4)()
+    _capi.check(lib, lib.rm_debug_counters(ctx(device_index), out, stream_ptr()), "rm_debug_counters")
+    return [int(v) for v in out]
+
+
 def raw_stream(device_index):
     """hipStream_t of torch's current stream on `device_index` as an int (the raw getter costs ~0.3 us; the Stream object of
     torch.cuda.current_stream() ~3 us, which sits on the host path between two calibrations)."""

@@ -102,6 +102,17 @@ class Emu:
                                       flags, ptr(heat), ptr(mm), None), "calibrate")
         return heat, mm
 
+    def workspace(self, name, shape, dtype=np.float64):
+        """A copy of the context's workspace buffer `name` (rm_debug_workspace) as an array of `shape`."""
+        out = np.empty(shape, dtype=dtype)
+        self.ck(self.lib.rm_debug_workspace(self.ctx, name.encode(), ptr(out), out.nbytes, None), "workspace")
+        return out
+
+    def counters(self):
+        out = np.zeros(4, np.int64)
+        self.ck(self.lib.rm_debug_counters(self.ctx, ptr(out), None), "counters")
+        return [int(v) for v in out]
+
     def heatmap_to_roi(self, heat, threshold=20, clip_frame=False, labelling=-1):
         heat = np.ascontiguousarray(heat, dtype=np.float64)
         H, W = heat.shape

@@ -941,3 +941,88 @@ def test_emu_small_pyramid_split_over_workgroups(emu, oracle):
         assert emu.locate(fr, 10.0, levels=7, skip=4) == oracle.locate(fr, 10, pyramid_levels=7, skip_levels_at_top=4)
     finally:
         emu.debug_set("ff_parts", 0)
+
+
+def _level1_footprint_extrema(oracle, c2, H, W):
+    """min / max of pyrUp(C_2[u]) over every 64 x 16 tile's level-1 footprint (rows 8 ty - 1 .. 8 ty + 8 by columns 32 tx - 1 ..
+    32 tx + 32, clipped to the image): what rm_bounds_l1.h must write, from the oracle's pyrUp."""
+    h1, w1 = (H + 1) // 2, (W + 1) // 2
+    nty, ntx = (H + 15) // 16, (W + 63) // 64
+    lo = np.empty((c2.shape[0], nty, ntx)); hi = np.empty_like(lo)
+    for u in range(c2.shape[0]):
+        l1 = oracle.pyrUp(c2[u], (w1, h1))
+        for ty in range(nty):
+            y0, y1 = max(8 * ty - 1, 0), min(8 * ty + 8, h1 - 1)
+            for tx in range(ntx):
+                x0, x1 = max(32 * tx - 1, 0), min(32 * tx + 32, w1 - 1)
+                f = l1[y0:y1 + 1, x0:x1 + 1]
+                lo[u, ty, tx] = f.min(); hi[u, ty, tx] = f.max()
+    return lo.reshape(c2.shape[0], -1), hi.reshape(c2.shape[0], -1)
+
+
+def test_emu_level1_tile_bounds(emu, oracle):
+    """rm_bounds_l1.h (round 6): at skip 2 the tile bounds are the extrema of the LEVEL-1 footprint, formed by a streaming kernel
+    (three tile columns per wave, DPP neighbours, bands of tile rows).  The bounds themselves must equal the oracle's pyrUp of the
+    collapsed level bit for bit, on ragged widths / heights, several column chunks and bands; the heatmap must not change by a bit
+    against the level-2 bounds and against exhaustive evaluation; and the selection must not keep more pairs than before."""
+    rng = np.random.default_rng(61)
+    cases = [(4, 40, 200, 4, 2, 0), (3, 70, 450, 5, 2, 2), (5, 33, 131, 4, 2, 1), (2, 130, 70, 6, 2, 4), (3, 17, 64, 4, 2, 0),
+             (2, 96, 388, 4, 2, 1), (3, 5, 7, 4, 2, 0)]
+    for (T, H, W, L, S, trb) in cases:
+        v = rng.random((T, H, W))
+        v[:, : H // 2, : W // 3] *= 0.05          # a quiet corner: some pairs can be pruned at all
+        emu.debug_set("bounds_l1_rows", trb)
+        emu.debug_set("bounds_l1", 0)
+        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512)     # (512: one launch per level -- the separate bounds kernel runs)
+        kept_l2 = emu.counters()[2]
+        emu.debug_set("bounds_l1", 1)
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512)
+        kept_l1 = emu.counters()[2]
+        assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (T, H, W, L, S, trb)
+        assert kept_l1 <= kept_l2, (T, H, W, kept_l1, kept_l2)
+        Th = T // 2 + 1
+        h2, w2 = ((H + 1) // 2 + 1) // 2, ((W + 1) // 2 + 1) // 2
+        ntiles = ((H + 15) // 16) * ((W + 63) // 64)
+        c2 = emu.workspace("cS", (Th, h2, w2))
+        lo = emu.workspace("tile_lo", (Th, ntiles)); hi = emu.workspace("tile_hi", (Th, ntiles))
+        want_lo, want_hi = _level1_footprint_extrema(oracle, c2, H, W)
+        assert np.array_equal(lo, want_lo) and np.array_equal(hi, want_hi), (T, H, W, L, S, trb)
+        exhaustive, mm3 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512 | 1)
+        assert np.array_equal(got, exhaustive) and tuple(mm) == tuple(mm3), (T, H, W, "no prune")
+        for f in (128, 256):                      # the store-less and the store-based sum on the new bounds
+            alt, mm4 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512 | f)
+            assert np.array_equal(alt, ref) and tuple(mm) == tuple(mm4), (T, H, W, f)
+        emu.debug_set("dense_t_low", 1)           # ... and the TileEval sum (what large frames take), which re-tests every pair against the exact top
+        alt, mm4 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512 | 128)
+        emu.debug_set("dense_t_low", -1)
+        assert np.array_equal(alt, ref) and tuple(mm) == tuple(mm4), (T, H, W, "k_dense_sum_t")
+    emu.debug_set("bounds_l1_rows", 0)
+    emu.debug_set("bounds_l1", 1)
+
+
+def test_emu_labelling_rule_counts_not_clocks(emu, oracle):
+    """whether the next ROI extraction of a geometry is labelled on the device is decided from what the previous
+    one COUNTED (contours met, border steps walked on the host), never from how long it took -- so a stream takes the same path in
+    every run.  A frame-spanning comb (two components, ~6 000 border steps) with the step bar lowered to 1 000: extraction 1 follows
+    every border on the host, extractions 2 .. are labelled; with the bar at its default (24 000) every extraction stays on the
+    host; the sequence of paths is the same when the whole experiment is repeated; the ROI never changes."""
+    comb = np.zeros((72, 192), bool); comb[2, :] = True; comb[2:70, ::2] = True; comb[60:70, 1:40] = True
+    heat = comb.astype(np.float64)
+    want = oracle.roi_from_heatmap_u8(oracle.heatmap_u8(heat[None])[1], 20)
+    runs = []
+    for rep in range(2):
+        seq = []
+        for bar in (1000, 0):
+            emu.debug_set("label_host_steps", bar)
+            emu.heatmap_to_roi(np.zeros((8, 64)), threshold=20)          # another geometry: the rule's memory starts afresh
+            for k in range(4):
+                roi, _, _ = emu.heatmap_to_roi(heat, threshold=20)
+                seq.append((bar, k, roi, emu.contour_stats()[1], emu.roi_path()))
+        runs.append(seq)
+    emu.debug_set("label_host_steps", 0)
+    assert runs[0] == runs[1]
+    rois = {s[2] for s in runs[0]}
+    assert len(rois) == 1 and None not in rois
+    assert rois == {want}
+    lab = [(s[0], s[3]) for s in runs[0]]
+    assert lab == [(1000, 0), (1000, 1), (1000, 1), (1000, 1), (0, 0), (0, 0), (0, 0), (0, 0)], lab

@@ -976,6 +976,7 @@ def test_streaming_tile_bounds_equal_table_form(hip):
     for (T, H, W, L, S) in [(6, 300, 1100, 4, 2), (4, 203, 2100, 5, 3), (5, 160, 1040, 3, 1), (3, 540, 3840, 6, 2)]:
         buf = torch.from_numpy(rng.random((T, H, W))).cuda()
         kw = dict(pyramid_levels=L, skip_levels_at_top=S, flags=512)     # (per-level filter-first path: the bounds are a kernel of their own)
+        device.debug_set("bounds_l1", 0)                                 # (skip 2 would take the level-1 bounds of rm_bounds_l1.h: tested below)
         device.debug_set("bounds_scalar", 1)
         ref, mm = dist.hip_calibrate(buf, 10, return_minmax=True, **kw)
         device.debug_set("bounds_scalar", 2)
@@ -984,6 +985,73 @@ def test_streaming_tile_bounds_equal_table_form(hip):
         assert torch.equal(got, ref) and mm == mm2, (T, H, W, L, S)
         exhaustive = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 1)
         assert torch.equal(got, exhaustive), (T, H, W, L, S, "no prune")
+        device.debug_set("bounds_l1", 1)
+
+
+def test_level1_tile_bounds(hip, oracle):
+    """rm_bounds_l1.h (round 6): at skip 2 the tile bounds are the extrema of the LEVEL-1 footprint (one pyrUp below the collapsed
+    level), formed by a streaming kernel -- three tile columns per wave, DPP wave rotations for the horizontal neighbours, bands of
+    tile rows.  (a) the bounds equal the oracle's pyrUp of the collapsed level bit for bit (ragged shapes, several chunks and
+    bands); (b) the heatmap and the extrema do not change by a bit against the level-2 bounds, exhaustive evaluation, and either sum
+    path; (c) on a noisy stream the selection keeps far fewer pairs."""
+    import torch
+    from respmon_amd import device, dist
+    rng = np.random.default_rng(61)
+    for (T, H, W, L, S, trb) in [(6, 300, 1100, 4, 2, 0), (5, 203, 2100, 5, 2, 2), (4, 131, 450, 4, 2, 1), (3, 540, 3840, 6, 2, 0),
+                                 (6, 720, 1280, 4, 2, 0), (4, 70, 64, 4, 2, 16)]:
+        v = rng.random((T, H, W))
+        v[:, : H // 2, : W // 3] *= 0.05
+        buf = torch.from_numpy(v).cuda()
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S, flags=512)
+        device.debug_set("bounds_l1_rows", trb)
+        device.debug_set("bounds_l1", 0)
+        ref, mm = dist.hip_calibrate(buf, 10, return_minmax=True, **kw)
+        kept_l2 = device.debug_counters()[2]
+        device.debug_set("bounds_l1", 1)
+        got, mm2 = dist.hip_calibrate(buf, 10, return_minmax=True, **kw)
+        kept_l1 = device.debug_counters()[2]
+        assert torch.equal(got, ref) and mm == mm2, (T, H, W, L, S, trb)
+        assert kept_l1 <= kept_l2, (T, H, W, kept_l1, kept_l2)
+        Th = T // 2 + 1
+        h1, w1 = (H + 1) // 2, (W + 1) // 2
+        h2, w2 = (h1 + 1) // 2, (w1 + 1) // 2
+        nty, ntx = (H + 15) // 16, (W + 63) // 64
+        c2 = device.debug_workspace("cS", (Th, h2, w2))
+        lo = device.debug_workspace("tile_lo", (Th, nty, ntx)); hi = device.debug_workspace("tile_hi", (Th, nty, ntx))
+        for u in range(Th):
+            l1 = oracle.pyrUp(c2[u], (w1, h1))
+            for ty in range(nty):
+                y0, y1 = max(8 * ty - 1, 0), min(8 * ty + 8, h1 - 1)
+                rows = l1[y0:y1 + 1]
+                for tx in range(ntx):
+                    f = rows[:, max(32 * tx - 1, 0): min(32 * tx + 32, w1 - 1) + 1]
+                    assert lo[u, ty, tx] == f.min() and hi[u, ty, tx] == f.max(), (T, H, W, u, ty, tx)
+        exhaustive = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 1)
+        assert torch.equal(got, exhaustive), (T, H, W, "no prune")
+        for f in (128, 256):
+            alt = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | f)
+            assert torch.equal(alt, ref), (T, H, W, f)
+        device.debug_set("dense_t_low", 1)
+        alt = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 128)
+        device.debug_set("dense_t_low", -1)
+        assert torch.equal(alt, ref), (T, H, W, "k_dense_sum_t")
+    device.debug_set("bounds_l1_rows", 0)
+    # (c) speckle at the scale of one level-2 pixel over a smooth breathing signal: the level-2 footprint bound keeps (nearly) every
+    # pair, the level-1 bound far fewer -- and the ROI is the oracle's
+    from respmon_amd import synth
+    from respmon_amd.base import RespiratoryMonitor
+    v8 = synth.synth_breathing(32, 360, 640, seed=1234)
+    frames = oracle.uint8_to_float(v8)
+    buf = torch.from_numpy(frames).cuda()
+    device.debug_set("bounds_l1", 0)
+    dist.hip_calibrate(buf, 10, pyramid_levels=4, skip_levels_at_top=2, flags=512)
+    kept_l2 = device.debug_counters()[2]
+    device.debug_set("bounds_l1", 1)
+    dist.hip_calibrate(buf, 10, pyramid_levels=4, skip_levels_at_top=2, flags=512)
+    pairs, _, kept_l1, _ = device.debug_counters()
+    assert kept_l1 < kept_l2, (kept_l1, kept_l2, pairs)
+    roi = RespiratoryMonitor.locate(buf, 10, pyramid_levels=4, skip_levels_at_top=2)
+    assert roi == oracle.locate(frames, 10, pyramid_levels=4, skip_levels_at_top=2)
 
 
 def test_value_store_grows_with_the_selection(hip, oracle):

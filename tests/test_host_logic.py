@@ -2,8 +2,10 @@
 operator (host function) matches the golden vectors, and the RespiratoryMonitor state machine reproduces the
 reference's frame accounting (G6) when driven through a recording test double of the backend."""
 import ctypes
+import json
 import os
 import re
+import sys
 
 import numpy as np
 
@@ -288,3 +290,74 @@ def test_multi_gpu_dry_run_plan_and_shard_coverage():
             assert all(r["frames"] == [0, T] for r in plan["ranks"]) and plan["scaling"] == "weak"
             assert sorted(r["stream_seed"] for r in plan["ranks"]) == list(range(1234, 1242))
         assert any("ncclAllGather" in line for line in plan["step"])
+
+
+def _bench_ranks(nproc, fault, extra_args=(), timeout=240):
+    """bench.py as `nproc` ranks of a torch.distributed.run job on the CPU (gloo), with a fault injected (RESPMON_BENCH_FAULT)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"RESPMON_BENCH_BACKEND": "gloo", "RESPMON_BENCH_FAULT": fault, "OMP_NUM_THREADS": "1"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "0", "--cpu-frames", "0"]
+    p = subprocess.run(cmd + list(extra_args), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = []
+    for line in p.stdout.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            lines.append(json.loads(line))
+    return p, lines
+
+
+def test_bench_multi_gpu_failure_leaves_one_json_line():
+    """first contact with a multi-GPU node must be diagnosable.  Two gloo ranks on the CPU; rank 1 is killed right
+    after the rendezvous (what a rank dying inside ncclCommInitRank looks like to the others).  Rank 0 -- stuck in the collective
+    that follows, then told to stop by the launcher, or failing on its own -- still prints exactly ONE JSON line: n_gpus, "error",
+    the stage it was in, and what every rank left behind (the stage it had reached, the injected fault)."""
+    p, lines = _bench_ranks(2, "1:rendezvous_done:kill")
+    assert p.returncode != 0
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["value"] is None and j["error"] and j["steps"] == 1
+    assert j["stage"] in ("rendezvous_done", "device"), j["stage"]
+    assert j["earliest_stage_of_any_rank"] == "rendezvous_done"
+    assert set(j["ranks"]) == {"0", "1"}
+    assert j["ranks"]["1"]["stage"] == "rendezvous_done" and "fault injected" in (j["ranks"]["1"]["stderr_tail"] or "")
+    # rank 0 stuck where no error ever reaches it (a hang inside a collective): the launcher's SIGTERM makes its watcher thread print
+    p, lines = _bench_ranks(2, "1:rendezvous_done:kill,0:rendezvous_done:hang")
+    assert p.returncode != 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    j = lines[0]
+    assert j["n_gpus"] == 2 and "SIGTERM" in j["error"] and j["stage"] == "rendezvous_done"
+    assert "fault injected" in (j["ranks"]["1"]["stderr_tail"] or "")
+    # ... and the watchdog when nothing ends the job at all
+    p, lines = _bench_ranks(2, "1:rendezvous_done:hang,0:rendezvous_done:hang", extra_args=("--stage-timeout", "3"))
+    assert p.returncode != 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "no progress" in lines[0]["error"] and lines[0]["stage"] == "rendezvous_done"
+    # a rank that raises (a Python-level failure: IPC refused, out of memory) leaves its traceback for rank 0's line as well
+    p, lines = _bench_ranks(2, "1:rendezvous_done:raise")
+    assert p.returncode != 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["error"]
+    assert "fault injected at stage rendezvous_done" in (j["ranks"]["1"]["stderr_tail"] or "")
+
+
+def test_bench_launcher_reports_and_retries_when_no_rank_prints(tmp_path):
+    """`python bench.py --gpus 2` as its own launcher: the ranks die before any of them can print (here: no GPU at all, and rank 0 is
+    killed at the device stage) -- the launcher still prints ONE JSON line with n_gpus, "error", the earliest stage, the per-rank
+    records of the first attempt and of the retry on the torch.distributed collectives."""
+    import subprocess
+    env = dict(os.environ)
+    env.update({"RESPMON_BENCH_BACKEND": "gloo", "RESPMON_BENCH_FAULT": "0:device:kill", "OMP_NUM_THREADS": "1"})
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-frames", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    lines = [json.loads(x) for x in p.stdout.splitlines() if x.strip().startswith("{")]
+    assert p.returncode != 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["value"] is None and j["error"]
+    assert j["stage"] in ("device", "rendezvous_done"), j["stage"]
+    assert j["first_attempt"]["ranks"]["0"]["stage"] == "device"
+    assert j["retry_with_torch_distributed_collectives"] is not None
