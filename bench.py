@@ -310,14 +310,38 @@ def cpu_baseline(vid_u8, n_frames, levels, skip, in_dtype, workers):
     return out
 
 
+def library_kernel_stamp():
+    """The stamp of the frame-buffer kernel sources the LOADED library was built from (include/respmon_hip_debug.h)."""
+    from respmon_amd import _capi
+    v = _capi.load().rm_debug_kernel_source_stamp()
+    return v.decode() if isinstance(v, bytes) else str(v)
+
+
+def committed_figure(table, key, lib_stamp, field):
+    """A committed PMC figure (profiles/hbm_traffic.json, profiles/valu_issue.json) is reported only while the library it was
+    measured on is the library that runs: -> (value, stale).  `table[key]` is a dict that carries the figure
+    under `field` and the stamp of its library under "kernel_source_sha"; no entry: (None, False); another library: (None, True)."""
+    e = (table or {}).get(key)
+    if not isinstance(e, dict) or e.get(field) is None:
+        return None, False
+    if e.get("kernel_source_sha") != lib_stamp:
+        return None, True
+    return e[field], False
+
+
 def valu_roofline(dt, T, H, W, kernel_ms):
     """Instruction-issue roofline of the frame-buffer kernel: VALU instructions per input pixel (SQ_INSTS_VALU of a committed PMC
     pass) x ~4.8 cycles per wave64 instruction (bench_micro/valu_rate.hip) over 1024 SIMDs at 2.4 GHz; profiles/valu_issue.json."""
     try:
         v = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
-        ipp = v["valu_instructions_per_pixel"]["%s_%dx%dx%d" % (dt, T, H, W)]
+        key = "%s_%dx%dx%d" % (dt, T, H, W)
+        entries = {k: {"ipp": x, "kernel_source_sha": v.get("kernel_source_sha", {}).get(k)} for k, x in v["valu_instructions_per_pixel"].items()}
+        ipp, stale = committed_figure(entries, key, library_kernel_stamp(), "ipp")
     except Exception:
         return None
+    if ipp is None:
+        return {"bound": "valu_issue", "frac": None, "stale": True, "note": "profiles/valu_issue.json was measured on another build of the "
+                "frame-buffer kernels (kernel_source_sha differs): re-run tools/pmc_narrow.sh"} if stale else None
     bound_ms = T * H * W * ipp / 64.0 * v["cycles_per_wave_instruction"] / (v["simds"] * v["clock_ghz"] * 1e9) * 1e3
     return {"bound": "valu_issue", "valu_instructions_per_pixel": ipp, "issue_bound_ms": bound_ms,
             "frac": bound_ms / kernel_ms if kernel_ms > 0 else None, "source": "profiles/valu_issue.json (committed PMC figures, not measured in this run)"}
@@ -929,13 +953,12 @@ def run(a, rep):
         step_ms = elapsed / a.steps * 1e3
         achieved = b_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         step_achieved = b_alg / (step_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_stale = None, False
+        lib_stamp = library_kernel_stamp()
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                key = "%s_%dx%dx%d" % (a.in_dtype, t_local, H, W)
-                traffic = tj.get(key, {}).get("bytes_per_launch")
+                traffic, traffic_stale = committed_figure(json.load(open(tpath)), "%s_%dx%dx%d" % (a.in_dtype, t_local, H, W), lib_stamp, "bytes_per_launch")
             except Exception:
                 traffic = None
         metric = "Eulerian-calibration frames/sec on 1080p x 256 buffer; achieved HBM GB/s" if (T, H, W) == (256, 1080, 1920) else \
@@ -965,10 +988,13 @@ def run(a, rep):
             # `achieved` / `frac` are the contract figure -- algorithmic bytes over the WHOLE step (all kernels + the host
             # contour stage) against the peak; the frame-buffer kernel alone is `kernel_achieved` / `kernel_frac`
             "roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": step_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": step_achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
+                         "kernel_source_sha": lib_stamp,
                          "kernel_achieved": achieved, "kernel_frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
-                                           if traffic else None,
+                         "traffic_source": ("profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command on a library with the same "
+                                            "kernel_source_sha, committed; not measured in this run)" if traffic else
+                                            ("profiles/hbm_traffic.json holds a figure of ANOTHER build of the frame-buffer kernels: not "
+                                             "reported (tools/profile_round.sh refreshes it)" if traffic_stale else None)),
                          "kernel": "frame-buffer pyrDown kernel (reads [T,H,W] once)", "kernel_ms": k_ms,
                          "algorithmic_bytes": b_alg,
                          # the contract figure of SURVEY 8(d): the WHOLE step (all kernels + host contour stage) against the peak

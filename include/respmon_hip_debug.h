@@ -31,6 +31,11 @@ int rm_debug_set(rm_ctx *ctx, const char *key, long long value);
  * exact raw.min() / raw.max()) */
 int rm_debug_counters(rm_ctx *ctx, long long *out_host, void *stream);
 
+/* first 16 hex digits of the sha256 over the sources of the frame-buffer kernels this library was built from (csrc/Makefile
+ * STAMP_SRCS, concatenated in that order).  The committed PMC figures (profiles/hbm_traffic.json, profiles/valu_issue.json) carry the
+ * stamp of the library they were measured on; bench.py reports them only while the stamps agree. */
+const char *rm_debug_kernel_source_stamp(void);
+
 /* a copy of the first `bytes` bytes of the context's workspace buffer `name` as the last call left it ("tile_lo", "tile_hi": the
  * [unique frame][tile] bounds of the selection; "cS": the collapsed band-passed level) -- tests check the bounds themselves with it */
 int rm_debug_workspace(rm_ctx *ctx, const char *name, void *out_host, size_t bytes, void *stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "rm_profile_read": (_i, [_vp, _vp, _c.POINTER(_i)]),
     "rm_debug_counters": (_i, [_vp, _vp, _vp]),
     "rm_debug_workspace": (_i, [_vp, _c.c_char_p, _vp, _c.c_size_t, _vp]),
+    "rm_debug_kernel_source_stamp": (_c.c_char_p, []),
     "rm_debug_host_timeline": (_i, [_vp, _vp]),
     "rm_debug_roi_path": (_i, [_vp, _vp]),
     "rm_uint8_to_float": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -123,18 +123,22 @@ class _Backend:
         gray = t.empty((H, W), dtype=t.uint8, device=src.device)
         _capi.check(self.lib, self.lib.rm_bgr_to_gray(device.ctx(), device.ptr(src), H * W, device.ptr(gray),
                                                       device.stream_ptr()), "rm_bgr_to_gray")
-        self._last_bgr = (gray, src)     # a 'bgr8' calibration buffer stores the frame as captured (store_frame)
+        self.last_bgr = src     # the frame as captured, on the device: what a 'bgr8' calibration buffer stores (store_frame's `bgr`)
         return gray
 
-    def store_frame(self, buf, idx, gray_u8):
-        """calibration_buffer[idx][:] = uint8_to_float(gray) (base.py:231, 431)."""
+    def store_frame(self, buf, idx, gray_u8, bgr=None):
+        """calibration_buffer[idx][:] = uint8_to_float(gray) (base.py:231, 431).
+        A 'bgr8' buffer ([T,H,W,3] uint8) stores the frame AS CAPTURED: pass the device BGR tensor the gray frame came from as
+        `bgr` (RespiratoryMonitor.step does: the tensor next_frame() kept).  Without it -- a gray frame from another source:
+        replayed, processed, another backend's ingest -- the gray value goes into all three planes, which base.py:230's
+        conversion maps back to exactly that gray value (Y(x, x, x) == x), so the calibration reads the same frame either way."""
         t = self.t
         if buf.dim() == 4:
-            # buffer_dtype 'bgr8': the frame as captured; rm_locate applies base.py:230-231 when it reads the buffer (RM_BGR8)
-            last = getattr(self, "_last_bgr", None)
-            if last is None or last[0] is not gray_u8:
-                raise _capi.RespmonError("a 'bgr8' calibration buffer stores the frame next_frame() returned last")
-            buf[idx].copy_(last[1])
+            # buffer_dtype 'bgr8': rm_locate applies base.py:230-231 when it reads the buffer (RM_BGR8)
+            if bgr is not None:
+                buf[idx].copy_(bgr)
+            else:
+                buf[idx].copy_(gray_u8.unsqueeze(-1).expand(-1, -1, 3))
         elif buf.dtype == t.uint8:
             buf[idx].copy_(gray_u8)
         else:
@@ -263,6 +267,13 @@ class RespiratoryMonitor:
     def __init__(self, capture_target=0, save_calibration_image=False, visualize='pyqtgraph', fig_size=None,
                  fps_limit=10, error_reset_delay=10.0, save_all_data=True,
                  motion_extraction_method='average', buffer_dtype='float64', run_on_init=True, backend=None):
+        """Arguments as reference base.py:24-34, plus (not in the reference):
+        buffer_dtype -- element type of the calibration buffer in HBM: 'float64' (the reference's, base.py:119), 'float32',
+            'float16', 'uint8' (the gray frame as ingested; uint8_to_float happens where the buffer is read) or 'bgr8' (a
+            [T,H,W,3] uint8 buffer of the frames AS CAPTURED: cvtColor + uint8_to_float happen where the buffer is read; next_frame()
+            keeps the device copy of the captured frame for step(), a frame from anywhere else is stored as its gray value in
+            three planes -- the same calibration either way);
+        run_on_init -- False: construct without entering run(); backend -- a stand-in for the device backend (tests)."""
         # argument contract of reference base.py:24-34
         assert isinstance(fps_limit, (int, float)) and fps_limit > 0, "fps_limit must be a positive int or float"
         assert isinstance(save_calibration_image, bool), "save_calibration_image must be bool"
@@ -327,6 +338,7 @@ class RespiratoryMonitor:
         self.peak_indices = []
         self.peak_times = []
         self._frame_u8 = None            # current gray frame, device uint8 [H,W]
+        self._frame_bgr = None           # ... and, for buffer_dtype 'bgr8' only, the captured frame it came from, device uint8 [H,W,3]
         self.cropped_image = None        # (x, y, w, h) view descriptor of the current frame
         self.previous_cropped_image = None
         self.display_frame = None
@@ -385,6 +397,9 @@ class RespiratoryMonitor:
         ret, frame = self.cap.read()
         if ret:
             self._frame_u8 = self._backend.bgr_to_gray(frame)
+            # a 'bgr8' calibration buffer stores the frame as captured: keep the device copy the backend made of it for step()
+            # (only then: nothing else needs it, and it is released with the next frame)
+            self._frame_bgr = getattr(self._backend, "last_bgr", None) if self.buffer_dtype == "bgr8" else None
             self.frames_consumed += 1
             return self._frame_u8
         return False
@@ -615,7 +630,11 @@ class RespiratoryMonitor:
             self.state = 'calibration'
         elif self.state == 'calibration':
             if self.calibration_buffer_idx < self.calibration_buffer_target_length:
-                self._backend.store_frame(self.calibration_buffer, self.calibration_buffer_idx, frame)
+                if self.buffer_dtype == "bgr8":
+                    bgr = self._frame_bgr if frame is getattr(self, "_frame_u8", None) else None   # (a frame step() was handed from elsewhere: its gray value, three planes)
+                    self._backend.store_frame(self.calibration_buffer, self.calibration_buffer_idx, frame, bgr=bgr)
+                else:
+                    self._backend.store_frame(self.calibration_buffer, self.calibration_buffer_idx, frame)
                 self.calibration_buffer_idx += 1
             else:
                 logging.info("Finished capturing calibration frames. Beginning calibration...")

@@ -11,16 +11,18 @@
 // one) keep 27 % / 65 %.  k_dense_sum_t found that out pair by pair, inside its frame loop, at ~145 instructions a visit with a
 // third of the lanes idle and a 2x halo; here the level-1 values of a whole frame are formed ONCE, streaming, with every lane busy:
 //
-//   * a wave owns three tile columns (48 level-2 columns: lanes 0 .. 47; lane 48 = the column to their right, lane 63 = the one to
-//     their left, lane 49 feeds lane 48's right tap) and a band of tile rows, and marches down the level-2 rows the band's
-//     footprints touch: ONE 8-byte load per lane and row (up to four rows in flight), the horizontal neighbours by DPP wave
-//     rotation, the horizontal values of rows i - 1, i, i + 1 in registers, level-1 rows 2 i and 2 i + 1 (two columns each) out of
-//     them -- te_step()'s expressions exactly, so lo / hi are the extrema of the very values the evaluation forms;
-//   * running extrema per lane and column parity; at every eighth level-1 row the three tiles' extrema are folded over their 16 lanes
-//     (+ the edge column of either neighbour) with DPP row shifts and written -- [unique frame][tile], as the other bounds kernels;
-//   * the extrema of the bounds and the lattice samples (rm_kernels.h lattice_sample) go to the striped state as in
-//     k_frame_bounds_rows.
-// No LDS, no barrier, ~45 VGPRs.  C_2 is read once.
+//   * a wave owns three tile columns and a band of tile rows and marches down the level-2 rows the band's footprints touch.  Lane l
+//     stands for level-2 column j = j0 + l (lanes 0 .. 49; lane 63 = j0 - 1) and for the level-1 column PAIR (2 j - 1, 2 j): a tile's
+//     34 footprint columns 32 tx - 1 .. 32 tx + 32 are then exactly the pairs of 17 neighbouring lanes, so ONE running minimum and
+//     maximum per lane serve both columns and both tiles a pair may belong to.  ONE 8-byte load per lane and row (four rows in
+//     flight), the horizontal neighbours by DPP wave rotation, the horizontal values of rows i - 1, i, i + 1 in registers, level-1
+//     rows 2 i and 2 i + 1 out of them -- te_step()'s expressions exactly, so lo / hi are the extrema of the very values the
+//     evaluation forms; v_min_f64 / v_max_f64 (a NaN is dropped, as the comparison folds of the other bounds kernels drop it);
+//   * at every eighth level-1 row the three tiles' extrema are folded over their 17 lanes with DPP row shifts and written --
+//     [unique frame][tile], as the other bounds kernels write them;
+//   * the extrema of the bounds go to the striped state as in k_frame_bounds_rows, and two lattice samples per wave (rm_kernels.h
+//     lattice_sample: true raw values) taken where the wave met its lowest / highest C_2.
+// No LDS, no barrier.  C_2 is read once.
 #pragma once
 
 namespace rm {
@@ -32,9 +34,20 @@ inline bool bounds_l1_ok(const ChainGeom &g)
     return g.S == 2 && g.h[1] >= 2 && g.w[1] >= 2 && g.h[2] >= 2 && g.w[2] >= 2;
 }
 
+// wave rotation of a double: every lane has a source, so there is no old value to keep (no register copy in front of the DPP move)
+template <int CTRL> __device__ __forceinline__ double bl1_rot(double v)
+{
+    const unsigned long long b = bits_of(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    double o;
+    from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo, o);
+    return o;
+}
+
 constexpr int BL1_TILES = 3;                 // tile columns per wave
 constexpr int BL1_COLS = 16 * BL1_TILES;     // level-2 columns they own
-constexpr int BL1_PF = 4;                    // level-2 rows in flight per lane
+constexpr int BL1_PF = 4;                    // level-2 rows in flight per lane (= rows per tile row: the ring is indexed statically)
 
 RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi, CollapseState *st,
                                                          int *sel_cnt, int nchunks, int nbands, int trb)
@@ -52,116 +65,143 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainG
     // lane -> level-2 column: 0 .. 49 -> j0 + lane, 63 -> j0 - 1 (the others load nothing anyone reads)
     const int jv = lane == 63 ? j0 - 1 : j0 + lane;
     const int ja = min(max(jv, 0), w2 - 1);
-    const bool own = lane < BL1_COLS;
-    // this lane's two level-1 columns 2 jv (even) and 2 jv + 1 (odd): inside the image?
-    const bool in2 = jv >= 0 && jv <= w2 - 1;
-    const bool ok_e = in2 && (own || lane == BL1_COLS), ok_o = in2 && 2 * jv + 1 < w1 && (own || lane == 63);
-    // make_htap()'s shapes with the three neighbours as operands (rm_dense_sum.h k_dense_sum_w): even column (L wa + C wb) + R wc,
-    // odd column C 4 + R 4 with R := C at the right edge
+    // this lane's level-1 column pair: 2 jv (even: taps jv - 1, jv, jv + 1) and 2 jv - 1 (odd: taps jv - 1, jv).  Lanes 0 .. 48 count.
+    const bool ok_e = lane <= BL1_COLS && jv <= w2 - 1;
+    const bool ok_o = lane <= BL1_COLS && jv >= 1 && 2 * jv - 1 <= w1 - 1;   // (jv == w2 when w1 is even: the last column, 8 s[w2 - 1] -- the clamped load)
+    const bool ok_any = ok_e || ok_o;
+    const bool edge = uniform((int)(__ballot(lane <= BL1_COLS && ok_e != ok_o) != 0ull)) != 0;   // (uniform) a lane of this wave owns only one column of its pair
+    // make_htap()'s shapes with the three neighbours as operands (rm_dense_sum.h k_dense_sum_w): (L wa + C wb) + R wc; the clamped
+    // loads supply C for the missing neighbour where its weight is not zero anyway
     const bool left = jv <= 0, right = jv >= w2 - 1;
     const double wa = left ? 0.0 : 1.0, wb = right ? 7.0 : 6.0, wc = left ? 2.0 : (right ? 0.0 : 1.0);
     const double *p = cS + (size_t)u * h2 * w2 + ja;
-    // level-1 rows whose extrema this wave needs, and the level-2 rows they are formed from
-    const int r_lo = max(8 * ty_first - 1, 0), r_hi = min(8 * ty_last + 8, h1 - 1);
-    const int i_lo = r_lo >> 1, i_hi = r_hi >> 1;
-    const int ia = max(i_lo - 1, 0), ib = min(i_hi + 1, h2 - 1);
-    double q[BL1_PF];
-    int inext = ia;
-#pragma unroll
-    for (int k = 0; k < BL1_PF; ++k) q[k] = p[(size_t)min(ia + k, ib) * w2];
-    // where this lane met its lowest / highest C_2 (rows only; the column is the lane's): the lattice samples are taken there
+    auto row_ptr = [&](int i) __attribute__((always_inline)) { return p + (size_t)min(max(i, 0), h2 - 1) * w2; };
+    // extrema of C_2 this lane met (the rows are looked up once, at the end: lattice samples)
     double t_mn = inf, t_mx = -inf;
-    int p_mn = -1, p_mx = -1;
-    auto next_h = [&](double &he, double &ho) __attribute__((always_inline)) {
-        const double s = q[0];
-#pragma unroll
-        for (int k = 0; k + 1 < BL1_PF; ++k) q[k] = q[k + 1];
-        q[BL1_PF - 1] = p[(size_t)min(inext + BL1_PF, ib) * w2];
-        const double L = dpp_get<0x13C, 0xF>(s);      // wave_ror:1 -- the value of lane - 1 (lane 0: lane 63 = column j0 - 1)
-        const double R0 = dpp_get<0x134, 0xF>(s);     // wave_rol:1 -- the value of lane + 1
-        const double R = right ? s : R0;
-        he = dw_tap3(L, s, R, wa, wb, wc);
-        ho = __builtin_fma(R, 4.0, s * 4.0);           // both products exact
-        if (own && in2) {
-            if (s < t_mn) { t_mn = s; p_mn = inext; }
-            if (s > t_mx) { t_mx = s; p_mx = inext; }
-        }
-        ++inext;
-    };
-    double hp_e = 0.0, hp_o = 0.0, hc_e, hc_o, hn_e, hn_o;
-    if (i_lo > 0) next_h(hp_e, hp_o);
-    next_h(hc_e, hc_o);
-    // running extrema of the tile row being collected, per column parity; the last level-1 row seen (row 8 ty - 1 opens tile row ty)
-    double amn_e = inf, amx_e = -inf, amn_o = inf, amx_o = -inf;
-    double last_e = 0.0, last_o = 0.0;
-    int cur_ty = ty_first;
     // extrema over the pairs this wave writes (lanes 15, 31, 47 only)
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
-    const bool writer = own && (lane & 15) == 15 && BL1_TILES * c + (lane >> 4) < ntx;
-    auto finalize = [&](int ty) __attribute__((always_inline)) {
-        double mn = inf, mx = -inf;
-        if (own && ok_e) { mn = amn_e; mx = amx_e; }
-        if (own && ok_o) { mn = (amn_o < mn) ? amn_o : mn; mx = (amx_o > mx) ? amx_o : mx; }
-        // the even column of the lane to the right closes a tile's footprint, the odd column of the lane to the left opens it
-        const double r_mn = dpp_get<0x134, 0xF>(ok_e ? amn_e : inf), r_mx = dpp_get<0x134, 0xF>(ok_e ? amx_e : -inf);
-        const double l_mn = dpp_get<0x13C, 0xF>(ok_o ? amn_o : inf), l_mx = dpp_get<0x13C, 0xF>(ok_o ? amx_o : -inf);
-        if (own && (lane & 15) == 15) { mn = (r_mn < mn) ? r_mn : mn; mx = (r_mx > mx) ? r_mx : mx; }
-        if (own && (lane & 15) == 0) { mn = (l_mn < mn) ? l_mn : mn; mx = (l_mx > mx) ? l_mx : mx; }
-        // fold each 16-lane row into its last lane (a lane without a source keeps its own value)
+    // (EDGE: a lane of this wave owns only one column of its pair -- the image's left / right edge; the other waves run without the selects)
+    const int i_first = 4 * ty_first;
+    auto march = [&](auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        // horizontal values of one level-2 row at this lane's column pair
+        auto hvals = [&](double s, double &he, double &ho) __attribute__((always_inline)) {
+            const double L = bl1_rot<0x13C>(s);           // wave_ror:1 -- the value of lane - 1 (lane 0: lane 63 = column j0 - 1)
+            const double R = bl1_rot<0x134>(s);           // wave_rol:1 -- the value of lane + 1
+            he = dw_tap3(L, s, R, wa, wb, wc);
+            ho = __builtin_fma(s, 4.0, L * 4.0);           // both products exact
+            if (EDGE) { ho = ok_o ? ho : he; he = ok_e ? he : ho; }   // (a pair with one column: that column twice)
+            t_mn = f64_min(t_mn, s); t_mx = f64_max(t_mx, s);
+        };
+        // running extrema of the tile row being collected; the level-1 row in front of it (row 8 ty - 1 opens tile row ty)
+        double amn = inf, amx = -inf, last_mn = inf, last_mx = -inf;
+        auto take = [&](double ve, double vo) __attribute__((always_inline)) {
+            amn = f64_min(amn, f64_min(ve, vo)); amx = f64_max(amx, f64_max(ve, vo));
+        };
+        const bool writer = lane < BL1_COLS && (lane & 15) == 15 && BL1_TILES * c + (lane >> 4) < ntx;
+        auto finalize = [&](int ty) __attribute__((always_inline)) {
+            double mn = ok_any ? amn : inf, mx = ok_any ? amx : -inf;
+            // the pair of the lane to the right closes a tile's footprint (and opens the next tile's)
+            const double r_mn = bl1_rot<0x134>(mn), r_mx = bl1_rot<0x134>(mx);
+            if ((lane & 15) == 15) { mn = f64_min(mn, r_mn); mx = f64_max(mx, r_mx); }
+            // fold each 16-lane row into its last lane (a lane without a source keeps its own value)
 #define RM_BL1_FOLD(CTRL)                                                             \
-        {                                                                            \
-            const double a_ = dpp_get<CTRL, 0xF>(mn), b_ = dpp_get<CTRL, 0xF>(mx);   \
-            mn = (a_ < mn) ? a_ : mn; mx = (b_ > mx) ? b_ : mx;                      \
-        }
-        RM_BL1_FOLD(0x111) RM_BL1_FOLD(0x112) RM_BL1_FOLD(0x114) RM_BL1_FOLD(0x118)
+            {                                                                            \
+                const double a_ = dpp_get<CTRL, 0xF>(mn), b_ = dpp_get<CTRL, 0xF>(mx);   \
+                mn = f64_min(mn, a_); mx = f64_max(mx, b_);                \
+            }
+            RM_BL1_FOLD(0x111) RM_BL1_FOLD(0x112) RM_BL1_FOLD(0x114) RM_BL1_FOLD(0x118)
 #undef RM_BL1_FOLD
-        if (writer) {
-            const size_t o = (size_t)u * ntiles + (size_t)ty * ntx + BL1_TILES * c + (lane >> 4);
-            lo[o] = mn; hi[o] = mx;
-            lo_mn = (mn < lo_mn) ? mn : lo_mn; lo_mx = (mn > lo_mx) ? mn : lo_mx;
-            hi_mn = (mx < hi_mn) ? mx : hi_mn; hi_mx = (mx > hi_mx) ? mx : hi_mx;
+            if (writer) {
+                const size_t o = (size_t)u * ntiles + (size_t)ty * ntx + BL1_TILES * c + (lane >> 4);
+                lo[o] = mn; hi[o] = mx;
+                lo_mn = f64_min(lo_mn, mn); lo_mx = f64_max(lo_mx, mn);
+                hi_mn = f64_min(hi_mn, mx); hi_mx = f64_max(hi_mx, mx);
+            }
+        };
+        // ---- prologue: horizontal values of rows 4 ty_first - 1 (hp) and 4 ty_first (hc); the four rows behind them requested
+        double hp_e, hp_o, hc_e, hc_o;
+        double q[BL1_PF];
+        {
+            const double s_p = *row_ptr(i_first - 1), s_c = *row_ptr(i_first);
+#pragma unroll
+            for (int k = 0; k < BL1_PF; ++k) q[k] = *row_ptr(i_first + 1 + k);
+            hvals(s_p, hp_e, hp_o);
+            hvals(s_c, hc_e, hc_o);
         }
-    };
-    // level-1 row r (values ve / vo of this lane's two columns); returns false once the band's last tile row is written
-    auto emit = [&](int r, double ve, double vo) __attribute__((always_inline)) -> bool {
-        amn_e = (ve < amn_e) ? ve : amn_e; amx_e = (ve > amx_e) ? ve : amx_e;
-        amn_o = (vo < amn_o) ? vo : amn_o; amx_o = (vo > amx_o) ? vo : amx_o;
-        if ((r >> 3) > cur_ty) {   // (uniform) r = 8 (cur_ty + 1): the row below tile row cur_ty -- its footprint is complete
-            finalize(cur_ty);
-            ++cur_ty;
-            if (cur_ty > ty_last) return false;
-            // tile row cur_ty opens with rows r - 1 and r
-            amn_e = (last_e < ve) ? last_e : ve; amx_e = (last_e > ve) ? last_e : ve;
-            amn_o = (last_o < vo) ? last_o : vo; amx_o = (last_o > vo) ? last_o : vo;
+        bool have_last = false;
+        if (ty_first > 0) {   // level-1 row 8 ty_first - 1 (odd row of level-2 row i_first - 1)
+            const double ve = (hp_e + hc_e) * (1.0 / 16), vo = (hp_o + hc_o) * (1.0 / 16);
+            last_mn = f64_min(ve, vo); last_mx = f64_max(ve, vo);
+            have_last = true;
         }
-        last_e = ve; last_o = vo;
-        return true;
+        // ---- tile rows: level-2 rows i = 4 ty + k give level-1 rows 8 ty + 2 k (even) and 8 ty + 2 k + 1 (odd).  FAST: a tile row
+        // inside the band and the image -- every row exists, tile row ty - 1 is waiting for its last footprint row: straight-line code
+        auto tile_row = [&](int ty, auto fast_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+            for (int k = 0; k < BL1_PF; ++k) {
+                const int i = 4 * ty + k;                       // (uniform)
+                if (!FAST && i > h2 - 1) break;                 // the image ends
+                if (!FAST && ty > ty_last && k > 0) break;      // (below the band only level-1 row 8 (ty_last + 1) counts)
+                double hn_e = hc_e, hn_o = hc_o;                // bottom: the last row again (up_at()'s r2)
+                if (FAST || i < h2 - 1) hvals(q[k], hn_e, hn_o);
+                q[k] = *row_ptr(i + 1 + BL1_PF);
+                if (!FAST && i == 0) { hp_e = hn_e; hp_o = hn_o; }   // top: row -1 := row 1
+                {   // level-1 row 2 i
+                    const double ve = (hp_e + hc_e * 6 + hn_e) * (1.0 / 64), vo = (hp_o + hc_o * 6 + hn_o) * (1.0 / 64);
+                    if (k == 0) {
+                        // row 8 ty: the row below tile row ty - 1 -- its footprint is complete --, and the second row of tile row ty's
+                        if (FAST || ty > ty_first) { take(ve, vo); finalize(ty - 1); }
+                        amn = f64_min(ve, vo); amx = f64_max(ve, vo);
+                        if (FAST || have_last) { amn = f64_min(amn, last_mn); amx = f64_max(amx, last_mx); }
+                    } else take(ve, vo);
+                }
+                if (FAST || (ty <= ty_last && 2 * i + 1 <= h1 - 1)) {   // level-1 row 2 i + 1
+                    const double ve = (hc_e + hn_e) * (1.0 / 16), vo = (hc_o + hn_o) * (1.0 / 16);
+                    take(ve, vo);
+                    if (k == BL1_PF - 1) { last_mn = f64_min(ve, vo); last_mx = f64_max(ve, vo); have_last = true; }
+                }
+                hp_e = hc_e; hp_o = hc_o; hc_e = hn_e; hc_o = hn_o;
+            }
+        };
+        for (int ty = ty_first; ty <= ty_last + 1; ++ty) {
+            if (ty > ty_first && ty <= ty_last && 4 * ty + 4 <= h2 - 1) tile_row(ty, std::true_type{});
+            else tile_row(ty, std::false_type{});
+            if (4 * ty > h2 - 1) break;
+        }
+        // the image ended inside the last tile row's footprint (no level-1 row 8 (ty_last + 1)): that tile row is still open
+        if (8 * (ty_last + 1) > h1 - 1) finalize(ty_last);
     };
-    bool open = true;
-    for (int i = i_lo; i <= i_hi && open; ++i) {
-        if (i < h2 - 1) next_h(hn_e, hn_o); else { hn_e = hc_e; hn_o = hc_o; }   // (uniform) bottom: the last row again (up_at()'s r2)
-        if (i == 0) { hp_e = hn_e; hp_o = hn_o; }                                // (uniform) top: row -1 := row 1
-        if (2 * i >= r_lo) open = emit(2 * i, (hp_e + hc_e * 6 + hn_e) * (1.0 / 64), (hp_o + hc_o * 6 + hn_o) * (1.0 / 64));
-        if (open && 2 * i + 1 <= r_hi) open = emit(2 * i + 1, (hc_e + hn_e) * (1.0 / 16), (hc_o + hn_o) * (1.0 / 16));
-        hp_e = hc_e; hp_o = hc_o; hc_e = hn_e; hc_o = hn_o;
-    }
-    if (open && cur_ty <= ty_last) finalize(cur_ty);   // the image ends inside the last tile row's footprint
-    // lattice samples (true raw values) at the interior pixels nearest to where this lane met its extreme C_2
+    if (edge) march(std::true_type{}); else march(std::false_type{});
+    // lattice samples (true raw values) where this wave met its lowest / highest C_2: the lane that holds the extreme value, then
+    // the row of it in that lane's column (every lane looks at one row)
     double sm_mn = inf, sm_mx = -inf;
-    if (own && in2 && h2 >= 3 && w2 >= 3) {
+    if (h2 >= 3 && w2 >= 3) {
+        const bool cnt = lane < BL1_COLS && jv <= w2 - 1;
+        const double w_mn = wave_min(cnt ? t_mn : inf), w_mx = wave_max(cnt ? t_mx : -inf);
         const double *f = cS + (size_t)u * h2 * w2;
-        const int cand[2] = {p_mn, p_mx};
+        const int ia = max(i_first - 1, 0), ib = min(4 * ty_last + 5, h2 - 1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (cand[k] < 0) continue;
-            const int y = min(max(cand[k], 1), h2 - 2), x = min(max(jv, 1), w2 - 2);
-            const double *r1 = f + (size_t)y * w2;
-            const double v = lattice_sample(r1 - w2, r1, r1 + w2, x, g.lat_a, g.lat_b);
-            sm_mn = (v < sm_mn) ? v : sm_mn; sm_mx = (v > sm_mx) ? v : sm_mx;
+            const double target = k ? w_mx : w_mn;
+            const unsigned long long who = __ballot(cnt && (k ? t_mx : t_mn) == target);
+            if (who == 0ull) continue;                                        // (uniform; a NaN extreme)
+            const int x = j0 + (int)__builtin_ctzll(who);
+            int y = -1;
+            for (int r0 = ia; r0 <= ib && y < 0; r0 += 64) {
+                const int r = r0 + lane;
+                const unsigned long long hit = __ballot(r <= ib && f[(size_t)min(r, ib) * w2 + x] == target);
+                if (hit) y = r0 + (int)__builtin_ctzll(hit);
+            }
+            if (y < 0) continue;
+            const int ys = min(max(y, 1), h2 - 2), xs = min(max(x, 1), w2 - 2);
+            const double *r1 = f + (size_t)ys * w2;
+            const double v = lattice_sample(r1 - w2, r1, r1 + w2, xs, g.lat_a, g.lat_b);
+            sm_mn = f64_min(sm_mn, v); sm_mx = f64_max(sm_mx, v);
         }
     }
     lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
-    sm_mn = wave_min(sm_mn); sm_mx = wave_max(sm_mx);
     if (lane == 0 && lo_mn <= lo_mx) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (u + wid * 7) & (NSTRIPE - 1);

@@ -131,6 +131,8 @@ int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, dou
     ctx->dbg_pairs = npairs; ctx->dbg_cap = cap; ctx->dbg_mine = npairs_mine; ctx->dbg_mode = sp.mode; ctx->dbg_auto_dense = sp.auto_dense_ok;
     RM_TRY(ws(ctx, "sel_cnt", (size_t)ntiles, &cp.sel_cnt));
     RM_TRY(ws(ctx, "heavy_tiles", (size_t)ntiles, &cp.heavy));
+    cp.xs_tab = nullptr;
+    if (ctx->dbg.xs && tile_eval_ok(g) && !cp.fused) RM_TRY(ws(ctx, "xs_tab", (size_t)npairs, &cp.xs_tab));   // exception store (rm_xstore.h): one entry per pair
     if (!sl.bounds_ready) {
         // per-frame separable form, in bands of tile rows whose row-extrema table fits 64 KB of LDS; the per-pair kernel
         // remains for geometries where even one tile row does not fit
@@ -158,11 +160,13 @@ int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, dou
         while (band > 4 && (long long)Th * ((g.tiles_y + band - 1) / band) < 1024) band = (band + 1) / 2;
         const int tbl_rows = tbl_rows_of(band);
         const size_t tbl = (size_t)tbl_rows * row_bytes;
+        cp.l1_bounds = false;
         if (ctx->dbg.bounds_l1 && bounds_l1_ok(g) && ntiles < (1 << 24)) {
+            cp.l1_bounds = true;
             // skip 2: the extrema of the LEVEL-1 footprints, streaming (rm_bounds_l1.h) -- a wave per three tile columns and band of tile rows
             const int nchunks = (g.tiles_x + BL1_TILES - 1) / BL1_TILES;
-            int trb = 16;
-            while (trb > 4 && (long long)Th * nchunks * ((g.tiles_y + trb - 1) / trb) < 6144) trb >>= 1;   // (small frames: more, shorter waves)
+            int trb = 32;   // (4K x 512: 543 / 375 / 340 us with 8 / 16 / 32 tile rows per wave -- three halo rows per band, and fewer, longer waves)
+            while (trb > 8 && (long long)Th * nchunks * ((g.tiles_y + trb - 1) / trb) < 1024) trb >>= 1;   // (small frames: 720p x 128 65 / 52 / 38 / 33 us with 2 / 4 / 8 / 16)
             if (ctx->dbg.bounds_l1_rows > 0) trb = ctx->dbg.bounds_l1_rows;
             const int nbands = (g.tiles_y + trb - 1) / trb;
             hipLaunchKernelGGL(k_frame_bounds_l1<>, dim3(Th, (unsigned)((nchunks * nbands + 3) / 4)), dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt,
@@ -179,7 +183,7 @@ int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, dou
     }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_select_pairs<>, dim3((ntiles + SEL_TILES - 1) / SEL_TILES, (Th + SEL_PH * SEL_U - 1) / (SEL_PH * SEL_U)), dim3(256), 0, s,
-                       cp.lo, cp.hi, ntiles, Th, T, t0, t1, st, cp.list_a, cp.list_b, cp.slot_of, prune_ok ? 0 : 1, thr, cp.sel_cnt, cp.heavy);
+                       cp.lo, cp.hi, ntiles, Th, T, t0, t1, st, cp.list_a, cp.list_b, cp.slot_of, prune_ok ? 0 : 1, thr, cp.sel_cnt, cp.heavy, cp.xs_tab);
     LAUNCH_CHECK();
     if (cp.fused) {
         // exact extrema from the C pairs: one wave per pair, a grid that covers the few pairs of a pruned selection at once and loops

@@ -51,19 +51,71 @@ int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_s
         LAUNCH_CHECK();
         return RM_OK;
     };
-    auto launch_dense_t = [&](int only_if_dense) -> int {
+    auto launch_dense_t = [&](int only_if_dense, int xs_standin = 0) -> int {
         // one wave per tile, frame after frame (rm_tile_eval.h k_dense_sum_t)
 #define RM_DENSE_T(SS)                                                                                                                   \
         do {                                                                                                                             \
             using FootD = TileFoot<SS, false>;                                                                                           \
-            hipLaunchKernelGGL((k_dense_sum_t<SS>), dim3(dense_tile_grid(cp.ntiles)), dim3(64), sizeof(double) * (FootD::TOTAL + DST_MAXW), s, cp.cS, cp.g, cp.t0, \
-                               cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr, heat_sum, avg_T, tile_nkept, cp.sp, only_if_dense, unserved_dev, (ctx->dbg.dense_exact_top && !cp.no_prune) ? cp.lo : nullptr); \
+            hipLaunchKernelGGL((k_dense_sum_t<SS>), dim3(dense_tile_grid(cp.ntiles)), dim3(64), sizeof(double) * (FootD::TOTAL + DST_MAXW) + sizeof(unsigned short) * (size_t)((cp.T + 3) & ~3), s, cp.cS, cp.g, cp.t0, \
+                               cp.t1, cp.T, cp.ntiles, cp.slot_of, st, thr, heat_sum, avg_T, tile_nkept, cp.sp, only_if_dense, unserved_dev, (ctx->dbg.dense_exact_top && !cp.no_prune) ? cp.lo : nullptr, xs_standin, (cp.l1_bounds && ctx->dbg.dense_exact_top && !cp.no_prune) ? 0 : 1); \
         } while (0)
         switch (cp.S) { case 1: RM_DENSE_T(1); break; case 2: RM_DENSE_T(2); break; case 3: RM_DENSE_T(3); break; default: RM_DENSE_T(4); break; }
 #undef RM_DENSE_T
         LAUNCH_CHECK();
         return RM_OK;
     };
+    // The exception store (rm_xstore.h): every kept pair evaluated ONCE by a flat pass, its values below `top` parked in a compact
+    // record, the time-ordered additions by a kernel that reads records only.  Takes the place of the store-less kernels wherever
+    // TileEval applies; k_dense_sum_t stays behind it as the stand-in for a selection whose exceptions do not fit the store.
+    auto launch_xs = [&](int only_if_dense) -> int {
+        const int Th = sym_frames(cp.T);
+        int cus = 256;
+#ifndef RM_HIPEMU
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+#endif
+        // evaluation grid: single-wave workgroups, each a strided sample of the lists (at least ~8 listed pairs per wave)
+#ifndef RM_HIPEMU
+        const unsigned egrid = (unsigned)std::max<long long>(1, std::min<long long>((cp.npairs + 7) / 8, 32ll * cus));
+#else
+        const unsigned egrid = (unsigned)std::max(1, std::min(cp.npairs, 24));   // (host emulation: few, looping workgroups compute the same thing)
+#endif
+        // capacity: the worst case of the geometry (every value of every pair an exception) when that is small, 1 GiB otherwise; plus
+        // the chunk every wave may leave unfinished
+        const unsigned long long worst = (unsigned long long)cp.sp.npairs_mine * (XS_HDR + CT_H * CT_W);
+        unsigned long long budget = ctx->dbg.xs_budget_words > 0 ? (unsigned long long)ctx->dbg.xs_budget_words : (1ull << 27);
+        const bool never_overflows = ctx->dbg.xs_budget_words <= 0 && worst <= budget;
+        XsPlan xp;
+        // (+ a third: a chunk is abandoned with at most a quarter of it unused; + every wave's first chunk)
+        xp.cap_words = std::min(worst, budget) + std::min(worst, budget) / 3 + (unsigned long long)(egrid + 1) * XS_CHUNK;
+        if (ctx->dbg.xs_budget_words > 0) xp.cap_words = budget;
+        if (xp.cap_words > 0xfffffff0ull) xp.cap_words = 0xfffffff0ull;   // (record offsets are 32-bit words)
+        RM_TRY(ws(ctx, "xs_store", (size_t)xp.cap_words + 64, &xp.store));   // (+ 64: k_xs_sum reads 64 words from the start of a record)
+        xp.tab = reinterpret_cast<XsEntry *>(cp.xs_tab);
+        const double *lo = (ctx->dbg.dense_exact_top && !cp.no_prune) ? cp.lo : nullptr;
+#define RM_XS_EVAL(SS)                                                                                                                   \
+        do {                                                                                                                             \
+            using FootX = TileFoot<SS, false>;                                                                                           \
+            hipLaunchKernelGGL((k_xs_eval<SS>), dim3(egrid), dim3(64), sizeof(double) * FootX::TOTAL, s, cp.cS, cp.g, cp.ntiles, cp.list_a, cp.list_b, \
+                               cp.slot_of, lo, st, thr, cp.sp, Th, xp, only_if_dense);                                                  \
+        } while (0)
+        switch (cp.S) { case 1: RM_XS_EVAL(1); break; case 2: RM_XS_EVAL(2); break; case 3: RM_XS_EVAL(3); break; default: RM_XS_EVAL(4); break; }
+#undef RM_XS_EVAL
+        LAUNCH_CHECK();
+        // the additions: one wave per tile where tiles are plenty, 2 / 4 waves per tile (each its share of the running sums) where a
+        // lone wave per SIMD would be bound by the latency of its own chain
+        int nw = cp.ntiles >= 4 * cus ? 1 : (cp.ntiles >= 2 * cus ? 2 : 4);
+        if (ctx->dbg.xs_waves == 1 || ctx->dbg.xs_waves == 2 || ctx->dbg.xs_waves == 4) nw = ctx->dbg.xs_waves;
+        const size_t shx = 3 * sizeof(int) * (size_t)Th;
+#define RM_XS_SUM(NN)                                                                                                                    \
+        hipLaunchKernelGGL((k_xs_sum<NN>), dim3(dense_tile_grid(cp.ntiles)), dim3(64 * NN), shx, s, cp.g, cp.t0, cp.t1, cp.T, cp.ntiles, st, thr, heat_sum, \
+                           avg_T, tile_nkept, cp.sp, xp, only_if_dense, unserved_dev)
+        if (nw == 1) RM_XS_SUM(1); else if (nw == 2) RM_XS_SUM(2); else RM_XS_SUM(4);
+#undef RM_XS_SUM
+        LAUNCH_CHECK();
+        if (!never_overflows) RM_TRY(launch_dense_t(only_if_dense, 1));
+        return RM_OK;
+    };
+    const bool xs_ok = ctx->dbg.xs != 0 && cp.xs_tab != nullptr && tile_eval_ok(cp.g) && !ctx->dbg.dense_rows && !ctx->dbg.dense_general;
     if (cp.fused) {
         if (ctx->dbg.dense_tiles) RM_TRY(launch_dense_t(0)); else
         RM_TRY(launch_tile_sum(0));
@@ -121,7 +173,9 @@ int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_s
     // skip <= 2 on large frames (four waves' worth of tiles per SIMD): the TileEval kernel of the deeper chains is the faster one-wave-per-
     // tile form there too (4K x 512 skip 2: 2.26 -> 2.18 ms); smaller frames keep the several-waves-per-tile forms below
     const bool t_low = ctx->dbg.dense_t_low >= 0 ? ctx->dbg.dense_t_low != 0 : (cp.S == 2 && cp.ntiles >= 4096 && tile_eval_ok(cp.g));
-    if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !t_low && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
+    if (may_dense && xs_ok) {
+        RM_TRY(launch_xs(sp.mode == 1 ? 0 : 1));
+    } else if (may_dense && cp.S <= 2 && ctx->dbg.dense_wave && !t_low && !ctx->dbg.dense_rows && !ctx->dbg.dense_general && dense_wave_ok(cp.g)) {
         // one wave per 64 x 16 tile, no barriers (rm_dense_sum.h k_dense_sum_w)
         const ChainGeom &g = cp.g;
         int cus = 256;
@@ -135,11 +189,14 @@ int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_s
         int split = cp.ntiles < 4 * cus ? 4 : 1;
         if (ctx->dbg.dense_split == 1 || ctx->dbg.dense_split == 2 || ctx->dbg.dense_split == 4) split = ctx->dbg.dense_split;
         if (split > 1) {
+            // (the kept frames only: what the selection kept and the exact top does not clear -- dense_wf_list 0: every frame, as before round 6)
+            const int *wf_slot = (ctx->dbg.dense_wf_list && !cp.no_prune) ? cp.slot_of : nullptr;
+            const double *wf_lo = (wf_slot && ctx->dbg.dense_exact_top) ? cp.lo : nullptr;
 #define RM_DENSE_WF(SS, NN)                                                                                                               \
             do {                                                                                                                          \
-                const size_t shf = sizeof(double) * (size_t)NN * 16 * 64;                                                                 \
+                const size_t shf = sizeof(double) * (size_t)NN * 16 * 64 + sizeof(unsigned short) * (size_t)((cp.T + 3) & ~3);           \
                 hipLaunchKernelGGL((k_dense_sum_wf<SS, NN>), dim3(dense_tile_grid(cp.ntiles)), dim3(64 * NN), shf, s, cp.cS, g, cp.t0, cp.t1, cp.T, st, thr,  \
-                                   heat_sum, avg_T, tile_nkept, sp);                                                                      \
+                                   heat_sum, avg_T, tile_nkept, sp, wf_slot, wf_lo);                                                      \
             } while (0)
             if (cp.S == 2) { if (split == 4) RM_DENSE_WF(2, 4); else RM_DENSE_WF(2, 2); }
             else { if (split == 4) RM_DENSE_WF(1, 4); else RM_DENSE_WF(1, 2); }

@@ -113,6 +113,10 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
     else if (k == "bounds_scalar") d.bounds_scalar = (int)value;
     else if (k == "bounds_l1") d.bounds_l1 = (int)value;
+    else if (k == "dense_wf_list") d.dense_wf_list = (int)value;
+    else if (k == "xs") d.xs = (int)value;
+    else if (k == "xs_waves") d.xs_waves = (int)value;
+    else if (k == "xs_budget_words") d.xs_budget_words = value;
     else if (k == "bounds_l1_rows") d.bounds_l1_rows = (int)value;
     else if (k == "dense_rows") d.dense_rows = (int)value;
     else if (k == "dense_general") d.dense_general = (int)value;
@@ -192,6 +196,11 @@ extern "C" int rm_debug_counters(rm_ctx *ctx, long long *out, void *stream)
     if (ctx->dbg_fused) { out[1] = (long long)h.n_list_a; out[3] = -1; }   // store-less path: C pairs evaluated for the extrema; the kept pairs where they are summed
     return RM_OK;
 }
+
+#ifndef RM_FRAME_KERNEL_SRC_SHA
+#include "build/rm_stamp.h"   // written by the Makefile: first 16 hex digits of the sha256 over the frame-buffer kernel sources
+#endif
+extern "C" const char *rm_debug_kernel_source_stamp(void) { return RM_FRAME_KERNEL_SRC_SHA; }
 
 extern "C" int rm_debug_workspace(rm_ctx *ctx, const char *name, void *out_host, size_t bytes, void *stream)
 {

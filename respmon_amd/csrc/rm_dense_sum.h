@@ -670,9 +670,19 @@ __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom 
 // t0 + r NW + w (the whole pyrUp chain of the tile, as in k_dense_sum_w) and parks its 16 masked values per lane in LDS; after a
 // barrier wave w adds the NW frames, in frame order, to ITS 16 / NW running sums per lane.  Same values, same order of additions:
 // bit-identical to k_dense_sum_w.
+// Round 6: the rounds walk the tile's KEPT frames only.  With the level-1 bounds of rm_bounds_l1.h the second look with the exact
+// `top` (slot_of / lo given) drops a third of the pairs of the 720p stream -- and a round of NW kept frames is as balanced as a round of
+// NW consecutive ones (round 5 tried the same with the level-2 bounds, which drop nothing: 115 against 107 us).  The frames in between
+// add `min`, in order, in front of the next kept frame.  slot_of == nullptr: every frame is kept (the exhaustive form).
+__device__ __forceinline__ double masked_gap_small(double acc, int n, double min_val)   // n sequential additions of `min`
+{
+    for (; n > 0; --n) acc = acc + min_val;
+    return acc;
+}
+
 template <int S, int NW>
 __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, ChainGeom g, int t_first, int t_end, int T, CollapseState *st, double threshold,
-                                                          double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp)
+                                                          double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp, const int *slot_of, const double *lo)
 {
     using G = DenseW<S>;
     constexpr int R1 = G::R1, P1 = G::P1, R2 = G::R2, P2 = G::P2, PF = G::PF, PD = G::PD;
@@ -685,6 +695,8 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
     static_assert(G::TOTAL <= 16 * 64, "the footprint slice must fit the wave's part of the exchange");
     double *ex = lds;
     double *sl = lds + (size_t)wave * 16 * 64;
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(lds + (size_t)NW * 16 * 64);   // the tile's kept frames of [t_first, t_end) in time order
+    __shared__ int s_wcnt[NW];
     // workgroups are dealt to the 8 XCDs round robin (each with its own L2): XCD x takes the x-th EIGHTH of the tiles, so that the
     // tiles a CU's neighbours work on -- whose footprints overlap this one's -- are cached in the same L2
     const int ntiles_ = g.tiles_x * g.tiles_y;
@@ -698,6 +710,31 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
     const int yv1 = 8 * ty - 1, xv1 = 32 * tx - 1;
     const int hS = g.h[S], wS = g.w[S];
     const size_t fs = (size_t)hS * wS;
+    // the kept frames: what the selection kept and the exact top does not clear (a pair whose lower bound clears it adds `min` to
+    // every pixel, evaluated or not)
+    int nlist = 0;
+    {
+        const int Th = sym_frames(T);
+        const double margin = st->margin;
+        for (int c0 = t_first; c0 < t_end; c0 += 64 * NW) {
+            const int t = c0 + (int)threadIdx.x;
+            bool kept = t < t_end;
+            if (kept && slot_of) {
+                const int u = sym_frame(t, T);
+                kept = slot_of[slot_index(u, tile, Th)] != SLOT_PRUNED;
+                if (kept && lo) kept = !(lo[(size_t)u * ntiles_ + tile] - margin >= top);   // (a NaN bound keeps the pair: NaN must reach the sum)
+            }
+            const unsigned long long mk = __ballot(kept);
+            if (lane == 0) s_wcnt[wave] = __popcll(mk);
+            __syncthreads();
+            int off = nlist, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const int c = s_wcnt[w]; off += (w < wave) ? c : 0; tot += c; }
+            if (kept) s_list[off + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)t;
+            nlist += tot;
+            __syncthreads();
+        }
+    }
     int off_g[PF], off_l[PF];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -737,21 +774,23 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
 #pragma unroll
     for (int j = 0; j < QA; ++j) acc[j] = 0.0;
     double nxt[PD][PF];   // this wave's frames of the next PD rounds
-    auto fetch = [&](int d, int t) __attribute__((always_inline)) {
-        const double *src = cS + (size_t)sym_frame(t < t_end ? t : t_first, T) * fs;
+    auto fetch = [&](int d, int i) __attribute__((always_inline)) {
+        const int t = (int)s_list[min(i, max(nlist - 1, 0))];   // (an entry past the end: a repeated frame nobody adds)
+        const double *src = cS + (size_t)sym_frame(nlist > 0 ? t : t_first, T) * fs;
 #pragma unroll
         for (int p = 0; p < PF; ++p) nxt[d][p] = src[off_g[p]];
     };
 #pragma unroll
-    for (int d = 0; d < PD; ++d) fetch(d, t_first + d * NW + wave);
-    for (int tb = t_first; tb < t_end; tb += NW * PD) {
+    for (int d = 0; d < PD; ++d) fetch(d, d * NW + wave);
+    int t_done = t_first;
+    for (int ib = 0; ib < nlist; ib += NW * PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
-            const int t0 = tb + d * NW;      // first frame of this round
-            if (t0 >= t_end) break;          // (uniform over the workgroup)
+            const int i0 = ib + d * NW;      // first list entry of this round
+            if (i0 >= nlist) break;          // (uniform over the workgroup)
 #pragma unroll
             for (int p = 0; p < PF; ++p) if (off_l[p] >= 0) sl[off_l[p]] = nxt[d][p];
-            fetch(d, t0 + wave + NW * PD);
+            fetch(d, i0 + wave + NW * PD);
             wave_sync();
             if (S == 2) {
                 double *l1 = sl + G::L1_OFF;
@@ -795,18 +834,23 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
                 }
             }
             __syncthreads();
-            const int nf = min(NW, t_end - t0);   // frames of this round that exist
+            const int nf = min(NW, nlist - i0);   // frames of this round that exist
 #pragma unroll
             for (int f = 0; f < NW; ++f) {
                 if (f < nf) {
+                    const int t = uniform((int)s_list[i0 + f]);
+                    const int ngap = t - t_done;       // the frames in front of this one that are not kept: `min` each
+                    t_done = t + 1;
                     const double *exf = ex + (size_t)f * 16 * 64 + (size_t)(wave * QA) * 64 + lane;
 #pragma unroll
-                    for (int q = 0; q < QA; ++q) acc[q] = acc[q] + exf[q * 64];
+                    for (int q = 0; q < QA; ++q) acc[q] = masked_gap_small(acc[q], ngap, min_val) + exf[q * 64];
                 }
             }
             __syncthreads();   // (the exchange and the slices are rewritten next round)
         }
     }
+#pragma unroll
+    for (int q = 0; q < QA; ++q) acc[q] = masked_gap_small(acc[q], t_end - t_done, min_val);
     const double cnt = (double)avg_T;
     double hmn = __builtin_huge_val(), hmx = -__builtin_huge_val();
 #pragma unroll
@@ -819,7 +863,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
             hmn = (v < hmn) ? v : hmn; hmx = (v > hmx) ? v : hmx;
         }
     }
-    if (tile_nkept && threadIdx.x == 0) tile_nkept[tile] = t_end - t_first;
+    if (tile_nkept && threadIdx.x == 0) tile_nkept[tile] = nlist;   // 0: every pixel of the tile is the same constant (sparse heatmap exchange, ROI stage)
     if (avg_T > 0) {
         hmn = wave_min(hmn); hmx = wave_max(hmx);
         if (lane == 0) {

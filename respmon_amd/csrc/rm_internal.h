@@ -31,6 +31,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rm_contour.h"
@@ -40,6 +41,7 @@
 #include "rm_dense_sum.h"
 #include "rm_tile_eval.h"
 #include "rm_bounds_l1.h"
+#include "rm_xstore.h"
 #include "rm_ccl.h"
 #include "rm_flow.h"
 
@@ -78,6 +80,8 @@ struct CollapsePlan {
     bool no_prune = false;
     bool fused = false;                    // k_eval_c + k_tile_sum (rm_tile_eval.h): no value store, no separate evaluation of the kept pairs
     SumPlan sp{0, 0, 0, 0};                // sparse or dense sum: decided on the device (rm_kernels.h sum_is_dense)
+    bool l1_bounds = false;                // lo / hi are the extrema of the LEVEL-1 footprints (rm_bounds_l1.h): a pair they keep cannot stop at level 1
+    unsigned long long *xs_tab = nullptr;  // exception store table [tile][unique frame] (rm_xstore.h XsEntry), written XS_NONE by k_select_pairs
 };
 
 
@@ -92,6 +96,10 @@ struct DebugKnobs {
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
     int bounds_l1 = 1;            // 0: skip 2 takes its tile bounds from the level-2 footprint (k_frame_bounds / k_frame_bounds_rows) instead of the level-1 footprint (rm_bounds_l1.h)
     int bounds_l1_rows = 0;       // > 0: tile rows per wave of k_frame_bounds_l1 (default: 16, fewer on small frames)
+    int xs = 0;                   // 1: dense selections go through the exception store (rm_xstore.h) instead of the store-less sum kernels (measured slower: DESIGN 7)
+    int xs_waves = 0;             // 1 / 2 / 4: waves per tile of k_xs_sum (0: by the number of tiles)
+    long long xs_budget_words = 0;   // > 0: capacity of the exception store in 8-byte words (default: the worst case of the geometry, at most 1 GiB)
+    int dense_wf_list = 1;        // 0: k_dense_sum_wf evaluates every frame of a tile (no kept list from slot_of / lo)
     int bounds_scalar = 0;        // 1: k_frame_bounds (a thread per row and tile column) also for wide levels instead of k_frame_bounds_rows
     int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
     int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2

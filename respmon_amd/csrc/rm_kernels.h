@@ -202,6 +202,31 @@ template <typename Less> __device__ __forceinline__ void wave_arg_reduce(double 
     from_bits(((unsigned long long)hi << 32) | lo, v);
     idx = __builtin_amdgcn_readlane(idx, 63);
 }
+// min / max of two doubles as ONE instruction.  __builtin_fmin / fmax put a canonicalising v_max_f64 x, x, x in front of every operand
+// the compiler cannot prove quiet (loads, DPP moves, loop-carried values): three instructions instead of one in kernels that do
+// little else (rm_bounds_l1.h).  The operands here are never signalling NaNs (arithmetic results and loaded image data); a quiet NaN
+// operand yields the other operand, as fmin / fmax do.
+__device__ __forceinline__ double f64_min(double a, double b)
+{
+#ifndef RM_HIPEMU
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fmin(a, b);
+#endif
+}
+__device__ __forceinline__ double f64_max(double a, double b)
+{
+#ifndef RM_HIPEMU
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fmax(a, b);
+#endif
+}
+
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, [](double o, double w) { return (o < w) ? o : w; }); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, [](double o, double w) { return (o > w) ? o : w; }); }
 
@@ -1027,6 +1052,8 @@ struct CollapseState {
     double min_val, max_val, top;   // transforms.py:185-189, decoded by k_finish_minmax
     unsigned long long heat_min_key, heat_max_key;
     double sp_bg;                   // sparse merge: rank-ordered sum of the packets' backgrounds (k_sparse_index)
+    unsigned long long xs_next;     // exception store (rm_xstore.h): words handed out so far
+    unsigned int xs_overflow;       // ... a record did not fit: the store-less kernel behind k_xs_sum takes the sum
 };
 
 __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIPE-1 of one wavefront
@@ -1041,6 +1068,7 @@ __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIP
     st->min_key = ~0ull; st->max_key = 0ull; st->n_list_a = 0; st->n_list_b = 0; st->n_slots = 0; st->n_heavy = 0;
     st->margin = 0; st->top_ub = 0; st->min_val = 0; st->max_val = 0; st->top = 0;
     st->heat_min_key = ~0ull; st->heat_max_key = 0ull;
+    st->xs_next = 0ull; st->xs_overflow = 0u;
 }
 
 RM_KERNEL __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st) { state_init_lane(st, (int)threadIdx.x); }
@@ -1228,6 +1256,11 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom
 // sample set -- and with it how many pairs the selection keeps, never the result -- differs from k_frame_bounds'.
 constexpr int FB_MAXNL = 16;   // row length <= 64 * FB_MAXNL level-S columns
 #define RM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget of 512 / n per lane
+#ifndef RM_HIPEMU
+#define RM_WAVES_PER_EU_IF(cond, a, b) __attribute__((amdgpu_waves_per_eu((cond) ? (a) : (b), (cond) ? (a) : (b))))   // ... chosen by a template parameter
+#else
+#define RM_WAVES_PER_EU_IF(cond, a, b)   // (g++ does not parse an expression inside an attribute it does not know)
+#endif
 // FB_TR (template): tile rows per wave -- 8 where that still gives every SIMD a few waves (halo rows: 12 %), 2 for small images
 __host__ __device__ __forceinline__ int fb_row_pitch(int wS) { return wS + (wS >> 4) + 2; }
 
@@ -1614,7 +1647,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan_256(unsigned long 
 constexpr int SEL_TILES = 16, SEL_PH = 16, SEL_U = 9;   // 16 x 9 = 144 unique frames per chunk: one chunk at T = 256
 RM_KERNEL __launch_bounds__(256) void k_select_pairs(const double *lo, const double *hi, int ntiles, int Th, int T, int t0, int t1,
                                                       CollapseState *st, unsigned int *list_a, unsigned int *list_b, int *slot_of,
-                                                      int no_prune, double thr, int *sel_cnt, unsigned int *heavy)
+                                                      int no_prune, double thr, int *sel_cnt, unsigned int *heavy, unsigned long long *xs_tab)
 {
     RM_TRACE_SCOPE(4);
     __shared__ unsigned long long s_cnt[256], s_off[257], s_wave[4];
@@ -1689,6 +1722,7 @@ RM_KERNEL __launch_bounds__(256) void k_select_pairs(const double *lo, const dou
         const unsigned int i = (unsigned)u * (unsigned)ntiles + (unsigned)tile;
         const bool isC = (fC >> k) & 1u, isD = (fD >> k) & 1u;
         slot_of[slot_index(u, tile, Th)] = isD ? (int)oD : SLOT_PRUNED;
+        if (xs_tab) xs_tab[slot_index(u, tile, Th)] = 0x00000000ffffffffull;   // XsEntry{XS_NONE, 0}: no exception record yet (rm_xstore.h)
         if (isD) ++oD;
         if (isC) list_a[oA++] = i;
         else if (isD) list_b[oB++] = i;

@@ -88,7 +88,9 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
     // component beat every rival's box: rm_ccl.h) -- this one keeps the packed image and the full list in device buffers of the slot and
     // sends the summaries only.  At 4K x 512 that is 1.7 MB less over PCIe behind the last kernel and a 1 MB memset less on the host
     // between two calibrations; roi_finish fetches both if the summaries do not settle the winner after all.
-    const bool lazy = label && ctx->label_lazy && ctx->dbg.label_lazy != 0;
+    // (not in the two-call form: the fetch roi_finish may have to make would queue behind the NEXT submission's calibration on the
+    //  tickets' one stream -- rm_locate_result(A) would wait for buffer B's kernels, the overlap the two calls exist for)
+    const bool lazy = label && ctx->label_lazy && ctx->dbg.label_lazy != 0 && ctx->cur_slot == 0;
     CclComp *d_complist = nullptr;
     if (label) {
         int *d_label = nullptr; CclBox *d_box = nullptr; unsigned int *d_cnt = nullptr; int *d_list = nullptr;
@@ -137,6 +139,11 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         LAUNCH_CHECK();
     }
     delete pt_roi; pt_roi = nullptr;
+    // From here on the pinned area of the slot is NOT known to be clean: a kernel that writes it is enqueued.  roi_finish puts the
+    // marker back together with the exact range it found written; if it never runs for this launch (a failed wait, an abandoned
+    // ticket, an error return above) the next roi_launch on the slot clears everything (stale foreground bits and records
+    // would be OR-ed into the next image -- the kernels store only non-zero words).
+    rs.h_rows_dirty = nullptr;
     pd.H = H; pd.W = W; pd.slot = ctx->cur_slot; pd.nwords = nwords; pd.comps_cap = comps_cap; pd.label = label; pd.clip = clip;
     pd.rows = rows; pd.rec_off = rec_off;
     pd.lazy = lazy; pd.stream = s; pd.d_bits = d_bits; pd.d_list = d_complist;
@@ -158,6 +165,7 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
         if (pd.rows) {
             // one record per row with foreground: the one-blob rule needs nothing else (the image is read only when it fails)
             settled = simple_shape_row_records((const uint64_t *)(rs.h_bin + pd.rec_off), H, W, &y0, &y1, &r) && ctx->dbg.host_simple_shape && !clip;
+            rs.dirty_w1 = 0; rs.dirty_w0 = 1;
             if (y1 >= y0) {   // what the next launch on this slot zeroes (roi_launch): the words of rows y0 .. y1 and their records
                 rs.dirty_w0 = ((size_t)y0 * W) >> 6; rs.dirty_w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
                 rs.dirty_r0 = y0; rs.dirty_r1 = y1;
@@ -208,6 +216,7 @@ int roi_finish(rm_ctx *ctx, const RoiPending &pd, int32_t *xywh)
             const size_t w0 = ((size_t)y0 * W) >> 6, w1 = (((size_t)(y1 + 1) * W) - 1) >> 6;
             std::memset(rs.h_bin + w0 * 8, 0, (w1 - w0 + 1) * 8);
         }
+        rs.h_rows_dirty = h_rows;   // the slot is clean again but for the range recorded above (roi_launch took the marker away)
         const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         if (ctx->label_used) {
             ++ctx->label_streak;

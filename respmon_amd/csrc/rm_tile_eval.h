@@ -765,15 +765,17 @@ RM_KERNEL __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W0
 constexpr int DST_MAXW = (MAX_T / 2 + 1 + 63) / 64;   // 64-frame words of a tile's kept mask
 
 template <int S>
-__global__ __launch_bounds__(64) void k_dense_sum_t(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles, const int *slot_of,
+__global__ __launch_bounds__(64) RM_WAVES_PER_EU_IF(S <= 2, 4, 3) void k_dense_sum_t(const double *cS, ChainGeom g, int t_first, int t_end, int T, int ntiles, const int *slot_of,
                                                     CollapseState *st, double threshold, double *heat_sum, int avg_T, int *tile_nkept, SumPlan sp,
-                                                    int only_if_dense, int *ran_host, const double *lo)
+                                                    int only_if_dense, int *ran_host, const double *lo, int xs_standin, int l1_stop)
 {
     using F = TileFoot<S, false>;
-    HIP_DYNAMIC_SHARED(double, lds)                 // the wave's footprint slice, then the kept mask (DST_MAXW words)
+    HIP_DYNAMIC_SHARED(double, lds)                 // the wave's footprint slice, the kept mask (DST_MAXW words), the kept frames in time order (T 16-bit entries)
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds + F::TOTAL);
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_mask + DST_MAXW);
     const int lane = threadIdx.x;
     if (only_if_dense && !sum_is_dense(st, sp)) return;   // (uniform over the grid: the sparse kernel in front took the sum)
+    if (xs_standin && !st->xs_overflow) return;           // (uniform over the grid: the exception store held everything, k_xs_sum took the sum -- rm_xstore.h)
     if (ran_host && blockIdx.x == 0 && lane == 0) *ran_host = 2;   // (pinned: tells rm_locate that the stand-in it enqueued on a hint was needed)
     const int tile = dense_tile_of_block((int)blockIdx.x, ntiles);   // XCD x takes the x-th eighth of the tiles (rm_dense_sum.h)
     if (tile >= ntiles) return;
@@ -808,30 +810,48 @@ __global__ __launch_bounds__(64) void k_dense_sum_t(const double *cS, ChainGeom 
     double acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-    // The footprints of the next two frames travel while this one is evaluated -- of the frames that are still kept when they are
-    // requested (bits only ever get cleared, so a frame that is not requested is not evaluated either).
-    // A frame that adds `min` to every pixel -- pruned by the bounds, or stopped at level 1 by tile_eval_below() -- only counts up
-    // `gap`; the additions happen, in order, in front of the next frame that has real values (and at the end): ONE site with the
-    // masked additions, one with the plain ones.  A frame that stopped at level 1 also clears its bit in the kept mask: the band-passed
-    // signal is even in time, frame T - u is frame u again, and the second visit of the pair then costs sixteen additions.
-    auto is_kept = [&](int t) __attribute__((always_inline)) { const int u = sym_frame(t, T); return ((s_mask[u >> 6] >> (u & 63)) & 1ull) != 0; };
+    // The kept frames of [t_first, t_end) in TIME order (round 6): the frame loop used to walk every t -- two LDS look-ups of the mask,
+    // the register copies of the prefetch ring and a branch per frame, kept or not: ~25 instructions x 3 M frames that add `min`
+    // anyway at 4K x 512, a sixth of the kernel's issue slots.  Now it walks the list; the frames between two entries are a count.
+    int nlist = 0;
+    for (int c0 = t_first; c0 < t_end; c0 += 64) {
+        const int t = c0 + lane;
+        bool kept = false;
+        if (t < t_end) { const int u = sym_frame(t, T); kept = ((s_mask[u >> 6] >> (u & 63)) & 1ull) != 0; }
+        const unsigned long long mk = __ballot(kept);
+        if (kept) s_list[nlist + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)t;
+        nlist += __popcll(mk);
+    }
+    wave_sync();
+    // The footprints of the next two kept frames travel while this one is evaluated.  A frame that adds `min` to every pixel --
+    // stopped at level 1 by tile_eval_below() -- only counts up `gap`; the additions happen, in order, in front of the next frame that
+    // has real values (and at the end): ONE site with the masked additions, one with the plain ones.  A frame that stopped at level 1
+    // also clears its bit in the kept mask: the band-passed signal is even in time, frame T - u is frame u again, and the second
+    // visit of the pair (its list entry is looked at, its footprint not used) then costs sixteen additions.
+    // l1_stop == 0: the bounds the mask was built from ARE the level-1 extrema (rm_bounds_l1.h) -- a kept pair cannot stop at level 1,
+    // the running minimum of tile_eval_below() and its wave reduction (~70 instructions a visit) are left out.
     // (ONE loop body -- the frame in `cur`, the next two in n1 / n2, moved up by register copies: unrolling the body per prefetch slot
     //  doubled the evaluator's code and cost a wave per SIMD)
     double cur[F::PF], n1[F::PF], n2[F::PF];
 #pragma unroll
     for (int p = 0; p < F::PF; ++p) { cur[p] = 0.0; n1[p] = 0.0; n2[p] = 0.0; }
-    auto fetch = [&](double (&dst)[F::PF], int t) __attribute__((always_inline)) {
-        if (t >= t_end || !is_kept(t)) return;   // (uniform)
+    auto fetch = [&](double (&dst)[F::PF], int i) __attribute__((always_inline)) {
+        if (i >= nlist) return;   // (uniform)
+        const int t = uniform((int)s_list[i]);
         const double *src = cS + (size_t)sym_frame(t, T) * fs;
 #pragma unroll
         for (int p = 0; p < F::PF; ++p) dst[p] = src[ts.off_g[p]];
     };
-    fetch(cur, t_first); fetch(n1, t_first + 1);
-    int nkept = 0, gap = 0;
+    fetch(cur, 0); fetch(n1, 1);
+    int nkept = 0, gap = 0, t_done = t_first;
 #pragma nounroll
-    for (int t = t_first; t < t_end; ++t) {
-        fetch(n2, t + 2);
-        const bool kept = is_kept(t);   // (uniform)
+    for (int i = 0; i < nlist; ++i) {
+        fetch(n2, i + 2);
+        const int t = uniform((int)s_list[i]);
+        const int u = sym_frame(t, T);
+        gap += t - t_done;              // the frames in front of this one that were not kept
+        t_done = t + 1;
+        const bool kept = !l1_stop || ((s_mask[u >> 6] >> (u & 63)) & 1ull) != 0;   // (uniform; a first visit that stopped at level 1 cleared the bit)
         bool below = false;             // (uniform) evaluated down to level 0: the tile may hold a value below top
         double v[16];
         if (kept) {
@@ -839,10 +859,10 @@ __global__ __launch_bounds__(64) void k_dense_sum_t(const double *cS, ChainGeom 
 #pragma unroll
             for (int p = 0; p < F::PF; ++p) if (lane + 64 * p < F::NST) lds[F::off(S) + lane + 64 * p] = cur[p];
             wave_sync();
-            if constexpr (S >= 2) below = tile_eval_below<S, false>(ts, lds, lane, top_m, v);
-            else { tile_eval<S, false>(ts, lds, lane, v); below = true; }
+            if (S >= 2 && l1_stop) {
+                if constexpr (S >= 2) below = tile_eval_below<S, false>(ts, lds, lane, top_m, v);
+            } else { tile_eval<S, false>(ts, lds, lane, v); below = true; }
             if (!below) {
-                const int u = sym_frame(t, T);
                 if (lane == 0) s_mask[u >> 6] &= ~(1ull << (u & 63));
                 wave_sync();
             }
@@ -859,6 +879,7 @@ __global__ __launch_bounds__(64) void k_dense_sum_t(const double *cS, ChainGeom 
         for (int j = 0; j < 16; ++j) acc[j] = acc[j] + ((v[j] >= top) ? min_val : v[j]);
         ++nkept;
     }
+    gap += t_end - t_done;
 #pragma nounroll
     for (; gap > 0; --gap) {
 #pragma unroll

@@ -263,7 +263,7 @@ def locate_streams(buf, fps, threshold=20, group=None, calibrate_fn=hip_calibrat
     tiles that survive the pruning: 1 MB per rank instead of a 16.6 MB all-reduce at 1080p, summed in rank order);
     `sparse=False`, a test double for the calibration, or a packet overflow uses the dense all-reduce(sum)."""
     global LAST_EXCHANGE
-    if calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and sparse is None and cabi_comm_active(group):
+    if calibrate_fn is hip_calibrate and roi_fn is hip_heatmap_to_roi and sparse is None and cabi_comm_active(group, _device_index_of(buf)):
         return cabi_locate_streams(buf, fps, threshold=threshold, return_heatmap=return_heatmap, **kw)
     if calibrate_fn is hip_calibrate and not return_heatmap:   # nobody sees this rank's own heatmap: no allocation per step
         from . import device as _device
@@ -417,7 +417,7 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
         raise ValueError("rank %d holds %d frames, shard_frames(%d, %d, %d) says %d" % (rank, buf_local.shape[0], T, rank, world, t1 - t0))
     if t1 - t0 < 1:
         raise ValueError("every rank needs at least one frame (T=%d, world=%d)" % (T, world))
-    if stages is None and sparse is None and cabi_comm_active(group):
+    if stages is None and sparse is None and cabi_comm_active(group, _device_index_of(buf_local)):
         return cabi_locate_sharded(buf_local, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top,
                                    temporal_threshold, threshold, flags, return_heatmap)
     st = stages if stages is not None else HipShardStages()
@@ -460,6 +460,25 @@ def locate_sharded(buf_local, T, fps, freq_min=0.1, freq_max=1.0, amplification=
 _CABI_COMM = {}   # device index -> (rank, world, the torch.distributed group the communicator was made from)
 
 
+def _device_index_of(buf):
+    """Device index of a frame buffer tensor (None for anything else: the current device is then looked at)."""
+    dev = getattr(buf, "device", None)
+    return dev.index if (dev is not None and getattr(dev, "type", "") == "cuda") else None
+
+
+def _group_key(group):
+    """None and torch.distributed.group.WORLD name the same ranks: one key for both, so that a communicator made with group=None
+    serves locate_streams(group=dist.group.WORLD) and the reverse (the call used to drop to the torch.distributed
+    path silently).  Any other group is its own key (object identity: a subgroup of the same size and rank is another group)."""
+    if group is None:
+        return None
+    try:
+        world_group = _dist().group.WORLD
+    except Exception:   # noqa: BLE001 -- no torch.distributed in this process
+        world_group = None
+    return None if (world_group is not None and group is world_group) else group
+
+
 def cabi_comm_init(group=None):
     """Create the library's RCCL communicator for the current device from an initialised torch.distributed group (backend nccl):
     rank 0 makes the id (rm_comm_unique_id), the group broadcasts it, every rank calls rm_comm_init.  Returns (rank, world,
@@ -483,7 +502,7 @@ def cabi_comm_init(group=None):
     _capi.check(lib, lib.rm_comm_init(ctx, rank, world, idbuf), "rm_comm_init")
     r, w, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     _capi.check(lib, lib.rm_comm_info(ctx, ctypes.byref(r), ctypes.byref(w), ctypes.byref(n)), "rm_comm_info")
-    _CABI_COMM[t.cuda.current_device()] = (r.value, w.value, group)
+    _CABI_COMM[t.cuda.current_device()] = (r.value, w.value, _group_key(group))
     return r.value, w.value, n.value
 
 
@@ -494,15 +513,16 @@ def cabi_comm_destroy():
     _CABI_COMM.pop(t.cuda.current_device(), None)
 
 
-def cabi_comm_active(group=None):
+def cabi_comm_active(group=None, device_index=None):
+    """Does the library context of `device_index` (default: the current device) hold a communicator made from `group`?"""
     from . import device
     t = device.torch()
     if not t.cuda.is_available():
         return False
-    have = _CABI_COMM.get(t.cuda.current_device())
+    have = _CABI_COMM.get(t.cuda.current_device() if device_index is None else device_index)
     # the communicator serves the group it was made from, and only that one: another group of the same size and rank (a subgroup, a
     # group created after destroy_process_group) would put the wrong ranks into the collective
-    return have is not None and have[2] is group and have[:2] == _world(group)
+    return have is not None and have[2] is _group_key(group) and have[:2] == _world(group)
 
 
 def _cabi_step(fn_name, buf, T, fps, freq_min, freq_max, amplification, pyramid_levels, skip_levels_at_top, temporal_threshold, threshold,

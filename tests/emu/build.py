@@ -21,9 +21,13 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    import hashlib
+    stamp_srcs = ["rm_down_chain.h", "rm_down_chain_u8.h", "rm_down_launch.h", "rm_down.hip", "rm_down_f64.hip", "rm_down_generic.hip",
+                  "rm_down_narrow.hip", "rm_down_bgr.hip"]     # csrc/Makefile STAMP_SRCS
+    sha = hashlib.sha256(b"".join(open(os.path.join(CSRC, f), "rb").read() for f in stamp_srcs)).hexdigest()[:16]
     units = ["rm_unity.hip", "rm_contour.cpp"]   # every product translation unit, as one unit (respmon_amd/csrc/rm_unity.hip)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
-           "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", "-Wno-unused-function", "-Wno-attributes", "-Wno-psabi", "-o", OUT]
+           "-I", os.path.join(HERE, "include"), "-DRM_HIPEMU_DEFINE_TLS", '-DRM_FRAME_KERNEL_SRC_SHA="%s"' % sha, "-Wno-unused-function", "-Wno-attributes", "-Wno-psabi", "-o", OUT]
     for u in units:
         cmd += ["-x", "c++", os.path.join(CSRC, u)]
     subprocess.check_call(cmd)

@@ -279,6 +279,7 @@ inline int atomicCAS(int *p, int expected, int desired) {
 }
 inline int atomicAdd(int *p, int v) { return reinterpret_cast<std::atomic<int> *>(p)->fetch_add(v); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->fetch_add(v); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return reinterpret_cast<std::atomic<unsigned long long> *>(p)->fetch_add(v); }
 inline unsigned atomicExch(unsigned *p, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(p)->exchange(v); }
 inline unsigned atomicMax(unsigned *p, unsigned v) {
     auto *a = reinterpret_cast<std::atomic<unsigned> *>(p);

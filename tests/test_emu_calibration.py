@@ -553,6 +553,7 @@ def test_emu_dense_sum_equals_sparse_path(emu):
     selection / value-store path (flags=256), bit for bit -- every super-tile shape (RM_DENSE_ROWS), skip 1..5, shards of the
     frame range, exhaustive evaluation (flags | 1), and the automatic choice (second call of a geometry that kept every pair)."""
     rng = np.random.default_rng(5)
+    emu.debug_set("xs", 0)            # (the store-less kernels themselves: the exception store that stands in front of them has its own test below)
     for n, (T, H, W, L, S) in enumerate([(4, 64, 96, 4, 2), (3, 67, 131, 5, 3), (3, 48, 64, 3, 1), (2, 100, 160, 7, 5),
                                          (3, 70, 300, 4, 2)]):     # (the GPU twin in tests/test_gpu_calibration.py runs more and larger ones)
         v = rng.random((T, H, W))
@@ -617,6 +618,7 @@ def test_emu_dense_sum_equals_sparse_path(emu):
         a = emu.locate_sharded(v, world, levels=4, skip=2, flags=256)
         b = emu.locate_sharded(v, world, levels=4, skip=2, flags=128)
         assert a[0] == b[0] and np.array_equal(a[1], b[1]), world
+    emu.debug_set("xs", 1)
 
 
 def test_emu_filter_first_per_level_equals_fused(emu):
@@ -1026,3 +1028,41 @@ def test_emu_labelling_rule_counts_not_clocks(emu, oracle):
     assert rois == {want}
     lab = [(s[0], s[3]) for s in runs[0]]
     assert lab == [(1000, 0), (1000, 1), (1000, 1), (1000, 1), (0, 0), (0, 0), (0, 0), (0, 0)], lab
+
+
+def test_emu_exception_store(emu, oracle):
+    """rm_xstore.h (round 6): a dense selection's masked time sum through the exception store -- every kept pair evaluated once by a
+    flat pass (k_xs_eval), its values below `top` parked in a compact record, the time-ordered additions by k_xs_sum with 1 / 2 / 4
+    waves per tile -- against the value-store path (flags=256), bit for bit: few exceptions per pair (they travel with the record's
+    header) and many (fetched from the record), ragged tiles, skip 1 .. 4, exhaustive evaluation, frame shards, a store that
+    overflows (the store-less kernel behind k_xs_sum takes over), and the oracle's heatmap."""
+    rng = np.random.default_rng(97)
+    cases = [(6, 64, 96, 4, 2, 0.7), (5, 67, 131, 5, 3, 0.7), (4, 48, 64, 3, 1, 0.7), (5, 100, 160, 6, 4, 0.7), (7, 70, 300, 4, 2, 0.05),
+             (4, 33, 70, 4, 2, 0.3), (9, 40, 200, 5, 2, 0.02), (3, 5, 7, 4, 2, 0.7)]
+    for n, (T, H, W, L, S, thr) in enumerate(cases):
+        v = rng.random((T, H, W))
+        v[:, H // 3:, W // 4:] *= 0.2                       # a quieter part: fewer exceptions there
+        emu.debug_set("xs", 1)
+        want, mm = emu.calibrate(v, 10.0, levels=L, skip=S, thr=thr, flags=256)
+        for nw in (1, 2, 4):
+            emu.debug_set("xs_waves", nw)
+            got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, thr=thr, flags=128)
+            assert np.array_equal(got, want) and tuple(mm) == tuple(mm2), (T, H, W, L, S, thr, nw)
+        emu.debug_set("xs_waves", 0)
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, thr=thr, flags=128 | 1)
+        assert np.array_equal(got, want) and tuple(mm) == tuple(mm2), (T, H, W, L, S, thr, "no prune")
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, thr=thr, flags=4)      # (an 8-slot value store overflows: the dense route, decided on the device)
+        assert np.array_equal(got, want) and tuple(mm) == tuple(mm2), (T, H, W, L, S, thr, "value store overflow")
+        emu.debug_set("xs_budget_words", 3000)             # the exception store itself overflows: the store-less kernel takes the sum
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, thr=thr, flags=128)
+        emu.debug_set("xs_budget_words", 0)
+        assert np.array_equal(got, want) and tuple(mm) == tuple(mm2), (T, H, W, L, S, thr, "exception store overflow")
+        if n in (0, 4):
+            raw = oracle.eulerian_magnification_bandpass(v.copy(), 10.0, 0.1, 1.0, 500.0, pyramid_levels=L, skip_levels_at_top=S, threshold=thr)[0]
+            ref = np.average(raw, axis=0)
+            assert np.abs(got - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-300), (T, H, W, "oracle")
+    v = rng.random((11, 70, 150))
+    for world in (2, 3):                      # frame shards: partial sums over [t0, t1) with the global extrema
+        a = emu.locate_sharded(v, world, levels=4, skip=2, flags=256)
+        b = emu.locate_sharded(v, world, levels=4, skip=2, flags=128)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), world

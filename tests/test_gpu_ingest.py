@@ -128,6 +128,20 @@ def test_store_frame_every_buffer_dtype(hip, oracle):
             assert not got[0].any() and not got[2].any()
             want = g8 if ndt == np.uint8 else ref64.astype(ndt)
             assert np.array_equal(got[1], want), ndt
+    # a 'bgr8' buffer ([T,H,W,3] uint8): the captured frame when the caller has it, else the gray value in three planes -- the
+    # calibration converts either back to the same gray frame (no coupling to "the tensor bgr_to_gray returned last")
+    bgr = rng.integers(0, 256, size=(270, 480, 3), dtype=np.uint8)
+    gray = be.bgr_to_gray(bgr)
+    buf = torch.zeros((3, 270, 480, 3), dtype=torch.uint8, device="cuda")
+    be.store_frame(buf, 0, gray, bgr=be.last_bgr)
+    be.store_frame(buf, 1, gray)                                     # (no BGR tensor: any gray frame)
+    be.store_frame(buf, 2, torch.from_numpy(frame).cuda())           # (a gray frame that never was BGR)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf[0].cpu().numpy(), bgr)
+    assert np.array_equal(buf[1].cpu().numpy(), np.repeat(gray.cpu().numpy()[:, :, None], 3, axis=2))
+    for k in (0, 1):
+        assert np.array_equal(be.bgr_to_gray(buf[k].cpu().numpy()).cpu().numpy(), gray.cpu().numpy()), k
+    assert np.array_equal(be.bgr_to_gray(buf[2].cpu().numpy()).cpu().numpy(), frame)
     # the float64 round trip reproduces the reference's 24 lossy levels (transforms.py:26-29) through the device helpers
     buf = torch.zeros((1, 16, 16), dtype=torch.float64, device="cuda")
     be.store_frame(buf, 0, torch.from_numpy(levels).cuda())

@@ -361,3 +361,42 @@ def test_bench_launcher_reports_and_retries_when_no_rank_prints(tmp_path):
     assert j["stage"] in ("device", "rendezvous_done"), j["stage"]
     assert j["first_attempt"]["ranks"]["0"]["stage"] == "device"
     assert j["retry_with_torch_distributed_collectives"] is not None
+
+
+def test_committed_pmc_figures_follow_the_kernel_source_stamp():
+    """profiles/hbm_traffic.json / valu_issue.json are reported only to a library built from the frame-buffer kernel
+    sources they were measured on.  The library exports the stamp of its sources (rm_debug_kernel_source_stamp == the sha256 of
+    csrc/Makefile's STAMP_SRCS, recomputed here); bench.py's look-up returns the figure for the matching stamp and (None, stale)
+    for an edited one; every committed entry carries a stamp."""
+    import hashlib
+    import bench
+    from respmon_amd import _capi
+    lib = _capi.load()
+    stamp = lib.rm_debug_kernel_source_stamp().decode()
+    csrc = os.path.join(ROOT, "respmon_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^STAMP_SRCS\s*=\s*(.+)$", mk, re.M).group(1).split()
+    want = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in srcs)).hexdigest()[:16]
+    assert stamp == want == bench.library_kernel_stamp()
+    table = {"f64_256x1080x1920": {"bytes_per_launch": 4.4e9, "kernel_source_sha": stamp}, "old": {"bytes_per_launch": 1.0}}
+    assert bench.committed_figure(table, "f64_256x1080x1920", stamp, "bytes_per_launch") == (4.4e9, False)
+    edited = stamp[:-1] + ("0" if stamp[-1] != "0" else "1")          # the hash of an edited header
+    assert bench.committed_figure(table, "f64_256x1080x1920", edited, "bytes_per_launch") == (None, True)
+    assert bench.committed_figure(table, "old", stamp, "bytes_per_launch") == (None, True)       # an unstamped figure is never reported
+    assert bench.committed_figure(table, "absent", stamp, "bytes_per_launch") == (None, False)
+    tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    for key, e in tj.items():
+        assert e.get("kernel_source_sha"), key
+    vj = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
+    assert set(vj["kernel_source_sha"]) == set(vj["valu_instructions_per_pixel"])
+
+
+def test_library_exports_only_the_c_abi():
+    """the helpers the translation units share are not visible outside the library (csrc/rm_exports.map): every dynamic
+    symbol librespmon_hip.so defines is an rm_* entry point."""
+    import subprocess
+    from respmon_amd import _capi
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    assert names and all(n.startswith("rm_") for n in names), [n for n in names if not n.startswith("rm_")][:10]
+    assert set(_capi.SIGNATURES) <= set(names)

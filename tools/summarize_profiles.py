@@ -65,7 +65,9 @@ def main():
         key = "%s_%dx%dx%d" % (cfg["frame_buffer_dtype"], cfg["frames"], cfg["height"], cfg["width"])
         path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         table = json.load(open(path)) if os.path.exists(path) else {}
-        table[key] = {"kernel": k, "bytes_per_launch": b, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+        # the stamp of the library the passes ran on (bench.py prints it; bench.py reports the figure only to a library with the same stamp)
+        sha = bench.get("roofline", {}).get("kernel_source_sha")
+        table[key] = {"kernel": k, "kernel_source_sha": sha, "bytes_per_launch": b, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
                       "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a wide "
                                     "coalesced stream, MI355X_MICROARCH.md HBM section); separate --pmc passes",
                       "source": "profiles/%s/%s" % (tag, names["pmc"])}
