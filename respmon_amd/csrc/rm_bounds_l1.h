@@ -217,4 +217,248 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainG
     }
 }
 
+// ---- the same bounds in single precision, with a margin (round 6) -------------------------------------------------------------------
+// A bound only has to be SOUND: lo <= every level-1 value of the footprint <= hi.  k_frame_bounds_l1 forms the level-1 values in the
+// chain's own float64 operations (lo / hi are then the exact extrema) at ~60 instructions per level-2 row and lane -- the kernel is
+// bound by instruction issue, not by the 1 GB it reads.  Here the values are formed in float32 -- both columns of a lane's pair in ONE
+// packed instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), extrema with v_min3_f32 / v_max3_f32, 32-bit DPP moves -- and
+// the bounds are widened by what float32 can have lost:
+//     every level-1 value is a positive combination (weights summing to one) of the 3 x 3 level-2 values around it; rounding the
+//     inputs to float32 and each of the <= 6 operations of a path (products with 1, 2, 4 and 1/16, 1/64 are exact) moves it by less
+//     than 7 u M, u = 2^-24, M = the largest |C_2| of the support (standard running error bound of a sum of non-negative terms:
+//     every intermediate is bounded by M); eps = 2^-20 M + 2^-140 (16 u M: twice the bound and more; the constant covers float32
+//     underflow) with M = the largest |C_2| the lanes of the tile AND their neighbours have met so far in the band.
+//     lo = float(min) - eps, hi = float(max) + eps, formed in float64 (both conversions are exact).
+// The selection's own margin (PRUNE_REL_MARGIN) comes on top as before.  ~1e-6 of the value range: no measurable loss of pruning.
+typedef RM_VEC(float, 2) bl1_v2f;
+
+__device__ __forceinline__ bl1_v2f bl1_fma2(bl1_v2f a, bl1_v2f b, bl1_v2f c)
+{
+#ifndef RM_HIPEMU
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    bl1_v2f r;
+    r[0] = __builtin_fmaf(a[0], b[0], c[0]); r[1] = __builtin_fmaf(a[1], b[1], c[1]);
+    return r;
+#endif
+}
+__device__ __forceinline__ float bl1_min3(float a, float b, float c)
+{
+#ifndef RM_HIPEMU
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return __builtin_fminf(a, __builtin_fminf(b, c));
+#endif
+}
+__device__ __forceinline__ float bl1_max3(float a, float b, float c)
+{
+#ifndef RM_HIPEMU
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return __builtin_fmaxf(a, __builtin_fmaxf(b, c));
+#endif
+}
+// min / max of two floats as ONE instruction (f64_min's reason: no canonicalising v_max_f32 x, x in front of the operands)
+__device__ __forceinline__ float bl1_minf(float a, float b)
+{
+#ifndef RM_HIPEMU
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fminf(a, b);
+#endif
+}
+__device__ __forceinline__ float bl1_maxf(float a, float b)
+{
+#ifndef RM_HIPEMU
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fmaxf(a, b);
+#endif
+}
+// v = min / max(v, v of the lane N to the left inside its 16-lane row) as ONE instruction: the DPP operand of v_min_f32 / v_max_f32
+// itself; a lane without a source keeps its value (the instruction does not write it).  (s_nop 1: the two wait states between
+// a VALU write of a register and a DPP read of it, which the compiler cannot see inside the asm)
+#ifndef RM_HIPEMU
+#define RM_BL1_FOLD_MIN(v, N) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
+#define RM_BL1_FOLD_MAX(v, N) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
+#else
+#define RM_BL1_FOLD_MIN(v, N) v = __builtin_fminf(v, bl1_shrf<0x110 + N>(v))
+#define RM_BL1_FOLD_MAX(v, N) v = __builtin_fmaxf(v, bl1_shrf<0x110 + N>(v))
+#endif
+template <int CTRL> __device__ __forceinline__ float bl1_shrf(float v);
+template <int CTRL> __device__ __forceinline__ float bl1_rotf(float v)   // wave rotation: every lane has a source
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ float bl1_shrf(float v)   // row shift: a lane without a source keeps its own value
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1f(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi, CollapseState *st,
+                                                          int *sel_cnt, int nchunks, int nbands, int trb)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < ntiles; i += 256) sel_cnt[i] = 0;   // k_select_pairs counts into it
+    const double inf = __builtin_huge_val();
+    const float finf = __builtin_huge_valf();
+    const int h2 = g.h[2], w2 = g.w[2], h1 = g.h[1], w1 = g.w[1], ntx = g.tiles_x, nty = g.tiles_y;
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wid = uniform((int)blockIdx.y * 4 + wave);
+    if (wid >= nchunks * nbands) return;   // (whole waves; nothing below synchronises across waves)
+    const int c = wid % nchunks, b = wid / nchunks;
+    const int ty_first = b * trb, ty_last = min(ty_first + trb, nty) - 1;
+    const int j0 = BL1_COLS * c;
+    const int jv = lane == 63 ? j0 - 1 : j0 + lane;          // (k_frame_bounds_l1's lane -> column map and column pairs)
+    const int ja = min(max(jv, 0), w2 - 1);
+    const bool ok_e = lane <= BL1_COLS && jv <= w2 - 1;
+    const bool ok_o = lane <= BL1_COLS && jv >= 1 && 2 * jv - 1 <= w1 - 1;
+    const bool ok_any = ok_e || ok_o;
+    const bool edge = uniform((int)(__ballot(lane <= BL1_COLS && ok_e != ok_o) != 0ull)) != 0;
+    const bool left = jv <= 0, right = jv >= w2 - 1;
+    // the pair (even column, odd column): (L wa + C wb + R wc, L 4 + C 4)
+    bl1_v2f wL, wC, wR;
+    wL[0] = left ? 0.0f : 1.0f; wL[1] = 4.0f;
+    wC[0] = right ? 7.0f : 6.0f; wC[1] = 4.0f;
+    wR[0] = left ? 2.0f : (right ? 0.0f : 1.0f); wR[1] = 0.0f;
+    const double *p = cS + (size_t)u * h2 * w2 + ja;
+    auto row_ptr = [&](int i) __attribute__((always_inline)) { return p + (size_t)min(max(i, 0), h2 - 1) * w2; };
+    float t_mn = finf, t_mx = -finf;     // extrema of float(C_2) this lane met (lattice samples)
+    float am = 0.0f;                     // largest |C_2| this lane or its neighbours met (the margin)
+    double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
+    const int i_first = 4 * ty_first;
+    auto march = [&](auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        auto hvals = [&](double sd) __attribute__((always_inline)) -> bl1_v2f {
+            const float s = (float)sd;
+            const float L = bl1_rotf<0x13C>(s), R = bl1_rotf<0x134>(s);
+            bl1_v2f vL, vC, vR;
+            vL[0] = L; vL[1] = L; vC[0] = s; vC[1] = s; vR[0] = R; vR[1] = R;
+            bl1_v2f h = bl1_fma2(vR, wR, bl1_fma2(vL, wL, vC * wC));
+            if (EDGE) { h[1] = ok_o ? h[1] : h[0]; h[0] = ok_e ? h[0] : h[1]; }
+            t_mn = bl1_minf(t_mn, s); t_mx = bl1_maxf(t_mx, s);
+            am = bl1_max3(am, __builtin_fabsf(L), __builtin_fabsf(R)); am = bl1_maxf(am, __builtin_fabsf(s));
+            return h;
+        };
+        float amn = finf, amx = -finf, last_mn = finf, last_mx = -finf;
+        auto take = [&](bl1_v2f v) __attribute__((always_inline)) { amn = bl1_min3(amn, v[0], v[1]); amx = bl1_max3(amx, v[0], v[1]); };
+        const bool writer = lane < BL1_COLS && (lane & 15) == 15 && BL1_TILES * c + (lane >> 4) < ntx;
+        auto finalize = [&](int ty) __attribute__((always_inline)) {
+            float mn = ok_any ? amn : finf, mx = ok_any ? amx : -finf, m = am;
+            const float r_mn = bl1_rotf<0x134>(mn), r_mx = bl1_rotf<0x134>(mx), r_m = bl1_rotf<0x134>(m);
+            if ((lane & 15) == 15) { mn = bl1_minf(mn, r_mn); mx = bl1_maxf(mx, r_mx); m = bl1_maxf(m, r_m); }
+            RM_BL1_FOLD_MIN(mn, 1); RM_BL1_FOLD_MAX(mx, 1); RM_BL1_FOLD_MAX(m, 1);
+            RM_BL1_FOLD_MIN(mn, 2); RM_BL1_FOLD_MAX(mx, 2); RM_BL1_FOLD_MAX(m, 2);
+            RM_BL1_FOLD_MIN(mn, 4); RM_BL1_FOLD_MAX(mx, 4); RM_BL1_FOLD_MAX(m, 4);
+            RM_BL1_FOLD_MIN(mn, 8); RM_BL1_FOLD_MAX(mx, 8); RM_BL1_FOLD_MAX(m, 8);
+            if (writer) {
+                const double eps = (double)m * (1.0 / 1048576.0) + 0x1p-140;
+                const double dlo = (double)mn - eps, dhi = (double)mx + eps;
+                const size_t o = (size_t)u * ntiles + (size_t)ty * ntx + BL1_TILES * c + (lane >> 4);
+                lo[o] = dlo; hi[o] = dhi;
+                lo_mn = f64_min(lo_mn, dlo); lo_mx = f64_max(lo_mx, dlo);
+                hi_mn = f64_min(hi_mn, dhi); hi_mx = f64_max(hi_mx, dhi);
+            }
+        };
+        bl1_v2f hp, hc;
+        double q[BL1_PF];
+        {
+            const double s_p = *row_ptr(i_first - 1), s_c = *row_ptr(i_first);
+#pragma unroll
+            for (int k = 0; k < BL1_PF; ++k) q[k] = *row_ptr(i_first + 1 + k);
+            hp = hvals(s_p);
+            hc = hvals(s_c);
+        }
+        bool have_last = false;
+        if (ty_first > 0) {
+            const bl1_v2f v = (hp + hc) * (1.0f / 16);
+            last_mn = bl1_minf(v[0], v[1]); last_mx = bl1_maxf(v[0], v[1]);
+            have_last = true;
+        }
+        auto tile_row = [&](int ty, auto fast_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+            for (int k = 0; k < BL1_PF; ++k) {
+                const int i = 4 * ty + k;                       // (uniform)
+                if (!FAST && i > h2 - 1) break;
+                if (!FAST && ty > ty_last && k > 0) break;
+                bl1_v2f hn = hc;
+                if (FAST || i < h2 - 1) hn = hvals(q[k]);
+                q[k] = *row_ptr(i + 1 + BL1_PF);
+                if (!FAST && i == 0) hp = hn;
+                {   // level-1 row 2 i
+                    bl1_v2f six; six[0] = 6.0f; six[1] = 6.0f;
+                    const bl1_v2f v = (bl1_fma2(hc, six, hp) + hn) * (1.0f / 64);
+                    if (k == 0) {
+                        if (FAST || ty > ty_first) { take(v); finalize(ty - 1); }
+                        amn = bl1_minf(v[0], v[1]); amx = bl1_maxf(v[0], v[1]);
+                        if (FAST || have_last) { amn = bl1_minf(amn, last_mn); amx = bl1_maxf(amx, last_mx); }
+                    } else take(v);
+                }
+                if (FAST || (ty <= ty_last && 2 * i + 1 <= h1 - 1)) {   // level-1 row 2 i + 1
+                    const bl1_v2f v = (hc + hn) * (1.0f / 16);
+                    take(v);
+                    if (k == BL1_PF - 1) { last_mn = bl1_minf(v[0], v[1]); last_mx = bl1_maxf(v[0], v[1]); have_last = true; }
+                }
+                hp = hc; hc = hn;
+            }
+        };
+        for (int ty = ty_first; ty <= ty_last + 1; ++ty) {
+            if (ty > ty_first && ty <= ty_last && 4 * ty + 4 <= h2 - 1) tile_row(ty, std::true_type{});
+            else tile_row(ty, std::false_type{});
+            if (4 * ty > h2 - 1) break;
+        }
+        if (8 * (ty_last + 1) > h1 - 1) finalize(ty_last);
+    };
+    if (edge) march(std::true_type{}); else march(std::false_type{});
+    // lattice samples where this wave met its lowest / highest float(C_2)  (k_frame_bounds_l1)
+    double sm_mn = inf, sm_mx = -inf;
+    if (h2 >= 3 && w2 >= 3) {
+        const bool cnt = lane < BL1_COLS && jv <= w2 - 1;
+        const float w_mn = (float)wave_min(cnt ? (double)t_mn : inf), w_mx = (float)wave_max(cnt ? (double)t_mx : -inf);
+        const double *f = cS + (size_t)u * h2 * w2;
+        const int ia = max(i_first - 1, 0), ib = min(4 * ty_last + 5, h2 - 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float target = k ? w_mx : w_mn;
+            const unsigned long long who = __ballot(cnt && (k ? t_mx : t_mn) == target);
+            if (who == 0ull) continue;                                        // (uniform; a NaN extreme)
+            const int x = j0 + (int)__builtin_ctzll(who);
+            int y = -1;
+            for (int r0 = ia; r0 <= ib && y < 0; r0 += 64) {
+                const int r = r0 + lane;
+                const unsigned long long hit = __ballot(r <= ib && (float)f[(size_t)min(r, ib) * w2 + x] == target);
+                if (hit) y = r0 + (int)__builtin_ctzll(hit);
+            }
+            if (y < 0) continue;
+            const int ys = min(max(y, 1), h2 - 2), xs = min(max(x, 1), w2 - 2);
+            const double *r1 = f + (size_t)ys * w2;
+            const double v = lattice_sample(r1 - w2, r1, r1 + w2, xs, g.lat_a, g.lat_b);
+            sm_mn = f64_min(sm_mn, v); sm_mx = f64_max(sm_mx, v);
+        }
+    }
+    lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
+    if (lane == 0 && lo_mn <= lo_mx) {
+        const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
+        const int sp = (u + wid * 7) & (NSTRIPE - 1);
+        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        if (sm_mn <= sm_mx) {
+            const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
+            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
+            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+        }
+    }
+}
+
 }  // namespace rm

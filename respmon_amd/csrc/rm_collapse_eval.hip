@@ -169,8 +169,14 @@ int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, dou
             while (trb > 8 && (long long)Th * nchunks * ((g.tiles_y + trb - 1) / trb) < 1024) trb >>= 1;   // (small frames: 720p x 128 65 / 52 / 38 / 33 us with 2 / 4 / 8 / 16)
             if (ctx->dbg.bounds_l1_rows > 0) trb = ctx->dbg.bounds_l1_rows;
             const int nbands = (g.tiles_y + trb - 1) / trb;
-            hipLaunchKernelGGL(k_frame_bounds_l1<>, dim3(Th, (unsigned)((nchunks * nbands + 3) / 4)), dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt,
-                               nchunks, nbands, trb);
+            // (bounds_l1 2, the default: the level-1 values in packed float32, the bounds widened by what float32 can have lost; 1: in the
+            //  chain's own float64 operations -- the exact extrema)
+            if (ctx->dbg.bounds_l1 >= 2)
+                hipLaunchKernelGGL(k_frame_bounds_l1f<>, dim3(Th, (unsigned)((nchunks * nbands + 3) / 4)), dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt,
+                                   nchunks, nbands, trb);
+            else
+                hipLaunchKernelGGL(k_frame_bounds_l1<>, dim3(Th, (unsigned)((nchunks * nbands + 3) / 4)), dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt,
+                                   nchunks, nbands, trb);
         } else if (by_rows) {
             hipLaunchKernelGGL(k_frame_bounds_rows<8>, dim3(Th, (unsigned)((g.tiles_y + 31) / 32)), dim3(256), rowbufs, s, sl.cS, g, ntiles, cp.lo, cp.hi, st, cp.sel_cnt);
         } else if (tbl <= std::max(tbl_max, (size_t)64 * 1024) && ntiles < (1 << 24)) {

@@ -94,7 +94,7 @@ struct DebugKnobs {
     int dc_lds_front_end = 0;     // 1: narrow frame buffers through the LDS front end of k_down_chain instead of rm_down_chain_u8.h
     int no_fused_bounds = 0;      // 1: k_small_collapse + k_frame_bounds instead of k_small_collapse_bounds
     long long bounds_table_bytes = 0;   // > 0: LDS budget of k_frame_bounds' row-extrema table (forces small bands)
-    int bounds_l1 = 1;            // 0: skip 2 takes its tile bounds from the level-2 footprint (k_frame_bounds / k_frame_bounds_rows) instead of the level-1 footprint (rm_bounds_l1.h)
+    int bounds_l1 = 2;            // skip 2: tile bounds from the level-1 footprint (rm_bounds_l1.h) -- 2: formed in packed float32 and widened (default), 1: in float64 (the exact extrema); 0: from the level-2 footprint (k_frame_bounds / k_frame_bounds_rows)
     int bounds_l1_rows = 0;       // > 0: tile rows per wave of k_frame_bounds_l1 (default: 16, fewer on small frames)
     int xs = 0;                   // 1: dense selections go through the exception store (rm_xstore.h) instead of the store-less sum kernels (measured slower: DESIGN 7)
     int xs_waves = 0;             // 1 / 2 / 4: waves per tile of k_xs_sum (0: by the number of tiles)

@@ -977,7 +977,7 @@ def test_emu_level1_tile_bounds(emu, oracle):
         emu.debug_set("bounds_l1", 0)
         ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512)     # (512: one launch per level -- the separate bounds kernel runs)
         kept_l2 = emu.counters()[2]
-        emu.debug_set("bounds_l1", 1)
+        emu.debug_set("bounds_l1", 1)                                      # the level-1 values in the chain's own float64 operations: the exact extrema
         got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512)
         kept_l1 = emu.counters()[2]
         assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (T, H, W, L, S, trb)
@@ -989,6 +989,14 @@ def test_emu_level1_tile_bounds(emu, oracle):
         lo = emu.workspace("tile_lo", (Th, ntiles)); hi = emu.workspace("tile_hi", (Th, ntiles))
         want_lo, want_hi = _level1_footprint_extrema(oracle, c2, H, W)
         assert np.array_equal(lo, want_lo) and np.array_equal(hi, want_hi), (T, H, W, L, S, trb)
+        emu.debug_set("bounds_l1", 2)                                      # (the default) packed float32 + margin: SOUND, and within 2^-19 max|C_2| of the exact extrema
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512)
+        assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (T, H, W, L, S, trb, "float32 bounds")
+        assert emu.counters()[2] <= kept_l2
+        lo = emu.workspace("tile_lo", (Th, ntiles)); hi = emu.workspace("tile_hi", (Th, ntiles))
+        slack = np.abs(c2).max() * 2.0 ** -19 + 1e-40
+        assert (lo <= want_lo).all() and (hi >= want_hi).all(), (T, H, W, "float32 bounds must contain the exact extrema")
+        assert (lo >= want_lo - slack).all() and (hi <= want_hi + slack).all(), (T, H, W, "float32 bounds too loose")
         exhaustive, mm3 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=512 | 1)
         assert np.array_equal(got, exhaustive) and tuple(mm) == tuple(mm3), (T, H, W, "no prune")
         for f in (128, 256):                      # the store-less and the store-based sum on the new bounds
@@ -999,7 +1007,7 @@ def test_emu_level1_tile_bounds(emu, oracle):
         emu.debug_set("dense_t_low", -1)
         assert np.array_equal(alt, ref) and tuple(mm) == tuple(mm4), (T, H, W, "k_dense_sum_t")
     emu.debug_set("bounds_l1_rows", 0)
-    emu.debug_set("bounds_l1", 1)
+    emu.debug_set("bounds_l1", 2)
 
 
 def test_emu_labelling_rule_counts_not_clocks(emu, oracle):

@@ -1029,7 +1029,7 @@ def test_streaming_tile_bounds_equal_table_form(hip):
         assert torch.equal(got, ref) and mm == mm2, (T, H, W, L, S)
         exhaustive = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 1)
         assert torch.equal(got, exhaustive), (T, H, W, L, S, "no prune")
-        device.debug_set("bounds_l1", 1)
+        device.debug_set("bounds_l1", 2)
 
 
 def test_level1_tile_bounds(hip, oracle):
@@ -1062,6 +1062,11 @@ def test_level1_tile_bounds(hip, oracle):
         nty, ntx = (H + 15) // 16, (W + 63) // 64
         c2 = device.debug_workspace("cS", (Th, h2, w2))
         lo = device.debug_workspace("tile_lo", (Th, nty, ntx)); hi = device.debug_workspace("tile_hi", (Th, nty, ntx))
+        device.debug_set("bounds_l1", 2)         # (the default) packed float32 + margin
+        got2 = dist.hip_calibrate(buf, 10, **kw)
+        assert torch.equal(got2, ref) and device.debug_counters()[2] <= kept_l2, (T, H, W, "float32 bounds")
+        lo32 = device.debug_workspace("tile_lo", (Th, nty, ntx)); hi32 = device.debug_workspace("tile_hi", (Th, nty, ntx))
+        slack = np.abs(c2).max() * 2.0 ** -19 + 1e-40
         for u in range(Th):
             l1 = oracle.pyrUp(c2[u], (w1, h1))
             for ty in range(nty):
@@ -1070,6 +1075,7 @@ def test_level1_tile_bounds(hip, oracle):
                 for tx in range(ntx):
                     f = rows[:, max(32 * tx - 1, 0): min(32 * tx + 32, w1 - 1) + 1]
                     assert lo[u, ty, tx] == f.min() and hi[u, ty, tx] == f.max(), (T, H, W, u, ty, tx)
+                    assert f.min() - slack <= lo32[u, ty, tx] <= f.min() and f.max() <= hi32[u, ty, tx] <= f.max() + slack, (T, H, W, u, ty, tx, "float32")
         exhaustive = dist.hip_calibrate(buf, 10, pyramid_levels=L, skip_levels_at_top=S, flags=512 | 1)
         assert torch.equal(got, exhaustive), (T, H, W, "no prune")
         for f in (128, 256):
@@ -1080,6 +1086,7 @@ def test_level1_tile_bounds(hip, oracle):
         device.debug_set("dense_t_low", -1)
         assert torch.equal(alt, ref), (T, H, W, "k_dense_sum_t")
     device.debug_set("bounds_l1_rows", 0)
+    device.debug_set("bounds_l1", 2)
     # (c) speckle at the scale of one level-2 pixel over a smooth breathing signal: the level-2 footprint bound keeps (nearly) every
     # pair, the level-1 bound far fewer -- and the ROI is the oracle's
     from respmon_amd import synth
@@ -1090,7 +1097,7 @@ def test_level1_tile_bounds(hip, oracle):
     device.debug_set("bounds_l1", 0)
     dist.hip_calibrate(buf, 10, pyramid_levels=4, skip_levels_at_top=2, flags=512)
     kept_l2 = device.debug_counters()[2]
-    device.debug_set("bounds_l1", 1)
+    device.debug_set("bounds_l1", 2)
     dist.hip_calibrate(buf, 10, pyramid_levels=4, skip_levels_at_top=2, flags=512)
     pairs, _, kept_l1, _ = device.debug_counters()
     assert kept_l1 <= kept_l2, (kept_l1, kept_l2, pairs)
