@@ -838,6 +838,7 @@ __global__ __launch_bounds__(64) RM_WAVES_PER_EU_IF(S <= 2, 4, 3) void k_dense_s
     auto fetch = [&](double (&dst)[F::PF], int i) __attribute__((always_inline)) {
         if (i >= nlist) return;   // (uniform)
         const int t = uniform((int)s_list[i]);
+        if (l1_stop) { const int u = sym_frame(t, T); if (!((s_mask[u >> 6] >> (u & 63)) & 1ull)) return; }   // (uniform) its first visit stopped at level 1: nothing to fetch
         const double *src = cS + (size_t)sym_frame(t, T) * fs;
 #pragma unroll
         for (int p = 0; p < F::PF; ++p) dst[p] = src[ts.off_g[p]];
