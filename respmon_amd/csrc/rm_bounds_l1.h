@@ -461,4 +461,69 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1f(const double *cS, Chain
     }
 }
 
+// ---- skip 3 / 4: the bounds of a DENSE stream refined one level down (round 6) -------------------------------------------------------------
+// At skip >= 3 the tile bounds come from the level-S footprint inside the per-frame kernel that builds the small pyramid
+// (k_small_filter_first): the 1080p headline stream keeps 1 % of its pairs with them and nothing more is needed.  Sensor noise in every
+// pixel is another matter -- CPU study with the oracle, 1080p, skip 4 (tools/r06_l1_study.py noise): 8.3 % of the pairs hold a value
+// below `top`; the level-4 footprint bound keeps 56.7 %, the level-3 bound 17.5 %, level 2 11.6 %, level 1 9.3 %.  One pyrUp step
+// does most of it, as at skip 2.  This kernel overwrites lo / hi with the extrema of the level-(S - 1) footprint -- a thread per
+// (tile, unique frame): the tile's level-S block (4 x 7 values at skip 4, 5 x 11 at skip 3) into registers, the level-(S - 1) values
+// column by column (up_at()'s expressions: horizontal 3-tap with make_htap()'s weights, then the even / odd row forms), extrema on the
+// fly; every index compile-time.  The level is small (8 MB at 1080p x 256): ~10 us -- too much for the headline path, so rm_locate asks
+// for it only behind a call that kept many pairs (rm_collapse_eval.hip, ctx->refine_hint).  The extrema of the bounds in the state stay
+// those of the level-S bounds (looser, still valid).
+template <int S>
+__global__ __launch_bounds__(256) void k_bounds_up1(const double *cS, ChainGeom g, int ntiles, double *lo, double *hi)
+{
+    static_assert(S == 3 || S == 4, "skip 3 / 4 (skip 2 has the streaming kernels above)");
+    using F = TileFoot<S, false>;
+    constexpr int K = S - 1;
+    constexpr int NRD = F::nr(K), NCD = F::nc(K);   // the footprint at level S - 1: 5 x 11 (skip 4), 7 x 19 (skip 3)
+    constexpr int NRS = F::nr(S), NCS = F::nc(S);   // the level-S block it is formed from: 4 x 7, 5 x 11
+    static_assert(NCS >= (NCD - 1) / 2 + 2 && NRS >= (NRD - 1) / 2 + 2, "the block holds every tap");
+    const int u = blockIdx.y;
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= ntiles) return;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const int hs = g.h[S], ws = g.w[S], hd = g.h[K], wd = g.w[K];
+    const int Y = (16 * ty) >> S, X = (64 * tx) >> S;   // the block starts at virtual (Y - 1, X - 1), the footprint at (2 Y - 1, 2 X - 1)
+    const double *src = cS + (size_t)u * hs * ws;
+    double s[NRS][NCS];
+#pragma unroll
+    for (int r = 0; r < NRS; ++r) {
+        const int yv = Y - 1 + r;
+        const int ya = yv < 0 ? min(1, hs - 1) : min(yv, hs - 1);     // pyrUp's rows: -1 := 1, past the bottom the last one again (up_at()'s r0 / r2)
+#pragma unroll
+        for (int c = 0; c < NCS; ++c) s[r][c] = src[(size_t)ya * ws + min(max(X - 1 + c, 0), ws - 1)];
+    }
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+#pragma unroll
+    for (int c = 0; c < NCD; ++c) {
+        const int xv = 2 * X - 1 + c;                 // level-(S - 1) column; odd for even c
+        if (xv < 0 || xv > wd - 1) continue;
+        // horizontal values of the block's rows at this column (make_htap()'s shapes; the clamped loads supply the repeated column)
+        double h[NRS];
+        if ((c & 1) == 0) {                           // odd column: (s[j] + s[j + 1]) * 4, j = X - 1 + c / 2
+#pragma unroll
+            for (int r = 0; r < NRS; ++r) h[r] = __builtin_fma(s[r][c / 2 + 1], 4.0, s[r][c / 2] * 4.0);
+        } else {                                      // even column: taps j - 1, j, j + 1, j = X + (c - 1) / 2
+            const int j = X + (c - 1) / 2;
+            const bool left = j == 0, right = j == ws - 1;
+            const double wa = left ? 0.0 : 1.0, wb = right ? 7.0 : 6.0, wc = left ? 2.0 : (right ? 0.0 : 1.0);
+#pragma unroll
+            for (int r = 0; r < NRS; ++r) h[r] = dw_tap3(s[r][(c - 1) / 2], s[r][(c - 1) / 2 + 1], s[r][(c - 1) / 2 + 2], wa, wb, wc);
+        }
+#pragma unroll
+        for (int p = 0; p < NRD; ++p) {
+            const int yv = 2 * Y - 1 + p;             // level-(S - 1) row; odd for even p
+            if (yv < 0 || yv > hd - 1) continue;
+            const double v = (p & 1) ? (h[(p - 1) / 2] + h[(p - 1) / 2 + 1] * 6 + h[(p - 1) / 2 + 2]) * (1.0 / 64)
+                                     : (h[p / 2] + h[p / 2 + 1]) * (1.0 / 16);
+            mn = (v < mn) ? v : mn; mx = (v > mx) ? v : mx;
+        }
+    }
+    const size_t o = (size_t)u * ntiles + tile;
+    lo[o] = mn; hi[o] = mx;
+}
+
 }  // namespace rm

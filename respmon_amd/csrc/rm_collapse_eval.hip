@@ -187,6 +187,13 @@ int collapse_eval(rm_ctx *ctx, const SmallLevels &sl, int T, int t0, int t1, dou
         }
         LAUNCH_CHECK();
     }
+    // skip 3 / 4 behind a call that kept many pairs (a stream of noise): the bounds once more, from the level-(S - 1) footprint
+    if ((sl.S == 3 || sl.S == 4) && tile_eval_ok(g) && !no_prune && (ctx->dbg.bounds_up1 == 1 || (ctx->dbg.bounds_up1 < 0 && ctx->refine_hint))) {
+        const dim3 rgrid((unsigned)((ntiles + 255) / 256), (unsigned)Th);
+        if (sl.S == 4) hipLaunchKernelGGL(k_bounds_up1<4>, rgrid, dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi);
+        else hipLaunchKernelGGL(k_bounds_up1<3>, rgrid, dim3(256), 0, s, sl.cS, g, ntiles, cp.lo, cp.hi);
+        LAUNCH_CHECK();
+    }
     const int prune_ok = (!no_prune && thr >= 0.0 && thr <= 1.0) ? 1 : 0;
     hipLaunchKernelGGL(k_select_pairs<>, dim3((ntiles + SEL_TILES - 1) / SEL_TILES, (Th + SEL_PH * SEL_U - 1) / (SEL_PH * SEL_U)), dim3(256), 0, s,
                        cp.lo, cp.hi, ntiles, Th, T, t0, t1, st, cp.list_a, cp.list_b, cp.slot_of, prune_ok ? 0 : 1, thr, cp.sel_cnt, cp.heavy, cp.xs_tab);

@@ -134,8 +134,8 @@ int collapse_sum(rm_ctx *ctx, const CollapsePlan &cp, double thr, double *heat_s
     const bool may_dense = sp.mode == 1 || auto_dense || (overflow_only && (!host_rescue || ctx->dense_hint));
     if (overflow_only && host_rescue) {
         RoiSlot &rs = ctx->slots[ctx->cur_slot];
-        if (!rs.h_unserved) HIP_TRY(hipHostMalloc((void **)&rs.h_unserved, sizeof(int), hipHostMallocDefault));
-        *rs.h_unserved = 0;
+        if (!rs.h_unserved) HIP_TRY(hipHostMalloc((void **)&rs.h_unserved, 2 * sizeof(int), hipHostMallocDefault));   // [0]: the word above; [1]: pairs the selection kept
+        rs.h_unserved[0] = 0; rs.h_unserved[1] = 0;
         HIP_TRY(hipHostGetDevicePointer((void **)&unserved_dev, rs.h_unserved, 0));
     }
     if (may_sparse) {

@@ -113,6 +113,7 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "bounds_table_bytes") d.bounds_table_bytes = value;
     else if (k == "bounds_scalar") d.bounds_scalar = (int)value;
     else if (k == "bounds_l1") d.bounds_l1 = (int)value;
+    else if (k == "bounds_up1") d.bounds_up1 = (int)value;
     else if (k == "dense_wf_list") d.dense_wf_list = (int)value;
     else if (k == "xs") d.xs = (int)value;
     else if (k == "xs_waves") d.xs_waves = (int)value;

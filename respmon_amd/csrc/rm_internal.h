@@ -100,6 +100,7 @@ struct DebugKnobs {
     int xs_waves = 0;             // 1 / 2 / 4: waves per tile of k_xs_sum (0: by the number of tiles)
     long long xs_budget_words = 0;   // > 0: capacity of the exception store in 8-byte words (default: the worst case of the geometry, at most 1 GiB)
     int dense_wf_list = 1;        // 0: k_dense_sum_wf evaluates every frame of a tile (no kept list from slot_of / lo)
+    int bounds_up1 = -1;          // skip 3 / 4: bounds refined from the level-(S - 1) footprint (k_bounds_up1): 1 always, 0 never, -1 behind a call that kept many pairs (ctx->refine_hint)
     int bounds_scalar = 0;        // 1: k_frame_bounds (a thread per row and tile column) also for wide levels instead of k_frame_bounds_rows
     int dense_rows = 0;           // 16 / 32 / 64: super-tile rows of the dense sum kernel
     int dense_general = 0;        // 1: k_dense_sum instead of the table-driven k_dense_sum_s2 at skip <= 2
@@ -196,6 +197,7 @@ struct rm_ctx {
     int *h_flag = nullptr;          // pinned: {overflow flag, largest per-rank tile count} of the sparse heatmap merge
     void *comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator (rm_comm_init); none: one rank
     ExchangeState xp_streams, xp_sharded;
+    int refine_hint = 0;            // the last rm_locate of this context kept many pairs at skip >= 3: the next one refines its bounds one level down (rm_bounds_l1.h k_bounds_up1)
     int dense_hint = 0;             // the last rm_locate of this context met a dense selection (more than a quarter of the pairs kept)
     long long store_hint_slots = 0; // slots a selection of this context needed when it overflowed the value store (rm_locate grows the store to it)
     // measurement hook (rm_profile_*)

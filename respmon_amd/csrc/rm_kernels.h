@@ -1993,6 +1993,7 @@ RM_KERNEL __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int
     int slot0 = SLOT_PRUNED;
     if (t_first + tid < t_end) slot0 = slot_of[slot_index(sym_frame(t_first + tid, T), tile0, sym_frames(T))];
     const int nitems = (int)st->n_heavy * MS_Q;
+    if (unserved_host && blockIdx.x == 0 && threadIdx.x == 0) unserved_host[1] = (int)st->n_slots;   // (pinned: how many pairs this call's selection kept -- rm_locate's refine_hint)
     if (sum_is_dense(st, sp)) {   // (uniform over the grid: k_dense_sum takes the sum)
         // unserved_host (pinned, nullable): no dense kernel follows on the stream -- the caller synchronises anyway and enqueues it
         // itself when it finds this word set (rm_locate: the rare value-store overflow costs the common case no launch)

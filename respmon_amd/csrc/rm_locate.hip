@@ -25,6 +25,10 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     int rc = heatmap_to_roi_impl(ctx, heat, H, W, threshold, xywh, nullptr, nullptr, stream, true);
     const int unserved_word = rs.h_unserved ? *rs.h_unserved : 0;   // 1: the sparse kernel stood down and nothing took the sum; 2: the stand-in did
     const bool unserved = unserved_word == 1;
+    // how many pairs did this call's selection keep (skip >= 3 with a capped value store: the sparse sum kernel leaves the count beside the
+    // word)?  Many: the next call of the context refines its bounds one level down before it selects (k_bounds_up1: ~10 us that the
+    // headline stream -- 2 600 pairs -- must not pay); on until a REFINED selection keeps few
+    if (rs.h_unserved && cp.valid && cp.S >= 3) ctx->refine_hint = rs.h_unserved[1] > (ctx->refine_hint ? 2048 : 8192) ? 1 : 0;
     if (rs.h_unserved) *rs.h_unserved = 0;
     if (ctx->dense_hint && unserved_word != 2) ctx->dense_hint = 0;   // (the stand-in enqueued on the hint was not needed: back to the plain path)
     if (rc >= 0 && cp.valid && unserved) {

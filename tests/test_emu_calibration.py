@@ -1074,3 +1074,38 @@ def test_emu_exception_store(emu, oracle):
         a = emu.locate_sharded(v, world, levels=4, skip=2, flags=256)
         b = emu.locate_sharded(v, world, levels=4, skip=2, flags=128)
         assert a[0] == b[0] and np.array_equal(a[1], b[1]), world
+
+
+def test_emu_bounds_refined_one_level_down(emu, oracle):
+    """rm_bounds_l1.h k_bounds_up1 (round 6): at skip 3 / 4 the tile bounds of a dense stream are taken once more from the
+    level-(S - 1) footprint.  The refined bounds lie inside the level-S bounds, still contain every full-resolution value of their
+    pair (checked against the materialised raw video), keep no more pairs, and change no bit of the heatmap -- ragged shapes, both
+    skips, the store-less and the store-based sum."""
+    rng = np.random.default_rng(131)
+    for (T, H, W, L, S) in [(4, 67, 131, 5, 3), (5, 100, 160, 6, 4), (3, 48, 200, 6, 4), (4, 33, 70, 5, 3), (6, 135, 240, 7, 4)]:
+        v = rng.random((T, H, W))
+        v[:, : H // 2] *= 0.1
+        emu.debug_set("bounds_up1", 0)
+        ref, mm = emu.calibrate(v, 10.0, levels=L, skip=S)
+        kept0 = emu.counters()[2]
+        Th = T // 2 + 1
+        nty, ntx = (H + 15) // 16, (W + 63) // 64
+        lo0 = emu.workspace("tile_lo", (Th, nty, ntx)); hi0 = emu.workspace("tile_hi", (Th, nty, ntx))
+        emu.debug_set("bounds_up1", 1)
+        got, mm2 = emu.calibrate(v, 10.0, levels=L, skip=S)
+        kept1 = emu.counters()[2]
+        lo1 = emu.workspace("tile_lo", (Th, nty, ntx)); hi1 = emu.workspace("tile_hi", (Th, nty, ntx))
+        assert np.array_equal(got, ref) and tuple(mm) == tuple(mm2), (T, H, W, L, S)
+        assert kept1 <= kept0, (T, H, W, kept1, kept0)
+        tol = 1e-12 * max(abs(mm[0]), abs(mm[1]))
+        assert (lo1 >= lo0 - tol).all() and (hi1 <= hi0 + tol).all(), (T, H, W, "refined bounds must lie inside the level-S bounds")
+        _, raw, _ = emu.eulerian(v, 10.0, 0.1, 1.0, 500.0, L, S)
+        for u in range(Th):
+            for ty in range(nty):
+                for tx in range(ntx):
+                    blk = raw[u, 16 * ty: 16 * ty + 16, 64 * tx: 64 * tx + 64]
+                    assert lo1[u, ty, tx] - tol <= blk.min() and blk.max() <= hi1[u, ty, tx] + tol, (T, H, W, u, ty, tx)
+        for f in (128, 256, 1):
+            alt, mm3 = emu.calibrate(v, 10.0, levels=L, skip=S, flags=f)
+            assert np.array_equal(alt, ref) and tuple(mm) == tuple(mm3), (T, H, W, f)
+    emu.debug_set("bounds_up1", -1)

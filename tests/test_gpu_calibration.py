@@ -832,6 +832,44 @@ def test_exception_store_few_and_many_exceptions(hip, oracle):
     device.debug_set("xs_budget_words", 0)
 
 
+def test_bounds_refined_one_level_down_behind_a_dense_selection(hip, oracle):
+    """rm_bounds_l1.h k_bounds_up1 (round 6): skip 3 / 4 bounds from the level-(S - 1) footprint.  Forced on: the heatmap does not
+    change by a bit and the selection keeps no more pairs (ragged shapes, both skips).  Automatic: on a stream of sensor noise the
+    first locate() keeps most pairs; the next calls of the context refine their bounds first, keep far fewer, and return the same
+    ROI -- the oracle's; the headline stream (few pairs kept) never pays for the refinement."""
+    import torch
+    from respmon_amd import device, dist, synth
+    from respmon_amd.base import RespiratoryMonitor
+    rng = np.random.default_rng(131)
+    for (T, H, W, L, S) in [(4, 67, 131, 5, 3), (5, 270, 480, 7, 4), (6, 540, 1936, 8, 4), (3, 300, 2000, 6, 3)]:
+        v = rng.random((T, H, W)); v[:, : H // 2] *= 0.1
+        buf = torch.from_numpy(v).cuda()
+        kw = dict(pyramid_levels=L, skip_levels_at_top=S)
+        device.debug_set("bounds_up1", 0)
+        ref = dist.hip_calibrate(buf, 10, **kw); kept0 = device.debug_counters()[2]
+        device.debug_set("bounds_up1", 1)
+        got = dist.hip_calibrate(buf, 10, **kw); kept1 = device.debug_counters()[2]
+        assert torch.equal(got, ref) and kept1 <= kept0, (T, H, W, L, S, kept1, kept0)
+        for f in (128, 256):
+            assert torch.equal(dist.hip_calibrate(buf, 10, flags=f, **kw), ref), (T, H, W, f)
+    device.debug_set("bounds_up1", -1)
+    v8 = synth.synth_noise_only(64, 1080, 1920)
+    buf = torch.from_numpy(v8).cuda()
+    rois, kept = [], []
+    for k in range(4):
+        rois.append(RespiratoryMonitor.locate(buf, 10))
+        kept.append(device.debug_counters()[2])
+    assert len(set(rois)) == 1, rois
+    assert kept[1] < 0.7 * kept[0] and kept[2] == kept[1] == kept[3], kept      # the hint: refined from the second call on, and stable
+    frames = oracle.uint8_to_float(v8)
+    assert rois[0] == oracle.locate(frames, 10)
+    buf = torch.from_numpy(synth.synth_breathing(64, 1080, 1920, seed=1234)).cuda()
+    k0 = []
+    for k in range(3):
+        RespiratoryMonitor.locate(buf, 10); k0.append(device.debug_counters()[2])
+    assert k0[1] == k0[2] and max(k0) < 8192, k0       # (a sparse stream after a dense one: one refined call at most, then the plain path)
+
+
 def test_fused_collapse_equals_store_path(hip, oracle):
     """rm_tile_eval.h against the selection / value-store path (flags=256), bit for bit: skip 1..4, every frame dtype, ragged sizes,
     whole-tile and half-tile work items, exhaustive evaluation; plus the oracle's ROI on a breathing video."""

@@ -4,6 +4,46 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import respmon_oracle as o
 from respmon_amd import synth
+NOISE = r"""
+T,H,W,L,S = 64,1080,1920,9,4
+v8 = synth.synth_noise_only(T,H,W)
+frames = o.uint8_to_float(v8)
+pyr = o.create_laplacian_video_pyramid(frames, L)
+bp = [np.zeros(p.shape) for p in pyr]
+for i in range(S, L-1):
+    bp[i] = o.temporal_bandpass_filter_fft(pyr[i], 10, 0.1, 1.0, amplification_factor=500)
+# collapse down to level S
+sizes = [(p.shape[2], p.shape[1]) for p in pyr]
+C = bp[L-1]
+lv = {}
+cur = bp[L-1]
+for l in range(L-2, -1, -1):
+    cur = np.stack([o.pyrUp(cur[t], sizes[l]) for t in range(T)]) + bp[l]
+    lv[l] = cur
+raw = lv[0]
+mn, mx = raw.min(), raw.max(); top = mx-(mx-mn)*0.7
+print("min max top", mn, mx, top)
+ty, tx = (H+15)//16, W//64
+Hc = H//16*16
+ex = (raw[:, :Hc] < top).reshape(T, Hc//16, 16, tx, 64).any(axis=(2,4))
+print("pairs with a value below top", ex.mean())
+def foot(a, k, nr, nc):
+    # rows (16ty>>k)-1 .. +nr-1, cols (64tx>>k)-1 .. +nc-1, clipped
+    T_,h,w = a.shape
+    out = np.full((T_, Hc//16, tx), np.inf)
+    for iy in range(Hc//16):
+        y0 = max(((16*iy)>>k)-1, 0); y1 = min(((16*iy)>>k)-1+nr-1, h-1)
+        for ix in range(tx):
+            x0 = max(((64*ix)>>k)-1, 0); x1 = min(((64*ix)>>k)-1+nc-1, w-1)
+            out[:,iy,ix] = a[:, y0:y1+1, x0:x1+1].min(axis=(1,2))
+    return out
+for k, nr, nc in ((4,4,7),(3,5,11),(2,7,19),(1,10,34)):
+    m = foot(lv[k], k, nr, nc)
+    print("level-%d footprint bound keeps" % k, (m < top).mean())
+"""
+if len(sys.argv) > 1 and sys.argv[1] == "noise":   # 1080p, skip 4, sensor noise in every pixel: what the level-k footprint bounds keep (k_bounds_up1)
+    exec(NOISE)
+    sys.exit(0)
 T,H,W,L,S = 128,720,1280,4,2
 v8 = synth.synth_breathing(T,H,W,seed=1234)
 frames = o.uint8_to_float(v8)
