@@ -4,6 +4,12 @@
 
 using namespace rm;
 
+// kept pairs of a call at skip >= 3 beyond which the next call refines its bounds first (k_bounds_up1, ~13 us at 1080p x 256), and below
+// which a refined call turns that off again.  On = what the value store starts with (16 384 slots): a selection that overflows it goes to the
+// store-less sum, whose time is the number of kept pairs.  The streams the sparse path serves lose by the refinement (measured, same
+// process, on / off: sixteen blobs -- 5 100 pairs -- 0.966 / 0.960 ms, four blobs + noise 0.919 / 0.908; headline, 2 600 pairs: never on).
+constexpr int REFINE_ON_PAIRS = 16384, REFINE_OFF_PAIRS = 8192;
+
 extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int H, int W, double fps, double fmin, double fmax,
                          double amp, int levels, int skip, double temporal_thr, int threshold, unsigned flags, int32_t *xywh,
                          void *stream)
@@ -28,7 +34,7 @@ extern "C" int rm_locate(rm_ctx *ctx, const void *frames, int dtype, int T, int 
     // how many pairs did this call's selection keep (skip >= 3 with a capped value store: the sparse sum kernel leaves the count beside the
     // word)?  Many: the next call of the context refines its bounds one level down before it selects (k_bounds_up1: ~10 us that the
     // headline stream -- 2 600 pairs -- must not pay); on until a REFINED selection keeps few
-    if (rs.h_unserved && cp.valid && cp.S >= 3) ctx->refine_hint = rs.h_unserved[1] > (ctx->refine_hint ? 2048 : 8192) ? 1 : 0;
+    if (rs.h_unserved && cp.valid && cp.S >= 3) ctx->refine_hint = rs.h_unserved[1] > (ctx->refine_hint ? REFINE_OFF_PAIRS : REFINE_ON_PAIRS) ? 1 : 0;
     if (rs.h_unserved) *rs.h_unserved = 0;
     if (ctx->dense_hint && unserved_word != 2) ctx->dense_hint = 0;   // (the stand-in enqueued on the hint was not needed: back to the plain path)
     if (rc >= 0 && cp.valid && unserved) {
