@@ -1147,8 +1147,8 @@ def test_value_store_grows_with_the_selection(hip, oracle):
     """rm_locate on streams that keep more pairs than the value store starts with.  (a) A moderately dense selection (a breathing video
     against a store of 64 slots): the first call finds the store overflowed after its host synchronisation, allocates one that holds
     the selection and runs evaluation + sum again; later calls go straight through the grown store.  (b) A dense selection (noise:
-    every pair kept): the store-less sum (k_dense_sum_t) takes over, from the second call on enqueued without waiting for the host.
-    Same ROI as the path with a slot per pair (flags=256) every time."""
+    every pair kept): the store-less sum (k_dense_sum_t) takes over; the following calls refine their bounds first (round 6) and take whichever
+    path their smaller selection needs -- the same one every time.  Same ROI as the path with a slot per pair (flags=256) every time."""
     import ctypes
     import torch
     from respmon_amd import _capi, device, dist, synth
@@ -1176,14 +1176,23 @@ def test_value_store_grows_with_the_selection(hip, oracle):
         _capi.check(hip, hip.rm_ctx_create(torch.cuda.current_device(), ctypes.byref(fresh)), "rm_ctx_create")
         if case == "grow":
             _capi.check(hip, hip.rm_debug_set(fresh, b"store_default_slots", 64), "rm_debug_set")
-        for call in range(3):
+        for call in range(4):
             roi = run(fresh, buf, L, S)
             assert roi == ref, (case, call, roi, ref)
             if case == "grow":
                 assert 64 < dbg[2] and dbg[2] * 4 <= dbg[0]                        # more than the starting store, not a dense selection
                 assert dbg[3] >= dbg[2], "the store must hold the selection (grown inside the first call)"
-            else:
+            elif call == 0:
                 assert dbg[2] > 16384 and dbg[3] == 0                              # dense: no store in use
+                kept_first = dbg[2]
+            else:
+                # round 6: behind a call that kept that many pairs the bounds are refined one level down first (k_bounds_up1): fewer pairs --
+                # through the store if they fit it now, store-less otherwise; the same on every later call (no flip-flop between the two)
+                assert dbg[2] < kept_first and (dbg[3] == 0 or dbg[3] >= dbg[2]), (call, dbg[2], dbg[3], kept_first)
+                if call == 1:
+                    second = (dbg[2], dbg[3] == 0)
+                else:
+                    assert (dbg[2], dbg[3] == 0) == second, (call, dbg[2], dbg[3], second)
         _capi.check(hip, hip.rm_ctx_destroy(fresh), "rm_ctx_destroy")
 
 
