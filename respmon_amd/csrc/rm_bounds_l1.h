@@ -76,8 +76,10 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainG
     const double wa = left ? 0.0 : 1.0, wb = right ? 7.0 : 6.0, wc = left ? 2.0 : (right ? 0.0 : 1.0);
     const double *p = cS + (size_t)u * h2 * w2 + ja;
     auto row_ptr = [&](int i) __attribute__((always_inline)) { return p + (size_t)min(max(i, 0), h2 - 1) * w2; };
-    // extrema of C_2 this lane met (the rows are looked up once, at the end: lattice samples)
-    double t_mn = inf, t_mx = -inf;
+    // extrema of C_2 this lane met, and the tile row whose close saw each of them move last (the rows are looked up once, at the end,
+    // among the nine level-2 rows that close covers: lattice samples)
+    double t_mn = inf, t_mx = -inf, seen_mn = inf, seen_mx = -inf;
+    int ty_mn = 0, ty_mx = 0;
     // extrema over the pairs this wave writes (lanes 15, 31, 47 only)
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
     // (EDGE: a lane of this wave owns only one column of its pair -- the image's left / right edge; the other waves run without the selects)
@@ -100,6 +102,9 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainG
         };
         const bool writer = lane < BL1_COLS && (lane & 15) == 15 && BL1_TILES * c + (lane >> 4) < ntx;
         auto finalize = [&](int ty) __attribute__((always_inline)) {
+            // (rows consumed since the previous close: 4 ty + 2 .. 4 ty + 5; the band's first close starts at 4 ty - 1)
+            if (t_mn < seen_mn) { seen_mn = t_mn; ty_mn = ty; }
+            if (t_mx > seen_mx) { seen_mx = t_mx; ty_mx = ty; }
             double mn = ok_any ? amn : inf, mx = ok_any ? amx : -inf;
             // the pair of the lane to the right closes a tile's footprint (and opens the next tile's)
             const double r_mn = bl1_rot<0x134>(mn), r_mx = bl1_rot<0x134>(mx);
@@ -187,14 +192,12 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainG
             const double target = k ? w_mx : w_mn;
             const unsigned long long who = __ballot(cnt && (k ? t_mx : t_mn) == target);
             if (who == 0ull) continue;                                        // (uniform; a NaN extreme)
-            const int x = j0 + (int)__builtin_ctzll(who);
-            int y = -1;
-            for (int r0 = ia; r0 <= ib && y < 0; r0 += 64) {
-                const int r = r0 + lane;
-                const unsigned long long hit = __ballot(r <= ib && f[(size_t)min(r, ib) * w2 + x] == target);
-                if (hit) y = r0 + (int)__builtin_ctzll(hit);
-            }
-            if (y < 0) continue;
+            const int src = (int)__builtin_ctzll(who), x = j0 + src;
+            const int tyw = __builtin_amdgcn_readlane(k ? ty_mx : ty_mn, src);
+            const int ra = max(4 * tyw - 3, ia), rb = min(4 * tyw + 5, ib), r = ra + lane;   // (nine rows, one per lane)
+            const unsigned long long hit = __ballot(r <= rb && f[(size_t)min(r, rb) * w2 + x] == target);
+            if (hit == 0ull) continue;
+            const int y = ra + (int)__builtin_ctzll(hit);
             const int ys = min(max(y, 1), h2 - 2), xs = min(max(x, 1), w2 - 2);
             const double *r1 = f + (size_t)ys * w2;
             const double v = lattice_sample(r1 - w2, r1, r1 + w2, xs, g.lat_a, g.lat_b);
@@ -331,8 +334,8 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1f(const double *cS, Chain
     wR[0] = left ? 2.0f : (right ? 0.0f : 1.0f); wR[1] = 0.0f;
     const double *p = cS + (size_t)u * h2 * w2 + ja;
     auto row_ptr = [&](int i) __attribute__((always_inline)) { return p + (size_t)min(max(i, 0), h2 - 1) * w2; };
-    float t_mn = finf, t_mx = -finf;     // extrema of float(C_2) this lane met (lattice samples)
-    float am = 0.0f;                     // largest |C_2| this lane or its neighbours met (the margin)
+    float t_mn = finf, t_mx = -finf, seen_mn = finf, seen_mx = -finf;     // extrema of float(C_2) this lane met (lattice samples)
+    int ty_mn = 0, ty_mx = 0;                                              // ... and the tile row whose close saw them move last
     double lo_mn = inf, lo_mx = -inf, hi_mn = inf, hi_mx = -inf;
     const int i_first = 4 * ty_first;
     auto march = [&](auto edge_tag) __attribute__((always_inline)) {
@@ -345,14 +348,19 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1f(const double *cS, Chain
             bl1_v2f h = bl1_fma2(vR, wR, bl1_fma2(vL, wL, vC * wC));
             if (EDGE) { h[1] = ok_o ? h[1] : h[0]; h[0] = ok_e ? h[0] : h[1]; }
             t_mn = bl1_minf(t_mn, s); t_mx = bl1_maxf(t_mx, s);
-            am = bl1_max3(am, __builtin_fabsf(L), __builtin_fabsf(R)); am = bl1_maxf(am, __builtin_fabsf(s));
             return h;
         };
         float amn = finf, amx = -finf, last_mn = finf, last_mx = -finf;
         auto take = [&](bl1_v2f v) __attribute__((always_inline)) { amn = bl1_min3(amn, v[0], v[1]); amx = bl1_max3(amx, v[0], v[1]); };
         const bool writer = lane < BL1_COLS && (lane & 15) == 15 && BL1_TILES * c + (lane >> 4) < ntx;
         auto finalize = [&](int ty) __attribute__((always_inline)) {
-            float mn = ok_any ? amn : finf, mx = ok_any ? amx : -finf, m = am;
+            if (t_mn < seen_mn) { seen_mn = t_mn; ty_mn = ty; }
+            if (t_mx > seen_mx) { seen_mx = t_mx; ty_mx = ty; }
+            // M of the margin: the largest |C_2| this lane has met in the band so far (its running extrema say it) -- and its two
+            // neighbours', whose values its taps read: the fold below then covers every column the tile's level-1 values draw on
+            float m = bl1_maxf(__builtin_fabsf(t_mn), __builtin_fabsf(t_mx));
+            m = bl1_max3(m, bl1_rotf<0x13C>(m), bl1_rotf<0x134>(m));
+            float mn = ok_any ? amn : finf, mx = ok_any ? amx : -finf;
             const float r_mn = bl1_rotf<0x134>(mn), r_mx = bl1_rotf<0x134>(mx), r_m = bl1_rotf<0x134>(m);
             if ((lane & 15) == 15) { mn = bl1_minf(mn, r_mn); mx = bl1_maxf(mx, r_mx); m = bl1_maxf(m, r_m); }
             RM_BL1_FOLD_MIN(mn, 1); RM_BL1_FOLD_MAX(mx, 1); RM_BL1_FOLD_MAX(m, 1);
@@ -431,14 +439,12 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1f(const double *cS, Chain
             const float target = k ? w_mx : w_mn;
             const unsigned long long who = __ballot(cnt && (k ? t_mx : t_mn) == target);
             if (who == 0ull) continue;                                        // (uniform; a NaN extreme)
-            const int x = j0 + (int)__builtin_ctzll(who);
-            int y = -1;
-            for (int r0 = ia; r0 <= ib && y < 0; r0 += 64) {
-                const int r = r0 + lane;
-                const unsigned long long hit = __ballot(r <= ib && (float)f[(size_t)min(r, ib) * w2 + x] == target);
-                if (hit) y = r0 + (int)__builtin_ctzll(hit);
-            }
-            if (y < 0) continue;
+            const int src = (int)__builtin_ctzll(who), x = j0 + src;
+            const int tyw = __builtin_amdgcn_readlane(k ? ty_mx : ty_mn, src);
+            const int ra = max(4 * tyw - 3, ia), rb = min(4 * tyw + 5, ib), r = ra + lane;
+            const unsigned long long hit = __ballot(r <= rb && (float)f[(size_t)min(r, rb) * w2 + x] == target);
+            if (hit == 0ull) continue;
+            const int y = ra + (int)__builtin_ctzll(hit);
             const int ys = min(max(y, 1), h2 - 2), xs = min(max(x, 1), w2 - 2);
             const double *r1 = f + (size_t)ys * w2;
             const double v = lattice_sample(r1 - w2, r1, r1 + w2, xs, g.lat_a, g.lat_b);
