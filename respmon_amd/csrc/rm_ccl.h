@@ -66,13 +66,11 @@ __device__ inline void ccl_union(int *label, int a, int b)
     }
 }
 
-RM_KERNEL __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits, size_t npix, int H, int W, int *label)
+// the unions of ONE foreground pixel p = (x, y): with the word to the left (a run that continues from the previous word of its row)
+// and with the row above
+__device__ inline void ccl_pixel_unions(const unsigned long long *bits, int *label, size_t p, int y, int x, int W)
 {
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix || !ccl_bit(bits, p)) return;
-    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
     const bool w_fg = x > 0 && ccl_bit(bits, p - 1);
-    // a run that continues from the previous word of the same row
     if (w_fg && (p & 63) == 0) ccl_union(label, (int)p, (int)p - 1);
     if (y == 0) return;
     const size_t up = p - (size_t)W;
@@ -88,6 +86,14 @@ RM_KERNEL __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits
         const bool e_fg = ccl_bit(bits, p + 1);
         if (!e_fg) ccl_union(label, (int)p, (int)(up + 1));        // otherwise east joins with it (it is east's north)
     }
+}
+
+RM_KERNEL __launch_bounds__(256) void k_ccl_union(const unsigned long long *bits, size_t npix, int H, int W, int *label)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix || !ccl_bit(bits, p)) return;
+    const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * W);
+    ccl_pixel_unions(bits, label, p, y, x, W);
 }
 
 // A workgroup = a tile of 64 columns x CCL_BOX_ROWS rows, one thread per pixel.  The first pixel of a piece of a run (a run cut at
@@ -287,6 +293,227 @@ RM_KERNEL __launch_bounds__(256) void k_ccl_publish(const int *roots, const CclB
         host[1 + 2 * blockIdx.x] = t;
         host[2 + 2 * blockIdx.x] = sec;
     }
+}
+
+// ---- rows of whole words (W % 64 == 0: 720p, 1080p, 4K): the components of a TILE first, in LDS (round 6) -------------------------------
+// k_ccl_union / k_ccl_bbox above take every union and every find through global memory: an L2 round trip per link, a thread per pixel,
+// one box fold per piece.  Most of that work is local.  Here a workgroup owns a tile of one word x CCL_TILE_ROWS rows:
+//   k_ccl_tile  the words into LDS; labels (local pixel index, root = smallest) start at each pixel's run start inside its word; the
+//               unions with the row above INSIDE the tile on the LDS labels (the per-pixel rule of ccl_pixel_unions; what it reads
+//               beyond the word's first / last bit is left to the seams); every piece's box and 2 N - P folded into its local
+//               root's; out go: label[] of every foreground pixel = its tile component's first pixel (the "tile root"), that
+//               pixel's box[] = the tile component's, and the tile's list of tile roots (a fixed segment per tile: no counter shared
+//               between workgroups)
+//   k_ccl_seam  the unions the tiles could not see, through global memory as before but 1 / 32 of the rows and 2 / 64 of the columns:
+//               the complete rule for the pixels of the first row of every tile; for the other rows the first pixel of every word
+//               (run continues from the previous word; north-west neighbour) and the last one (north-east neighbour)
+//   k_ccl_fold  a workgroup per CCL_FOLD_TILES tiles walks their tile roots: a tile root that is its own root is a component (listed
+//               for k_ccl_publish, one reservation per workgroup); the others fold their box and count into the root's through the LDS
+//               table of k_ccl_bbox<true> -- one set of atomics per root and workgroup
+// The result is the one the other path leaves: root = first pixel of the component, box[root] and box[root].cnt complete, the roots
+// listed in no particular order.
+constexpr int CCL_TILE_ROWS = 32;
+constexpr int CCL_TILE_CAP = 16 * CCL_TILE_ROWS;   // tile roots a tile can hold: 32 pieces in a word, on every other row
+constexpr int CCL_FOLD_TILES = 8;
+
+__device__ inline int ccl_lds_find(int *lab, int a)
+{
+    int l = lab[a];
+    if (l != a) {
+        int prev = a, next;
+        while (l > (next = lab[l])) { lab[prev] = next; prev = l; l = next; }
+    }
+    return l;
+}
+__device__ inline void ccl_lds_union(int *lab, int a, int b)
+{
+    for (;;) {
+        a = ccl_lds_find(lab, a);
+        b = ccl_lds_find(lab, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&lab[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ccl_tile(const unsigned long long *bits, int H, int W, int *label, CclBox *box, int *troots, int *tile_n)
+{
+    constexpr int TR = CCL_TILE_ROWS, NP = TR * 64;
+    __shared__ unsigned long long s_w[TR + 2], s_side[2 * TR];   // rows y0 - 1 .. y0 + TR of the tile's word; the words left / right of rows y0 .. y0 + TR - 1
+    __shared__ int s_lab[NP], s_minx[NP], s_maxx[NP], s_maxy[NP], s_cnt[NP];
+    __shared__ int s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wpr = W >> 6, wx = blockIdx.x, y0 = blockIdx.y * TR, x0 = wx * 64;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    // every word the tile looks at, in ONE round of loads: thread k < TR + 2 its own column's row y0 - 1 + k, the next 2 TR the neighbours'
+    if (tid < TR + 2) {
+        const int y = y0 - 1 + tid;
+        s_w[tid] = (y >= 0 && y < H) ? bits[(size_t)y * wpr + wx] : 0ull;
+    } else if (tid < 3 * TR + 2) {
+        const int k = tid - (TR + 2), r = k >> 1, y = y0 + r, wn = (k & 1) ? wx + 1 : wx - 1;
+        s_side[k] = (y < H && wn >= 0 && wn < wpr) ? bits[(size_t)y * wpr + wn] : 0ull;
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const unsigned long long *sw = s_w + 1;   // sw[r]: row y0 + r
+    if (__ballot(lane < TR && sw[lane < TR ? lane : 0] != 0ull) == 0ull) {   // (the same answer in every wave) nothing in the tile
+        if (tid == 0) tile_n[tile] = 0;
+        return;
+    }
+    // ---- start state: label = the pixel's run start inside its word; a run start holds its piece's box (columns local to the tile) and 2 N - P
+    for (int r = wave; r < TR; r += NW) {
+        const unsigned long long m = sw[r];
+        if (!((m >> lane) & 1ull)) continue;
+        CclWords ww;
+        ww.cur = m; ww.up = sw[r - 1]; ww.down = sw[r + 1];
+        ww.left_fg = (s_side[2 * r] >> 63) != 0ull; ww.right_fg = (s_side[2 * r + 1] & 1ull) != 0ull;
+        const unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);
+        const int run0 = zeros_below ? 64 - __builtin_clzll(zeros_below) : 0;
+        const int q = r * 64 + lane;
+        s_lab[q] = r * 64 + run0;
+        if (run0 == lane) {
+            const unsigned long long zeros_above = ~(m >> lane);
+            int len = zeros_above ? __builtin_ctzll(zeros_above) : 64;
+            if (len > 64 - lane) len = 64 - lane;
+            s_minx[q] = lane; s_maxx[q] = lane + len - 1; s_maxy[q] = r;
+            s_cnt[q] = ccl_piece_2n_minus_p_words(ww, lane);
+        }
+    }
+    __syncthreads();
+    // ---- the unions with the row above inside the tile, by levels: first the odd rows with the even row above them (pairs of rows), then
+    // the first row of every second pair with the pair above, ... -- the trees two blocks of rows bring to a level are as deep as the
+    // level at most.  (All rows at once: a blob that fills the tile hooks row r under row r - 1 before that one is hooked itself, 32 links
+    // deep, and every find walks them through LDS one round trip at a time: 31 us at 1080p.)
+    for (int lvl = 0; (1 << lvl) < TR; ++lvl) {
+        for (int r = (1 << lvl) + wave * (2 << lvl); r < TR; r += NW * (2 << lvl)) {
+            const unsigned long long m = sw[r], u = sw[r - 1];
+            if (m == 0ull || u == 0ull) continue;                     // (uniform)
+            if (!((m >> lane) & 1ull)) continue;
+            const int q = r * 64 + lane, qu = q - 64;
+            const bool n_fg = (u >> lane) & 1ull;
+            const bool w_fg = lane > 0 && ((m >> (lane - 1)) & 1ull), nw_fg = lane > 0 && ((u >> (lane - 1)) & 1ull);
+            if (n_fg) {
+                if (!(w_fg && nw_fg)) ccl_lds_union(s_lab, q, qu);
+                continue;
+            }
+            if (nw_fg && !w_fg) ccl_lds_union(s_lab, q, qu - 1);
+            if (lane < 63 && ((u >> (lane + 1)) & 1ull) && !((m >> (lane + 1)) & 1ull)) ccl_lds_union(s_lab, q, qu + 1);
+        }
+        __syncthreads();
+    }
+    // ---- every piece's box and count into its local root's (a non-root's entries are only its own piece's: nobody folds into it)
+    for (int r = wave; r < TR; r += NW) {
+        const unsigned long long m = sw[r];
+        if (!((m >> lane) & 1ull) || (lane > 0 && ((m >> (lane - 1)) & 1ull))) continue;
+        const int q = r * 64 + lane;
+        const int root = ccl_lds_find(s_lab, q);
+        if (root == q) continue;
+        s_lab[q] = root;
+        atomicMin(&s_minx[root], s_minx[q]); atomicMax(&s_maxx[root], s_maxx[q]); atomicMax(&s_maxy[root], s_maxy[q]);
+        atomicAdd(&s_cnt[root], s_cnt[q]);
+    }
+    __syncthreads();
+    // ---- out: the labels of the foreground pixels, the tile roots with their boxes
+    for (int r = wave; r < TR; r += NW) {
+        const unsigned long long m = sw[r];
+        if (!((m >> lane) & 1ull)) continue;
+        const int q = r * 64 + lane;
+        int root = s_lab[q];                                     // (pixel -> its run start -> the root, as a rule)
+        while (s_lab[root] != root) root = s_lab[root];
+        const size_t g = (size_t)(y0 + r) * W + x0 + lane;
+        const int groot = (y0 + (root >> 6)) * W + x0 + (root & 63);
+        label[g] = groot;
+        if (root == q) {
+            CclBox e; e.minx = x0 + s_minx[q]; e.maxx = x0 + s_maxx[q]; e.maxy = y0 + s_maxy[q]; e.cnt = s_cnt[q];
+            box[g] = e;
+            troots[(size_t)tile * CCL_TILE_CAP + atomicAdd(&s_n, 1)] = groot;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) tile_n[tile] = s_n;
+}
+
+RM_KERNEL __launch_bounds__(256) void k_ccl_seam(const unsigned long long *bits, int H, int W, int *label)
+{
+    constexpr int TR = CCL_TILE_ROWS;
+    const int wpr = W >> 6;
+    const size_t na = (size_t)((H - 1) / TR) * W;      // a thread per pixel of the rows TR, 2 TR, ... (the first row of a tile below another)
+    const size_t nb = (size_t)H * wpr;                 // a thread per word of the other rows: its first and its last pixel
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) {
+        const int y = ((int)(i / (size_t)W) + 1) * TR, x = (int)(i % (size_t)W);
+        const size_t p = (size_t)y * W + x;
+        if (ccl_bit(bits, p)) ccl_pixel_unions(bits, label, p, y, x, W);
+        return;
+    }
+    if (i - na >= nb) return;
+    const size_t j = i - na;
+    const int y = (int)(j / (size_t)wpr), wj = (int)(j % (size_t)wpr);
+    if (y > 0 && y % TR == 0) return;                  // (that row's pixels all ran above)
+    const unsigned long long m = bits[j];
+    if (!(m & 1ull) && !(m >> 63)) return;
+    const size_t p = j << 6;
+    const bool w_fg = wj > 0 && (bits[j - 1] >> 63);
+    if ((m & 1ull) && w_fg) ccl_union(label, (int)p, (int)p - 1);
+    if (y == 0) return;
+    const unsigned long long u = bits[j - wpr];
+    if ((m & 1ull) && !(u & 1ull) && !w_fg && wj > 0 && (bits[j - wpr - 1] >> 63)) ccl_union(label, (int)p, (int)(p - W - 1));
+    if ((m >> 63) && !(u >> 63) && wj + 1 < wpr && (bits[j - wpr + 1] & 1ull) && !(bits[j + 1] & 1ull))
+        ccl_union(label, (int)p + 63, (int)(p + 63 - W + 1));
+}
+
+RM_KERNEL __launch_bounds__(256) void k_ccl_fold(int W, const int *label, CclBox *box, const int *troots, const int *tile_n, int ntiles,
+                                                  unsigned int *counters, int *roots, unsigned int cap)
+{
+    __shared__ int s_key[CCL_BOX_SLOTS], s_minx[CCL_BOX_SLOTS], s_maxx[CCL_BOX_SLOTS], s_maxy[CCL_BOX_SLOTS], s_cnt[CCL_BOX_SLOTS];
+    __shared__ int s_off[CCL_FOLD_TILES + 1];
+    __shared__ int s_roots[CCL_FOLD_TILES * CCL_TILE_CAP];
+    __shared__ unsigned int s_nroots, s_base;
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * CCL_FOLD_TILES;
+    if (tid == 0) {
+        int o = 0;
+        for (int k = 0; k < CCL_FOLD_TILES; ++k) { s_off[k] = o; o += t0 + k < ntiles ? tile_n[t0 + k] : 0; }
+        s_off[CCL_FOLD_TILES] = o;
+        s_nroots = 0;
+    }
+    if (tid < CCL_BOX_SLOTS) { s_key[tid] = -1; s_minx[tid] = 0x7fffffff; s_maxx[tid] = -1; s_maxy[tid] = -1; s_cnt[tid] = 0; }
+    __syncthreads();
+    const int total = s_off[CCL_FOLD_TILES];
+    if (total == 0) return;                            // (uniform)
+    for (int i = tid; i < total; i += 256) {
+        int k = 0;
+        while (i >= s_off[k + 1]) ++k;
+        const int g = troots[(size_t)(t0 + k) * CCL_TILE_CAP + (i - s_off[k])];
+        const int r = ccl_find(label, g);
+        if (r == g) { s_roots[atomicAdd(&s_nroots, 1u)] = g; continue; }
+        const CclBox mine = box[g];
+        unsigned int h = ((unsigned int)r * 2654435761u) >> 27;
+        int q = 0;
+        for (; q < CCL_BOX_SLOTS; ++q, h = (h + 1) & (CCL_BOX_SLOTS - 1)) {
+            const int seen = atomicCAS(&s_key[h], -1, r);
+            if (seen == -1 || seen == r) break;
+        }
+        if (q < CCL_BOX_SLOTS) {
+            atomicMin(&s_minx[h], mine.minx); atomicMax(&s_maxx[h], mine.maxx); atomicMax(&s_maxy[h], mine.maxy); atomicAdd(&s_cnt[h], mine.cnt);
+        } else {
+            ccl_box_fold(box, r, mine.minx, mine.maxx, mine.maxy);
+            atomicAdd(&box[r].cnt, mine.cnt);
+        }
+    }
+    __syncthreads();
+    if (tid < CCL_BOX_SLOTS && s_key[tid] >= 0) {
+        ccl_box_fold(box, s_key[tid], s_minx[tid], s_maxx[tid], s_maxy[tid]);
+        atomicAdd(&box[s_key[tid]].cnt, s_cnt[tid]);
+    }
+    if (s_nroots == 0) return;                         // (uniform)
+    if (tid == 0) s_base = atomicAdd(&counters[0], s_nroots);
+    __syncthreads();
+    for (unsigned int i = tid; i < s_nroots; i += 256)
+        if (s_base + i < cap) roots[s_base + i] = s_roots[i];
 }
 
 }  // namespace rm

@@ -145,6 +145,8 @@ extern "C" int rm_debug_set(rm_ctx *ctx, const char *key, long long value)
     else if (k == "dense_t_low") d.dense_t_low = (int)value;
     else if (k == "dense_exact_top") d.dense_exact_top = (int)value;
     else if (k == "ccl_table") d.ccl_table = (int)value;
+    else if (k == "ccl_tiles") d.ccl_tiles = (int)value;
+    else if (k == "ccl_tile_waves") d.ccl_tile_waves = (int)value;
     else if (k == "label_host_steps") d.label_host_steps = value;
     else if (k == "sum_sym") d.sum_sym = (int)value;
     else if (k == "sum_rows") d.sum_rows = (int)value;

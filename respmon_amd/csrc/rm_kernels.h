@@ -2316,7 +2316,7 @@ RM_KERNEL __launch_bounds__(256) void k_heat_to_u8(const double *heat, size_t np
             if (bits_dev) {   // device labelling of the components (rm_ccl.h) follows: every word, and the start state of its
                               // union-find -- the ballot IS the pixel's word, so no separate pass has to read it back
                 if (lane == 0) bits_dev[base >> 6] = m;
-                if (b) {
+                if (b && ccl_label) {   // (null: k_ccl_tile builds the start state itself, in LDS)
                     // label = first pixel of the run of ones that ends here (inside this word, not crossing the row start).  Only
                     // such a first pixel can end up a root, and only it carries a box: that of its piece of the run
                     const unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);

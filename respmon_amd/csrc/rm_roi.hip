@@ -108,10 +108,29 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         }
         CclComp *dev_comps = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev_comps, rs.h_comps, 0));
+        // rows of whole words: the components of every 64 x 32 tile in LDS first, then the seams (rm_ccl.h k_ccl_tile / k_ccl_seam / k_ccl_fold)
+        const bool tiles = (W & 63) == 0 && ctx->dbg.ccl_tiles != 0;
         hipLaunchKernelGGL(k_heat_to_u8<>, dim3(nblk(npix, 256, 2048)), dim3(256), 0, s, heat, npix, W, st, threshold, avg_u8, binary,
                            lazy ? (unsigned long long *)nullptr : (unsigned long long *)dev_bin, lazy ? (uint8_t *)nullptr : dev_bin + nwords * 8,
-                           d_bits, d_label, d_box, d_cnt, tile_const);
+                           d_bits, tiles ? (int *)nullptr : d_label, d_box, d_cnt, tile_const);
         LAUNCH_CHECK();
+        if (tiles) {
+            const int ntx = W >> 6, nty = (H + CCL_TILE_ROWS - 1) / CCL_TILE_ROWS, ntiles = ntx * nty;
+            int *d_troots = nullptr, *d_tile_n = nullptr;
+            RM_TRY(ws(ctx, "ccl_tile_roots", (size_t)ntiles * CCL_TILE_CAP, &d_troots));
+            RM_TRY(ws(ctx, "ccl_tile_n", (size_t)ntiles, &d_tile_n));
+            const int tw = ctx->dbg.ccl_tile_waves;
+            if (tw == 4) hipLaunchKernelGGL(k_ccl_tile<4>, dim3((unsigned)ntx, (unsigned)nty), dim3(256), 0, s, d_bits, H, W, d_label, d_box, d_troots, d_tile_n);
+            else if (tw == 8) hipLaunchKernelGGL(k_ccl_tile<8>, dim3((unsigned)ntx, (unsigned)nty), dim3(512), 0, s, d_bits, H, W, d_label, d_box, d_troots, d_tile_n);
+            else hipLaunchKernelGGL(k_ccl_tile<16>, dim3((unsigned)ntx, (unsigned)nty), dim3(1024), 0, s, d_bits, H, W, d_label, d_box, d_troots, d_tile_n);
+            LAUNCH_CHECK();
+            const size_t nseam = (size_t)((H - 1) / CCL_TILE_ROWS) * W + (size_t)H * ntx;
+            hipLaunchKernelGGL(k_ccl_seam<>, dim3((unsigned)((nseam + 255) / 256)), dim3(256), 0, s, d_bits, H, W, d_label);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_ccl_fold<>, dim3((unsigned)((ntiles + CCL_FOLD_TILES - 1) / CCL_FOLD_TILES)), dim3(256), 0, s, W, d_label, d_box, d_troots,
+                               d_tile_n, ntiles, d_cnt, d_list, (unsigned int)comps_cap);
+            LAUNCH_CHECK();
+        } else {
         // (a thread per 64-bit word walking its set bits through the same rule was measured: 97 / 95 us instead of 21 / 19 at 720p --
         //  ten dependent find / atomic round trips per thread cost more than launching 84 % idle threads)
         const dim3 grid((unsigned)((npix + 255) / 256));
@@ -123,6 +142,7 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
         if (table) hipLaunchKernelGGL(k_ccl_bbox<true>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         else hipLaunchKernelGGL(k_ccl_bbox<false>, bgrid, dim3(64 * CCL_BOX_ROWS), 0, s, d_bits, npix, H, W, d_label, d_box, d_cnt, d_list, (unsigned int)comps_cap);
         LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(k_ccl_publish<>, dim3(CCL_PUB_BLOCKS), dim3(256), 0, s, d_list, d_box, W, d_cnt, (unsigned int)comps_cap, dev_comps,
                            lazy ? d_complist : dev_comps + 1 + 2 * CCL_PUB_BLOCKS);
         LAUNCH_CHECK();

@@ -688,6 +688,20 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
         m = rng.random((72, 200)) < 0.1
         m |= ndi.gaussian_filter(rng.standard_normal((72, 200)), 9.0) > -0.02
         masks.append(m); fire.append(len(masks) - 1)
+    # rows of whole words taller than one 64 x 32 tile (rm_ccl.h k_ccl_tile / k_ccl_seam / k_ccl_fold): specks, blobs that cross the
+    # seams in every direction, a tile holding as many one-pixel components as it can
+    for (h, w, dens) in [(70, 128, 0.2), (100, 256, 0.45), (33, 192, 0.6), (65, 64, 0.3), (96, 128, 0.03)]:
+        masks.append(rng.random((h, w)) < dens)
+    for k in range(3):
+        m = rng.random((90, 192)) < 0.12
+        masks.append(m | (ndi.gaussian_filter(rng.standard_normal((90, 192)), 5.0) > 0.04))
+    dots64 = np.zeros((66, 128), bool); dots64[::2, ::2] = True
+    masks.append(dots64)
+    diag = np.zeros((80, 192), bool); diag[np.arange(80), np.arange(80) + 30] = True; diag[np.arange(80), 150 - np.arange(80)] = True
+    masks.append(diag)
+    snake = np.zeros((70, 128), bool); snake[::4, :] = True; snake[2::8, 127] = True; snake[1::8, 127] = True; snake[3::8, 127] = True
+    snake[6::8, 0] = True; snake[5::8, 0] = True; snake[7::8, 0] = True
+    masks.append(snake)
     n_fired = 0
     for im, m in enumerate(masks):
         heat = m.astype(np.float64)
@@ -702,12 +716,16 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
         roi_l, u8, binary = emu.heatmap_to_roi(heat, threshold=20, labelling=1)
         path_l = emu.roi_path()
         assert roi_l == roi_f and path_f != 4, (m.shape, roi_l, roi_f, path_f)
+        emu.debug_set("ccl_tiles", 0)   # rows of whole words through the global-memory kernels too
         for table in (0, 1):     # k_ccl_bbox without / with its per-tile LDS table (the default picks by the last component count)
             emu.debug_set("ccl_table", table)
             try:
                 assert emu.heatmap_to_roi(heat, threshold=20, labelling=1)[0] == roi_l and emu.roi_path() == path_l, (m.shape, table)
             finally:
                 emu.debug_set("ccl_table", -1)
+        n_flat, _ = emu.contour_stats()
+        emu.debug_set("ccl_tiles", 1)
+        assert emu.heatmap_to_roi(heat, threshold=20, labelling=1)[0] == roi_l and emu.contour_stats()[0] == n_flat, (m.shape, "components counted")
         n_fired += path_l == 4
         if im in fire:
             assert path_l == 4, (im, path_l)

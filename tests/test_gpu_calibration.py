@@ -988,12 +988,16 @@ def test_contour_stage_device_labelling(hip, oracle):
         roi_l = dist.hip_heatmap_to_roi(heat, 20, labelling=True)
         assert roi_l == roi_f and dist.roi_path() in (3, 4), (m.shape, roi_l, roi_f)
         path_l = dist.roi_path()
+        device.debug_set("ccl_tiles", 0)   # rows of whole words through the global-memory kernels too (the default: tile by tile in LDS, k_ccl_tile)
         for table in (0, 1):     # k_ccl_bbox without / with its per-tile LDS table (the default picks by the last component count)
             device.debug_set("ccl_table", table)
             try:
                 assert dist.hip_heatmap_to_roi(heat, 20, labelling=True) == roi_l and dist.roi_path() == path_l, (m.shape, table)
             finally:
                 device.debug_set("ccl_table", -1)
+        n_flat = dist.contour_stats()[0]
+        device.debug_set("ccl_tiles", 1)
+        assert dist.hip_heatmap_to_roi(heat, 20, labelling=True) == roi_l and dist.roi_path() == path_l and dist.contour_stats()[0] == n_flat, m.shape
         # ... exactly when scipy's labels say it can: 2 N - P - 2 of the component with the largest box beats every other box bound
         lab, n = ndi.label(m, structure=np.ones((3, 3)))
         pad = np.pad(m, 1); c = pad[1:-1, 1:-1]
