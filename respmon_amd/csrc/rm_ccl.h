@@ -20,6 +20,8 @@
 //   k_ccl_union   joins with the row above / the word to the left, lock-free (atomicMin on the larger root)
 //   k_ccl_bbox    the first pixel of every piece folds the piece's box into its root's
 //   k_ccl_publish the roots k_ccl_bbox listed -> {root, minx, width-1, height-1} records + their count in pinned host memory
+// Rows of whole 64-pixel words (720p, 1080p, 4K) take k_ccl_tile / k_ccl_seam / k_ccl_fold (at the end of this file) in place of the first
+// two: the components of every 64 x 32 tile on LDS labels first, then the seams.  Same roots, boxes and counts for k_ccl_publish.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
