@@ -345,8 +345,11 @@ __global__ __launch_bounds__(64 * NW) void k_ccl_tile(const unsigned long long *
 {
     constexpr int TR = CCL_TILE_ROWS, NP = TR * 64;
     __shared__ unsigned long long s_w[TR + 2], s_side[2 * TR];   // rows y0 - 1 .. y0 + TR of the tile's word; the words left / right of rows y0 .. y0 + TR - 1
-    __shared__ int s_lab[NP], s_minx[NP], s_maxx[NP], s_maxy[NP], s_cnt[NP];
+    // boxes and counts live at the run starts only, and two run starts of a row are at least two columns apart: slot (row, column / 2)
+    constexpr int NB = TR * 32;
+    __shared__ int s_lab[NP], s_minx[NB], s_maxx[NB], s_maxy[NB], s_cnt[NB];
     __shared__ int s_n;
+    auto bi = [](int q) __attribute__((always_inline)) { return ((q >> 6) << 5) | ((q & 63) >> 1); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wpr = W >> 6, wx = blockIdx.x, y0 = blockIdx.y * TR, x0 = wx * 64;
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
@@ -380,8 +383,9 @@ __global__ __launch_bounds__(64 * NW) void k_ccl_tile(const unsigned long long *
             const unsigned long long zeros_above = ~(m >> lane);
             int len = zeros_above ? __builtin_ctzll(zeros_above) : 64;
             if (len > 64 - lane) len = 64 - lane;
-            s_minx[q] = lane; s_maxx[q] = lane + len - 1; s_maxy[q] = r;
-            s_cnt[q] = ccl_piece_2n_minus_p_words(ww, lane);
+            const int b = bi(q);
+            s_minx[b] = lane; s_maxx[b] = lane + len - 1; s_maxy[b] = r;
+            s_cnt[b] = ccl_piece_2n_minus_p_words(ww, lane);
         }
     }
     __syncthreads();
@@ -414,8 +418,9 @@ __global__ __launch_bounds__(64 * NW) void k_ccl_tile(const unsigned long long *
         const int root = ccl_lds_find(s_lab, q);
         if (root == q) continue;
         s_lab[q] = root;
-        atomicMin(&s_minx[root], s_minx[q]); atomicMax(&s_maxx[root], s_maxx[q]); atomicMax(&s_maxy[root], s_maxy[q]);
-        atomicAdd(&s_cnt[root], s_cnt[q]);
+        const int b = bi(q), br = bi(root);
+        atomicMin(&s_minx[br], s_minx[b]); atomicMax(&s_maxx[br], s_maxx[b]); atomicMax(&s_maxy[br], s_maxy[b]);
+        atomicAdd(&s_cnt[br], s_cnt[b]);
     }
     __syncthreads();
     // ---- out: the labels of the foreground pixels, the tile roots with their boxes
@@ -429,7 +434,8 @@ __global__ __launch_bounds__(64 * NW) void k_ccl_tile(const unsigned long long *
         const int groot = (y0 + (root >> 6)) * W + x0 + (root & 63);
         label[g] = groot;
         if (root == q) {
-            CclBox e; e.minx = x0 + s_minx[q]; e.maxx = x0 + s_maxx[q]; e.maxy = y0 + s_maxy[q]; e.cnt = s_cnt[q];
+            const int b = bi(q);
+            CclBox e; e.minx = x0 + s_minx[b]; e.maxx = x0 + s_maxx[b]; e.maxy = y0 + s_maxy[b]; e.cnt = s_cnt[b];
             box[g] = e;
             troots[(size_t)tile * CCL_TILE_CAP + atomicAdd(&s_n, 1)] = groot;
         }

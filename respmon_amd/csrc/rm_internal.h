@@ -116,7 +116,7 @@ struct DebugKnobs {
     int sum_sym = 0;              // 1: k_masked_sum_sym instead of k_masked_sum_tiles for whole-buffer sums (measured slower: 31 us against 21 at 1080p x 256)
     long long label_host_steps = 0;   // > 0: border steps of an unlabelled host stage beyond which the next extraction is labelled on the device (default LABEL_MIN_STEPS)
     int ccl_tiles = 1;            // 0: rows of whole words labelled through global memory as the others are (k_ccl_union / k_ccl_bbox), not tile by tile in LDS
-    int ccl_tile_waves = 16;      // waves of a k_ccl_tile workgroup (4 / 8 / 16: eight / four / two rows of the tile per wave)
+    int ccl_tile_waves = 0;       // waves of a k_ccl_tile workgroup (4 / 8 / 16: eight / four / two rows of the tile per wave; 0: by the number of tiles)
     int ccl_table = -1;           // k_ccl_bbox: 1 with / 0 without the per-tile LDS table of boxes, -1 by the last component count
     int heat_const_tiles = 1;     // 0: k_heat_to_u8 reads every pixel of rm_locate's heatmap (no use of the sum kernel's constant-tile flags)
     int ff_parts = 0;             // > 0: workgroups per frame of k_small_filter_first (default: 2 when one per frame would leave CUs idle)

@@ -119,7 +119,10 @@ int roi_launch(rm_ctx *ctx, const double *heat, int H, int W, int threshold, uin
             int *d_troots = nullptr, *d_tile_n = nullptr;
             RM_TRY(ws(ctx, "ccl_tile_roots", (size_t)ntiles * CCL_TILE_CAP, &d_troots));
             RM_TRY(ws(ctx, "ccl_tile_n", (size_t)ntiles, &d_tile_n));
-            const int tw = ctx->dbg.ccl_tile_waves;
+            // waves per tile workgroup: 16 (two rows each) while one round of workgroups covers the image -- the kernel's time is then one
+            // workgroup's life (1080p noise 1.0475 / 1.0532 ms with 16 / 8, 720p 0.4634 / 0.4644) --, 8 (four 25 KB workgroups per CU instead
+            // of two) where the tiles come in several rounds (4K x 512: 5.119 / 5.097 ms)
+            const int tw = ctx->dbg.ccl_tile_waves > 0 ? ctx->dbg.ccl_tile_waves : (ntiles >= 2048 ? 8 : 16);
             if (tw == 4) hipLaunchKernelGGL(k_ccl_tile<4>, dim3((unsigned)ntx, (unsigned)nty), dim3(256), 0, s, d_bits, H, W, d_label, d_box, d_troots, d_tile_n);
             else if (tw == 8) hipLaunchKernelGGL(k_ccl_tile<8>, dim3((unsigned)ntx, (unsigned)nty), dim3(512), 0, s, d_bits, H, W, d_label, d_box, d_troots, d_tile_n);
             else hipLaunchKernelGGL(k_ccl_tile<16>, dim3((unsigned)ntx, (unsigned)nty), dim3(1024), 0, s, d_bits, H, W, d_label, d_box, d_troots, d_tile_n);
