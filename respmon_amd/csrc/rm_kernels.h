@@ -1701,19 +1701,30 @@ RM_KERNEL __launch_bounds__(256) void k_select_pairs(const double *lo, const dou
     unsigned long long total = 0;
     const unsigned long long ex = block_excl_scan_256(s_cnt[threadIdx.x], s_wave, total);
     s_off[threadIdx.x] = ex;
-    if (threadIdx.x == 0) {
-        s_off[256] = total;
-        const unsigned int totD = (unsigned)(total & 0xfffffu), totA = (unsigned)((total >> 20) & 0xfffffu), totB = (unsigned)(total >> 40);
-        s_base[0] = totD ? atomicAdd(&st->n_slots, totD) : 0u;
-        s_base[1] = totA ? atomicAdd(&st->n_list_a, totA) : 0u;
-        s_base[2] = totB ? atomicAdd(&st->n_list_b, totB) : 0u;
+    if (threadIdx.x == 0) s_off[256] = total;
+    if (threadIdx.x < 3) {   // the three reservations by three lanes: ONE round trip instead of three in a row (every thread holds `total`)
+        const unsigned int tot = threadIdx.x == 0 ? (unsigned)(total & 0xfffffu) : threadIdx.x == 1 ? (unsigned)((total >> 20) & 0xfffffu) : (unsigned)(total >> 40);
+        unsigned int *ctr = threadIdx.x == 0 ? &st->n_slots : threadIdx.x == 1 ? &st->n_list_a : &st->n_list_b;
+        s_base[threadIdx.x] = tot ? atomicAdd(ctr, tot) : 0u;
     }
     __syncthreads();
     const unsigned long long mo = s_off[ti * SEL_PH + ph];
     unsigned int oD = s_base[0] + (unsigned)(mo & 0xfffffu), oA = s_base[1] + (unsigned)((mo >> 20) & 0xfffffu), oB = s_base[2] + (unsigned)(mo >> 40);
+    bool new_heavy = false;           // this chunk adds the tile's first kept pairs
     if (ph == 0 && tile < ntiles) {   // kept pairs of this tile in this chunk
         const unsigned int tot = (unsigned)((s_off[(ti + 1) * SEL_PH] - s_off[ti * SEL_PH]) & 0xfffffu);
-        if (tot && atomicAdd(&sel_cnt[tile], (int)tot) == 0) heavy[atomicAdd(&st->n_heavy, 1u)] = (unsigned)tile;
+        new_heavy = tot && atomicAdd(&sel_cnt[tile], (int)tot) == 0;
+    }
+    if (threadIdx.x < 64) {   // (phase 0 = lanes 0 .. 15 of wave 0) ONE reservation on n_heavy for the workgroup's new tiles: at 4K x 512 every
+                              // tile of a noisy stream is heavy, and 8 100 returning atomics on one address were most of the kernel's 58 us
+        const unsigned long long mk = __ballot(new_heavy);
+        if (mk) {
+            const int lane = threadIdx.x, first = __builtin_ctzll(mk);
+            unsigned int base = 0;
+            if (lane == first) base = atomicAdd(&st->n_heavy, (unsigned)__popcll(mk));
+            base = (unsigned)__shfl((int)base, first);
+            if (new_heavy) heavy[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned)tile;
+        }
     }
 #pragma unroll
     for (int k = 0; k < SEL_U; ++k) {
