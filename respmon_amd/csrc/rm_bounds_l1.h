@@ -208,14 +208,19 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1(const double *cS, ChainG
     if (lane == 0 && lo_mn <= lo_mx) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (u + wid * 7) & (NSTRIPE - 1);
-        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
-        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
-        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
-        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        // (the six current values requested together, then the comparisons: a load-compare-atomic at a time was six round trips in a row
+        //  at the end of every wave's life)
+        const unsigned long long c_lb_mx = *(volatile unsigned long long *)&st->lb_max_keys[sp], c_lb_mn = *(volatile unsigned long long *)&st->lb_min_keys[sp];
+        const unsigned long long c_ub_mx = *(volatile unsigned long long *)&st->ub_max_keys[sp], c_ub_mn = *(volatile unsigned long long *)&st->ub_min_keys[sp];
+        const unsigned long long c_s_mn = *(volatile unsigned long long *)&st->smp_min_keys[sp], c_s_mx = *(volatile unsigned long long *)&st->smp_max_keys[sp];
+        if (k_lo_mx > c_lb_mx) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        if (k_lo_mn < c_lb_mn) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        if (k_hi_mx > c_ub_mx) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        if (k_hi_mn < c_ub_mn) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
         if (sm_mn <= sm_mx) {
             const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
-            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
-            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+            if (k_mn < c_s_mn) atomicMin(&st->smp_min_keys[sp], k_mn);
+            if (k_mx > c_s_mx) atomicMax(&st->smp_max_keys[sp], k_mx);
         }
     }
 }
@@ -434,35 +439,40 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds_l1f(const double *cS, Chain
         const float w_mn = (float)wave_min(cnt ? (double)t_mn : inf), w_mx = (float)wave_max(cnt ? (double)t_mx : -inf);
         const double *f = cS + (size_t)u * h2 * w2;
         const int ia = max(i_first - 1, 0), ib = min(4 * ty_last + 5, h2 - 1);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float target = k ? w_mx : w_mn;
-            const unsigned long long who = __ballot(cnt && (k ? t_mx : t_mn) == target);
-            if (who == 0ull) continue;                                        // (uniform; a NaN extreme)
-            const int src = (int)__builtin_ctzll(who), x = j0 + src;
-            const int tyw = __builtin_amdgcn_readlane(k ? ty_mx : ty_mn, src);
-            const int ra = max(4 * tyw - 3, ia), rb = min(4 * tyw + 5, ib), r = ra + lane;
-            const unsigned long long hit = __ballot(r <= rb && (float)f[(size_t)min(r, rb) * w2 + x] == target);
-            if (hit == 0ull) continue;
-            const int y = ra + (int)__builtin_ctzll(hit);
-            const int ys = min(max(y, 1), h2 - 2), xs = min(max(x, 1), w2 - 2);
-            const double *r1 = f + (size_t)ys * w2;
-            const double v = lattice_sample(r1 - w2, r1, r1 + w2, xs, g.lat_a, g.lat_b);
-            sm_mn = f64_min(sm_mn, v); sm_mx = f64_max(sm_mx, v);
-        }
+        // both look-ups side by side, without a branch between their loads (two round trips at the end of the wave's life instead of four):
+        // an extreme nobody holds (NaN) looks at valid addresses and is dropped at the end
+        const unsigned long long who0 = __ballot(cnt && t_mn == w_mn), who1 = __ballot(cnt && t_mx == w_mx);
+        const int src0 = who0 ? (int)__builtin_ctzll(who0) : 0, src1 = who1 ? (int)__builtin_ctzll(who1) : 0;
+        const int x0 = j0 + src0, x1 = j0 + src1;
+        const int tyw0 = __builtin_amdgcn_readlane(ty_mn, src0), tyw1 = __builtin_amdgcn_readlane(ty_mx, src1);
+        const int ra0 = min(max(4 * tyw0 - 3, ia), ib), rb0 = max(min(4 * tyw0 + 5, ib), ra0);
+        const int ra1 = min(max(4 * tyw1 - 3, ia), ib), rb1 = max(min(4 * tyw1 + 5, ib), ra1);
+        const float c0 = (float)f[(size_t)min(ra0 + lane, rb0) * w2 + x0], c1 = (float)f[(size_t)min(ra1 + lane, rb1) * w2 + x1];
+        const unsigned long long hit0 = __ballot(ra0 + lane <= rb0 && c0 == w_mn), hit1 = __ballot(ra1 + lane <= rb1 && c1 == w_mx);
+        const int y0 = ra0 + (hit0 ? (int)__builtin_ctzll(hit0) : 0), y1 = ra1 + (hit1 ? (int)__builtin_ctzll(hit1) : 0);
+        const double *p0 = f + (size_t)min(max(y0, 1), h2 - 2) * w2, *p1 = f + (size_t)min(max(y1, 1), h2 - 2) * w2;
+        const double v0 = lattice_sample(p0 - w2, p0, p0 + w2, min(max(x0, 1), w2 - 2), g.lat_a, g.lat_b);
+        const double v1 = lattice_sample(p1 - w2, p1, p1 + w2, min(max(x1, 1), w2 - 2), g.lat_a, g.lat_b);
+        if (who0 && hit0) { sm_mn = f64_min(sm_mn, v0); sm_mx = f64_max(sm_mx, v0); }
+        if (who1 && hit1) { sm_mn = f64_min(sm_mn, v1); sm_mx = f64_max(sm_mx, v1); }
     }
     lo_mn = wave_min(lo_mn); lo_mx = wave_max(lo_mx); hi_mn = wave_min(hi_mn); hi_mx = wave_max(hi_mx);
     if (lane == 0 && lo_mn <= lo_mx) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (u + wid * 7) & (NSTRIPE - 1);
-        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
-        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
-        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
-        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        // (the six current values requested together, then the comparisons: a load-compare-atomic at a time was six round trips in a row
+        //  at the end of every wave's life)
+        const unsigned long long c_lb_mx = *(volatile unsigned long long *)&st->lb_max_keys[sp], c_lb_mn = *(volatile unsigned long long *)&st->lb_min_keys[sp];
+        const unsigned long long c_ub_mx = *(volatile unsigned long long *)&st->ub_max_keys[sp], c_ub_mn = *(volatile unsigned long long *)&st->ub_min_keys[sp];
+        const unsigned long long c_s_mn = *(volatile unsigned long long *)&st->smp_min_keys[sp], c_s_mx = *(volatile unsigned long long *)&st->smp_max_keys[sp];
+        if (k_lo_mx > c_lb_mx) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
+        if (k_lo_mn < c_lb_mn) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
+        if (k_hi_mx > c_ub_mx) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
+        if (k_hi_mn < c_ub_mn) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
         if (sm_mn <= sm_mx) {
             const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
-            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
-            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+            if (k_mn < c_s_mn) atomicMin(&st->smp_min_keys[sp], k_mn);
+            if (k_mx > c_s_mx) atomicMax(&st->smp_max_keys[sp], k_mx);
         }
     }
 }
