@@ -238,8 +238,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum(const double *cS, ChainGe
         if (tid == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp = blockIdx.x & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp, kmn, kmx);
         }
     }
 }
@@ -438,8 +437,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_s2(const double *cS, Chai
         if (tid == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp = blockIdx.x & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp, kmn, kmx);
         }
     }
 }
@@ -658,8 +656,7 @@ __global__ __launch_bounds__(64) void k_dense_sum_w(const double *cS, ChainGeom 
         if (lane == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp_ = blockIdx.x & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
         }
     }
 }
@@ -869,8 +866,7 @@ __global__ __launch_bounds__(64 * NW) void k_dense_sum_wf(const double *cS, Chai
         if (lane == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp_ = (blockIdx.x * NW + wave) & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
         }
     }
 }

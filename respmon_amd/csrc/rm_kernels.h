@@ -1073,6 +1073,15 @@ __device__ void state_init_lane(CollapseState *st, int i)   // lanes 0 .. NSTRIP
 
 RM_KERNEL __launch_bounds__(NSTRIPE) void k_state_init(CollapseState *st) { state_init_lane(st, (int)threadIdx.x); }
 
+// min / max of a pair of striped targets: skipped when they cannot change the result.  Both current words are requested before either is
+// compared -- a load-compare-atomic at a time is a round trip per target at the end of a wave's life (rm_bounds_l1.h)
+__device__ __forceinline__ void striped_min_max(unsigned long long *mins, unsigned long long *maxs, int sp, unsigned long long kmn, unsigned long long kmx)
+{
+    const unsigned long long cmn = *(volatile unsigned long long *)&mins[sp], cmx = *(volatile unsigned long long *)&maxs[sp];
+    if (kmn < cmn) atomicMin(&mins[sp], kmn);
+    if (kmx > cmx) atomicMax(&maxs[sp], kmx);
+}
+
 // fold the stripes of one target (plus its unstriped word); every lane of the wave gets the result
 __device__ __forceinline__ unsigned long long fold_min_keys(const unsigned long long *stripes, unsigned long long word)
 {
@@ -1139,10 +1148,8 @@ RM_KERNEL __launch_bounds__(256) void k_tile_bounds(const double *cS, ChainGeom 
     if (threadIdx.x == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = blockIdx.x & (NSTRIPE - 1);
-        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
-        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
-        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
-        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        striped_min_max(st->lb_min_keys, st->lb_max_keys, sp, k_lo_mn, k_lo_mx);
+        striped_min_max(st->ub_min_keys, st->ub_max_keys, sp, k_hi_mn, k_hi_mx);
     }
 }
 
@@ -1233,14 +1240,11 @@ RM_KERNEL __launch_bounds__(256) void k_frame_bounds(const double *cS, ChainGeom
     if (threadIdx.x == 0) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (blockIdx.x + blockIdx.y * 7) & (NSTRIPE - 1);
-        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
-        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
-        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
-        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        striped_min_max(st->lb_min_keys, st->lb_max_keys, sp, k_lo_mn, k_lo_mx);
+        striped_min_max(st->ub_min_keys, st->ub_max_keys, sp, k_hi_mn, k_hi_mx);
         if (sm_mn <= sm_mx) {
             const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
-            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
-            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+            striped_min_max(st->smp_min_keys, st->smp_max_keys, sp, k_mn, k_mx);
         }
     }
 }
@@ -1366,14 +1370,11 @@ __global__ __launch_bounds__(256) void k_frame_bounds_rows(const double *cS, Cha
     if (lane == 0 && have) {
         const unsigned long long k_lo_mx = f64_key(lo_mx), k_lo_mn = f64_key(lo_mn), k_hi_mx = f64_key(hi_mx), k_hi_mn = f64_key(hi_mn);
         const int sp = (blockIdx.x + (blockIdx.y * 4 + wave) * 7) & (NSTRIPE - 1);
-        if (k_lo_mx > *(volatile unsigned long long *)&st->lb_max_keys[sp]) atomicMax(&st->lb_max_keys[sp], k_lo_mx);
-        if (k_lo_mn < *(volatile unsigned long long *)&st->lb_min_keys[sp]) atomicMin(&st->lb_min_keys[sp], k_lo_mn);
-        if (k_hi_mx > *(volatile unsigned long long *)&st->ub_max_keys[sp]) atomicMax(&st->ub_max_keys[sp], k_hi_mx);
-        if (k_hi_mn < *(volatile unsigned long long *)&st->ub_min_keys[sp]) atomicMin(&st->ub_min_keys[sp], k_hi_mn);
+        striped_min_max(st->lb_min_keys, st->lb_max_keys, sp, k_lo_mn, k_lo_mx);
+        striped_min_max(st->ub_min_keys, st->ub_max_keys, sp, k_hi_mn, k_hi_mx);
         if (sm_mn <= sm_mx) {
             const unsigned long long k_mn = f64_key(sm_mn), k_mx = f64_key(sm_mx);
-            if (k_mn < *(volatile unsigned long long *)&st->smp_min_keys[sp]) atomicMin(&st->smp_min_keys[sp], k_mn);
-            if (k_mx > *(volatile unsigned long long *)&st->smp_max_keys[sp]) atomicMax(&st->smp_max_keys[sp], k_mx);
+            striped_min_max(st->smp_min_keys, st->smp_max_keys, sp, k_mn, k_mx);
         }
     }
 }
@@ -1927,8 +1928,7 @@ RM_KERNEL __launch_bounds__(64) void k_eval_pairs(const double *cS, ChainGeom g,
         // striped, and skipped when they cannot change the result
         const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
         const int sp_ = blockIdx.x & (NSTRIPE - 1);
-        if (kmn < *(volatile unsigned long long *)&st->min_keys[sp_]) atomicMin(&st->min_keys[sp_], kmn);
-        if (kmx > *(volatile unsigned long long *)&st->max_keys[sp_]) atomicMax(&st->max_keys[sp_], kmx);
+        striped_min_max(st->min_keys, st->max_keys, sp_, kmn, kmx);
     }
 }
 
@@ -2100,8 +2100,7 @@ RM_KERNEL __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int
             if (tid == 0) {
                 const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
                 const int sp = blockIdx.x & (NSTRIPE - 1);
-                if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
-                if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+                striped_min_max(st->heat_min_keys, st->heat_max_keys, sp, kmn, kmx);
             }
         }
         RM_TRACE_MARK(6, 13);
@@ -2141,8 +2140,7 @@ RM_KERNEL __launch_bounds__(64 * MS_RQ) void k_masked_sum_tiles(int t_first, int
     if (any && tid == 0 && avg_T > 0) {
         const unsigned long long kv = f64_key(v);
         const int sp = blockIdx.x & (NSTRIPE - 1);
-        if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kv);
-        if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kv);
+        striped_min_max(st->heat_min_keys, st->heat_max_keys, sp, kv, kv);
     }
 }
 
@@ -2605,8 +2603,7 @@ RM_KERNEL __launch_bounds__(256) void k_sparse_merge(const double *packets, size
     if (threadIdx.x == 0) {
         const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
         const int sp = blockIdx.x & (NSTRIPE - 1);
-        if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp]) atomicMin(&st->heat_min_keys[sp], kmn);
-        if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp]) atomicMax(&st->heat_max_keys[sp], kmx);
+        striped_min_max(st->heat_min_keys, st->heat_max_keys, sp, kmn, kmx);
     }
 }
 

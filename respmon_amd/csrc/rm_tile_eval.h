@@ -270,8 +270,7 @@ __global__ __launch_bounds__(64) void k_eval_c(const double *cS, ChainGeom g, in
     if (lane == 0 && blockIdx.x < nA) {
         const unsigned long long kmn = f64_key(mn), kmx = f64_key(mx);
         const int sp_ = blockIdx.x & (NSTRIPE - 1);
-        if (kmn < *(volatile unsigned long long *)&st->min_keys[sp_]) atomicMin(&st->min_keys[sp_], kmn);
-        if (kmx > *(volatile unsigned long long *)&st->max_keys[sp_]) atomicMax(&st->max_keys[sp_], kmx);
+        striped_min_max(st->min_keys, st->max_keys, sp_, kmn, kmx);
     }
 }
 
@@ -488,8 +487,7 @@ RM_KERNEL __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int ntil
         if (tid == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp_ = blockIdx.x & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
         }
         RM_TRACE_MARK(6, 13);
         __syncthreads();   // s_ku is rewritten by the next item
@@ -528,8 +526,7 @@ RM_KERNEL __launch_bounds__(64 * MS_RQ, 2) void k_masked_sum_sym(int T, int ntil
     if (any && tid == 0) {
         const unsigned long long kv = f64_key(fv);
         const int sp_ = blockIdx.x & (NSTRIPE - 1);
-        if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kv);
-        if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kv);
+        striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kv, kv);
     }
 }
 
@@ -750,8 +747,7 @@ RM_KERNEL __launch_bounds__(64) void k_masked_sum_rows(int T, int ntiles, int W0
     if (lane == 0 && hmn <= hmx) {
         const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
         const int sp_ = blockIdx.x & (NSTRIPE - 1);
-        if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-        if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+        striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
     }
 }
 
@@ -910,8 +906,7 @@ __global__ __launch_bounds__(64) RM_WAVES_PER_EU_IF(S <= 2, 4, 3) void k_dense_s
         if (lane == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp_ = blockIdx.x & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
         }
     }
 }
@@ -1043,8 +1038,7 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
             if (lane == 0 && wave < NV) {
                 const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
                 const int sp_ = (blockIdx.x * NW + wave) & (NSTRIPE - 1);
-                if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-                if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+                striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
             }
         }
         RM_TRACE_MARK(6, 14);
@@ -1080,8 +1074,7 @@ __device__ __forceinline__ void tile_sum_body(const double *cS, const ChainGeom 
     if (any && tid == 0 && avg_T > 0) {
         const unsigned long long kv = f64_key(fv);
         const int sp_ = blockIdx.x & (NSTRIPE - 1);
-        if (kv < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kv);
-        if (kv > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kv);
+        striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kv, kv);
     }
 }
 

@@ -318,8 +318,7 @@ __global__ __launch_bounds__(64 * NW) RM_WAVES_PER_EU(8) void k_xs_sum(ChainGeom
         if (lane == 0) {
             const unsigned long long kmn = f64_key(hmn), kmx = f64_key(hmx);
             const int sp_ = ((int)blockIdx.x * NW + wave) & (NSTRIPE - 1);
-            if (kmn < *(volatile unsigned long long *)&st->heat_min_keys[sp_]) atomicMin(&st->heat_min_keys[sp_], kmn);
-            if (kmx > *(volatile unsigned long long *)&st->heat_max_keys[sp_]) atomicMax(&st->heat_max_keys[sp_], kmx);
+            striped_min_max(st->heat_min_keys, st->heat_max_keys, sp_, kmn, kmx);
         }
     }
 }
