@@ -690,7 +690,7 @@ def test_emu_contour_stage_device_labelling(emu, oracle):
         masks.append(m); fire.append(len(masks) - 1)
     # rows of whole words taller than one 64 x 32 tile (rm_ccl.h k_ccl_tile / k_ccl_seam / k_ccl_fold): specks, blobs that cross the
     # seams in every direction, a tile holding as many one-pixel components as it can
-    for (h, w, dens) in [(70, 128, 0.2), (100, 256, 0.45), (33, 192, 0.6), (65, 64, 0.3), (96, 128, 0.03)]:
+    for (h, w, dens) in [(70, 128, 0.2), (100, 256, 0.45), (33, 192, 0.6), (65, 64, 0.3), (96, 128, 0.03), (1, 128, 0.5), (7, 64, 0.6), (32, 64, 0.97)]:
         masks.append(rng.random((h, w)) < dens)
     for k in range(3):
         m = rng.random((90, 192)) < 0.12
